@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference; CPU fp32, torch 2.10).  The
+reference's modules are imported unmodified (``torchvision`` is absent here and used only by
+``get_dataset``, so empty stub modules are registered for it).  Nothing from the reference
+is written into the repo except input/output TENSORS of its functions.
+
+Usage:  python tools/gen_golden.py            # rewrites tests/golden/*.npz
+Fixtures follow SURVEY.md section 8(c): G1 layer-wise fwd, G2 DM class term, G3 DM step x2,
+G4 hallucinator, G5 s2d DM step, G6 match_loss KATs, G7 evaluate_synset/epoch, G8 is G3
+re-used by the sharding tests.
+"""
+import os
+import random
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+REF = os.environ.get("VD_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def import_reference():
+    for name in ("torchvision", "torchvision.datasets", "torchvision.transforms", "torchvision.utils"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].datasets = sys.modules["torchvision.datasets"]
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.path.insert(0, REF)
+    import networks  # noqa
+    import utils  # noqa
+    return networks, utils
+
+
+def make_net(networks, seed, num_classes, im, frames):
+    # bypass get_network's wall-clock reseed; same settings as utils.py:608-609
+    torch.manual_seed(seed)
+    return networks.ConvNet3D(channel=3, num_classes=num_classes, net_width=128, net_depth=3,
+                              net_act='relu', net_norm='none', net_pooling='maxpooling',
+                              im_size=(im, im), frames=frames)
+
+
+def npz(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **conv)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def param_checksum(net):
+    return np.array([float(p.double().sum()) for p in net.parameters()] +
+                    [float(p.double().abs().sum()) for p in net.parameters()])
+
+
+def g1(networks):
+    seed = 11
+    net = make_net(networks, seed, 50, 64, 8).eval()
+    g = torch.Generator().manual_seed(101)
+    x = torch.randn(2, 8, 3, 64, 64, generator=g)
+    outs = []
+    cur = x.permute(0, 2, 1, 3, 4)
+    for layer in net.features:
+        cur = layer(cur.clone())  # ReLU is in-place in the reference
+        outs.append(cur.clone())
+    embed = net.embed(x)
+    logits = net(x)
+    # one 112x112x16 sample: embed + logits only
+    net112 = make_net(networks, seed, 50, 112, 16).eval()
+    g = torch.Generator().manual_seed(102)
+    x112 = torch.randn(1, 16, 3, 112, 112, generator=g)
+    npz("g1_layers.npz", seed=seed, x_seed=101, x=x[:, :, :, ::8, ::8],  # strided probe of x only
+        conv0=outs[0][:, ::8, :, ::4, ::4], pool0=outs[2][:, ::8, :, ::2, ::2],
+        conv1=outs[3][:, ::16], pool1=outs[5][:, ::8], conv2=outs[6][:, ::8], pool2=outs[8],
+        embed=embed, logits=logits, checksum=param_checksum(net),
+        w0_probe=net.features[0].weight[:4], b2=net.features[6].bias,
+        x112_seed=102, embed112=net112.embed(x112), logits112=net112(x112))
+
+
+def g2_g3(networks):
+    seed = 21
+    net = make_net(networks, seed, 50, 64, 8).train()
+    for p in net.parameters():
+        p.requires_grad = False
+    g = torch.Generator().manual_seed(201)
+    real = torch.randn(4, 8, 3, 64, 64, generator=g)
+    syn = torch.randn(1, 8, 3, 64, 64, generator=g).requires_grad_(True)
+    out_real = net.embed(real).detach()
+    out_syn = net.embed(syn)
+    loss = torch.sum((torch.mean(out_real, dim=0) - torch.mean(out_syn, dim=0)) ** 2)
+    loss.backward()
+    npz("g2_dm_class.npz", seed=seed, data_seed=201, loss=loss, grad_syn=syn.grad,
+        feat_real_mean=out_real.mean(0), feat_syn=out_syn)
+
+    # G3: two DM iterations, C=3 classes, ipc=1, batch_real=4, SGD(lr, momentum .5)
+    C, ipc, lr = 3, 1, 0.5
+    g = torch.Generator().manual_seed(301)
+    image_syn = torch.randn(C * ipc, 8, 3, 64, 64, generator=g).requires_grad_(True)
+    opt = torch.optim.SGD([image_syn], lr=lr, momentum=0.5)
+    losses, syn_after, grads = [], [], []
+    for it in range(2):
+        net = make_net(networks, 31 + it, 50, 64, 8).train()
+        for p in net.parameters():
+            p.requires_grad = False
+        gr = torch.Generator().manual_seed(310 + it)
+        loss = torch.tensor(0.0)
+        for c in range(C):
+            img_real = torch.randn(4, 8, 3, 64, 64, generator=gr)
+            img_syn = image_syn[c * ipc:(c + 1) * ipc].reshape((ipc, 8, 3, 64, 64))
+            output_real = net.embed(img_real).detach()
+            output_syn = net.embed(img_syn)
+            loss += torch.sum((torch.mean(output_real, dim=0) - torch.mean(output_syn, dim=0)) ** 2)
+        opt.zero_grad()
+        loss.backward()
+        grads.append(image_syn.grad.clone())
+        opt.step()
+        losses.append(float(loss))
+        syn_after.append(image_syn.detach().clone())
+    npz("g3_dm_steps.npz", net_seeds=[31, 32], syn_seed=301, real_seeds=[310, 311], lr=lr,
+        momentum=0.5, losses=losses, grad0=grads[0][:, ::2, :, ::4, ::4], grad1=grads[1][:, ::2, :, ::4, ::4],
+        syn1=syn_after[0][:, ::2, :, ::4, ::4], syn2=syn_after[1][:, ::2, :, ::4, ::4],
+        syn2_sum=float(syn_after[1].double().sum()), syn2_abs=float(syn_after[1].double().abs().sum()))
+
+
+def g4_g5(networks, utils):
+    torch.manual_seed(41)
+    hal = utils.Conv3DNet()
+    g = torch.Generator().manual_seed(401)
+    static = torch.randn(3, 3, 64, 64, generator=g).requires_grad_(True)
+    dynamic = torch.randn(3, 8, 1, 64, 64, generator=g).requires_grad_(True)
+    up = torch.randn(3, 8, 3, 64, 64, generator=g)
+    out = hal(static, dynamic)
+    (out * up).sum().backward()
+    npz("g4_hallucinator.npz", weight=hal.encoder.weight, bias=hal.encoder.bias, data_seed=401,
+        out=out[:, :, :, ::2, ::2], out_sum=float(out.double().sum()),
+        g_dynamic=dynamic.grad[:, :, :, ::2, ::2], g_static=static.grad[:, :, ::2, ::2],
+        g_weight=hal.encoder.weight.grad, g_bias=hal.encoder.bias.grad,
+        g_dynamic_abs=float(dynamic.grad.double().abs().sum()), g_static_abs=float(static.grad.double().abs().sum()))
+
+    # G5: one s2d DM step, C=3, vpc=1, spc=2, dpc=2, static frozen, SGD(.95) on dynamic + hal
+    C, vpc, spc, dpc = 3, 1, 2, 2
+    torch.manual_seed(51)
+    hal = utils.Conv3DNet()
+    w0, b0 = hal.encoder.weight.detach().clone(), hal.encoder.bias.detach().clone()
+    g = torch.Generator().manual_seed(501)
+    static_syn = torch.randn(C * spc, 3, 64, 64, generator=g)
+    dynamic_syn = torch.randn(C, dpc, 8, 1, 64, 64, generator=g).requires_grad_(True)
+    draws_dyn = torch.tensor([1, 0, 1])
+    draws_sta = torch.tensor([0, 1, 1])
+    opt_d = torch.optim.SGD([dynamic_syn], lr=10.0, momentum=0.95)
+    opt_h = torch.optim.SGD(hal.parameters(), lr=0.01, momentum=0.95)
+    net = make_net(networks, 52, 50, 64, 8).train()
+    for p in net.parameters():
+        p.requires_grad = False
+    label = torch.tensor(np.stack([np.ones(vpc) * i for i in range(0, C)]), dtype=torch.long).view(-1)
+    ran = torch.arange(0, C * vpc)
+    idx = ran % vpc
+    dynamic_idx = 2 * idx + draws_dyn
+    static_idx = spc * label + 2 * idx + draws_sta
+    image_syn = hal(static_syn[static_idx], dynamic_syn[label, dynamic_idx])
+    gr = torch.Generator().manual_seed(510)
+    loss = torch.tensor(0.0)
+    for c in range(C):
+        img_real = torch.randn(4, 8, 3, 64, 64, generator=gr)
+        img_syn = image_syn[c * vpc:(c + 1) * vpc].reshape((vpc, 8, 3, 64, 64))
+        loss += torch.sum((torch.mean(net.embed(img_real).detach(), dim=0) - torch.mean(net.embed(img_syn), dim=0)) ** 2)
+    opt_d.zero_grad(); opt_h.zero_grad()
+    loss.backward()
+    gd = dynamic_syn.grad.clone()
+    gw, gb = hal.encoder.weight.grad.clone(), hal.encoder.bias.grad.clone()
+    opt_d.step(); opt_h.step()
+    npz("g5_s2d_step.npz", hal_w=w0, hal_b=b0, data_seed=501, net_seed=52, real_seed=510,
+        draws_dyn=draws_dyn, draws_sta=draws_sta, dynamic_idx=dynamic_idx, static_idx=static_idx,
+        loss=float(loss), g_dynamic=gd[:, :, :, :, ::4, ::4], g_dynamic_abs=float(gd.double().abs().sum()),
+        g_dynamic_rowabs=gd.abs().sum(dim=(2, 3, 4, 5)), g_hal_w=gw, g_hal_b=gb,
+        hal_w_after=hal.encoder.weight, hal_b_after=hal.encoder.bias,
+        dynamic_after_sum=float(dynamic_syn.detach().double().sum()),
+        dynamic_after=dynamic_syn.detach()[:, :, :, :, ::4, ::4])
+
+
+class _Args:
+    pass
+
+
+def g6(networks, utils):
+    args = _Args(); args.device = 'cpu'
+    g = torch.Generator().manual_seed(601)
+    shapes = [(4, 3, 3, 7, 7), (4,), (5, 4, 3, 7, 7), (5,), (6, 5), (6,), (2, 3, 4), (3, 2, 2, 2)]
+    gr = [torch.randn(s, generator=g) for s in shapes]
+    gs = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    gr[0][1, 2, 0, 3] = 0.0  # zero-norm row in a 5-D member -> epsilon path
+    rec = {"n": len(shapes)}
+    for i, (a, b) in enumerate(zip(gr, gs)):
+        rec["r%d" % i] = a; rec["s%d" % i] = b.detach()
+    for metric in ("ours", "mse", "cos"):
+        args.dis_metric = metric
+        for b in gs:
+            b.grad = None
+        val = utils.match_loss(gs, gr, args)
+        val.backward()
+        rec["val_" + metric] = val.detach()
+        for i, b in enumerate(gs):
+            rec["grad_%s_%d" % (metric, i)] = b.grad if b.grad is not None else torch.zeros_like(b)
+    # per-layer 'ours' values (documents the 5-D fall-through and 1-D -> 0)
+    rec["ours_per_layer"] = np.array([float(utils.distance_wb(a, b.detach())) for a, b in zip(gr, gs)])
+    # a real ConvNet3D gradient pair (dropout made deterministic by seeding)
+    net = make_net(networks, 61, 5, 64, 8).train()
+    gd = torch.Generator().manual_seed(602)
+    xr = torch.randn(2, 8, 3, 64, 64, generator=gd); yr = torch.tensor([1, 3])
+    xs = torch.randn(2, 8, 3, 64, 64, generator=gd); ys = torch.tensor([1, 3])
+    crit = torch.nn.CrossEntropyLoss()
+    torch.manual_seed(611); gw_real = torch.autograd.grad(crit(net(xr), yr), list(net.parameters()))
+    torch.manual_seed(611); gw_syn = torch.autograd.grad(crit(net(xs), ys), list(net.parameters()))
+    for metric in ("ours", "mse", "cos"):
+        args.dis_metric = metric
+        rec["net_" + metric] = utils.match_loss(list(gw_syn), list(gw_real), args)
+    rec["net_seed"] = 61; rec["net_data_seed"] = 602; rec["net_drop_seed"] = 611
+    rec["net_gw_real_l1"] = np.array([float(t.double().abs().sum()) for t in gw_real])
+    npz("g6_match_loss.npz", **rec)
+
+
+def g7(networks, utils):
+    # evaluate_synset / epoch on a tiny problem, dropout disabled (p=0) so RNG does not matter.
+    C, n_test = 3, 6
+    args = _Args()
+    args.device = 'cpu'; args.lr_net = 0.01; args.epoch_eval_train = 4; args.batch_train = 256
+    args.model = 'ConvNet3D'; args.eval_mode = 'SS'
+    g = torch.Generator().manual_seed(701)
+    images = torch.randn(C, 8, 3, 64, 64, generator=g)
+    labels = torch.arange(C)
+    test_x = torch.randn(n_test, 8, 3, 64, 64, generator=g)
+    test_y = torch.arange(n_test) % C
+    testloader = torch.utils.data.DataLoader(utils.TensorDataset(test_x, test_y), batch_size=4, shuffle=False)
+    net = make_net(networks, 71, C, 64, 8)
+    net.dropout.p = 0.0
+    p0 = [p.detach().clone() for p in net.parameters()]
+    # record the shuffle order the DataLoader will draw: seed the global RNG, replay with randperm
+    torch.manual_seed(711); random.seed(711); np.random.seed(711)
+    rec_losses = []
+    orig_epoch = utils.epoch
+
+    def spy(mode, loader, net_, opt, crit, a):
+        out = orig_epoch(mode, loader, net_, opt, crit, a)
+        rec_losses.append((mode, out[0], out[1]))
+        return out
+    utils.epoch = spy
+    try:
+        net_out, acc_train, acc_test, acc_per = utils.evaluate_synset(0, net, images, labels, testloader, args, mode='none')
+    finally:
+        utils.epoch = orig_epoch
+    train = [(l, a) for m, l, a in rec_losses if m == 'train']
+    test = [(l, a) for m, l, a in rec_losses if m == 'test']
+    # top5 layout
+    args.eval_mode = 'top5'
+    crit = torch.nn.CrossEntropyLoss()
+    with torch.no_grad():
+        l5, acc5, per5 = orig_epoch('test', testloader, net_out, None, crit, args)
+    npz("g7_evaluate.npz", net_seed=71, data_seed=701, C=C, n_test=n_test, lr_net=0.01, epochs=4,
+        train_loss=np.array([t[0] for t in train]), train_acc=np.array([t[1] for t in train]),
+        test_loss=np.array([t[0] for t in test]), test_acc=np.array([t[1] for t in test]),
+        acc_train=acc_train, acc_test=acc_test,
+        acc_per=np.array([np.nan if a is None else a for a in acc_per]),
+        top5=np.array(acc5), top5_loss=l5,
+        params_after_l1=np.array([float(p.double().abs().sum()) for p in net_out.parameters()]),
+        params_before_l1=np.array([float(p.double().abs().sum()) for p in p0]),
+        logit_w_after=net_out.logit.weight.detach().reshape(C, -1)[:, :16])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    networks, utils = import_reference()
+    g1(networks)
+    g2_g3(networks)
+    g4_g5(networks, utils)
+    g6(networks, utils)
+    g7(networks, utils)
+
+
+if __name__ == "__main__":
+    main()
