@@ -1,0 +1,115 @@
+"""numpy interpreter of the tile program that csrc/conv_mfma.hip executes on the GPU.
+
+It consumes exactly the tables the device consumes (ConvPlan.flat_tables(), boxes, widx) and
+follows the same dataflow (patch gather with zero fill -> per-row/tap A operand -> K-step
+products -> pooled / row epilogue), in fp64, so that the planner can be checked on the CPU.
+"""
+import numpy as np
+
+from video_distillation_amd import plan as P
+
+
+def pack_weights(plan, w_flat):
+    """[CC,S,NT,64,8] operand values (what vd_pack_weights writes, before 16-bit rounding)."""
+    idx = plan.widx
+    out = np.where(idx >= 0, w_flat[np.maximum(idx, 0)], 0.0)
+    return out
+
+
+def run_plan(plan, src, w_flat, bias, nclips, out):
+    """src: float array [nclips, CC, F, H, W, 8]; out: flat float64 array (pre-zeroed).
+    Returns argmax array (same indexing as out) for pooled epilogues."""
+    descs, tables = plan.flat_tables()
+    wp = pack_weights(plan, w_flat)                       # [CC,S,NT,64,8]
+    lane = np.arange(64)
+    col, half = lane & 31, lane >> 5
+    arg = {}
+    ngroups = -(-nclips // plan.ncl)
+    for grp in range(ngroups):
+        clip0 = grp * plan.ncl
+        for box in plan.boxes:
+            ty, f0, h0, w0, out_rel, _ = [int(v) for v in box]
+            pf, ph, pw, pitch_h, pitch_f, pitch_c, mt, a_ofs, o_ofs, t_ofs = [int(v) for v in descs[ty][:10]]
+            a_off = tables[a_ofs:a_ofs + mt * 32] // 16
+            tap_off = tables[t_ofs:t_ofs + 2 * plan.S] // 16
+            nout = mt * 4 if plan.epi != P.EPI_ROWS else mt * 32
+            out_tab = tables[o_ofs:o_ofs + nout]
+            acc = np.zeros((mt * 32, plan.NT * 32))
+            for cc in range(plan.CC):
+                patch = np.zeros((plan.ncl * pitch_c + 64, 8))
+                for ci in range(plan.ncl):
+                    b = clip0 + ci
+                    if b >= nclips:
+                        continue
+                    for f in range(pf):
+                        for h in range(ph):
+                            sf, sh = f0 + f, h0 + h
+                            if not (0 <= sf < plan.F and 0 <= sh < plan.H):
+                                continue
+                            wlo, whi = max(0, -w0), min(pw, plan.W - w0)
+                            if whi <= wlo:
+                                continue
+                            base = ci * pitch_c + f * pitch_f + h * pitch_h
+                            patch[base + wlo:base + whi] = src[b, cc, sf, sh, w0 + wlo:w0 + whi]
+                # A[row, s, half, j]
+                for s in range(plan.S):
+                    for hh in range(2):
+                        a = patch[a_off + tap_off[2 * s + hh]]            # [rows, 8]
+                        lanes = np.where(half == hh)[0]
+                        for nt in range(plan.NT):
+                            bmat = wp[cc, s, nt, lanes, :]                 # [32 cols, 8]
+                            acc[:, nt * 32:(nt + 1) * 32] += a @ bmat.T
+            n = np.arange(plan.NT * 32)
+            nvalid = n < plan.n_out
+            if bias is not None:
+                acc = acc + np.where(nvalid, np.pad(bias, (0, max(0, plan.NT * 32 - bias.size)))[:plan.NT * 32], 0.0)[None, :]
+            if plan.relu:
+                acc = np.maximum(acc, 0.0)
+            if plan.epi == P.EPI_ROWS:
+                for r in range(mt * 32):
+                    o = int(out_tab[r])
+                    if o < 0:
+                        continue
+                    base = clip0 * plan.out_clip_stride + out_rel + o
+                    ci = o // plan.out_clip_stride
+                    if clip0 + ci >= nclips:
+                        continue
+                    out[base + n[nvalid] * plan.n_stride] = acc[r, nvalid]
+            else:
+                for t in range(mt):
+                    for q in range(4):
+                        o = int(out_tab[t * 4 + q])
+                        if o < 0:
+                            continue
+                        ci = o // plan.out_clip_stride
+                        if clip0 + ci >= nclips:
+                            continue
+                        rows = [t * 32 + P._row_of(q, j) for j in range(8)]
+                        vals = acc[rows]                                   # [8, N]
+                        sets = [(0, slice(0, 8))] if plan.pool_t == 2 else [(0, slice(0, 4)), (1, slice(4, 8))]
+                        for dt, sl in sets:
+                            v = vals[sl]
+                            mx, am = v.max(axis=0), v.argmax(axis=0)
+                            base = clip0 * plan.out_clip_stride + out_rel + o + dt * plan.out_t_stride
+                            if plan.epi == P.EPI_POOL_FEAT:
+                                out[base + n * plan.n_stride] = mx
+                                for k in n:
+                                    arg[base + k * plan.n_stride] = am[k]
+                            else:   # CL slots: chunk = n//8, element n%8
+                                idxs = (base + (n // 8) * plan.out_chunk_stride) * 8 + (n % 8)
+                                out[idxs] = mx
+                                for k, ii in zip(n, idxs):
+                                    arg[ii] = am[k]
+    return arg
+
+
+def pix_to_slots(x_btchw):
+    """What vd_pix2slots produces: [B, 1, T*3, H, OW, 8] with slot = x[t,c,h,2ow-3..2ow+4]."""
+    B, T, C, H, W = x_btchw.shape
+    OW = (W + 6 - 7) // 2 + 1
+    xp = np.zeros((B, T, C, H, W + 8))
+    xp[..., 3:3 + W] = x_btchw
+    out = np.zeros((B, 1, T * C, H, OW, 8))
+    for ow in range(OW):
+        out[:, 0, :, :, ow, :] = xp[..., 2 * ow:2 * ow + 8].reshape(B, T * C, H, 8)
+    return out

@@ -1,0 +1,118 @@
+"""Replay the tile programs produced by video_distillation_amd.plan on the CPU (numpy fp64,
+tests/emulate.py) and compare with the oracle.  This pins every table the HIP kernel consumes
+(row origins, tap offsets, weight gather, output maps) without a GPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu as R
+from tests import emulate as E
+from video_distillation_amd import plan as P
+
+GEO = P.NetGeometry(8, 64, 64)
+
+
+@pytest.fixture(scope="module")
+def net():
+    return P.plan_network(GEO)
+
+
+@pytest.fixture(scope="module")
+def acts():
+    params = [p.double() for p in R.init_params(5)]
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 8, 3, 64, 64, generator=g).double()
+    col = []
+    R.feature_layers(x.permute(0, 2, 1, 3, 4), params, collect=col)
+    return params, x, col
+
+
+def cl_to_bcthw(flat, nclips, shape):
+    ccs, T, Ho, Wo, _ = shape
+    a = flat.reshape(nclips, ccs, T, Ho, Wo, 8)
+    return a.transpose(0, 1, 5, 2, 3, 4).reshape(nclips, ccs * 8, T, Ho, Wo)
+
+
+def bcthw_to_cl(a):
+    B, C, T, H, W = a.shape
+    return a.reshape(B, C // 8, 8, T, H, W).transpose(0, 1, 3, 4, 5, 2).copy()
+
+
+def test_plans_cover_and_fit(net):
+    for pl in net["fwd"] + [p for l in net["bwd"] for p in l]:
+        assert pl.lds_slots * 16 * 2 + 4096 <= 160 * 1024, pl.name  # hi+lo planes must fit LDS
+        assert pl.MTW in (7, 8) and pl.threads in (64, 128, 256)
+        for t in pl.types:
+            assert t.a_off.min() >= 0 and (t.a_off.max() + t.tap_off.max()) // 16 < pl.ncl * t.pitch_c + 1
+            assert t.a_off.size == pl.MW * pl.MTW * 32
+
+
+def test_forward_layer0(net, acts):
+    params, x, col = acts
+    pl = net["fwd"][0]
+    n = 2
+    src = E.pix_to_slots(x[:n].numpy())
+    out = np.zeros(n * int(np.prod(pl.out_shape)))
+    arg = E.run_plan(pl, src, params[0].numpy().ravel(), params[1].numpy(), n, out)
+    got = cl_to_bcthw(out, n, pl.out_shape)
+    np.testing.assert_allclose(got, col[2][:n].numpy(), rtol=1e-9, atol=1e-9)
+    assert len(arg) == out.size
+
+
+def test_forward_layer1(net, acts):
+    params, x, col = acts
+    pl = net["fwd"][1]
+    n = 1
+    src = bcthw_to_cl(col[2][:n].numpy())
+    out = np.zeros(n * int(np.prod(pl.out_shape)))
+    E.run_plan(pl, src, params[2].numpy().ravel(), params[3].numpy(), n, out)
+    np.testing.assert_allclose(cl_to_bcthw(out, n, pl.out_shape), col[5][:n].numpy(), rtol=1e-9, atol=1e-9)
+
+
+def test_forward_layer2_features_and_ragged_clip_group(net, acts):
+    params, x, col = acts
+    pl = net["fwd"][2]
+    n = 3 if pl.ncl > 1 else 1           # 3 clips with ncl=4: last group is ragged
+    src = bcthw_to_cl(col[5][:n].numpy())
+    out = np.zeros(n * GEO.num_feat)
+    arg = E.run_plan(pl, src, params[4].numpy().ravel(), params[5].numpy(), n, out)
+    want = col[8][:n].numpy().reshape(n, -1)
+    np.testing.assert_allclose(out.reshape(n, -1), want, rtol=1e-9, atol=1e-9)
+    # arg-max index convention: j = dt*4 + dh*2 + dw inside the 2x2x2 window
+    relu2 = col[7][0].numpy()            # (C, T, H, W) post-ReLU conv grid of clip 0
+    C, T, H, W = relu2.shape
+    win = relu2.reshape(C, T // 2, 2, H // 2, 2, W // 2, 2).transpose(0, 1, 3, 5, 2, 4, 6).reshape(C, -1, 8)
+    am = win.argmax(axis=2).ravel()
+    got = np.array([arg[i] for i in range(GEO.num_feat)])
+    np.testing.assert_array_equal(got, am)
+
+
+@pytest.mark.parametrize("li", [0, 1, 2])
+def test_input_gradient_passes(net, acts, li):
+    params, x, col = acts
+    cin, cout, t, h, w, T, OH, OW = net["dims"][li][:8]
+    g = torch.Generator().manual_seed(900 + li)
+    n = 2 if li == 2 else 1
+    dy = torch.randn(n, cout, T, OH, OW, generator=g).double()
+    xin = torch.zeros(n, cin, t, h, w, dtype=torch.double, requires_grad=True)
+    y = F.conv3d(xin, params[2 * li], None, stride=(1, 2, 2), padding=(1, 3, 3))
+    (want,) = torch.autograd.grad(y, xin, dy)
+    src = bcthw_to_cl(dy.numpy())
+    out = np.zeros(n * cin * t * h * w)
+    for pl in net["bwd"][li]:
+        E.run_plan(pl, src, params[2 * li].numpy().ravel(), None, n, out)
+    if li == 0:      # pixel layout (T, C, H, W)
+        got = out.reshape(n, t, cin, h, w).transpose(0, 2, 1, 3, 4)
+    else:            # (T, H, W, C)
+        got = out.reshape(n, t, h, w, cin).transpose(0, 4, 1, 2, 3)
+    np.testing.assert_allclose(got, want.numpy(), rtol=1e-9, atol=1e-9)
+
+
+def test_full_resolution_plans_build():
+    net = P.plan_network(P.NetGeometry(16, 112, 112))
+    f1 = net["fwd"][1]
+    assert f1.rows_useful == 16 * 14 * 14 and f1.rows_total == f1.rows_useful  # exact tiling, no wasted MFMA rows
+    assert net["fwd"][2].ncl == 2
+    for pl in net["fwd"] + [p for l in net["bwd"] for p in l]:
+        assert pl.lds_slots * 32 + 4096 <= 160 * 1024

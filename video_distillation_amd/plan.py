@@ -1,0 +1,556 @@
+"""Host-side planner for the table-driven MFMA convolution kernel (csrc/conv_mfma.hip).
+
+The device kernel knows nothing about convolution geometry.  It executes a *tile program*:
+
+  * a workgroup owns a *box* of output rows (<= MW*MTW*32) of ``ncl`` consecutive clips;
+  * it stages the input *patch* of that box (16-byte slots = 8 x 16-bit values, zero filled
+    outside the source grid) into LDS once per 8-wide input-channel chunk;
+  * output row ``r`` of MFMA tile ``i`` reads its A fragment for tap ``p`` at LDS byte address
+    ``a_off[i*32+r] + tap_off[p]``; two taps (lane halves) x 8 values form one K=16 step;
+  * B fragments come pre-packed in fragment order (``widx`` is the gather table used to pack);
+  * the epilogue is either max-pool over 8-row groups (+bias, ReLU, arg-max) or plain rows.
+
+Everything index-heavy lives here in numpy, where tests/test_plan_emulation.py replays the
+tile program on the CPU against the oracle before any GPU is involved.
+
+Geometry follows the reference's ConvNet3D (networks.py:792-814: Conv3d k(3,7,7) s(1,2,2)
+p(1,3,3) -> ReLU -> MaxPool3d) but nothing below is copied from it.
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+SLOT_BYTES = 16
+EPI_POOL_CL = 0      # pooled, channels-last 16-bit slots out (next layer's source)
+EPI_POOL_FEAT = 1    # pooled, fp32 features in (C,T,H,W) order (embed output)
+EPI_ROWS = 2         # plain fp32 rows (input-gradient passes)
+
+KT, KH, KW = 3, 7, 7
+# ds_read_b128 services a wave in four 16-lane groups (MI355X_MICROARCH.md, LDS table)
+_B128_GROUPS = (
+    (0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27),
+    (4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31),
+)
+
+
+@dataclass
+class BoxType:
+    pf: int
+    ph: int
+    pw: int
+    pitch_h: int
+    pitch_f: int
+    pitch_c: int
+    mt: int                      # MFMA row tiles in the workgroup (MW*MTW, padded)
+    a_off: np.ndarray            # int32 [mt*32] LDS byte offsets of row origins
+    out: np.ndarray              # int32 [mt*4] (pooled) or [mt*32] (rows); -1 = discard
+    tap_off: np.ndarray          # int32 [2*S] LDS byte offsets per tap
+    conflict_cycles: float = 0.0
+
+    @property
+    def patch_slots(self) -> int:
+        return self.pitch_c
+
+
+@dataclass
+class ConvPlan:
+    name: str
+    # source slot grid per clip
+    CC: int
+    F: int
+    H: int
+    W: int
+    # decomposition
+    NT: int
+    MW: int
+    MTW: int
+    S: int
+    ncl: int
+    boxes: np.ndarray            # int32 [nbox, 6]: type, f0, h0, w0, out_rel, clip_rel(always 0)
+    types: List[BoxType]
+    widx: np.ndarray             # int32 [CC, S, NT, 64, 8] gather into flat fp32 weights, -1 = 0
+    # epilogue
+    epi: int
+    pool_t: int
+    relu: bool
+    n_out: int                   # valid output channels
+    n_stride: int                # element stride between output channels (FEAT/ROWS)
+    out_clip_stride: int         # slots (CL, per channel chunk grid) or elements per clip
+    out_chunk_stride: int        # CL: slots per output channel chunk (Fo*Ho*Wo)
+    out_shape: Tuple[int, ...]   # logical output grid (for allocation / tests)
+    out_t_stride: int = 0        # pool_t == 1: distance between the two outputs of a row group
+    rows_total: int = 0
+    rows_useful: int = 0
+    meta: Dict = field(default_factory=dict)
+
+    @property
+    def nbox(self) -> int:
+        return int(self.boxes.shape[0])
+
+    @property
+    def threads(self) -> int:
+        return 64 * self.NT * self.MW
+
+    @property
+    def lds_slots(self) -> int:
+        return max(t.pitch_c * self.ncl for t in self.types)
+
+    def grid(self, nclips: int) -> int:
+        return ((nclips + self.ncl - 1) // self.ncl) * self.nbox
+
+    def flat_tables(self):
+        """Serialise box types into (type_desc int32 [ntypes,16], tables int32[...])."""
+        descs, chunks, pos = [], [], 0
+        for t in self.types:
+            a_ofs = pos; chunks.append(t.a_off.astype(np.int32)); pos += t.a_off.size
+            o_ofs = pos; chunks.append(t.out.astype(np.int32)); pos += t.out.size
+            t_ofs = pos; chunks.append(t.tap_off.astype(np.int32)); pos += t.tap_off.size
+            descs.append([t.pf, t.ph, t.pw, t.pitch_h, t.pitch_f, t.pitch_c, t.mt,
+                          a_ofs, o_ofs, t_ofs, 0, 0, 0, 0, 0, 0])
+        return np.asarray(descs, dtype=np.int32), np.concatenate(chunks).astype(np.int32)
+
+
+# ----------------------------------------------------------------------------------------
+# bank-conflict model for the A-fragment reads
+# ----------------------------------------------------------------------------------------
+def _conflict_cycles(slots_per_row: np.ndarray) -> float:
+    """Average LDS cycles per ds_read_b128 wave-instruction (4 = conflict-free) for one MFMA
+    tile whose 32 rows start at the given 16-byte slot indices (both lane halves read the
+    same rows at a tap-dependent but half-uniform offset, so taps do not matter)."""
+    total = 0
+    for grp in _B128_GROUPS:
+        banks = slots_per_row[list(grp)] % 16
+        total += np.bincount(banks, minlength=16).max()
+    return 2.0 * total  # two lane halves
+
+
+def _row_of(q: int, j: int) -> int:
+    """MFMA 32x32 C/D layout: group q (0..3) and in-group index j (0..7) -> row of the tile.
+    Rows of one group sit in ONE lane (registers 8*(q>>1)..+7 of lane half q&1)."""
+    return (j & 3) + 4 * (q & 1) + 8 * (j >> 2) + 16 * (q >> 1)
+
+
+def _choose_box(dims, group, rows_max, slot_fn, lds_budget):
+    """Pick the box shape (na,nb,nc) minimising boxes (then patch size) under the row and
+    LDS limits.  ``group`` is the (ga,gb,gc) granularity a box must respect."""
+    RA, RB, RC = dims
+    best = None
+    cand_a = [a for a in range(group[0], RA + group[0], group[0])]
+    cand_b = [b for b in range(group[1], RB + group[1], group[1])]
+    cand_c = [c for c in range(group[2], RC + group[2], group[2])]
+    for na, nb, nc in itertools.product(cand_a, cand_b, cand_c):
+        if na > RA + group[0] - 1 or nb > RB + group[1] - 1 or nc > RC + group[2] - 1:
+            continue
+        if na * nb * nc > rows_max:
+            continue
+        slots = slot_fn(na, nb, nc)
+        if slots > lds_budget:
+            continue
+        nbox = -(-RA // na) * -(-RB // nb) * -(-RC // nc)
+        key = (nbox, nc < min(8, RC), slots)   # narrow patch rows coalesce badly
+        if best is None or key < best[0]:
+            best = (key, (na, nb, nc))
+    if best is None:
+        raise ValueError("no box shape fits %s rows<=%d lds<=%d" % (dims, rows_max, lds_budget))
+    return best[1]
+
+
+_PERMS4 = list(itertools.permutations(range(4)))
+
+
+def _build_type(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, out_fn, valid_fn, ncl, pad_search=True,
+                slot_cap=1 << 30):
+    """Build one BoxType.  ``row_lin(a,b,c)`` -> (f,h,w) patch-relative slot coords of the row
+    origin; ``tap_list`` -> (df,dh,dw); ``out_fn`` gives the output index of a group / row.
+    Searches LDS pitches (and, for pooled tiles, which of a tile's four row groups sits in
+    which lane-half/register-half) for the fewest ds_read_b128 bank conflicts."""
+    na, nb, nc = box
+    pf, ph, pw = patch_ext
+    ga, gb, gc = group
+    if pooled:
+        groups = [(ci, a, b, c) for ci in range(ncl) for a in range(0, na, ga) for b in range(0, nb, gb)
+                  for c in range(0, nc, gc)]
+        ngr = len(groups)
+        # coordinates of the 8 rows of every group: [ngr, 8, 4] = (ci, f, h, w)
+        gcoord = np.zeros((ngr, 8, 4), dtype=np.int64)
+        for gi, (ci, a, b, c) in enumerate(groups):
+            for j in range(8):
+                dt, dh, dw = (j >> 2) & 1, (j >> 1) & 1, j & 1
+                f, h, w = row_lin(a + dt, b + dh, c + dw)
+                gcoord[gi, j] = (ci, f, h, w)
+        gout = np.array([out_fn(ci, a, b, c) if valid_fn(a, b, c) else -1 for ci, a, b, c in groups], dtype=np.int64)
+        ntile_used = -(-ngr // 4)
+        rows_of = np.array([[_row_of(q, j) for j in range(8)] for q in range(4)])
+    else:
+        rows = [(ci, a, b, c) for ci in range(ncl) for a in range(na) for b in range(nb) for c in range(nc)]
+        rcoord = np.array([(ci,) + tuple(row_lin(a, b, c)) for ci, a, b, c in rows], dtype=np.int64)
+        rout = np.array([out_fn(ci, a, b, c) if valid_fn(a, b, c) else -1 for ci, a, b, c in rows], dtype=np.int64)
+        ntile_used = -(-len(rows) // 32)
+    best = None
+    for dph in (range(0, 16) if pad_search else [0]):
+        pitch_h = pw + dph
+        for dpf in (range(0, 16) if pad_search else [0]):
+            pitch_f = ph * pitch_h + dpf
+            pitch_c = pf * pitch_f
+            if pitch_c * ncl > slot_cap and best is not None:
+                continue
+            a_off = np.zeros(mt_pad * 32, dtype=np.int64)
+            if pooled:
+                gslot = gcoord[:, :, 0] * pitch_c + gcoord[:, :, 1] * pitch_f + gcoord[:, :, 2] * pitch_h + gcoord[:, :, 3]
+                out = -np.ones(mt_pad * 4, dtype=np.int64)
+                cyc_sum = 0.0
+                for tile in range(ntile_used):
+                    gids = list(range(tile * 4, min(ngr, tile * 4 + 4)))
+                    gids += [gids[0]] * (4 - len(gids))          # pad with a duplicate (discarded)
+                    best_t = None
+                    for perm in _PERMS4:
+                        slots = np.zeros(32, dtype=np.int64)
+                        for q in range(4):
+                            slots[rows_of[q]] = gslot[gids[perm[q]]]
+                        cyc = _conflict_cycles(slots)
+                        if best_t is None or cyc < best_t[0]:
+                            best_t = (cyc, perm, slots)
+                        if cyc <= 4.0:
+                            break
+                    cyc, perm, slots = best_t
+                    cyc_sum += cyc
+                    a_off[tile * 32:(tile + 1) * 32] = slots
+                    for q in range(4):
+                        gi = tile * 4 + perm[q]
+                        out[tile * 4 + q] = gout[gi] if gi < ngr else -1
+                cyc = cyc_sum / ntile_used
+            else:
+                slots = rcoord[:, 0] * pitch_c + rcoord[:, 1] * pitch_f + rcoord[:, 2] * pitch_h + rcoord[:, 3]
+                a_off[:slots.size] = slots
+                out = -np.ones(mt_pad * 32, dtype=np.int64)
+                out[:rout.size] = rout
+                cyc = float(np.mean([_conflict_cycles(a_off[t * 32:(t + 1) * 32]) for t in range(ntile_used)]))
+            key = (round(float(cyc), 3), pitch_c)
+            if best is None or key < best[0]:
+                tap_off = np.array([(df * pitch_f + dh * pitch_h + dw) * SLOT_BYTES for df, dh, dw in tap_list],
+                                   dtype=np.int64)
+                best = (key, BoxType(pf, ph, pw, pitch_h, pitch_f, pitch_c, mt_pad,
+                                     (a_off * SLOT_BYTES).astype(np.int32), out.astype(np.int32),
+                                     tap_off.astype(np.int32), float(cyc)))
+            if cyc <= 4.0 + 1e-9:
+                break
+        if best is not None and best[0][0] <= 4.0 + 1e-9:
+            break
+    return best[1]
+
+
+def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps, widx_fn,
+               n_out, NT, MW, mtw_options, epi, pool_t, relu, out_index, out_valid, n_stride,
+               out_clip_stride, out_chunk_stride, out_shape, lds_budget, ncl_options=(1,), force_box=None):
+    """Generic planner.  Row (a,b,c) has its tap-(0,0,0) origin at source slot coords
+    (row_stride[0]*a+row_origin[0], ...).  ``taps`` is a list of non-negative (df,dh,dw)."""
+    F, H, W = src_grid
+    ntaps = len(taps)
+    S = (ntaps + 1) // 2
+    taps_p = list(taps) + [(0, 0, 0)] * (2 * S - ntaps)
+    mdf = max(t[0] for t in taps); mdh = max(t[1] for t in taps); mdw = max(t[2] for t in taps)
+    sa, sb, sc = row_stride
+    pooled = epi in (EPI_POOL_CL, EPI_POOL_FEAT)
+
+    def ext(na, nb, nc):
+        return (sa * (na - 1) + mdf + 1, sb * (nb - 1) + mdh + 1, sc * (nc - 1) + mdw + 1)
+
+    best = None
+    for MTW in mtw_options:
+        for ncl in ncl_options:
+            rows_max = (MW * MTW * 32) // ncl
+            if rows_max < group[0] * group[1] * group[2]:
+                continue
+
+            def slot_fn(na, nb, nc, ncl=ncl):
+                e = ext(na, nb, nc)
+                return int(ncl * e[0] * e[1] * e[2] * 1.06) + 16
+
+            try:
+                box = force_box or _choose_box(row_dims, group, rows_max, slot_fn, lds_budget)
+            except ValueError:
+                continue
+            nbox = -(-row_dims[0] // box[0]) * -(-row_dims[1] // box[1]) * -(-row_dims[2] // box[2])
+            cost = nbox * MTW * MW / ncl
+            if best is None or cost < best[0]:
+                best = (cost, MTW, ncl, box)
+    if best is None:
+        raise ValueError("%s: no feasible decomposition" % name)
+    _, MTW, ncl, box = best
+    na, nb, nc = box
+    mt_pad = MW * MTW
+
+    def row_lin(a, b, c):
+        return (sa * a, sb * b, sc * c)
+
+    types: List[BoxType] = []
+    type_key: Dict[Tuple, int] = {}
+    boxes = []
+    for a0 in range(0, row_dims[0], na):
+        for b0 in range(0, row_dims[1], nb):
+            for c0 in range(0, row_dims[2], nc):
+                # validity pattern of this box (edge boxes may hang over the row grid)
+                va = min(na, row_dims[0] - a0); vb = min(nb, row_dims[1] - b0); vc = min(nc, row_dims[2] - c0)
+                key = (va, vb, vc)
+                f0 = sa * a0 + row_origin[0]; h0 = sb * b0 + row_origin[1]; w0 = sc * c0 + row_origin[2]
+                if key not in type_key:
+                    def valid_fn(a, b, c, va=va, vb=vb, vc=vc):
+                        if pooled:
+                            return a + group[0] <= va and b + group[1] <= vb and c + group[2] <= vc
+                        return a < va and b < vb and c < vc
+
+                    def out_fn(ci, a, b, c):
+                        return out_index(ci, a, b, c)  # relative to the box's out_rel
+
+                    bt = _build_type(box, group, row_lin, taps_p, ext(na, nb, nc), mt_pad, pooled,
+                                     out_fn, valid_fn, ncl, slot_cap=int(lds_budget * 1.12))
+                    type_key[key] = len(types)
+                    types.append(bt)
+                boxes.append([type_key[key], f0, h0, w0, out_index(0, a0, b0, c0) - out_index(0, 0, 0, 0), 0])
+    # out tables were built relative to (0,0,0) of the grid; shift so that they are relative to the box
+    # origin: out_index is affine in (a,b,c), so out(ci,a0+a,..) = out(ci,a,..) + [out(0,a0,..)-out(0,0,0,0)].
+    widx = widx_fn(CC, S, NT, taps_p, ntaps)
+    rows_useful = row_dims[0] * row_dims[1] * row_dims[2]
+    return ConvPlan(name=name, CC=CC, F=F, H=H, W=W, NT=NT, MW=MW, MTW=MTW, S=S, ncl=ncl,
+                    boxes=np.asarray(boxes, dtype=np.int32), types=types, widx=widx, epi=epi,
+                    pool_t=pool_t, relu=relu, n_out=n_out, n_stride=n_stride,
+                    out_clip_stride=out_clip_stride, out_chunk_stride=out_chunk_stride,
+                    out_shape=tuple(out_shape), rows_total=len(boxes) * mt_pad * 32 // ncl,
+                    rows_useful=rows_useful, meta={"box": box})
+
+
+# ----------------------------------------------------------------------------------------
+# concrete layers
+# ----------------------------------------------------------------------------------------
+def conv_out_dim(n: int, k: int, s: int, p: int) -> int:
+    return (n + 2 * p - k) // s + 1
+
+
+def _lane_cols():
+    lane = np.arange(64)
+    return lane & 31, lane >> 5
+
+
+def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, pool_t: int,
+                    feat_out: bool, lds_budget: int = 3700, mtw_options=(7, 8)) -> ConvPlan:
+    """Forward Conv3d(cin->cout) + ReLU + MaxPool(pool_t,2,2) over a channels-last chunked
+    source [clip][cin/8][t][h][w] (slots of 8 channels)."""
+    assert cin % 8 == 0 and cout % 32 == 0
+    CC = cin // 8
+    T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
+    To, Ho, Wo = T // pool_t, OH // 2, OW // 2
+    rows = (To * pool_t, Ho * 2, Wo * 2)           # conv rows that survive floor pooling
+    taps = [(kt, kh, kw) for kt in range(KT) for kh in range(KH) for kw in range(KW)]
+    NT = cout // 32
+    MW = max(1, 4 // NT)
+    col, half = _lane_cols()
+
+    def widx_fn(CC_, S, NT_, taps_p, ntaps):
+        idx = -np.ones((CC_, S, NT_, 64, 8), dtype=np.int64)
+        for s in range(S):
+            for hh in range(2):
+                p = 2 * s + hh
+                if p >= ntaps:
+                    continue
+                kt, kh, kw = taps_p[p]
+                lanes = np.where(half == hh)[0]
+                for nt in range(NT_):
+                    n = nt * 32 + col[lanes]                           # [32]
+                    for cc in range(CC_):
+                        c = cc * 8 + np.arange(8)                      # [8]
+                        flat = (((n[:, None] * cin + c[None, :]) * KT + kt) * KH + kh) * KW + kw
+                        idx[cc, s, nt, lanes, :] = flat
+        return idx.astype(np.int32)
+
+    if feat_out:
+        epi = EPI_POOL_FEAT
+        npos = To * Ho * Wo
+        feat_stride = cout * npos
+
+        def out_index(ci, a, b, c):
+            return ci * feat_stride + ((a // pool_t) * Ho + b // 2) * Wo + c // 2
+        n_stride, clip_stride, chunk_stride = npos, feat_stride, 0
+        out_shape = (cout, To, Ho, Wo)
+    else:
+        epi = EPI_POOL_CL
+        chunk_stride = To * Ho * Wo
+        clip_stride = (cout // 8) * chunk_stride
+
+        def out_index(ci, a, b, c):
+            return ci * clip_stride + ((a // pool_t) * Ho + b // 2) * Wo + c // 2
+        n_stride = 0
+        out_shape = (cout // 8, To, Ho, Wo, 8)
+    max_ncl = max(1, (8 * 32 * MW) // (rows[0] * rows[1] * rows[2]))
+    ncl_options = sorted({1, max_ncl} | {n for n in (2, 4, 8) if n <= max_ncl})
+    return _make_plan(name, (t_in, h_in, w_in), CC, rows, (2, 2, 2), (-1, -3, -3), (1, 2, 2), taps,
+                      widx_fn, cout, NT, MW, mtw_options, epi, pool_t, True, out_index, None, n_stride,
+                      clip_stride, chunk_stride, out_shape, lds_budget, ncl_options)
+
+
+def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_budget: int = 3700,
+                     mtw_options=(7, 8)) -> ConvPlan:
+    """First layer: Conv3d(3->cout) + ReLU + MaxPool(1,2,2) over the 'kw-slot' source made by
+    vd_pix2slots: [clip][t*3+c][h][ow] where a slot holds x[t,c,h,2*ow-3 .. 2*ow+4]."""
+    cin = 3
+    T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
+    Ho, Wo = OH // 2, OW // 2
+    assert T % 2 == 0, "first-layer planner pairs frames (pool window rows are 2x2x2 groups)"
+    rows = (T, Ho * 2, Wo * 2)
+    taps = [(kt * cin + c, kh, 0) for kt in range(KT) for c in range(cin) for kh in range(KH)]
+    NT = cout // 32
+    MW = max(1, 2 // NT) if NT <= 2 else 1
+    col, half = _lane_cols()
+
+    def widx_fn(CC_, S, NT_, taps_p, ntaps):
+        idx = -np.ones((1, S, NT_, 64, 8), dtype=np.int64)
+        for s in range(S):
+            for hh in range(2):
+                p = 2 * s + hh
+                if p >= ntaps:
+                    continue
+                fc, kh, _ = taps_p[p]
+                kt, c = divmod(fc, cin)
+                lanes = np.where(half == hh)[0]
+                for nt in range(NT_):
+                    n = nt * 32 + col[lanes]
+                    kw = np.arange(7)
+                    flat = (((n[:, None] * cin + c) * KT + kt) * KH + kh) * KW + kw[None, :]
+                    idx[0, s, nt, lanes, :7] = flat
+        return idx.astype(np.int32)
+
+    chunk_stride = T * Ho * Wo
+    clip_stride = (cout // 8) * chunk_stride
+
+    def out_index(ci, a, b, c):
+        return ci * clip_stride + (a * Ho + b // 2) * Wo + c // 2
+    plan = _make_plan(name, (t_in * cin, h_in, OW), 1, rows, (2, 2, 2), (-cin, -3, 0), (cin, 2, 1), taps,
+                      widx_fn, cout, NT, MW, mtw_options, EPI_POOL_CL, 1, True, out_index, None, 0,
+                      clip_stride, chunk_stride, (cout // 8, T, Ho, Wo, 8), lds_budget, (1,))
+    plan.out_t_stride = Ho * Wo
+    return plan
+
+
+def dgrad_classes(h: int, w: int):
+    """Parity classes of a stride-2 7x7 convolution's input positions."""
+    return [(ph, pw) for ph in range(min(2, h)) for pw in range(min(2, w))]
+
+
+def plan_dgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, ph: int, pw: int,
+               pixel_out: bool, lds_budget: int = 3700, mtw_options=(7, 8)) -> ConvPlan:
+    """Input gradient of Conv3d(cin->cout, k(3,7,7), s(1,2,2), p(1,3,3)) for the input positions
+    (t, 2b+ph, 2c+pw).  Source: dense dy on the conv grid, channels-last chunks of cout.
+    dx[t,h,w,ci] = sum_{kt,kh,kw,n} dy[t+1-kt, (h+3-kh)/2, (w+3-kw)/2, n] * W[n,ci,kt,kh,kw]."""
+    assert cout % 8 == 0
+    CC = cout // 8
+    T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
+    khs = [kh for kh in range(KH) if (ph + 3 - kh) % 2 == 0]
+    kws = [kw for kw in range(KW) if (pw + 3 - kw) % 2 == 0]
+    # e = (p+3-k)/2 in [-1,2]; tap offset d = e+1 with row origin -1
+    tap_k = [(kt, kh, kw) for kt in range(KT) for kh in khs for kw in kws]
+    taps = [(2 - kt, (ph + 3 - kh) // 2 + 1, (pw + 3 - kw) // 2 + 1) for kt, kh, kw in tap_k]
+    RB = (h_in - ph + 1) // 2; RC = (w_in - pw + 1) // 2
+    rows = (t_in, RB, RC)
+    n_pad = -(-cin // 32) * 32
+    NT = n_pad // 32
+    MW = max(1, 4 // NT)
+    col, half = _lane_cols()
+
+    def widx_fn(CC_, S, NT_, taps_p, ntaps):
+        idx = -np.ones((CC_, S, NT_, 64, 8), dtype=np.int64)
+        for s in range(S):
+            for hh in range(2):
+                p = 2 * s + hh
+                if p >= ntaps:
+                    continue
+                kt, kh, kw = tap_k[p]
+                lanes = np.where(half == hh)[0]
+                for nt in range(NT_):
+                    ci = nt * 32 + col[lanes]
+                    ok = ci < cin
+                    for cc in range(CC_):
+                        n = cc * 8 + np.arange(8)
+                        flat = (((n[None, :] * cin + ci[:, None]) * KT + kt) * KH + kh) * KW + kw
+                        flat = np.where(ok[:, None], flat, -1)
+                        idx[cc, s, nt, lanes, :] = flat
+        return idx.astype(np.int32)
+
+    if pixel_out:   # (T, C, H, W) fp32 pixels of one clip, C = cin
+        clip_stride = t_in * cin * h_in * w_in
+        n_stride = h_in * w_in
+
+        def out_index(ci, a, b, c):
+            return ci * clip_stride + (a * cin * h_in + (2 * b + ph)) * w_in + 2 * c + pw
+        out_shape = (t_in, cin, h_in, w_in)
+    else:           # fp32 [t][h][w][cin]
+        clip_stride = t_in * h_in * w_in * cin
+        n_stride = 1
+
+        def out_index(ci, a, b, c):
+            return ci * clip_stride + ((a * h_in + (2 * b + ph)) * w_in + 2 * c + pw) * cin
+        out_shape = (t_in, h_in, w_in, cin)
+    max_ncl = max(1, (8 * 32 * MW) // (rows[0] * rows[1] * rows[2]))
+    ncl_options = sorted({1, max_ncl} | {n for n in (2, 4, 8) if n <= max_ncl})
+    plan = _make_plan(name, (T, OH, OW), CC, rows, (1, 1, 1), (-1, -1, -1), (1, 1, 1), taps, widx_fn,
+                      cin, NT, MW, mtw_options, EPI_ROWS, 0, False, out_index, None, n_stride,
+                      clip_stride, 0, out_shape, lds_budget, ncl_options)
+    plan.meta.update({"ph": ph, "pw": pw})
+    return plan
+
+
+# ----------------------------------------------------------------------------------------
+# whole network
+# ----------------------------------------------------------------------------------------
+@dataclass
+class NetGeometry:
+    frames: int
+    height: int
+    width: int
+    channel: int = 3
+    widths: Tuple[int, ...] = (64, 128, 128)
+    pools_t: Tuple[int, ...] = (1, 2, 2)
+
+    def layer_dims(self):
+        """[(cin, cout, t_in, h_in, w_in, T, OH, OW, To, Ho, Wo, pool_t)] per layer."""
+        out = []
+        cin, t, h, w = self.channel, self.frames, self.height, self.width
+        for cout, pt in zip(self.widths, self.pools_t):
+            T = conv_out_dim(t, KT, 1, 1); OH = conv_out_dim(h, KH, 2, 3); OW = conv_out_dim(w, KW, 2, 3)
+            To, Ho, Wo = T // pt, OH // 2, OW // 2
+            out.append((cin, cout, t, h, w, T, OH, OW, To, Ho, Wo, pt))
+            cin, t, h, w = cout, To, Ho, Wo
+        return out
+
+    @property
+    def num_feat(self) -> int:
+        d = self.layer_dims()[-1]
+        return d[1] * d[8] * d[9] * d[10]
+
+
+_PLAN_CACHE: Dict[Tuple, Dict[str, object]] = {}
+
+
+def plan_network(geo: NetGeometry, lds_budget: int = 3700) -> Dict[str, object]:
+    """All tile programs of one ConvNet3D geometry: forward L0..L2 and the input-gradient
+    passes (one per parity class per layer)."""
+    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget)
+    if key in _PLAN_CACHE:
+        return _PLAN_CACHE[key]
+    dims = geo.layer_dims()
+    assert geo.channel == 3 and geo.pools_t[0] == 1, "first layer planner assumes RGB clips and (1,2,2) pooling"
+    fwd = [plan_forward_pix("fwd0", dims[0][1], dims[0][2], dims[0][3], dims[0][4], lds_budget)]
+    for li in (1, 2):
+        cin, cout, t, h, w = dims[li][:5]
+        fwd.append(plan_forward_cl("fwd%d" % li, cin, cout, t, h, w, dims[li][11], feat_out=(li == 2),
+                                   lds_budget=lds_budget))
+    bwd = []
+    for li in range(3):
+        cin, cout, t, h, w = dims[li][:5]
+        bwd.append([plan_dgrad("bwd%d_%d%d" % (li, ph, pw), cin, cout, t, h, w, ph, pw, pixel_out=(li == 0),
+                               lds_budget=lds_budget) for ph, pw in dgrad_classes(h, w)])
+    out = {"geo": geo, "dims": dims, "fwd": fwd, "bwd": bwd}
+    _PLAN_CACHE[key] = out
+    return out
