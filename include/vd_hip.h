@@ -1,0 +1,115 @@
+/* C ABI of libvd_hip.so -- the MI355X (gfx950) kernels behind the DM / gradient-matching
+ * hot path of yuz1wan/video_distillation.
+ *
+ * The reference has no FFI: its boundary is Python (`get_network().embed`, `match_loss`,
+ * `Conv3DNet`, the SGD step on the synthetic pixels).  Each entry point below names the
+ * reference call it stands in for (paths under the reference repository).  All entry
+ * points take raw device pointers, sizes and a hipStream_t (passed as void*), enqueue work
+ * on that stream without synchronising, never allocate or free, and return 0 on success or
+ * a non-zero hipError_t / negative argument-error code.
+ */
+#ifndef VD_HIP_H
+#define VD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VD_ABI_VERSION 1
+
+/* operand precision of the MFMA contraction (accumulation is always fp32) */
+#define VD_PREC_BF16   0   /* bf16 operands, one MFMA per product                       */
+#define VD_PREC_F16    1   /* fp16 operands, one MFMA per product                       */
+#define VD_PREC_BF16X3 2   /* hi/lo split bf16 operands, three MFMAs (fp32-class error) */
+#define VD_PREC_F16X3  3   /* hi/lo split fp16 operands, three MFMAs                    */
+
+#define VD_EPI_POOL_CL   0
+#define VD_EPI_POOL_FEAT 1
+#define VD_EPI_ROWS      2
+
+/* One tile program (see video_distillation_amd/plan.py).  All pointers are device
+ * pointers; strides are in the units given. */
+typedef struct VdConvParams {
+    const void* src;              /* 16-byte slots, plane 0                                   */
+    int64_t src_plane_stride;     /* slots between the hi and lo planes (x3 precisions)        */
+    const void* wpk;              /* packed weights [CC][S][NT][64][8] 16-bit, plane 0        */
+    int64_t w_plane_stride;       /* 16-bit elements between hi and lo planes                 */
+    const float* bias;            /* [n_out] or NULL                                          */
+    void* dst;                    /* POOL_CL: 16-bit slots plane 0; otherwise fp32            */
+    int64_t dst_plane_stride;     /* POOL_CL: slots between hi and lo planes                  */
+    uint8_t* argmax;              /* pooled epilogues: arg-max byte per output, or NULL        */
+    const int32_t* type_desc;     /* [ntypes][16]                                             */
+    const int32_t* tables;        /* a_off / out / tap tables                                 */
+    const int32_t* boxes;         /* [nbox][6]                                                */
+    int32_t nbox, nclips, ncl;
+    int32_t CC, F, H, W, S, NT, MW, MTW;
+    int32_t epi, pool_t, relu, n_out, n_stride;
+    int64_t out_clip_stride;
+    int32_t out_chunk_stride, out_t_stride;
+    int32_t lds_plane_bytes;
+    int32_t prec;
+} VdConvParams;
+
+int vd_abi_version(void);
+
+/* Conv3d(k(3,7,7), s(1,2,2), p(1,3,3)) [+bias +ReLU +MaxPool3d] forward, or its input
+ * gradient, as one tile program.  Replaces nn.Conv3d / nn.ReLU / nn.MaxPool3d inside
+ * ConvNet3D.features (networks.py:757, 768-770, 799) and their autograd backward w.r.t. the
+ * input (distill_baseline.py:354, parameters frozen :336-337). */
+int vd_conv_mfma(const VdConvParams* params, void* stream);
+
+/* fp32 weights -> MFMA-fragment-ordered 16-bit operands (hi plane, and lo plane for the x3
+ * precisions) through the planner's gather table.  n = number of packed elements. */
+int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, void* out_hi, void* out_lo,
+                    int prec, void* stream);
+
+/* (B,T,3,H,W) fp32 clips (the reference's input layout, networks.py:748) -> first-layer
+ * source slots [B][T*3][H][OW][8]: slot = x[b,t,c,h,2*ow-3 .. 2*ow+4], zero padded. */
+int vd_pix2slots(const float* x, int64_t nclips, int T, int H, int W, void* out_hi, void* out_lo,
+                 int prec, void* stream);
+
+/* Backward of ReLU + MaxPool3d: scatter the pooled gradient to the arg-max position of the
+ * dense conv grid and emit it as channels-last slots (source of the input-gradient pass).
+ * g_layout 0: g/argmax indexed [clip][n][pos] (embed features); 1: g [clip][pos][n],
+ * argmax as channels-last bytes [clip][n/8][pos][8]. */
+int vd_unpool_relu_bwd(const float* g, const uint8_t* argmax, int64_t nclips, int C, int To, int Ho, int Wo,
+                       int pool_t, int T, int OH, int OW, int g_layout, void* out_hi, void* out_lo,
+                       int prec, void* stream);
+
+/* DM class term, forward and gradient (distill_baseline.py:351):
+ * loss[c] = sum_d (mean_b real[c,b,d] - mean_b syn[c,b,d])^2 ; g_syn = d loss / d syn. */
+int vd_dm_loss(const float* feat_real, const float* feat_syn, int nclass, int nreal, int nsyn, int dim,
+               float* loss_per_class, float* g_syn, void* stream);
+
+/* torch.optim.SGD(momentum, dampening 0) step on the synthetic pixels
+ * (distill_baseline.py:107, 355): buf = first ? g : mu*buf + g ; x -= lr*buf. */
+int vd_sgd_momentum(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, int first,
+                    void* stream);
+
+/* Conv3DNet 'concat' forward (utils.py:1186-1197) with the gathers of distill_s2d_ms.py:409-410
+ * folded in: out[i] = conv3d(cat(static[sidx[i]] repeated over T, dynamic[didx[i]]), w, b).
+ * static [ns][3][H][W], dynamic [nd][T][1][H][W], out [n][T][3][H][W]. sidx/didx may be NULL. */
+int vd_hallucinator_fwd(const float* stat, const float* dyn, const int64_t* sidx, const int64_t* didx,
+                        const float* w, const float* b, int n, int T, int H, int W, float* out, void* stream);
+
+/* Its backward: g_dyn (scatter-added into [nd][T][1][H][W], pre-zeroed by the caller),
+ * g_stat (optional, [ns][3][H][W], pre-zeroed), g_w [3*4*27], g_b [3] (pre-zeroed). */
+int vd_hallucinator_bwd(const float* g_out, const float* stat, const float* dyn, const int64_t* sidx,
+                        const int64_t* didx, const float* w, int n, int T, int H, int W,
+                        float* g_dyn, float* g_stat, float* g_w, float* g_b, void* stream);
+
+/* match_loss / distance_wb row reductions (utils.py:634-687).  For one gradient tensor viewed
+ * as [rows][len]: acc[0] += sum_rows (1 - <r,s>/(|r||s|+1e-6)), acc[1] += sum (s-r)^2,
+ * acc[2] += <r,s>, acc[3] += |r|^2, acc[4] += |s|^2.  acc is 5 fp32 (fp32 atomics). */
+int vd_match_rows_fwd(const float* gr, const float* gs, int64_t rows, int len, float* acc, void* stream);
+/* d/d gs of the three metrics; mode 0 'ours' (row cosine), 1 'mse', 2 'cos' (needs the global
+ * sums in acc as produced by the forward).  gout = upstream scalar gradient. */
+int vd_match_rows_bwd(const float* gr, const float* gs, int64_t rows, int len, int mode, const float* acc,
+                      const float* gout, float* g_gs, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VD_HIP_H */

@@ -1,0 +1,519 @@
+// HBM-bound helper kernels of the DM / gradient-matching hot path (gfx950).
+// Each is a coalesced streaming kernel: 16-byte accesses per lane where the layout allows,
+// wave64 shuffle reductions, one atomic (or one plain store) per workgroup.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vd_hip.h"
+
+typedef __bf16 bf16_t;
+
+__device__ __forceinline__ void split16p(int prec, float v, uint16_t& hi, uint16_t& lo) {
+    if (prec == VD_PREC_BF16 || prec == VD_PREC_BF16X3) {
+        __bf16 h = (__bf16)v;
+        __bf16 l = (__bf16)(v - (float)h);
+        hi = __builtin_bit_cast(uint16_t, h);
+        lo = __builtin_bit_cast(uint16_t, l);
+    } else {
+        _Float16 h = (_Float16)v;
+        _Float16 l = (_Float16)(v - (float)h);
+        hi = __builtin_bit_cast(uint16_t, h);
+        lo = __builtin_bit_cast(uint16_t, l);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum; result valid in thread 0.  blockDim.x <= 1024, multiple of 64.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) t += red[i];
+    }
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, const int32_t* __restrict__ widx, int64_t n,
+                                    uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int prec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t k = widx[i];
+    const float v = (k >= 0) ? w[k] : 0.f;
+    uint16_t h, l;
+    split16p(prec, v, h, l);
+    hi[i] = h;
+    if (lo != nullptr) lo[i] = l;
+}
+
+extern "C" int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, void* out_hi, void* out_lo,
+                               int prec, void* stream) {
+    if (n <= 0) return 0;
+    const int bs = 256;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0,
+                       reinterpret_cast<hipStream_t>(stream), w, widx, n, (uint16_t*)out_hi, (uint16_t*)out_lo, prec);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// one thread per output slot: (clip, f = t*3+c, h, ow) -> x[clip, t, c, h, 2ow-3 .. 2ow+4]
+__global__ void pix2slots_kernel(const float* __restrict__ x, int64_t nslots, int H, int W, int OW,
+                                 uint4* __restrict__ hi, uint4* __restrict__ lo, int prec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslots) return;
+    const int ow = (int)(i % OW);
+    const int64_t row = i / OW;                 // (clip, f, h) flattened == row of x
+    const float* xr = x + row * W;
+    const int w0 = 2 * ow - 3;
+    uint16_t h16[8], l16[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ww = w0 + j;
+        const float v = (ww >= 0 && ww < W) ? xr[ww] : 0.f;
+        split16p(prec, v, h16[j], l16[j]);
+    }
+    uint4 vh, vl;
+    vh.x = h16[0] | ((uint32_t)h16[1] << 16); vh.y = h16[2] | ((uint32_t)h16[3] << 16);
+    vh.z = h16[4] | ((uint32_t)h16[5] << 16); vh.w = h16[6] | ((uint32_t)h16[7] << 16);
+    hi[i] = vh;
+    if (lo != nullptr) {
+        vl.x = l16[0] | ((uint32_t)l16[1] << 16); vl.y = l16[2] | ((uint32_t)l16[3] << 16);
+        vl.z = l16[4] | ((uint32_t)l16[5] << 16); vl.w = l16[6] | ((uint32_t)l16[7] << 16);
+        lo[i] = vl;
+    }
+}
+
+extern "C" int vd_pix2slots(const float* x, int64_t nclips, int T, int H, int W, void* out_hi, void* out_lo,
+                            int prec, void* stream) {
+    const int OW = (W + 6 - 7) / 2 + 1;
+    const int64_t nslots = nclips * T * 3 * H * OW;
+    if (nslots <= 0) return 0;
+    const int bs = 256;
+    hipLaunchKernelGGL(pix2slots_kernel, dim3((unsigned)((nslots + bs - 1) / bs)), dim3(bs), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, nslots, H, W, OW, (uint4*)out_hi, (uint4*)out_lo, prec);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward of ReLU+MaxPool: one thread per output slot (clip, cc, t, oh, ow) of the dense conv grid.
+__global__ void unpool_relu_bwd_kernel(const float* __restrict__ g, const uint8_t* __restrict__ amax, int64_t nslots,
+                                       int C, int To, int Ho, int Wo, int pool_t, int T, int OH, int OW,
+                                       int g_layout, uint4* __restrict__ hi, uint4* __restrict__ lo, int prec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslots) return;
+    int64_t r = i;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH); r /= OH;
+    const int t = (int)(r % T); r /= T;
+    const int CC = C >> 3;
+    const int cc = (int)(r % CC);
+    const int64_t clip = r / CC;
+    const int pt = t / pool_t, pr = oh >> 1, pc = ow >> 1;
+    uint16_t h16[8], l16[8];
+    const bool inside = (pt < To) && (pr < Ho) && (pc < Wo);
+    const int j = (pool_t == 2 ? ((t & 1) << 2) : 0) | ((oh & 1) << 1) | (ow & 1);
+    const int64_t npos = (int64_t)To * Ho * Wo;
+    const int64_t pos = ((int64_t)pt * Ho + pr) * Wo + pc;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = 0.f;
+        if (inside) {
+            const int n = cc * 8 + e;
+            int64_t gi, ai;
+            if (g_layout == 0) { gi = (clip * C + n) * npos + pos; ai = gi; }
+            else { gi = (clip * npos + pos) * C + n; ai = ((clip * CC + cc) * npos + pos) * 8 + e; }
+            if (amax[ai] == (uint8_t)j) v = g[gi];
+        }
+        split16p(prec, v, h16[e], l16[e]);
+    }
+    uint4 vh, vl;
+    vh.x = h16[0] | ((uint32_t)h16[1] << 16); vh.y = h16[2] | ((uint32_t)h16[3] << 16);
+    vh.z = h16[4] | ((uint32_t)h16[5] << 16); vh.w = h16[6] | ((uint32_t)h16[7] << 16);
+    hi[i] = vh;
+    if (lo != nullptr) {
+        vl.x = l16[0] | ((uint32_t)l16[1] << 16); vl.y = l16[2] | ((uint32_t)l16[3] << 16);
+        vl.z = l16[4] | ((uint32_t)l16[5] << 16); vl.w = l16[6] | ((uint32_t)l16[7] << 16);
+        lo[i] = vl;
+    }
+}
+
+extern "C" int vd_unpool_relu_bwd(const float* g, const uint8_t* argmax, int64_t nclips, int C, int To, int Ho, int Wo,
+                                  int pool_t, int T, int OH, int OW, int g_layout, void* out_hi, void* out_lo,
+                                  int prec, void* stream) {
+    if (C % 8 != 0 || (pool_t != 1 && pool_t != 2)) return -2;
+    const int64_t nslots = nclips * (C / 8) * T * OH * OW;
+    if (nslots <= 0) return 0;
+    const int bs = 256;
+    hipLaunchKernelGGL(unpool_relu_bwd_kernel, dim3((unsigned)((nslots + bs - 1) / bs)), dim3(bs), 0,
+                       reinterpret_cast<hipStream_t>(stream), g, argmax, nslots, C, To, Ho, Wo, pool_t, T, OH, OW,
+                       g_layout, (uint4*)out_hi, (uint4*)out_lo, prec);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// DM class term: one workgroup per class; threads stride the feature dimension (coalesced
+// rows of the [b][d] matrices), wave-shuffle + LDS reduction of the squared distance.
+__global__ __launch_bounds__(256) void dm_loss_kernel(const float* __restrict__ fr, const float* __restrict__ fs,
+                                                       int nreal, int nsyn, int dim, float* __restrict__ loss,
+                                                       float* __restrict__ gsyn) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    const float* r = fr + (int64_t)c * nreal * dim;
+    const float* s = fs + (int64_t)c * nsyn * dim;
+    const float inv_r = 1.f / (float)nreal, inv_s = 1.f / (float)nsyn;
+    float part = 0.f;
+    for (int d = threadIdx.x; d < dim; d += blockDim.x) {
+        float mr = 0.f, ms = 0.f;
+        for (int b = 0; b < nreal; ++b) mr += r[(int64_t)b * dim + d];
+        for (int b = 0; b < nsyn; ++b) ms += s[(int64_t)b * dim + d];
+        const float diff = mr * inv_r - ms * inv_s;
+        part += diff * diff;
+        if (gsyn != nullptr) {
+            const float gv = -2.f * diff * inv_s;
+            for (int b = 0; b < nsyn; ++b) gsyn[((int64_t)c * nsyn + b) * dim + d] = gv;
+        }
+    }
+    const float tot = block_sum(part, red);
+    if (threadIdx.x == 0) loss[c] = tot;
+}
+
+extern "C" int vd_dm_loss(const float* feat_real, const float* feat_syn, int nclass, int nreal, int nsyn, int dim,
+                          float* loss_per_class, float* g_syn, void* stream) {
+    if (nclass <= 0) return 0;
+    if (nreal <= 0 || nsyn <= 0 || dim <= 0) return -2;
+    hipLaunchKernelGGL(dm_loss_kernel, dim3(nclass), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), feat_real,
+                       feat_syn, nreal, nsyn, dim, loss_per_class, g_syn);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void sgd_momentum_kernel(float* __restrict__ x, float* __restrict__ buf, const float* __restrict__ g,
+                                    int64_t n, float lr, float mu, int first) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gv = g[i];
+        const float b = first ? gv : buf[i] * mu + gv;
+        buf[i] = b;
+        x[i] -= lr * b;
+    }
+}
+
+extern "C" int vd_sgd_momentum(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, int first,
+                               void* stream) {
+    if (n <= 0) return 0;
+    const int bs = 256;
+    int64_t blocks = (n + bs - 1) / bs;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)blocks), dim3(bs), 0, reinterpret_cast<hipStream_t>(stream),
+                       x, buf, g, n, lr, momentum, first);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Hallucinator (Conv3d 4->3, 3x3x3, pad 1 over [static x3 broadcast in T | dynamic x1]).
+// One thread per (clip, t, h, w); the 3 output channels share every input read.  Weights
+// (324 floats) and bias live in LDS.
+__global__ __launch_bounds__(256) void hal_fwd_kernel(const float* __restrict__ stat, const float* __restrict__ dyn,
+                                                       const int64_t* __restrict__ sidx, const int64_t* __restrict__ didx,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       int n, int T, int H, int W, float* __restrict__ out) {
+    __shared__ float ws[3 * 4 * 27 + 3];
+    for (int k = threadIdx.x; k < 324; k += blockDim.x) ws[k] = w[k];
+    if (threadIdx.x < 3) ws[324 + threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    const int64_t total = (int64_t)n * T * H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t r = i;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H); r /= H;
+    const int t = (int)(r % T);
+    const int64_t clip = r / T;
+    const int64_t si = sidx ? sidx[clip] : clip, di = didx ? didx[clip] : clip;
+    const float* sp = stat + si * 3 * H * W;
+    const float* dp = dyn + di * (int64_t)T * H * W;
+    float a0 = ws[324], a1 = ws[325], a2 = ws[326];
+    for (int kt = 0; kt < 3; ++kt) {
+        const int tt = t + kt - 1;
+        if (tt < 0 || tt >= T) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int yy = y + kh - 1;
+            if (yy < 0 || yy >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int xx = x + kw - 1;
+                if (xx < 0 || xx >= W) continue;
+                const int tap = (kt * 3 + kh) * 3 + kw;
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    const float v = (ci < 3) ? sp[((int64_t)ci * H + yy) * W + xx] : dp[((int64_t)tt * H + yy) * W + xx];
+                    a0 += ws[(0 * 4 + ci) * 27 + tap] * v;
+                    a1 += ws[(1 * 4 + ci) * 27 + tap] * v;
+                    a2 += ws[(2 * 4 + ci) * 27 + tap] * v;
+                }
+            }
+        }
+    }
+    float* op = out + ((clip * T + t) * 3) * (int64_t)H * W + (int64_t)y * W + x;
+    op[0] = a0;
+    op[(int64_t)H * W] = a1;
+    op[2 * (int64_t)H * W] = a2;
+}
+
+extern "C" int vd_hallucinator_fwd(const float* stat, const float* dyn, const int64_t* sidx, const int64_t* didx,
+                                   const float* w, const float* b, int n, int T, int H, int W, float* out, void* stream) {
+    const int64_t total = (int64_t)n * T * H * W;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(hal_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), stat, dyn, sidx, didx, w, b, n, T, H, W, out);
+    return (int)hipGetLastError();
+}
+
+// Backward, data part: one thread per (clip, t, h, w) input position gathers from g_out.
+// g_dyn[didx[clip], t, 0, h, w] += sum_{co,taps} g_out[clip, t-kt+1, co, h-kh+1, w-kw+1] * W[co,3,kt,kh,kw]
+// g_stat[sidx[clip], ci, h, w]  += sum_t (same with W[co,ci,...])   (atomic: several clips/frames share a static)
+__global__ __launch_bounds__(256) void hal_bwd_data_kernel(const float* __restrict__ go, const int64_t* __restrict__ sidx,
+                                                            const int64_t* __restrict__ didx, const float* __restrict__ w,
+                                                            int n, int T, int H, int W, float* __restrict__ g_dyn,
+                                                            float* __restrict__ g_stat) {
+    __shared__ float ws[324];
+    for (int k = threadIdx.x; k < 324; k += blockDim.x) ws[k] = w[k];
+    __syncthreads();
+    const int64_t total = (int64_t)n * T * H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t r = i;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H); r /= H;
+    const int t = (int)(r % T);
+    const int64_t clip = r / T;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < 3; ++kt) {
+        const int tt = t - kt + 1;
+        if (tt < 0 || tt >= T) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int yy = y - kh + 1;
+            if (yy < 0 || yy >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int xx = x - kw + 1;
+                if (xx < 0 || xx >= W) continue;
+                const int tap = (kt * 3 + kh) * 3 + kw;
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    const float gv = go[(((clip * T + tt) * 3 + co) * (int64_t)H + yy) * W + xx];
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci) acc[ci] += gv * ws[(co * 4 + ci) * 27 + tap];
+                }
+            }
+        }
+    }
+    const int64_t di = didx ? didx[clip] : clip;
+    atomicAdd(&g_dyn[((di * T + t) * (int64_t)H + y) * W + x], acc[3]);
+    if (g_stat != nullptr) {
+        const int64_t si = sidx ? sidx[clip] : clip;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) atomicAdd(&g_stat[((si * 3 + ci) * (int64_t)H + y) * W + x], acc[ci]);
+    }
+}
+
+// Backward, parameter part: grid = (chunks, 3 output channels); each block reduces 108 weight
+// gradients + 1 bias gradient of its output channel over its slice of positions.
+__global__ __launch_bounds__(256) void hal_bwd_param_kernel(const float* __restrict__ go, const float* __restrict__ stat,
+                                                             const float* __restrict__ dyn, const int64_t* __restrict__ sidx,
+                                                             const int64_t* __restrict__ didx, int n, int T, int H, int W,
+                                                             float* __restrict__ g_w, float* __restrict__ g_b) {
+    __shared__ float red[16];
+    const int co = blockIdx.y;
+    const int64_t total = (int64_t)n * T * H * W;
+    float acc[109];
+#pragma unroll
+    for (int k = 0; k < 109; ++k) acc[k] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H); r /= H;
+        const int t = (int)(r % T);
+        const int64_t clip = r / T;
+        const float gv = go[(((clip * T + t) * 3 + co) * (int64_t)H + y) * W + x];
+        const int64_t si = sidx ? sidx[clip] : clip, di = didx ? didx[clip] : clip;
+        const float* sp = stat + si * 3 * H * W;
+        const float* dp = dyn + di * (int64_t)T * H * W;
+        acc[108] += gv;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            const int tt = t + kt - 1;
+            const bool tok = (tt >= 0 && tt < T);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int yy = y + kh - 1;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int xx = x + kw - 1;
+                    const bool ok = tok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                    const int tap = (kt * 3 + kh) * 3 + kw;
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci) {
+                        float v = 0.f;
+                        if (ok) v = (ci < 3) ? sp[((int64_t)ci * H + yy) * W + xx] : dp[((int64_t)tt * H + yy) * W + xx];
+                        acc[ci * 27 + tap] += gv * v;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 109; ++k) {
+        const float tot = block_sum(acc[k], red);
+        if (threadIdx.x == 0) {
+            if (k < 108) atomicAdd(&g_w[co * 108 + k], tot);
+            else atomicAdd(&g_b[co], tot);
+        }
+    }
+}
+
+extern "C" int vd_hallucinator_bwd(const float* g_out, const float* stat, const float* dyn, const int64_t* sidx,
+                                   const int64_t* didx, const float* w, int n, int T, int H, int W, float* g_dyn,
+                                   float* g_stat, float* g_w, float* g_b, void* stream) {
+    const int64_t total = (int64_t)n * T * H * W;
+    if (total <= 0) return 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(hal_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g_out, sidx, didx,
+                       w, n, T, H, W, g_dyn, g_stat);
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    if (g_w != nullptr && g_b != nullptr) {
+        int64_t chunks = (total + 256 * 16 - 1) / (256 * 16);
+        if (chunks > 512) chunks = 512;
+        hipLaunchKernelGGL(hal_bwd_param_kernel, dim3((unsigned)chunks, 3), dim3(256), 0, st, g_out, stat, dyn, sidx,
+                           didx, n, T, H, W, g_w, g_b);
+        e = (int)hipGetLastError();
+    }
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------
+// match_loss row reductions.  Short rows (len <= 64, e.g. the 7-wide rows of the 5-D Conv3d
+// gradients): one lane-group per row, 64/grp rows per wave.  Long rows: a wave per row.
+__global__ __launch_bounds__(256) void match_rows_fwd_kernel(const float* __restrict__ gr, const float* __restrict__ gs,
+                                                              int64_t rows, int len, float* __restrict__ acc) {
+    __shared__ float red[16];
+    float s_cos = 0.f, s_mse = 0.f, s_dot = 0.f, s_rr = 0.f, s_ss = 0.f;
+    if (len <= 8) {
+        // one thread per row
+        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+            float d = 0.f, a = 0.f, b = 0.f, m = 0.f;
+            for (int k = 0; k < len; ++k) {
+                const float x = gr[r * len + k], y = gs[r * len + k];
+                d += x * y; a += x * x; b += y * y; m += (y - x) * (y - x);
+            }
+            s_cos += 1.f - d / (sqrtf(a) * sqrtf(b) + 0.000001f);
+            s_mse += m; s_dot += d; s_rr += a; s_ss += b;
+        }
+    } else {
+        // one wave per row
+        const int lane = threadIdx.x & 63;
+        const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+        for (int64_t r = wid; r < rows; r += nw) {
+            float d = 0.f, a = 0.f, b = 0.f, m = 0.f;
+            for (int k = lane; k < len; k += 64) {
+                const float x = gr[r * len + k], y = gs[r * len + k];
+                d += x * y; a += x * x; b += y * y; m += (y - x) * (y - x);
+            }
+            d = wave_sum(d); a = wave_sum(a); b = wave_sum(b); m = wave_sum(m);
+            if (lane == 0) {
+                s_cos += 1.f - d / (sqrtf(a) * sqrtf(b) + 0.000001f);
+                s_mse += m; s_dot += d; s_rr += a; s_ss += b;
+            }
+        }
+    }
+    float v[5] = {s_cos, s_mse, s_dot, s_rr, s_ss};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float tot = block_sum(v[k], red);
+        if (threadIdx.x == 0) atomicAdd(&acc[k], tot);
+    }
+}
+
+extern "C" int vd_match_rows_fwd(const float* gr, const float* gs, int64_t rows, int len, float* acc, void* stream) {
+    if (rows <= 0 || len <= 0) return 0;
+    int64_t blocks = (len <= 8) ? (rows + 255) / 256 : (rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(match_rows_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       gr, gs, rows, len, acc);
+    return (int)hipGetLastError();
+}
+
+// d/d gs.  mode 0: per-row cosine distance; with n=|r|, m=|s|, den=n*m+eps:
+//   d(1 - <r,s>/den)/ds = -r/den + <r,s> * n * s / (m * den^2)
+// mode 1: 2*(s-r).  mode 2: the same cosine formula with the GLOBAL sums acc[2..4].
+__global__ __launch_bounds__(256) void match_rows_bwd_kernel(const float* __restrict__ gr, const float* __restrict__ gs,
+                                                              int64_t rows, int len, int mode, const float* __restrict__ acc,
+                                                              const float* __restrict__ gout, float* __restrict__ g) {
+    const float go = gout[0];
+    if (mode == 1) {
+        const int64_t n = rows * len;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            g[i] = go * 2.f * (gs[i] - gr[i]);
+        return;
+    }
+    if (mode == 2) {
+        const float d = acc[2], nr = sqrtf(acc[3]), ns = sqrtf(acc[4]);
+        const float den = nr * ns + 0.000001f;
+        const float c1 = -1.f / den, c2 = (ns > 0.f) ? d * nr / (ns * den * den) : 0.f;
+        const int64_t n = rows * len;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            g[i] = go * (c1 * gr[i] + c2 * gs[i]);
+        return;
+    }
+    if (len <= 8) {
+        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+            float d = 0.f, a = 0.f, b = 0.f;
+            for (int k = 0; k < len; ++k) {
+                const float x = gr[r * len + k], y = gs[r * len + k];
+                d += x * y; a += x * x; b += y * y;
+            }
+            const float nr = sqrtf(a), ns = sqrtf(b), den = nr * ns + 0.000001f;
+            const float c1 = -1.f / den, c2 = (ns > 0.f) ? d * nr / (ns * den * den) : 0.f;
+            for (int k = 0; k < len; ++k) g[r * len + k] = go * (c1 * gr[r * len + k] + c2 * gs[r * len + k]);
+        }
+    } else {
+        const int lane = threadIdx.x & 63;
+        const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+        for (int64_t r = wid; r < rows; r += nw) {
+            float d = 0.f, a = 0.f, b = 0.f;
+            for (int k = lane; k < len; k += 64) {
+                const float x = gr[r * len + k], y = gs[r * len + k];
+                d += x * y; a += x * x; b += y * y;
+            }
+            d = wave_sum(d); a = wave_sum(a); b = wave_sum(b);
+            const float nr = sqrtf(a), ns = sqrtf(b), den = nr * ns + 0.000001f;
+            const float c1 = -1.f / den, c2 = (ns > 0.f) ? d * nr / (ns * den * den) : 0.f;
+            for (int k = lane; k < len; k += 64) g[r * len + k] = go * (c1 * gr[r * len + k] + c2 * gs[r * len + k]);
+        }
+    }
+}
+
+extern "C" int vd_match_rows_bwd(const float* gr, const float* gs, int64_t rows, int len, int mode, const float* acc,
+                                 const float* gout, float* g_gs, void* stream) {
+    if (rows <= 0 || len <= 0) return 0;
+    if (mode < 0 || mode > 2) return -2;
+    int64_t blocks = (mode != 0 || len <= 8) ? (rows * (mode != 0 ? len : 1) + 255) / 256 : (rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(match_rows_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       gr, gs, rows, len, mode, acc, gout, g_gs);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vd_abi_version(void) { return VD_ABI_VERSION; }

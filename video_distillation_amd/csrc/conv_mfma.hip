@@ -1,0 +1,270 @@
+// Table-driven implicit-GEMM Conv3d for gfx950 (MI355X): v_mfma_f32_32x32x16_{bf16,f16}.
+//
+// One workgroup = one box of output rows (host planner: video_distillation_amd/plan.py).
+//   * the input patch of the box is staged ONCE per 8-channel chunk into LDS (16-byte slots,
+//     zero filled outside the source grid), so every source byte is fetched once per box and
+//     re-used by all taps (147 for the 3x7x7 kernels) out of LDS;
+//   * waves split the output channels (NT tiles of 32) and, if N < 128, the rows (MW);
+//     each wave keeps MTW 32x32 fp32 accumulator tiles in registers;
+//   * per K-step (2 taps x 8 channels) a wave issues ONE 1-KiB coalesced load of its
+//     pre-packed B fragment and MTW ds_read_b128 A fragments (bank-conflict-free row maps
+//     are chosen by the planner), then MTW (x1) or 3*MTW (x3 split precision) MFMAs;
+//   * epilogue: bias + ReLU + 2x2x2 / 1x2x2 max-pool with arg-max entirely in-lane (the
+//     planner puts the 8 rows of a pool window into one lane's registers), or plain rows.
+//
+// Replaces nn.Conv3d / nn.ReLU / nn.MaxPool3d of ConvNet3D.features (reference
+// networks.py:757, 768-770, 799) and the input-gradient half of their autograd backward.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vd_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, f32x16 c) {
+    if constexpr (PREC == VD_PREC_BF16 || PREC == VD_PREC_BF16X3) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+}
+
+template <int PREC>
+__device__ __forceinline__ void split16(float v, uint16_t& hi, uint16_t& lo) {
+    if constexpr (PREC == VD_PREC_BF16 || PREC == VD_PREC_BF16X3) {
+        __bf16 h = (__bf16)v;
+        __bf16 l = (__bf16)(v - (float)h);
+        hi = __builtin_bit_cast(uint16_t, h);
+        lo = __builtin_bit_cast(uint16_t, l);
+    } else {
+        _Float16 h = (_Float16)v;
+        _Float16 l = (_Float16)(v - (float)h);
+        hi = __builtin_bit_cast(uint16_t, h);
+        lo = __builtin_bit_cast(uint16_t, l);
+    }
+}
+
+__device__ __forceinline__ uint32_t fastdiv(uint32_t x, uint32_t magic) { return __umulhi(x, magic); }
+
+template <int PREC, int MTW>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const VdConvParams p) {
+    constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % p.NT;
+    const int wm = wave / p.NT;
+    const int half = lane >> 5;
+
+    const int bid = blockIdx.x;
+    const int grp = bid / p.nbox;
+    const int bi = bid - grp * p.nbox;
+    const int32_t* box = p.boxes + bi * 6;
+    const int ty = box[0], f0 = box[1], h0 = box[2], w0 = box[3], out_rel = box[4];
+    const int clip0 = grp * p.ncl;
+    const int32_t* desc = p.type_desc + ty * 16;
+    const int pf = desc[0], ph = desc[1], pw = desc[2];
+    const int pitch_h = desc[3], pitch_f = desc[4], pitch_c = desc[5];
+    const int32_t* a_tab = p.tables + desc[7];
+    const int32_t* o_tab = p.tables + desc[8];
+    const int32_t* t_tab = p.tables + desc[9];
+    (void)pf;
+
+    const int plane_bytes = p.lds_plane_bytes;
+    int* lds_tap = reinterpret_cast<int*>(smem + (X3 ? 2 : 1) * plane_bytes);
+    for (int k = tid; k < 2 * p.S; k += nthreads) lds_tap[k] = t_tab[k];
+
+    int a_off[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
+
+    f32x16 acc[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+
+    // exact x/d for x < 65536 (LDS slot indices): d*floor(2^32/d)+... see DESIGN.md
+    const uint32_t m_pc = 0xFFFFFFFFu / (uint32_t)pitch_c + 1u;
+    const uint32_t m_pf = 0xFFFFFFFFu / (uint32_t)pitch_f + 1u;
+    const uint32_t m_ph = 0xFFFFFFFFu / (uint32_t)pitch_h + 1u;
+    const int nslots = p.ncl * pitch_c;
+    const int64_t clip_slots = (int64_t)p.CC * p.F * p.H * p.W;
+    const int64_t chunk_slots = (int64_t)p.F * p.H * p.W;
+
+    const uint4* src = reinterpret_cast<const uint4*>(p.src);
+    const uint4* wbase = reinterpret_cast<const uint4*>(p.wpk);
+    const int64_t w_lo = p.w_plane_stride >> 3;  // uint4 units
+    const int wstep = p.NT * 64;                 // uint4 per K-step
+
+    for (int cc = 0; cc < p.CC; ++cc) {
+        __syncthreads();  // previous chunk's fragment reads are done
+        // ---- stage the patch of this channel chunk ------------------------------------
+        for (int idx = tid; idx < nslots; idx += nthreads) {
+            uint32_t ci = fastdiv(idx, m_pc);
+            uint32_t r1 = idx - ci * pitch_c;
+            uint32_t f = fastdiv(r1, m_pf);
+            uint32_t r2 = r1 - f * pitch_f;
+            uint32_t h = fastdiv(r2, m_ph);
+            uint32_t w = r2 - h * pitch_h;
+            const int sf = f0 + (int)f, sh = h0 + (int)h, sw = w0 + (int)w;
+            const int clip = clip0 + (int)ci;
+            const bool ok = (h < (uint32_t)ph) && (w < (uint32_t)pw) && (clip < p.nclips) &&
+                            ((unsigned)sf < (unsigned)p.F) && ((unsigned)sh < (unsigned)p.H) &&
+                            ((unsigned)sw < (unsigned)p.W);
+            uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const int64_t g = clip * clip_slots + cc * chunk_slots + ((int64_t)sf * p.H + sh) * p.W + sw;
+                vh = src[g];
+                if constexpr (X3) vl = src[g + p.src_plane_stride];
+            }
+            *reinterpret_cast<uint4*>(smem + idx * 16) = vh;
+            if constexpr (X3) *reinterpret_cast<uint4*>(smem + plane_bytes + idx * 16) = vl;
+        }
+        __syncthreads();
+
+        // ---- K loop over tap pairs ------------------------------------------------------
+        const uint4* wp = wbase + ((int64_t)cc * p.S * p.NT + wn) * 64 + lane;
+        uint4 bh_n = wp[0], bl_n = make_uint4(0, 0, 0, 0);
+        if constexpr (X3) bl_n = wp[w_lo];
+        for (int s = 0; s < p.S; ++s) {
+            const uint4 bh = bh_n, bl = bl_n;
+            const int sn = (s + 1 < p.S) ? s + 1 : s;
+            bh_n = wp[(int64_t)sn * wstep];
+            if constexpr (X3) bl_n = wp[(int64_t)sn * wstep + w_lo];
+            const int tapo = lds_tap[2 * s + half];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                const uint4 ah = *reinterpret_cast<const uint4*>(smem + a_off[i] + tapo);
+                if constexpr (X3) {
+                    const uint4 al = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tapo);
+                    acc[i] = mfma16<PREC>(al, bh, acc[i]);
+                    acc[i] = mfma16<PREC>(ah, bl, acc[i]);
+                }
+                acc[i] = mfma16<PREC>(ah, bh, acc[i]);
+            }
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------
+    const int n = wn * 32 + (lane & 31);
+    const bool n_ok = n < p.n_out;
+    const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+    const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
+    const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
+
+    if (p.epi == VD_EPI_ROWS) {
+        float* dst = reinterpret_cast<float*>(p.dst);
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int gi = wm * MTW + i;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int row = (k & 3) + 8 * (k >> 2) + 4 * half;
+                const int o = o_tab[gi * 32 + row];
+                const int64_t idx = out_base + o;
+                float v = acc[i][k] + bias;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (o >= 0 && n_ok && idx < out_total) dst[idx + (int64_t)n * p.n_stride] = v;
+            }
+        }
+        return;
+    }
+
+    // pooled epilogues: registers 8*qh .. 8*qh+7 of this lane are one 2x2x2 row group
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int gi = wm * MTW + i;
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) {
+            const int o = o_tab[gi * 4 + half + 2 * qh];
+            if (o < 0) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = acc[i][8 * qh + j] + bias;
+                if (p.relu) v[j] = fmaxf(v[j], 0.f);
+            }
+            const int nsets = (p.pool_t == 2) ? 1 : 2;
+            for (int st = 0; st < nsets; ++st) {
+                float mx;
+                int am;
+                if (p.pool_t == 2) {
+                    mx = v[0]; am = 0;
+#pragma unroll
+                    for (int j = 1; j < 8; ++j) if (v[j] > mx) { mx = v[j]; am = j; }
+                } else {
+                    const int b4 = st * 4;
+                    mx = v[b4]; am = 0;
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) if (v[b4 + j] > mx) { mx = v[b4 + j]; am = j; }
+                }
+                const uint8_t ab = (uint8_t)(am | (mx > 0.f ? 0 : 0x80));
+                const int64_t base = out_base + o + (int64_t)st * p.out_t_stride;
+                if (p.epi == VD_EPI_POOL_FEAT) {
+                    if (base < out_total && n_ok) {
+                        const int64_t idx = base + (int64_t)n * p.n_stride;
+                        reinterpret_cast<float*>(p.dst)[idx] = mx;
+                        if (p.argmax) p.argmax[idx] = ab;
+                    }
+                } else {
+                    if (base < out_total && n_ok) {
+                        const int64_t idx = (base + (int64_t)(n >> 3) * p.out_chunk_stride) * 8 + (n & 7);
+                        uint16_t hi, lo;
+                        split16<PREC>(mx, hi, lo);
+                        uint16_t* d16 = reinterpret_cast<uint16_t*>(p.dst);
+                        d16[idx] = hi;
+                        if constexpr (X3) d16[idx + p.dst_plane_stride * 8] = lo;
+                        if (p.argmax) p.argmax[idx] = ab;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int PREC, int MTW>
+static int launch(const VdConvParams& p, hipStream_t st) {
+    constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
+    const int groups = (p.nclips + p.ncl - 1) / p.ncl;
+    const int64_t grid = (int64_t)groups * p.nbox;
+    if (grid <= 0) return 0;
+    const size_t lds = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)2 * p.S * sizeof(int) + 16;
+    if (lds > 160 * 1024) return -3;
+    auto kern = conv_mfma_kernel<PREC, MTW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * p.NT * p.MW), lds, st, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
+    if (pp == nullptr) return -1;
+    const VdConvParams& p = *pp;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p.NT * p.MW < 1 || p.NT * p.MW > 4 || p.lds_plane_bytes % 16 != 0) return -2;
+    if (p.ncl * 65536 <= 0 || p.S <= 0 || p.CC <= 0) return -2;
+#define VD_DISPATCH(PR)                                                   \
+    case PR:                                                              \
+        if (p.MTW == 7) return launch<PR, 7>(p, st);                      \
+        if (p.MTW == 8) return launch<PR, 8>(p, st);                      \
+        return -2;
+    switch (p.prec) {
+        VD_DISPATCH(VD_PREC_BF16)
+        VD_DISPATCH(VD_PREC_F16)
+        VD_DISPATCH(VD_PREC_BF16X3)
+        VD_DISPATCH(VD_PREC_F16X3)
+        default: return -2;
+    }
+#undef VD_DISPATCH
+}

@@ -1,0 +1,186 @@
+"""Device-side execution of ConvNet3D.embed (forward and input gradient) on MI355X.
+
+`EmbedEngine` owns, for one clip geometry / precision / device: the uploaded tile programs
+(plan.py), the packed MFMA operands of the current network weights, and the activation
+workspaces, and drives the C ABI (hip.py).  It mirrors what the reference's
+``ConvNet3D.embed`` (networks.py:747-751) plus autograd's backward to the input do, for
+parameters that are frozen (distill_baseline.py:336-337).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import hip
+from . import plan as P
+
+
+class _DevPlan:
+    """A ConvPlan with its tables resident on the device and a reusable parameter block."""
+
+    def __init__(self, plan: P.ConvPlan, device, prec: int):
+        self.plan = plan
+        desc, tables = plan.flat_tables()
+        self.type_desc = torch.from_numpy(desc.copy()).to(device)
+        self.tables = torch.from_numpy(tables.copy()).to(device)
+        self.boxes = torch.from_numpy(plan.boxes.copy()).to(device)
+        self.widx = torch.from_numpy(plan.widx.reshape(-1).copy()).to(device)
+        self.n_w = int(self.widx.numel())
+        planes = 2 if hip.is_x3(prec) else 1
+        self.wpk = torch.empty((planes, self.n_w), dtype=torch.int16, device=device)
+        self.prec = prec
+        p = hip.VdConvParams()
+        p.type_desc = self.type_desc.data_ptr(); p.tables = self.tables.data_ptr(); p.boxes = self.boxes.data_ptr()
+        p.nbox = plan.nbox; p.ncl = plan.ncl
+        p.CC, p.F, p.H, p.W, p.S = plan.CC, plan.F, plan.H, plan.W, plan.S
+        p.NT, p.MW, p.MTW = plan.NT, plan.MW, plan.MTW
+        p.epi, p.pool_t, p.relu = plan.epi, plan.pool_t, int(plan.relu)
+        p.n_out, p.n_stride = plan.n_out, plan.n_stride
+        p.out_clip_stride = plan.out_clip_stride
+        p.out_chunk_stride, p.out_t_stride = plan.out_chunk_stride, plan.out_t_stride
+        p.lds_plane_bytes = (plan.lds_slots + 1) * 16
+        p.prec = prec
+        p.wpk = self.wpk.data_ptr(); p.w_plane_stride = self.n_w
+        self.params = p
+
+    def pack(self, w: torch.Tensor) -> None:
+        assert w.dtype == torch.float32 and w.is_contiguous()
+        lo = self.wpk[1] if self.wpk.shape[0] == 2 else None
+        hip.check(hip.lib().vd_pack_weights(hip.ptr(w), hip.ptr(self.widx), ctypes.c_int64(self.n_w),
+                                            hip.ptr(self.wpk[0]), hip.ptr(lo), self.prec, hip.stream_ptr(w.device)),
+                  "vd_pack_weights")
+
+    def run(self, src: torch.Tensor, src_plane_stride: int, bias: Optional[torch.Tensor], dst_ptr: int,
+            dst_plane_stride: int, argmax: Optional[torch.Tensor], nclips: int) -> None:
+        p = self.params
+        p.src = src.data_ptr(); p.src_plane_stride = src_plane_stride
+        p.bias = 0 if bias is None else bias.data_ptr()
+        p.dst = dst_ptr; p.dst_plane_stride = dst_plane_stride
+        p.argmax = 0 if argmax is None else argmax.data_ptr()
+        p.nclips = nclips
+        hip.check(hip.lib().vd_conv_mfma(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv_mfma(%s)" % self.plan.name)
+
+
+class EmbedEngine:
+    def __init__(self, geo: P.NetGeometry, prec: str = "bf16x3", device="cuda:0", chunk: int = 256):
+        if not torch.cuda.is_available():
+            raise RuntimeError("EmbedEngine needs a HIP device (no CPU fallback)")
+        hip.lib()
+        self.geo = geo
+        self.prec_name = prec
+        self.prec = hip.PREC[prec]
+        self.planes = 2 if hip.is_x3(self.prec) else 1
+        self.device = torch.device(device)
+        self.chunk = int(chunk)
+        net = P.plan_network(geo)
+        self.dims = net["dims"]
+        self.fwd = [_DevPlan(pl, self.device, self.prec) for pl in net["fwd"]]
+        self.bwd = [[_DevPlan(pl, self.device, self.prec) for pl in layer] for layer in net["bwd"]]
+        self.num_feat = geo.num_feat
+        self._weights: Optional[List[torch.Tensor]] = None
+        self._bwd_packed = False
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._saved = None
+
+    # ------------------------------------------------------------------------------------
+    def _buf(self, name: str, shape, dtype) -> torch.Tensor:
+        t = self._ws.get(name)
+        n = int(np.prod(shape))
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(n, dtype=dtype, device=self.device)
+            self._ws[name] = t
+        return t[:n].view(*shape)
+
+    def set_weights(self, params: Sequence[torch.Tensor]) -> None:
+        """params = [w0, b0, w1, b1, w2, b2] fp32 on the device (ConvNet3D.features order)."""
+        ws = [p.detach().to(self.device, torch.float32).contiguous() for p in params[:6]]
+        self._weights = ws
+        for li in range(3):
+            self.fwd[li].pack(ws[2 * li])
+        self._bwd_packed = False
+
+    def _pack_bwd(self) -> None:
+        if not self._bwd_packed:
+            for li in range(3):
+                for dp in self.bwd[li]:
+                    dp.pack(self._weights[2 * li])
+            self._bwd_packed = True
+
+    # ------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, keep: bool = False) -> torch.Tensor:
+        """x (B,T,3,H,W) fp32 on the device -> features (B, num_feat) fp32.  With ``keep`` the
+        pooling arg-max of every layer is retained for ``backward``."""
+        assert self._weights is not None, "set_weights() first"
+        g = self.geo
+        assert x.dim() == 5 and tuple(x.shape[1:]) == (g.frames, g.channel, g.height, g.width), x.shape
+        x = x.detach().to(torch.float32).contiguous()
+        B = x.shape[0]
+        feats = torch.empty((B, self.num_feat), dtype=torch.float32, device=self.device)
+        saved = []
+        L = hip.lib()
+        st = hip.stream_ptr(self.device)
+        d0, d1, d2 = self.dims
+        OW0 = d0[7]
+        for c0 in range(0, B, self.chunk):
+            nb = min(self.chunk, B - c0)
+            tag = "k%d_" % c0 if keep else ""
+            n_slots0 = nb * g.frames * 3 * g.height * OW0
+            slots0 = self._buf("slots0", (self.planes, n_slots0, 8), torch.int16)
+            lo = slots0[1] if self.planes == 2 else None
+            hip.check(L.vd_pix2slots(hip.ptr(x[c0:]), ctypes.c_int64(nb), g.frames, g.height, g.width,
+                                     hip.ptr(slots0[0]), hip.ptr(lo), self.prec, st), "vd_pix2slots")
+            n1 = nb * int(np.prod(self.fwd[0].plan.out_shape[:-1]))
+            act1 = self._buf("act1", (self.planes, n1, 8), torch.int16)
+            n2 = nb * int(np.prod(self.fwd[1].plan.out_shape[:-1]))
+            act2 = self._buf("act2", (self.planes, n2, 8), torch.int16)
+            am0 = am1 = am2 = None
+            if keep:
+                am0 = self._buf(tag + "am0", (n1 * 8,), torch.uint8)
+                am1 = self._buf(tag + "am1", (n2 * 8,), torch.uint8)
+                am2 = self._buf(tag + "am2", (nb * self.num_feat,), torch.uint8)
+            w = self._weights
+            self.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, am0, nb)
+            self.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, am1, nb)
+            self.fwd[2].run(act2, n2, w[5], feats[c0:].data_ptr(), 0, am2, nb)
+            if keep:
+                saved.append((c0, nb, am0, am1, am2))
+        self._saved = saved if keep else None
+        return feats
+
+    def backward(self, g_feat: torch.Tensor) -> torch.Tensor:
+        """d loss / d x for the clips of the last ``forward(..., keep=True)``."""
+        assert self._saved is not None, "forward(keep=True) first"
+        self._pack_bwd()
+        g = self.geo
+        g_feat = g_feat.detach().to(torch.float32).contiguous()
+        B = g_feat.shape[0]
+        dx = torch.empty((B, g.frames, g.channel, g.height, g.width), dtype=torch.float32, device=self.device)
+        L = hip.lib()
+        st = hip.stream_ptr(self.device)
+        d0, d1, d2 = self.dims
+        for c0, nb, am0, am1, am2 in self._saved:
+            grad = g_feat[c0:c0 + nb]
+            layout = 0
+            for li, am in ((2, am2), (1, am1), (0, am0)):
+                cin, cout, t, h, w, T, OH, OW, To, Ho, Wo, pt = self.dims[li]
+                nslots = nb * (cout // 8) * T * OH * OW
+                dy = self._buf("dy%d" % li, (self.planes, nslots, 8), torch.int16)
+                lo = dy[1] if self.planes == 2 else None
+                hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am), ctypes.c_int64(nb), cout, To, Ho, Wo, pt,
+                                               T, OH, OW, layout, hip.ptr(dy[0]), hip.ptr(lo), self.prec, st),
+                          "vd_unpool_relu_bwd")
+                if li == 0:
+                    out = dx[c0:c0 + nb]
+                else:
+                    out = self._buf("dx%d" % li, (nb, t, h, w, cin), torch.float32)
+                for dp in self.bwd[li]:
+                    dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb)
+                grad = out
+                layout = 1
+        return dx
+
+    def release(self) -> None:
+        self._saved = None

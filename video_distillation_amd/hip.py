@@ -1,0 +1,93 @@
+"""ctypes binding of libvd_hip.so (C ABI declared in include/vd_hip.h).
+
+PyTorch is used only as the owner of device memory and streams: every call passes
+``tensor.data_ptr()`` and the current HIP stream handle.  There is deliberately NO fallback:
+if the shared library is missing or a kernel launch fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvd_hip.so")
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("conv_mfma.hip", "aux_kernels.hip")]
+
+PREC = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
+EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_pack_weights", "vd_pix2slots", "vd_unpool_relu_bwd", "vd_dm_loss",
+           "vd_sgd_momentum", "vd_hallucinator_fwd", "vd_hallucinator_bwd", "vd_match_rows_fwd", "vd_match_rows_bwd")
+
+
+class VdConvParams(ctypes.Structure):
+    _fields_ = [
+        ("src", ctypes.c_void_p), ("src_plane_stride", ctypes.c_int64),
+        ("wpk", ctypes.c_void_p), ("w_plane_stride", ctypes.c_int64),
+        ("bias", ctypes.c_void_p),
+        ("dst", ctypes.c_void_p), ("dst_plane_stride", ctypes.c_int64),
+        ("argmax", ctypes.c_void_p),
+        ("type_desc", ctypes.c_void_p), ("tables", ctypes.c_void_p), ("boxes", ctypes.c_void_p),
+        ("nbox", ctypes.c_int32), ("nclips", ctypes.c_int32), ("ncl", ctypes.c_int32),
+        ("CC", ctypes.c_int32), ("F", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("S", ctypes.c_int32), ("NT", ctypes.c_int32), ("MW", ctypes.c_int32), ("MTW", ctypes.c_int32),
+        ("epi", ctypes.c_int32), ("pool_t", ctypes.c_int32), ("relu", ctypes.c_int32),
+        ("n_out", ctypes.c_int32), ("n_stride", ctypes.c_int32),
+        ("out_clip_stride", ctypes.c_int64),
+        ("out_chunk_stride", ctypes.c_int32), ("out_t_stride", ctypes.c_int32),
+        ("lds_plane_bytes", ctypes.c_int32), ("prec", ctypes.c_int32),
+    ]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into libvd_hip.so (in-tree)."""
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(s) for s in SOURCES + [os.path.join(_HERE, "..", "include", "vd_hip.h")])
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libvd_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU or eager fallback for the HIP path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise RuntimeError("libvd_hip.so does not export %s" % name)
+            getattr(L, name).restype = ctypes.c_int
+        if L.vd_abi_version() != 1:
+            raise RuntimeError("libvd_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def stream_ptr(device=None) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError("%s failed with code %d" % (what, code))
+
+
+def ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def is_x3(prec: int) -> bool:
+    return prec >= 2
