@@ -43,6 +43,8 @@ typedef struct VdConvParams {
     const int32_t* type_desc;     /* [ntypes][16]                                             */
     const int32_t* tables;        /* a_off / out / tap tables                                 */
     const int32_t* boxes;         /* [nbox][6]                                                */
+    const int32_t* gather;        /* [nbox][gather_stride]: LDS slot -> source slot | clip<<24 */
+    int64_t gather_stride;
     int32_t nbox, nclips, ncl;
     int32_t CC, F, H, W, S, NT, MW, MTW;
     int32_t epi, pool_t, relu, n_out, n_stride;

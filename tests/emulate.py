@@ -24,10 +24,12 @@ def run_plan(plan, src, w_flat, bias, nclips, out):
     lane = np.arange(64)
     col, half = lane & 31, lane >> 5
     arg = {}
+    gather = plan.gather_table()
+    src_flat = src.reshape(src.shape[0], src.shape[1], -1, 8)
     ngroups = -(-nclips // plan.ncl)
     for grp in range(ngroups):
         clip0 = grp * plan.ncl
-        for box in plan.boxes:
+        for bi, box in enumerate(plan.boxes):
             ty, f0, h0, w0, out_rel, _ = [int(v) for v in box]
             pf, ph, pw, pitch_h, pitch_f, pitch_c, mt, a_ofs, o_ofs, t_ofs = [int(v) for v in descs[ty][:10]]
             a_off = tables[a_ofs:a_ofs + mt * 32] // 16
@@ -37,20 +39,16 @@ def run_plan(plan, src, w_flat, bias, nclips, out):
             acc = np.zeros((mt * 32, plan.NT * 32))
             for cc in range(plan.CC):
                 patch = np.zeros((plan.ncl * pitch_c + 64, 8))
-                for ci in range(plan.ncl):
-                    b = clip0 + ci
+                gt = gather[bi]
+                for idx in range(plan.ncl * pitch_c):
+                    e = int(gt[idx])
+                    assert e != -2
+                    if e < 0:
+                        continue
+                    b = clip0 + (e >> 24)
                     if b >= nclips:
                         continue
-                    for f in range(pf):
-                        for h in range(ph):
-                            sf, sh = f0 + f, h0 + h
-                            if not (0 <= sf < plan.F and 0 <= sh < plan.H):
-                                continue
-                            wlo, whi = max(0, -w0), min(pw, plan.W - w0)
-                            if whi <= wlo:
-                                continue
-                            base = ci * pitch_c + f * pitch_f + h * pitch_h
-                            patch[base + wlo:base + whi] = src[b, cc, sf, sh, w0 + wlo:w0 + whi]
+                    patch[idx] = src_flat[b, cc, e & 0xFFFFFF]
                 # A[row, s, half, j]
                 for s in range(plan.S):
                     for hh in range(2):

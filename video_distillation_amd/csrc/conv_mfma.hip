@@ -47,11 +47,12 @@ __device__ __forceinline__ void split16(float v, uint16_t& hi, uint16_t& lo) {
     }
 }
 
-__device__ __forceinline__ uint32_t fastdiv(uint32_t x, uint32_t magic) { return __umulhi(x, magic); }
-
 template <int PREC, int MTW>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const VdConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
+    constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
+    constexpr int H1 = MTW - H0;
+    constexpr int LU = X3 ? 4 : 8;      // patch loads in flight per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -66,15 +67,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const VdConvParams p) {
     const int grp = bid / p.nbox;
     const int bi = bid - grp * p.nbox;
     const int32_t* box = p.boxes + bi * 6;
-    const int ty = box[0], f0 = box[1], h0 = box[2], w0 = box[3], out_rel = box[4];
+    const int ty = box[0], out_rel = box[4];
     const int clip0 = grp * p.ncl;
     const int32_t* desc = p.type_desc + ty * 16;
-    const int pf = desc[0], ph = desc[1], pw = desc[2];
-    const int pitch_h = desc[3], pitch_f = desc[4], pitch_c = desc[5];
     const int32_t* a_tab = p.tables + desc[7];
     const int32_t* o_tab = p.tables + desc[8];
     const int32_t* t_tab = p.tables + desc[9];
-    (void)pf;
+    const int32_t* gtab = p.gather + (int64_t)bi * p.gather_stride;
 
     const int plane_bytes = p.lds_plane_bytes;
     int* lds_tap = reinterpret_cast<int*>(smem + (X3 ? 2 : 1) * plane_bytes);
@@ -90,11 +89,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const VdConvParams p) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
 
-    // exact x/d for x < 65536 (LDS slot indices): d*floor(2^32/d)+... see DESIGN.md
-    const uint32_t m_pc = 0xFFFFFFFFu / (uint32_t)pitch_c + 1u;
-    const uint32_t m_pf = 0xFFFFFFFFu / (uint32_t)pitch_f + 1u;
-    const uint32_t m_ph = 0xFFFFFFFFu / (uint32_t)pitch_h + 1u;
-    const int nslots = p.ncl * pitch_c;
+    const int gstride = (int)p.gather_stride;
     const int64_t clip_slots = (int64_t)p.CC * p.F * p.H * p.W;
     const int64_t chunk_slots = (int64_t)p.F * p.H * p.W;
 
@@ -102,53 +97,104 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const VdConvParams p) {
     const uint4* wbase = reinterpret_cast<const uint4*>(p.wpk);
     const int64_t w_lo = p.w_plane_stride >> 3;  // uint4 units
     const int wstep = p.NT * 64;                 // uint4 per K-step
+    const int S = p.S;
 
     for (int cc = 0; cc < p.CC; ++cc) {
         __syncthreads();  // previous chunk's fragment reads are done
-        // ---- stage the patch of this channel chunk ------------------------------------
-        for (int idx = tid; idx < nslots; idx += nthreads) {
-            uint32_t ci = fastdiv(idx, m_pc);
-            uint32_t r1 = idx - ci * pitch_c;
-            uint32_t f = fastdiv(r1, m_pf);
-            uint32_t r2 = r1 - f * pitch_f;
-            uint32_t h = fastdiv(r2, m_ph);
-            uint32_t w = r2 - h * pitch_h;
-            const int sf = f0 + (int)f, sh = h0 + (int)h, sw = w0 + (int)w;
-            const int clip = clip0 + (int)ci;
-            const bool ok = (h < (uint32_t)ph) && (w < (uint32_t)pw) && (clip < p.nclips) &&
-                            ((unsigned)sf < (unsigned)p.F) && ((unsigned)sh < (unsigned)p.H) &&
-                            ((unsigned)sw < (unsigned)p.W);
-            uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const int64_t g = clip * clip_slots + cc * chunk_slots + ((int64_t)sf * p.H + sh) * p.W + sw;
-                vh = src[g];
-                if constexpr (X3) vl = src[g + p.src_plane_stride];
+        // ---- stage the patch of this channel chunk: LU independent 16-byte loads in flight ----
+        const uint4* csrc = src + (int64_t)clip0 * clip_slots + (int64_t)cc * chunk_slots;
+        // (the gather rows are padded with -2 = "no LDS slot" to a multiple of 2048 entries)
+        for (int base = tid; base < gstride; base += nthreads * LU) {
+            int e[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) e[u] = gtab[base + u * nthreads];
+            uint4 vh[LU], vl[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int ci = e[u] >> 24;
+                const bool ok = (e[u] >= 0) && (clip0 + ci < p.nclips);
+                // 32-bit offset inside this clip group's chunk (ncl * CC*F*H*W slots < 2^28)
+                const uint32_t off = ok ? ((uint32_t)ci * (uint32_t)clip_slots + (uint32_t)(e[u] & 0xFFFFFF)) : 0u;
+                vh[u] = csrc[off];
+                if constexpr (X3) vl[u] = csrc[off + p.src_plane_stride];
+                if (!ok) { vh[u] = make_uint4(0, 0, 0, 0); if constexpr (X3) vl[u] = make_uint4(0, 0, 0, 0); }
             }
-            *reinterpret_cast<uint4*>(smem + idx * 16) = vh;
-            if constexpr (X3) *reinterpret_cast<uint4*>(smem + plane_bytes + idx * 16) = vl;
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int idx = base + u * nthreads;
+                if (e[u] != -2) {
+                    *reinterpret_cast<uint4*>(smem + idx * 16) = vh[u];
+                    if constexpr (X3) *reinterpret_cast<uint4*>(smem + plane_bytes + idx * 16) = vl[u];
+                }
+            }
         }
         __syncthreads();
 
-        // ---- K loop over tap pairs ------------------------------------------------------
-        const uint4* wp = wbase + ((int64_t)cc * p.S * p.NT + wn) * 64 + lane;
-        uint4 bh_n = wp[0], bl_n = make_uint4(0, 0, 0, 0);
-        if constexpr (X3) bl_n = wp[w_lo];
-        for (int s = 0; s < p.S; ++s) {
-            const uint4 bh = bh_n, bl = bl_n;
-            const int sn = (s + 1 < p.S) ? s + 1 : s;
-            bh_n = wp[(int64_t)sn * wstep];
-            if constexpr (X3) bl_n = wp[(int64_t)sn * wstep + w_lo];
-            const int tapo = lds_tap[2 * s + half];
+        // ---- K loop over tap pairs: B fragments two steps ahead, A fragments half a step ahead ----
+        const uint4* wp = wbase + ((int64_t)cc * S * p.NT + wn) * 64 + lane;
+        uint4 b0h, b1h, b2h, b0l, b1l, b2l;
+        b0l = b1l = b2l = make_uint4(0, 0, 0, 0);
+        auto load_b = [&](int s, uint4& bh, uint4& bl) {
+            const int sc = (s < S) ? s : S - 1;
+            bh = wp[(int64_t)sc * wstep];
+            if constexpr (X3) bl = wp[(int64_t)sc * wstep + w_lo];
+        };
+        load_b(0, b0h, b0l);
+        load_b(1, b1h, b1l);
+        int tap_cur = lds_tap[half];
+        uint4 A0h[H0], A0l[H0], A1h[H1], A1l[H1];
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                const uint4 ah = *reinterpret_cast<const uint4*>(smem + a_off[i] + tapo);
-                if constexpr (X3) {
-                    const uint4 al = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tapo);
-                    acc[i] = mfma16<PREC>(al, bh, acc[i]);
-                    acc[i] = mfma16<PREC>(ah, bl, acc[i]);
-                }
-                acc[i] = mfma16<PREC>(ah, bh, acc[i]);
+        for (int i = 0; i < H0; ++i) {
+            A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_cur);
+            if constexpr (X3) A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_cur);
+        }
+        auto step = [&](int s, const uint4& bh, const uint4& bl) {
+            const int sn = (s + 1 < S) ? s + 1 : s;
+            const int tap_next = lds_tap[2 * sn + half];
+#pragma unroll
+            for (int i = 0; i < H1; ++i) {
+                A1h[i] = *reinterpret_cast<const uint4*>(smem + a_off[H0 + i] + tap_cur);
+                if constexpr (X3) A1l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[H0 + i] + tap_cur);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < H0; ++i) {
+                if constexpr (X3) {
+                    acc[i] = mfma16<PREC>(A0l[i], bh, acc[i]);
+                    acc[i] = mfma16<PREC>(A0h[i], bl, acc[i]);
+                }
+                acc[i] = mfma16<PREC>(A0h[i], bh, acc[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < H0; ++i) {
+                A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
+                if constexpr (X3) A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_next);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < H1; ++i) {
+                if constexpr (X3) {
+                    acc[H0 + i] = mfma16<PREC>(A1l[i], bh, acc[H0 + i]);
+                    acc[H0 + i] = mfma16<PREC>(A1h[i], bl, acc[H0 + i]);
+                }
+                acc[H0 + i] = mfma16<PREC>(A1h[i], bh, acc[H0 + i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            tap_cur = tap_next;
+        };
+        for (int s = 0; s < S; s += 3) {
+            load_b(s + 2, b2h, b2l);
+            __builtin_amdgcn_sched_barrier(0);
+            step(s, b0h, b0l);
+            if (s + 1 >= S) break;
+            load_b(s + 3, b0h, b0l);
+            __builtin_amdgcn_sched_barrier(0);
+            step(s + 1, b1h, b1l);
+            if (s + 2 >= S) break;
+            load_b(s + 4, b1h, b1l);
+            __builtin_amdgcn_sched_barrier(0);
+            step(s + 2, b2h, b2l);
         }
     }
 
@@ -256,6 +302,7 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     if (p.ncl * 65536 <= 0 || p.S <= 0 || p.CC <= 0) return -2;
 #define VD_DISPATCH(PR)                                                   \
     case PR:                                                              \
+        if (p.MTW == 4) return launch<PR, 4>(p, st);                      \
         if (p.MTW == 7) return launch<PR, 7>(p, st);                      \
         if (p.MTW == 8) return launch<PR, 8>(p, st);                      \
         return -2;

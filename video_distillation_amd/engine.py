@@ -28,12 +28,15 @@ class _DevPlan:
         self.tables = torch.from_numpy(tables.copy()).to(device)
         self.boxes = torch.from_numpy(plan.boxes.copy()).to(device)
         self.widx = torch.from_numpy(plan.widx.reshape(-1).copy()).to(device)
+        gt = plan.gather_table()
+        self.gather = torch.from_numpy(gt.copy()).to(device)
         self.n_w = int(self.widx.numel())
         planes = 2 if hip.is_x3(prec) else 1
         self.wpk = torch.empty((planes, self.n_w), dtype=torch.int16, device=device)
         self.prec = prec
         p = hip.VdConvParams()
         p.type_desc = self.type_desc.data_ptr(); p.tables = self.tables.data_ptr(); p.boxes = self.boxes.data_ptr()
+        p.gather = self.gather.data_ptr(); p.gather_stride = int(gt.shape[1])
         p.nbox = plan.nbox; p.ncl = plan.ncl
         p.CC, p.F, p.H, p.W, p.S = plan.CC, plan.F, plan.H, plan.W, plan.S
         p.NT, p.MW, p.MTW = plan.NT, plan.MW, plan.MTW

@@ -102,6 +102,27 @@ class ConvPlan:
     def grid(self, nclips: int) -> int:
         return ((nclips + self.ncl - 1) // self.ncl) * self.nbox
 
+    def gather_table(self) -> np.ndarray:
+        """int32 [nbox, stride]: for every LDS slot of a box's patch the source slot it is
+        filled from, relative to the (clip, channel-chunk) base, with the box-local clip index
+        in bits 24..30; -1 = zero fill (conv padding, pitch padding, outside the grid)."""
+        stride = -(-self.lds_slots // 2048) * 2048         # whole passes of 256 threads x 8 loads
+        out = np.full((self.nbox, stride), -2, dtype=np.int64)  # -2: beyond the patch, nothing to write
+        assert self.F * self.H * self.W < (1 << 24) and self.ncl < 128
+        for bi, box in enumerate(self.boxes):
+            t = self.types[int(box[0])]
+            f0, h0, w0 = int(box[1]), int(box[2]), int(box[3])
+            idx = np.arange(self.ncl * t.pitch_c)
+            ci, r1 = np.divmod(idx, t.pitch_c)
+            f, r2 = np.divmod(r1, t.pitch_f)
+            h, w = np.divmod(r2, t.pitch_h)
+            sf, sh, sw = f0 + f, h0 + h, w0 + w
+            ok = (f < t.pf) & (h < t.ph) & (w < t.pw) & (sf >= 0) & (sf < self.F) & (sh >= 0) & (sh < self.H) \
+                & (sw >= 0) & (sw < self.W)
+            rel = (sf * self.H + sh) * self.W + sw
+            out[bi, :idx.size] = np.where(ok, rel | (ci << 24), -1)
+        return out.astype(np.int32)
+
     def flat_tables(self):
         """Serialise box types into (type_desc int32 [ntypes,16], tables int32[...])."""
         descs, chunks, pos = [], [], 0
@@ -392,7 +413,7 @@ def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: 
 
 
 def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_budget: int = 3700,
-                     mtw_options=(7, 8)) -> ConvPlan:
+                     mtw_options=(4,)) -> ConvPlan:
     """First layer: Conv3d(3->cout) + ReLU + MaxPool(1,2,2) over the 'kw-slot' source made by
     vd_pix2slots: [clip][t*3+c][h][ow] where a slot holds x[t,c,h,2*ow-3 .. 2*ow+4]."""
     cin = 3
@@ -402,7 +423,7 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
     rows = (T, Ho * 2, Wo * 2)
     taps = [(kt * cin + c, kh, 0) for kt in range(KT) for c in range(cin) for kh in range(KH)]
     NT = cout // 32
-    MW = max(1, 2 // NT) if NT <= 2 else 1
+    MW = max(1, 4 // NT)
     col, half = _lane_cols()
 
     def widx_fn(CC_, S, NT_, taps_p, ntaps):
