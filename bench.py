@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DM distillation steps/s (miniUCF101 shape, IPC=1) on N MI355X.
+
+One step = one iteration of the reference's DM loop body (distill_baseline.py:334-355):
+fresh random ConvNet3D, C=50 class terms (64 real + ipc synthetic 112x112x16 clips each),
+backward to the synthetic pixels, SGD-momentum step.  Synthetic data (no dataset ships):
+randn clips standardised per channel, 93 clips per class, generated on the device.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 3
+
+Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+  roofline      -- the dominant kernel (conv_mfma, second conv layer, real-clip forward):
+                   algorithmic FLOP per launch / mean launch time (HIP events on the launch
+                   stream) against the 2.5 PFLOP/s dense 16-bit MFMA peak;
+  cpu_baseline  -- the CPU oracle (torch fp32 ops == what the reference runs on a CPU) timed on
+                   this host on a bounded sample (whole class terms), extrapolated to steps/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--classes", type=int, default=50)
+    ap.add_argument("--ipc", type=int, default=1)
+    ap.add_argument("--batch-real", type=int, default=64)
+    ap.add_argument("--pool-per-class", type=int, default=93)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=112)
+    ap.add_argument("--prec-real", default=os.environ.get("VD_PREC_REAL", "f16"))
+    ap.add_argument("--prec-syn", default=os.environ.get("VD_PREC_SYN", "f16x3"))
+    ap.add_argument("--chunk", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-classes", type=int, default=2, help="class terms timed for the CPU baseline")
+    return ap.parse_args()
+
+
+def conv_layer_macs(geo):
+    return [d[1] * d[5] * d[6] * d[7] * d[0] * 147 for d in geo.layer_dims()]
+
+
+def cpu_baseline(args, trainer, backend, it, geo):
+    """Time the oracle on `cpu_classes` whole class terms (fwd 64 real + ipc syn, bwd to pixels)
+    with the SAME weights and clips the GPU used for iteration `it`; also returns the loss
+    parity of those class terms."""
+    from oracle import ref_cpu as R
+    from video_distillation_amd import distill
+    torch.set_num_threads(os.cpu_count() or 1)
+    ncls = min(args.cpu_classes, len(trainer.classes))
+    classes = trainer.classes[:ncls]
+    weights = backend.new_network(seed=it)
+    params = [w.cpu() for w in weights]
+    idx = distill.sample_real_indices(it, trainer.pool.counts, trainer.pool.offsets, args.batch_real, classes)
+    real = trainer.pool.clips[torch.as_tensor(idx, device=trainer.pool.clips.device)].cpu()
+    syn = trainer.image_syn[:ncls * args.ipc].detach().clone()
+    # GPU loss of exactly these class terms
+    backend.set_weights(weights)
+    f_real = backend.embed_pool(trainer.pool.clips, torch.as_tensor(idx, device=syn.device))
+    f_syn, _ = backend.embed_keep(syn)
+    loss_gpu = float(backend.dm_loss(f_real, f_syn, ncls)[0].sum())
+    reals = [real[c * args.batch_real:(c + 1) * args.batch_real] for c in range(ncls)]
+    t0 = time.perf_counter()
+    loss_cpu, _ = R.dm_loss_and_grad(params, reals, syn.cpu(), args.ipc)
+    dt = time.perf_counter() - t0
+    per_step = dt / ncls * args.classes
+    return {"value": 1.0 / per_step, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of %d class terms (%d real + %d syn clips %dx%dx%d each, fwd + bwd to pixels), %.1f s, "
+                      "extrapolated x%d" % (ncls, args.classes, args.batch_real, args.ipc, args.size, args.size,
+                                            args.frames, dt, args.classes // ncls),
+            "loss_rel_err_vs_gpu": abs(loss_gpu - float(loss_cpu)) / abs(float(loss_cpu))}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from video_distillation_amd import distill, plan
+    geo = plan.NetGeometry(args.frames, args.size, args.size)
+    backend = distill.HipBackend(geo, device, prec_real=args.prec_real, prec_syn=args.prec_syn, chunk=args.chunk)
+    c_lo, c_hi = distill.class_range(args.classes, rank, world)
+    pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device,
+                                      seed=1234 + rank)
+    trainer = distill.DMTrainer(backend, pool, args.classes, args.ipc, args.batch_real, lr_img=1.0, momentum=0.5,
+                                rank=rank, world=world)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        trainer.step(it)
+    backend.eng_real.profile = []           # HIP-event pairs around the dominant kernel's launches
+    barrier()
+    t0 = time.perf_counter()
+    losses = []
+    for it in range(args.warmup, args.warmup + args.steps):
+        losses.append(trainer.global_loss(trainer.step(it)))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    prof = backend.eng_real.profile
+    backend.eng_real.profile = None
+
+    if rank == 0:
+        macs = conv_layer_macs(geo)
+        step_flop = 2.0 * sum(macs) * (args.classes * (args.batch_real + args.ipc) + args.classes * args.ipc)
+        ms_per_step = dt / args.steps * 1e3
+        out = {
+            "metric": "distillation steps/sec (DM, miniUCF101 IPC=%d)" % args.ipc,
+            "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16" if args.prec_real == "f16" else args.prec_real, "data": "synthetic",
+            "config": {"workload": "miniUCF101-shaped DM IPC=%d: C=%d classes x (%d real + %d syn) clips %dx%dx%d, "
+                                   "ConvNet3D depth 3, fresh net per step" % (args.ipc, args.classes, args.batch_real,
+                                                                               args.ipc, args.size, args.size, args.frames),
+                       "precision": {"real_clips": args.prec_real, "syn_clips": args.prec_syn, "accumulate": "f32"},
+                       "parallelism": "class-sharded x%d (owner-computes, no gradient exchange)" % world,
+                       "pool_per_class": args.pool_per_class},
+            "loss_last": float(losses[-1]) / args.classes,
+            "step_tflops": step_flop / (dt / args.steps) / 1e12,
+            "step_frac_of_mfma_peak": step_flop / (dt / args.steps) / 2.5e15,
+        }
+        # roofline of the dominant kernel: fwd conv layer 1 over the real clips
+        if prof:
+            times = [a.elapsed_time(b) * 1e-3 for (name, n, a, b) in prof if name == "fwd1"]
+            clips = [n for (name, n, a, b) in prof if name == "fwd1"]
+            flop_per_launch = 2.0 * macs[1] * float(np.mean(clips))
+            achieved = flop_per_launch / float(np.mean(times)) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<f16,MTW=7> (conv layer 1 fwd, real clips)",
+                               "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
+                               "traffic": None, "launches": len(times), "mean_launch_ms": float(np.mean(times)) * 1e3,
+                               "flop_per_launch": flop_per_launch}
+            for lname, li in (("fwd0", 0), ("fwd2", 2)):
+                tt = [a.elapsed_time(b) * 1e-3 for (name, n, a, b) in prof if name == lname]
+                cc = [n for (name, n, a, b) in prof if name == lname]
+                if tt:
+                    out["roofline"][lname + "_tflops"] = 2.0 * macs[li] * float(np.mean(cc)) / float(np.mean(tt)) / 1e12
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, trainer, backend, args.warmup + args.steps, geo)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

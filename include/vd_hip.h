@@ -68,9 +68,11 @@ int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, void* out_hi
                     int prec, void* stream);
 
 /* (B,T,3,H,W) fp32 clips (the reference's input layout, networks.py:748) -> first-layer
- * source slots [B][T*3][H][OW][8]: slot = x[b,t,c,h,2*ow-3 .. 2*ow+4], zero padded. */
-int vd_pix2slots(const float* x, int64_t nclips, int T, int H, int W, void* out_hi, void* out_lo,
-                 int prec, void* stream);
+ * source slots [B][T*3][H][OW][8]: slot = x[b,t,c,h,2*ow-3 .. 2*ow+4], zero padded.
+ * clip_index (optional, [nclips]) gathers batch clip b from x[clip_index[b]]: the on-device
+ * form of get_images() (distill_baseline.py:84-90) over a pool kept resident in HBM. */
+int vd_pix2slots(const float* x, const int64_t* clip_index, int64_t nclips, int T, int H, int W,
+                 void* out_hi, void* out_lo, int prec, void* stream);
 
 /* Backward of ReLU + MaxPool3d: scatter the pooled gradient to the arg-max position of the
  * dense conv grid and emit it as channels-last slots (source of the input-gradient pass).

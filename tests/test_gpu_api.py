@@ -1,0 +1,206 @@
+"""GPU parity of the reference-shaped API (networks.ConvNet3D, utils.*) and of the DM / s2d
+trainers against the oracle and the golden fixtures generated from the reference."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+
+def randn(seed, *shapes):
+    g = torch.Generator().manual_seed(int(seed))
+    return [torch.randn(*s, generator=g) for s in shapes]
+
+
+def make_net(seed, num_classes=50, im=64, frames=8):
+    from video_distillation_amd import networks
+    torch.manual_seed(seed)
+    return networks.ConvNet3D(channel=3, num_classes=num_classes, net_width=128, net_depth=3, net_act='relu',
+                              net_norm='none', net_pooling='maxpooling', im_size=(im, im), frames=frames)
+
+
+def test_module_surface_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g1_layers.npz"))
+    net = make_net(int(z["seed"]))
+    assert list(net.state_dict().keys()) == list(R.PARAM_NAMES)
+    chk = np.array([float(p.double().sum()) for p in net.parameters()] + [float(p.double().abs().sum()) for p in net.parameters()])
+    np.testing.assert_allclose(chk, z["checksum"], rtol=1e-12, atol=1e-9)   # same init stream as the reference
+    net = net.cuda().eval()
+    (x,) = randn(z["x_seed"], (2, 8, 3, 64, 64))
+    for p in net.parameters():
+        p.requires_grad = False
+    from video_distillation_amd import networks
+    networks.set_precision(real="f16x3", syn="f16x3")
+    emb = net.embed(x.cuda())
+    np.testing.assert_allclose(emb.cpu().numpy(), z["embed"], rtol=2e-4, atol=2e-5)
+    logits = net(x.cuda())       # torch-ROCm op path (training/eval graph)
+    np.testing.assert_allclose(logits.cpu().numpy(), z["logits"], rtol=2e-3, atol=2e-4)
+    with pytest.raises(RuntimeError):
+        net.embed(x)            # CPU tensor: no CPU path
+    networks.set_precision(real="f16", syn="f16x3")
+
+
+def test_g2_dm_class_term_through_autograd(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g2_dm_class.npz"))
+    net = make_net(int(z["seed"])).cuda().train()
+    for p in net.parameters():
+        p.requires_grad = False
+    real, syn = randn(z["data_seed"], (4, 8, 3, 64, 64), (1, 8, 3, 64, 64))
+    syn = syn.cuda().requires_grad_(True)
+    out_real = net.embed(real.cuda()).detach()
+    out_syn = net.embed(syn)
+    loss = torch.sum((torch.mean(out_real, dim=0) - torch.mean(out_syn, dim=0)) ** 2)
+    loss.backward()
+    rel = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+    gerr = float((syn.grad.cpu() - torch.tensor(z["grad_syn"])).norm() / torch.tensor(z["grad_syn"]).norm())
+    print("G2 loss rel err %.2e (mixed f16 real / f16x3 syn), grad rel-l2 %.2e" % (rel, gerr))
+    assert rel < 1e-3          # north_star bar
+    assert gerr < 1e-2         # arg-max flips allowed (see test_gpu_embed._grad_fp64)
+
+
+class _FixedNetBackend:
+    """HipBackend whose 'fresh network' is the reference-initialised net of the fixture."""
+
+    def __init__(self, inner, seeds):
+        self.inner, self.seeds = inner, seeds
+
+    def __getattr__(self, k):
+        return getattr(self.inner, k)
+
+    def new_network(self, seed):
+        return [p.cuda() for p in R.init_params(int(self.seeds[seed]))[:6]]
+
+
+def test_g3_two_dm_steps_trainer(golden_dir):
+    from video_distillation_amd import distill, plan
+    z = np.load(os.path.join(golden_dir, "g3_dm_steps.npz"))
+    geo = plan.NetGeometry(8, 64, 64)
+    be = _FixedNetBackend(distill.HipBackend(geo, "cuda:0", prec_real="f16x3", prec_syn="f16x3"), z["net_seeds"])
+    (syn,) = randn(z["syn_seed"], (3, 8, 3, 64, 64))
+    # pool = the exact real batches of both iterations, class-major: [it][class][4]
+    reals = [randn(z["real_seeds"][it], *[(4, 8, 3, 64, 64)] * 3) for it in range(2)]
+    clips = torch.cat([torch.cat(r) for r in reals]).cuda()
+
+    class Pool:
+        pass
+    pool = Pool(); pool.clips = clips; pool.counts = [4, 4, 4]; pool.offsets = [0, 4, 8]
+    tr = distill.DMTrainer(be, pool, 3, 1, 4, lr_img=float(z["lr"]), momentum=float(z["momentum"]), image_syn=syn.cuda())
+    import video_distillation_amd.distill as D
+    orig = D.sample_real_indices
+    losses = []
+    try:
+        for it in range(2):
+            D.sample_real_indices = lambda it_, counts, offsets, b, classes, it=it: np.concatenate(
+                [it * 12 + offsets[c] + np.arange(4) for c in classes]).astype(np.int64)
+            losses.append(float(tr.step(it)))
+    finally:
+        D.sample_real_indices = orig
+    np.testing.assert_allclose(losses, z["losses"], rtol=1e-4)
+    got = tr.image_syn.cpu()
+    np.testing.assert_allclose(got[:, ::2, :, ::4, ::4].numpy(), z["syn2"], rtol=1e-3, atol=2e-4)
+    assert abs(float(got.double().abs().sum()) / float(z["syn2_abs"]) - 1) < 1e-5
+
+
+def test_g4_hallucinator_module(golden_dir):
+    from video_distillation_amd import utils
+    z = np.load(os.path.join(golden_dir, "g4_hallucinator.npz"))
+    hal = utils.Conv3DNet().cuda()
+    assert list(hal.state_dict().keys()) == ["encoder.weight", "encoder.bias"]
+    with torch.no_grad():
+        hal.encoder.weight.copy_(torch.tensor(z["weight"])); hal.encoder.bias.copy_(torch.tensor(z["bias"]))
+    static, dynamic, up = [t.cuda() for t in randn(z["data_seed"], (3, 3, 64, 64), (3, 8, 1, 64, 64), (3, 8, 3, 64, 64))]
+    static.requires_grad_(True); dynamic.requires_grad_(True)
+    out = hal(static, dynamic)
+    assert out.shape == (3, 8, 3, 64, 64)
+    np.testing.assert_allclose(out[:, :, :, ::2, ::2].detach().cpu().numpy(), z["out"], rtol=1e-4, atol=1e-5)
+    (out * up).sum().backward()
+    np.testing.assert_allclose(dynamic.grad[:, :, :, ::2, ::2].cpu().numpy(), z["g_dynamic"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(static.grad[:, :, ::2, ::2].cpu().numpy(), z["g_static"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(hal.encoder.weight.grad.cpu().numpy(), z["g_weight"], rtol=1e-4, atol=2e-2)
+    np.testing.assert_allclose(hal.encoder.bias.grad.cpu().numpy(), z["g_bias"], rtol=1e-4, atol=2e-2)
+
+
+def test_g5_s2d_step_trainer(golden_dir):
+    from video_distillation_amd import distill, plan
+    z = np.load(os.path.join(golden_dir, "g5_s2d_step.npz"))
+    C, vpc, spc, dpc = 3, 1, 2, 2
+    geo = plan.NetGeometry(8, 64, 64)
+    be = _FixedNetBackend(distill.HipBackend(geo, "cuda:0", prec_real="f16x3", prec_syn="f16x3"), {0: int(z["net_seed"])})
+    static_syn, dynamic_syn = randn(z["data_seed"], (C * spc, 3, 64, 64), (C, dpc, 8, 1, 64, 64))
+    reals = randn(z["real_seed"], *[(4, 8, 3, 64, 64)] * C)
+
+    class Pool:
+        pass
+    pool = Pool(); pool.clips = torch.cat(reals).cuda(); pool.counts = [4] * C; pool.offsets = [0, 4, 8]
+    tr = distill.S2DTrainer(be, pool, C, vpc, spc, dpc, 4, static_syn.cuda(), dynamic_syn.cuda(),
+                            torch.tensor(z["hal_w"]).cuda(), torch.tensor(z["hal_b"]).cuda(), lr_dynamic=10.0, lr_hal=0.01)
+    import video_distillation_amd.distill as D
+    orig = D.sample_real_indices
+    try:
+        D.sample_real_indices = lambda it_, counts, offsets, b, classes: np.concatenate(
+            [offsets[c] + np.arange(4) for c in classes]).astype(np.int64)
+        loss = float(tr.step(0, draws=(z["draws_dyn"], z["draws_sta"])))
+    finally:
+        D.sample_real_indices = orig
+    assert abs(loss / float(z["loss"]) - 1) < 1e-4
+    g_dyn, g_w, g_b = tr.last_grads
+    g_dyn = g_dyn.view(C, dpc, 8, 1, 64, 64).cpu()
+    want = torch.tensor(z["g_dynamic"])
+    assert float((g_dyn[:, :, :, :, ::4, ::4] - want).norm() / want.norm()) < 1e-2
+    rowabs = g_dyn.abs().sum(dim=(2, 3, 4, 5))
+    assert int((rowabs == 0).sum()) == C * (dpc - 1)          # unselected dynamic memories: exactly zero
+    np.testing.assert_allclose(g_w.cpu().numpy(), z["g_hal_w"], rtol=2e-2, atol=1e-5)
+    np.testing.assert_allclose(tr.hal_w.cpu().numpy(), z["hal_w_after"], rtol=1e-4, atol=1e-6)
+    got = tr.dynamic.view(C, dpc, 8, 1, 64, 64)[:, :, :, :, ::4, ::4].cpu()
+    np.testing.assert_allclose(got.numpy(), z["dynamic_after"], rtol=1e-3, atol=1e-4)
+
+
+def test_g6_match_loss(golden_dir):
+    from video_distillation_amd import utils
+    z = np.load(os.path.join(golden_dir, "g6_match_loss.npz"))
+    n = int(z["n"])
+    args = types.SimpleNamespace(device="cuda", dis_metric="ours")
+    gr = [torch.tensor(z["r%d" % i]).cuda() for i in range(n)]
+    per = [float(utils.distance_wb(a, torch.tensor(z["s%d" % i]).cuda())) for i, a in enumerate(gr)]
+    np.testing.assert_allclose(per, z["ours_per_layer"], rtol=1e-4, atol=1e-5)
+    assert per[1] == 0.0                                       # 1-D member
+    for metric in ("ours", "mse", "cos"):
+        args.dis_metric = metric
+        gs = [torch.tensor(z["s%d" % i]).cuda().requires_grad_(True) for i in range(n)]
+        val = utils.match_loss(gs, gr, args)
+        assert val.dim() == 0 and val.is_cuda
+        np.testing.assert_allclose(float(val), float(z["val_" + metric]), rtol=1e-4)
+        val.backward()
+        for i, s in enumerate(gs):
+            got = s.grad.cpu().numpy() if s.grad is not None else np.zeros(s.shape, dtype=np.float32)
+            np.testing.assert_allclose(got, z["grad_%s_%d" % (metric, i)], rtol=1e-3, atol=1e-5)
+    args.dis_metric = "nope"
+    with pytest.raises(SystemExit):
+        utils.match_loss(gr, gr, args)
+
+
+def test_g7_evaluate_synset(golden_dir):
+    from video_distillation_amd import utils
+    z = np.load(os.path.join(golden_dir, "g7_evaluate.npz"))
+    C, n_test = int(z["C"]), int(z["n_test"])
+    images, test_x = randn(z["data_seed"], (C, 8, 3, 64, 64), (n_test, 8, 3, 64, 64))
+    net = make_net(int(z["net_seed"]), num_classes=C)
+    net.dropout.p = 0.0
+    args = types.SimpleNamespace(device="cuda", lr_net=float(z["lr_net"]), epoch_eval_train=int(z["epochs"]),
+                                 batch_train=256, model="ConvNet3D", eval_mode="SS")
+    testloader = torch.utils.data.DataLoader(utils.TensorDataset(test_x, torch.arange(n_test) % C), batch_size=4)
+    out = utils.evaluate_synset(0, net, images, torch.arange(C), testloader, args, mode='none')
+    assert len(out) == 4
+    net_out, acc_train, acc_test, acc_per = out
+    assert abs(acc_train - float(z["acc_train"])) < 1e-6
+    l1 = np.array([float(p.double().abs().sum()) for p in net_out.parameters()])
+    np.testing.assert_allclose(l1, z["params_after_l1"], rtol=2e-3)
+    with pytest.raises(NotImplementedError):
+        utils.evaluate_synset(0, net, images, torch.arange(C), testloader, args, mode='hallucinator')
+    with pytest.raises(SystemExit):
+        utils.get_network('NoSuchNet', 3, 10)

@@ -70,8 +70,8 @@ def test_embed_backward_small(prec):
     want = _grad_fp64(x, gf, params)
     eng = _engine((8, 64, 64), prec)
     eng.set_weights([p.cuda() for p in params])
-    eng.forward(x.cuda(), keep=True)
-    dx = eng.backward(gf.cuda())
+    _, sv = eng.forward(x.cuda(), keep=True)
+    dx = eng.backward(sv, gf.cuda())
     torch.cuda.synchronize()
     _grad_check(dx, want, prec)
     # the fp32 CPU reference path is itself no closer to fp64 than we are (x10 slack)
@@ -108,8 +108,8 @@ def test_embed_backward_full_resolution():
     want = _grad_fp64(x, gf, params)
     eng = _engine((16, 112, 112), "f16x3")
     eng.set_weights([p.cuda() for p in params])
-    eng.forward(x.cuda(), keep=True)
-    dx = eng.backward(gf.cuda())
+    _, sv = eng.forward(x.cuda(), keep=True)
+    dx = eng.backward(sv, gf.cuda())
     torch.cuda.synchronize()
     _grad_check(dx, want, "f16x3")
 

@@ -17,8 +17,8 @@ print("fp32 oracle vs fp64: %.3e" % rel(g32, g64))
 for prec in ("bf16x3", "f16x3", "f16", "bf16"):
     eng = engine.EmbedEngine(plan.NetGeometry(8, 64, 64), prec=prec)
     eng.set_weights([p.cuda() for p in params])
-    eng.forward(x.cuda(), keep=True)
-    dx = eng.backward(gf.cuda()).double().cpu()
+    _, sv = eng.forward(x.cuda(), keep=True)
+    dx = eng.backward(sv, gf.cuda()).double().cpu()
     d = (dx - g64)
     per = [(float(d[i].norm()/g64[i].norm())) for i in range(3)]
     nbad = int(((d.abs() > 1e-3 * g64.abs().max())).sum())

@@ -67,12 +67,17 @@ extern "C" int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, v
 
 // ------------------------------------------------------------------------------------------
 // one thread per output slot: (clip, f = t*3+c, h, ow) -> x[clip, t, c, h, 2ow-3 .. 2ow+4]
-__global__ void pix2slots_kernel(const float* __restrict__ x, int64_t nslots, int H, int W, int OW,
+__global__ void pix2slots_kernel(const float* __restrict__ x, const int64_t* __restrict__ clip_index, int64_t nslots,
+                                 int rows_per_clip, int H, int W, int OW,
                                  uint4* __restrict__ hi, uint4* __restrict__ lo, int prec) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nslots) return;
     const int ow = (int)(i % OW);
-    const int64_t row = i / OW;                 // (clip, f, h) flattened == row of x
+    int64_t row = i / OW;                       // (clip, f, h) flattened == row of x
+    if (clip_index != nullptr) {                // gather: clip b of the batch is pool clip clip_index[b]
+        const int64_t b = row / rows_per_clip;
+        row = clip_index[b] * rows_per_clip + (row - b * rows_per_clip);
+    }
     const float* xr = x + row * W;
     const int w0 = 2 * ow - 3;
     uint16_t h16[8], l16[8];
@@ -93,14 +98,15 @@ __global__ void pix2slots_kernel(const float* __restrict__ x, int64_t nslots, in
     }
 }
 
-extern "C" int vd_pix2slots(const float* x, int64_t nclips, int T, int H, int W, void* out_hi, void* out_lo,
-                            int prec, void* stream) {
+extern "C" int vd_pix2slots(const float* x, const int64_t* clip_index, int64_t nclips, int T, int H, int W,
+                            void* out_hi, void* out_lo, int prec, void* stream) {
     const int OW = (W + 6 - 7) / 2 + 1;
     const int64_t nslots = nclips * T * 3 * H * OW;
     if (nslots <= 0) return 0;
     const int bs = 256;
     hipLaunchKernelGGL(pix2slots_kernel, dim3((unsigned)((nslots + bs - 1) / bs)), dim3(bs), 0,
-                       reinterpret_cast<hipStream_t>(stream), x, nslots, H, W, OW, (uint4*)out_hi, (uint4*)out_lo, prec);
+                       reinterpret_cast<hipStream_t>(stream), x, clip_index, nslots, T * 3 * H, H, W, OW, (uint4*)out_hi,
+                       (uint4*)out_lo, prec);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,299 @@
+"""The outer distillation loop of the DM hot path, MI355X-first.
+
+What the reference does per iteration (distill_baseline.py:334-355; s2d twin
+distill_s2d_ms.py:393-438): draw a fresh random ConvNet3D, and for every class embed 64
+real clips (copied host->device per class) and the class's synthetic clips, sum the squared
+distances of the mean embeddings, back-propagate to the synthetic pixels and take an
+SGD-momentum step.
+
+What this module does with the same arithmetic:
+  * the real pool stays resident in HBM; a class batch is an index list and the gather is
+    fused into the first kernel (no per-class host->device copy);
+  * all classes of a rank go through each layer in a few large launches instead of 2*C
+    small ones (the network is the same for every class of an iteration);
+  * real clips (no gradient, 98.5 % of the FLOPs) use single-pass fp16 MFMA operands, the
+    synthetic clips (which carry the gradient) the split-precision path;
+  * classes are sharded over ranks in contiguous blocks; a rank owns its classes' synthetic
+    clips and momentum, so the pixel gradients never cross xGMI (owner-computes).  Per step
+    the only collective is a 4-byte all-reduce of the loss for logging; the s2d variant
+    all-reduces the 327 hallucinator gradients.  Synthetic clips are all-gathered only for
+    evaluation / saving.
+
+The compute backend is injected (``HipBackend`` in production).  Tests drive the same
+trainer logic with a CPU stand-in on ``gloo`` to check the sharding.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import plan as P
+
+PARAM_SHAPES = ((64, 3, 3, 7, 7), (64,), (128, 64, 3, 7, 7), (128,), (128, 128, 3, 7, 7), (128,))
+
+
+def class_range(num_classes: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of classes owned by ``rank`` (sizes differ by at most one)."""
+    base, extra = divmod(num_classes, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def sample_real_indices(it: int, counts: Sequence[int], offsets: Sequence[int], batch_real: int,
+                        classes: Sequence[int]) -> np.ndarray:
+    """Pool indices of the real batch of every class in ``classes`` for iteration ``it``: the
+    on-device counterpart of ``np.random.permutation(indices_class[c])[:n]``
+    (distill_baseline.py:85).  Seeded per (iteration, class) so that every sharding draws the
+    same batches."""
+    out = []
+    for c in classes:
+        rng = np.random.default_rng([it, c])
+        perm = rng.permutation(counts[c])[:batch_real]
+        if perm.size < batch_real:   # fewer clips than batch_real: the reference would just take them all
+            perm = np.resize(perm, batch_real)
+        out.append(offsets[c] + perm)
+    return np.concatenate(out).astype(np.int64) if out else np.zeros(0, dtype=np.int64)
+
+
+def fresh_network_weights(seed: int, device) -> List[torch.Tensor]:
+    """A fresh random ConvNet3D feature stack, drawn ON the device with PyTorch's default Conv3d
+    distribution (kaiming-uniform a=sqrt(5) == U(+-1/sqrt(fan_in)) for weight and bias), from a
+    seed shared by all ranks (no broadcast).  Stands in for ``get_network()`` at
+    distill_baseline.py:334, which reseeds from the wall clock."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    out = []
+    for wi in range(0, len(PARAM_SHAPES), 2):
+        fan_in = int(np.prod(PARAM_SHAPES[wi][1:]))
+        bound = 1.0 / math.sqrt(fan_in)
+        for shp in (PARAM_SHAPES[wi], PARAM_SHAPES[wi + 1]):
+            out.append(torch.empty(shp, device=device, dtype=torch.float32).uniform_(-bound, bound, generator=gen))
+    return out
+
+
+class HipBackend:
+    """Production backend: EmbedEngine (MFMA kernels) + the small HIP kernels."""
+
+    def __init__(self, geo: P.NetGeometry, device, prec_real: str = "f16", prec_syn: str = "f16x3", chunk: int = 512):
+        from . import engine, hip
+        self.hip = hip
+        self.device = torch.device(device)
+        self.geo = geo
+        self.eng_real = engine.EmbedEngine(geo, prec=prec_real, device=device, chunk=chunk)
+        self.eng_syn = self.eng_real if prec_syn == prec_real else engine.EmbedEngine(geo, prec=prec_syn, device=device, chunk=chunk)
+        self.num_feat = geo.num_feat
+
+    def new_network(self, seed: int):
+        return fresh_network_weights(seed, self.device)
+
+    def set_weights(self, weights) -> None:
+        self.eng_real.set_weights(weights)
+        if self.eng_syn is not self.eng_real:
+            self.eng_syn.set_weights(weights)
+
+    def embed_pool(self, pool: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+        return self.eng_real.forward(pool, index=index)
+
+    def embed_keep(self, x: torch.Tensor):
+        return self.eng_syn.forward(x, keep=True)
+
+    def embed_backward(self, handle, g: torch.Tensor) -> torch.Tensor:
+        return self.eng_syn.backward(handle, g)
+
+    def dm_loss(self, f_real: torch.Tensor, f_syn: torch.Tensor, nclass: int):
+        nreal, nsyn, dim = f_real.shape[0] // max(nclass, 1), f_syn.shape[0] // max(nclass, 1), self.num_feat
+        loss = torch.empty(nclass, dtype=torch.float32, device=self.device)
+        g = torch.empty_like(f_syn)
+        hip = self.hip
+        hip.check(hip.lib().vd_dm_loss(hip.ptr(f_real), hip.ptr(f_syn), nclass, nreal, nsyn, dim, hip.ptr(loss),
+                                       hip.ptr(g), hip.stream_ptr(self.device)), "vd_dm_loss")
+        return loss, g
+
+    def sgd(self, x: torch.Tensor, buf: torch.Tensor, g: torch.Tensor, lr: float, mu: float, first: bool) -> None:
+        hip = self.hip
+        hip.check(hip.lib().vd_sgd_momentum(hip.ptr(x), hip.ptr(buf), hip.ptr(g), ctypes.c_int64(x.numel()),
+                                            ctypes.c_float(lr), ctypes.c_float(mu), int(first),
+                                            hip.stream_ptr(self.device)), "vd_sgd_momentum")
+
+    def hallucinate(self, static, dynamic, sidx, didx, w, b):
+        hip = self.hip
+        n, T, H, W = int(sidx.numel()), dynamic.shape[-4], dynamic.shape[-2], dynamic.shape[-1]
+        out = torch.empty((n, T, 3, H, W), dtype=torch.float32, device=self.device)
+        hip.check(hip.lib().vd_hallucinator_fwd(hip.ptr(static), hip.ptr(dynamic), hip.ptr(sidx), hip.ptr(didx),
+                                                hip.ptr(w), hip.ptr(b), n, T, H, W, hip.ptr(out),
+                                                hip.stream_ptr(self.device)), "vd_hallucinator_fwd")
+        return out
+
+    def hallucinate_backward(self, g_out, static, dynamic, sidx, didx, w, need_static: bool):
+        hip = self.hip
+        n, T, H, W = int(sidx.numel()), dynamic.shape[-4], dynamic.shape[-2], dynamic.shape[-1]
+        g_dyn = torch.zeros_like(dynamic)
+        g_stat = torch.zeros_like(static) if need_static else None
+        g_w = torch.zeros(324, dtype=torch.float32, device=self.device)
+        g_b = torch.zeros(3, dtype=torch.float32, device=self.device)
+        hip.check(hip.lib().vd_hallucinator_bwd(hip.ptr(g_out), hip.ptr(static), hip.ptr(dynamic), hip.ptr(sidx),
+                                                hip.ptr(didx), hip.ptr(w), n, T, H, W, hip.ptr(g_dyn),
+                                                hip.ptr(g_stat), hip.ptr(g_w), hip.ptr(g_b),
+                                                hip.stream_ptr(self.device)), "vd_hallucinator_bwd")
+        return g_dyn, g_stat, g_w.view(3, 4, 3, 3, 3), g_b
+
+
+class RealPool:
+    """The rank's share of the real training clips, resident on the device:
+    ``clips`` (N,T,3,H,W) fp32 ordered by class, ``counts[c]`` clips for global class c,
+    ``offsets[c]`` = index of the class's first clip in ``clips`` (only owned classes used)."""
+
+    def __init__(self, clips: torch.Tensor, counts: Sequence[int], offsets: Sequence[int]):
+        self.clips, self.counts, self.offsets = clips, list(counts), list(offsets)
+
+    @staticmethod
+    def synthetic(num_classes: int, classes: Sequence[int], per_class: int, geo: P.NetGeometry, device, seed: int = 1234):
+        """randn clips standardised per channel, generated on the device."""
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        n = len(classes) * per_class
+        clips = torch.empty((n, geo.frames, 3, geo.height, geo.width), dtype=torch.float32, device=device)
+        step = 64
+        for i in range(0, n, step):
+            clips[i:i + step].normal_(generator=gen)
+        mean = clips.mean(dim=(0, 1, 3, 4), keepdim=True)
+        std = clips.std(dim=(0, 1, 3, 4), keepdim=True)
+        clips.sub_(mean).div_(std)
+        counts = [per_class] * num_classes
+        offsets = [0] * num_classes
+        for k, c in enumerate(classes):
+            offsets[c] = k * per_class
+        return RealPool(clips, counts, offsets)
+
+
+class DMTrainer:
+    """Baseline DM (distill_baseline.py DM branch, :292-361) over the classes owned by this rank."""
+
+    def __init__(self, backend, pool: RealPool, num_classes: int, ipc: int, batch_real: int, lr_img: float,
+                 momentum: float = 0.5, rank: int = 0, world: int = 1, image_syn: Optional[torch.Tensor] = None):
+        self.be, self.pool = backend, pool
+        self.num_classes, self.ipc, self.batch_real = num_classes, ipc, batch_real
+        self.lr_img, self.momentum = float(lr_img), float(momentum)
+        self.rank, self.world = rank, world
+        self.c_lo, self.c_hi = class_range(num_classes, rank, world)
+        self.classes = list(range(self.c_lo, self.c_hi))
+        if image_syn is None:   # --init real (distill_baseline.py:96-100): first ipc real clips of each class
+            idx = np.concatenate([pool.offsets[c] + np.arange(ipc) % pool.counts[c] for c in self.classes]) \
+                if self.classes else np.zeros(0, dtype=np.int64)
+            image_syn = pool.clips[torch.as_tensor(idx, device=pool.clips.device, dtype=torch.int64)].clone()
+        self.image_syn = image_syn.contiguous()
+        self.buf = torch.zeros_like(self.image_syn)
+        self.steps_done = 0
+
+    def step(self, it: int) -> torch.Tensor:
+        """One distillation iteration over this rank's classes; returns the rank-local loss sum
+        as a 0-dim device tensor (no host sync)."""
+        be, ncls = self.be, len(self.classes)
+        be.set_weights(be.new_network(seed=it))
+        idx = sample_real_indices(it, self.pool.counts, self.pool.offsets, self.batch_real, self.classes)
+        dev = self.image_syn.device
+        f_real = be.embed_pool(self.pool.clips, torch.as_tensor(idx, device=dev))
+        f_syn, handle = be.embed_keep(self.image_syn)
+        loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
+        grad = be.embed_backward(handle, g_syn)
+        be.sgd(self.image_syn, self.buf, grad, self.lr_img, self.momentum, first=(self.steps_done == 0))
+        self.steps_done += 1
+        return loss_c.sum()
+
+    def global_loss(self, local_loss: torch.Tensor) -> torch.Tensor:
+        """Sum of the per-rank losses (== the reference's ``loss`` before /num_classes)."""
+        if self.world > 1:
+            import torch.distributed as dist
+            local_loss = local_loss.clone()
+            dist.all_reduce(local_loss, op=dist.ReduceOp.SUM)
+        return local_loss
+
+    def gather_syn(self) -> torch.Tensor:
+        """All synthetic clips in class order on every rank (evaluation / ``images_*.pt``)."""
+        if self.world == 1:
+            return self.image_syn
+        import torch.distributed as dist
+        sizes = [(class_range(self.num_classes, r, self.world)[1] - class_range(self.num_classes, r, self.world)[0]) * self.ipc
+                 for r in range(self.world)]
+        mx = max(sizes)
+        pad = torch.zeros((mx,) + tuple(self.image_syn.shape[1:]), dtype=self.image_syn.dtype, device=self.image_syn.device)
+        pad[:self.image_syn.shape[0]] = self.image_syn
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad)
+        return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+class S2DTrainer:
+    """DM + static/dynamic memories (distill_s2d_ms.py DM branch, :393-438): the synthetic clip of
+    (class, v) is hallucinator(static[static_idx], dynamic[label, dynamic_idx]); static memory
+    frozen (``--no_train_static``) or trained; SGD(momentum .95) on dynamic memory and
+    hallucinator.  Dynamic rows are owned by the class's rank; the 327 hallucinator gradients
+    are summed over ranks."""
+
+    def __init__(self, backend, pool: RealPool, num_classes: int, vpc: int, spc: int, dpc: int, batch_real: int,
+                 static_syn: torch.Tensor, dynamic_syn: torch.Tensor, hal_w: torch.Tensor, hal_b: torch.Tensor,
+                 lr_dynamic: float, lr_hal: float, lr_static: float = 0.0, train_static: bool = False,
+                 momentum: float = 0.95, rank: int = 0, world: int = 1):
+        self.be, self.pool = backend, pool
+        self.num_classes, self.vpc, self.spc, self.dpc, self.batch_real = num_classes, vpc, spc, dpc, batch_real
+        self.rank, self.world = rank, world
+        self.c_lo, self.c_hi = class_range(num_classes, rank, world)
+        self.classes = list(range(self.c_lo, self.c_hi))
+        # local shards: static rows of owned classes, dynamic rows of owned classes (flattened (c,dpc))
+        self.static = static_syn[self.c_lo * spc:self.c_hi * spc].contiguous()
+        self.dynamic = dynamic_syn[self.c_lo:self.c_hi].reshape((-1,) + tuple(dynamic_syn.shape[2:])).contiguous()
+        self.hal_w, self.hal_b = hal_w.clone().contiguous(), hal_b.clone().contiguous()
+        self.lr_dynamic, self.lr_hal, self.lr_static = float(lr_dynamic), float(lr_hal), float(lr_static)
+        self.train_static, self.momentum = train_static, float(momentum)
+        self.buf_d = torch.zeros_like(self.dynamic)
+        self.buf_w, self.buf_b = torch.zeros_like(self.hal_w), torch.zeros_like(self.hal_b)
+        self.buf_s = torch.zeros_like(self.static) if train_static else None
+        self.steps_done = 0
+
+    def indices(self, it: int, draws: Optional[Tuple[np.ndarray, np.ndarray]] = None):
+        """distill_s2d_ms.py:402-406 for the owned classes; the two randint(2) draws are seeded per
+        (iteration, class) so that every sharding composes the same clips."""
+        ncls = len(self.classes)
+        label = np.repeat(np.arange(ncls), self.vpc)
+        idx = np.tile(np.arange(self.vpc), ncls)
+        if draws is None:
+            dd = np.concatenate([np.random.default_rng([it, c, 1]).integers(0, 2, self.vpc) for c in self.classes]) if ncls else idx
+            ds = np.concatenate([np.random.default_rng([it, c, 2]).integers(0, 2, self.vpc) for c in self.classes]) if ncls else idx
+        else:
+            dd, ds = draws[0][self.c_lo * self.vpc:self.c_hi * self.vpc], draws[1][self.c_lo * self.vpc:self.c_hi * self.vpc]
+        dynamic_idx = label * self.dpc + 2 * idx + dd      # row in the flattened (class, dpc) dynamic shard
+        static_idx = self.spc * label + 2 * idx + ds
+        return static_idx.astype(np.int64), dynamic_idx.astype(np.int64)
+
+    def step(self, it: int, draws=None) -> torch.Tensor:
+        be, ncls = self.be, len(self.classes)
+        dev = self.dynamic.device
+        be.set_weights(be.new_network(seed=it))
+        sidx_np, didx_np = self.indices(it, draws)
+        sidx, didx = torch.as_tensor(sidx_np, device=dev), torch.as_tensor(didx_np, device=dev)
+        image_syn = be.hallucinate(self.static, self.dynamic, sidx, didx, self.hal_w, self.hal_b)
+        idx = sample_real_indices(it, self.pool.counts, self.pool.offsets, self.batch_real, self.classes)
+        f_real = be.embed_pool(self.pool.clips, torch.as_tensor(idx, device=dev))
+        f_syn, handle = be.embed_keep(image_syn)
+        loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
+        g_img = be.embed_backward(handle, g_syn)
+        g_dyn, g_stat, g_w, g_b = be.hallucinate_backward(g_img, self.static, self.dynamic, sidx, didx, self.hal_w,
+                                                          self.train_static)
+        if self.world > 1:   # the hallucinator is shared by all classes: one 1.3 KB all-reduce
+            import torch.distributed as dist
+            flat = torch.cat([g_w.reshape(-1), g_b.reshape(-1)])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            g_w, g_b = flat[:324].view_as(g_w), flat[324:]
+        first = self.steps_done == 0
+        be.sgd(self.dynamic, self.buf_d, g_dyn, self.lr_dynamic, self.momentum, first)
+        be.sgd(self.hal_w, self.buf_w, g_w.contiguous(), self.lr_hal, self.momentum, first)
+        be.sgd(self.hal_b, self.buf_b, g_b.contiguous(), self.lr_hal, self.momentum, first)
+        if self.train_static:
+            be.sgd(self.static, self.buf_s, g_stat, self.lr_static, self.momentum, first)
+        self.steps_done += 1
+        self.last_grads = (g_dyn, g_w, g_b)
+        return loss_c.sum()

@@ -86,7 +86,7 @@ class EmbedEngine:
         self._weights: Optional[List[torch.Tensor]] = None
         self._bwd_packed = False
         self._ws: Dict[str, torch.Tensor] = {}
-        self._saved = None
+        self.profile = None   # list -> (layer, clips, start_event, end_event) per forward launch
 
     # ------------------------------------------------------------------------------------
     def _buf(self, name: str, shape, dtype) -> torch.Tensor:
@@ -113,49 +113,62 @@ class EmbedEngine:
             self._bwd_packed = True
 
     # ------------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor, keep: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, keep: bool = False, index: Optional[torch.Tensor] = None):
         """x (B,T,3,H,W) fp32 on the device -> features (B, num_feat) fp32.  With ``keep`` the
-        pooling arg-max of every layer is retained for ``backward``."""
+        pooling arg-max of every layer is retained and returned as a handle for ``backward``
+        (several forwards may be outstanding before their backwards, as in the reference's
+        per-class loop, distill_baseline.py:344-354)."""
         assert self._weights is not None, "set_weights() first"
         g = self.geo
         assert x.dim() == 5 and tuple(x.shape[1:]) == (g.frames, g.channel, g.height, g.width), x.shape
         x = x.detach().to(torch.float32).contiguous()
-        B = x.shape[0]
+        B = x.shape[0] if index is None else int(index.numel())
+        if index is not None:   # batch clip b = x[index[b]] (gather fused into the slot conversion)
+            index = index.to(self.device, torch.int64).contiguous()
         feats = torch.empty((B, self.num_feat), dtype=torch.float32, device=self.device)
         saved = []
         L = hip.lib()
         st = hip.stream_ptr(self.device)
-        d0, d1, d2 = self.dims
-        OW0 = d0[7]
+        OW0 = self.dims[0][7]
+        per1 = int(np.prod(self.fwd[0].plan.out_shape[:-1]))
+        per2 = int(np.prod(self.fwd[1].plan.out_shape[:-1]))
         for c0 in range(0, B, self.chunk):
             nb = min(self.chunk, B - c0)
-            tag = "k%d_" % c0 if keep else ""
             n_slots0 = nb * g.frames * 3 * g.height * OW0
             slots0 = self._buf("slots0", (self.planes, n_slots0, 8), torch.int16)
             lo = slots0[1] if self.planes == 2 else None
-            hip.check(L.vd_pix2slots(hip.ptr(x[c0:]), ctypes.c_int64(nb), g.frames, g.height, g.width,
+            xin = x[c0:] if index is None else x
+            hip.check(L.vd_pix2slots(hip.ptr(xin), hip.ptr(None if index is None else index[c0:]),
+                                     ctypes.c_int64(nb), g.frames, g.height, g.width,
                                      hip.ptr(slots0[0]), hip.ptr(lo), self.prec, st), "vd_pix2slots")
-            n1 = nb * int(np.prod(self.fwd[0].plan.out_shape[:-1]))
+            n1, n2 = nb * per1, nb * per2
             act1 = self._buf("act1", (self.planes, n1, 8), torch.int16)
-            n2 = nb * int(np.prod(self.fwd[1].plan.out_shape[:-1]))
             act2 = self._buf("act2", (self.planes, n2, 8), torch.int16)
             am0 = am1 = am2 = None
             if keep:
-                am0 = self._buf(tag + "am0", (n1 * 8,), torch.uint8)
-                am1 = self._buf(tag + "am1", (n2 * 8,), torch.uint8)
-                am2 = self._buf(tag + "am2", (nb * self.num_feat,), torch.uint8)
+                am0 = torch.empty(n1 * 8, dtype=torch.uint8, device=self.device)
+                am1 = torch.empty(n2 * 8, dtype=torch.uint8, device=self.device)
+                am2 = torch.empty(nb * self.num_feat, dtype=torch.uint8, device=self.device)
             w = self._weights
+            prof = self.profile
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if prof is not None else None
+            if ev: ev[0].record()
             self.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, am0, nb)
+            if ev: ev[1].record()
             self.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, am1, nb)
+            if ev: ev[2].record()
             self.fwd[2].run(act2, n2, w[5], feats[c0:].data_ptr(), 0, am2, nb)
+            if ev:
+                ev[3].record()
+                prof += [("fwd0", nb, ev[0], ev[1]), ("fwd1", nb, ev[1], ev[2]), ("fwd2", nb, ev[2], ev[3])]
             if keep:
                 saved.append((c0, nb, am0, am1, am2))
-        self._saved = saved if keep else None
+        if keep:
+            return feats, saved
         return feats
 
-    def backward(self, g_feat: torch.Tensor) -> torch.Tensor:
-        """d loss / d x for the clips of the last ``forward(..., keep=True)``."""
-        assert self._saved is not None, "forward(keep=True) first"
+    def backward(self, saved, g_feat: torch.Tensor) -> torch.Tensor:
+        """d loss / d x for the clips of a ``forward(..., keep=True)`` call (same weights)."""
         self._pack_bwd()
         g = self.geo
         g_feat = g_feat.detach().to(torch.float32).contiguous()
@@ -163,8 +176,7 @@ class EmbedEngine:
         dx = torch.empty((B, g.frames, g.channel, g.height, g.width), dtype=torch.float32, device=self.device)
         L = hip.lib()
         st = hip.stream_ptr(self.device)
-        d0, d1, d2 = self.dims
-        for c0, nb, am0, am1, am2 in self._saved:
+        for c0, nb, am0, am1, am2 in saved:
             grad = g_feat[c0:c0 + nb]
             layout = 0
             for li, am in ((2, am2), (1, am1), (0, am0)):
@@ -184,6 +196,3 @@ class EmbedEngine:
                 grad = out
                 layout = 1
         return dx
-
-    def release(self) -> None:
-        self._saved = None

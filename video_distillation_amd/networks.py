@@ -1,0 +1,193 @@
+"""ConvNet3D with the reference's module surface, executing ``embed`` on the HIP path.
+
+Mirrors ``networks.ConvNet3D`` of the reference (networks.py:727-814): same constructor
+arguments, the same sub-module names (``features.{0,3,6}``, ``avg_pool``, ``dropout``,
+``logit``) and therefore the same ``state_dict`` keys and ``parameters()`` order that MTT
+expert buffers rely on (buffer.py:75, 89).
+
+Execution
+  * ``embed(x)`` with frozen parameters on a HIP device -- the DM hot path
+    (distill_baseline.py:336-349) -- runs the hand-written MFMA kernels through
+    ``EmbedEngine``; the gradient w.r.t. ``x`` comes from the HIP input-gradient passes.
+    Clips that carry no gradient (the real batches) use the fast operand precision, clips
+    that do (the synthetic ones) the split precision (see ``set_precision``).
+  * anything that needs parameter gradients or double backward (``forward`` during
+    ``evaluate_synset``, DC / MTT callers using ``create_graph=True``) runs the same graph
+    through torch-ROCm ops; the HIP weight-gradient kernels are the next scope row
+    (SURVEY.md section 8(f)-1).
+There is no CPU compute path: ``embed`` on a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import plan as P
+
+_PRECISION = {"real": os.environ.get("VD_PREC_REAL", "f16"), "syn": os.environ.get("VD_PREC_SYN", "f16x3")}
+_ENGINES: Dict[Tuple, object] = {}
+
+
+def set_precision(real: str = None, syn: str = None) -> None:
+    """Operand precision of the MFMA contraction: ``real`` for inputs without gradient,
+    ``syn`` for inputs that need d/dx.  One of 'bf16', 'f16', 'bf16x3', 'f16x3'."""
+    from . import hip
+    for k, v in (("real", real), ("syn", syn)):
+        if v is not None:
+            if v not in hip.PREC:
+                raise ValueError("unknown precision %r" % v)
+            _PRECISION[k] = v
+
+
+def get_precision() -> Dict[str, str]:
+    return dict(_PRECISION)
+
+
+def get_engine(geo: P.NetGeometry, prec: str, device) -> "object":
+    from . import engine
+    device = torch.device(device)
+    key = (geo.frames, geo.height, geo.width, prec, device.index if device.index is not None else torch.cuda.current_device())
+    eng = _ENGINES.get(key)
+    if eng is None:
+        eng = engine.EmbedEngine(geo, prec=prec, device=device)
+        _ENGINES[key] = eng
+    return eng
+
+
+class _EmbedFunction(torch.autograd.Function):
+    """features = embed(x) on the HIP path; backward = HIP input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, net):
+        need_grad = ctx.needs_input_grad[0]
+        prec = _PRECISION["syn"] if need_grad else _PRECISION["real"]
+        geo = P.NetGeometry(x.shape[1], x.shape[3], x.shape[4])
+        eng = get_engine(geo, prec, x.device)
+        net._sync_engine(eng)
+        if need_grad:
+            feats, saved = eng.forward(x, keep=True)
+            ctx.saved = saved
+            ctx.eng = eng
+            ctx.wkey = net._weights_key()
+            ctx.net = net
+        else:
+            feats = eng.forward(x)
+        return feats
+
+    @staticmethod
+    def backward(ctx, g):
+        eng, net = ctx.eng, ctx.net
+        if net._weights_key() != ctx.wkey:
+            raise RuntimeError("ConvNet3D parameters changed between embed() and backward()")
+        net._sync_engine(eng)
+        return eng.backward(ctx.saved, g), None
+
+
+class ConvNet3D(nn.Module):
+    def __init__(self, channel, num_classes, net_width, net_depth, net_act, net_norm, net_pooling, frames,
+                 im_size=(32, 32), dropout_keep_prob=0.5):
+        super().__init__()
+        self.features, shape_feat = self._make_layers(channel, net_width, net_depth, net_norm, net_act,
+                                                      net_pooling, im_size, frames)
+        big = im_size[0] > 64
+        self.avg_pool = nn.AvgPool3d(kernel_size=(2, 2, 2) if big else (2, 1, 1), stride=(1, 1, 1))
+        self.dropout = nn.Dropout(dropout_keep_prob)
+        self.logit = nn.Conv3d(net_width, num_classes, kernel_size=(1, 1, 1), stride=(1, 1, 1), bias=True)
+        self._hip_ok = (channel == 3 and net_width == 128 and net_depth == 3 and net_act == 'relu'
+                        and net_norm == 'none' and net_pooling == 'maxpooling')
+        self._engine_keys: Dict[int, Tuple] = {}
+
+    # -- construction (same layer sequence / naming as networks.py:792-814) ------------------
+    @staticmethod
+    def _activation(net_act):
+        if net_act == 'relu':
+            return nn.ReLU(inplace=True)
+        if net_act == 'sigmoid':
+            return nn.Sigmoid()
+        if net_act == 'leakyrelu':
+            return nn.LeakyReLU(negative_slope=0.01)
+        exit('unknown activation function: %s' % net_act)
+
+    @staticmethod
+    def _pooling(net_pooling, first):
+        if net_pooling == 'maxpooling':
+            return nn.MaxPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2)) if first else nn.MaxPool3d(kernel_size=2, stride=2)
+        if net_pooling == 'avgpooling':
+            return nn.AvgPool3d(kernel_size=2, stride=2)
+        if net_pooling == 'none':
+            return None
+        exit('unknown net_pooling: %s' % net_pooling)
+
+    @staticmethod
+    def _norm(net_norm, shape_feat):
+        if net_norm == 'none':
+            return None
+        if net_norm == 'batchnorm':
+            return nn.BatchNorm3d(shape_feat[0], affine=True)
+        if net_norm == 'layernorm':
+            return nn.LayerNorm(shape_feat, elementwise_affine=True)
+        if net_norm == 'instancenorm':
+            return nn.GroupNorm(shape_feat[0], shape_feat[0], affine=True)
+        if net_norm == 'groupnorm':
+            return nn.GroupNorm(4, shape_feat[0], affine=True)
+        exit('unknown net_norm: %s' % net_norm)
+
+    def _make_layers(self, channel, net_width, net_depth, net_norm, net_act, net_pooling, im_size, frames):
+        layers = []
+        cin = channel
+        if im_size[0] == 28:
+            im_size = (32, 32)
+        shape_feat = [cin, frames, im_size[0], im_size[1]]
+        for d in range(net_depth):
+            cout = 64 if d == 0 else net_width
+            layers.append(nn.Conv3d(cin, cout, kernel_size=(3, 7, 7), padding=(1, 3, 3), stride=(1, 2, 2)))
+            shape_feat = [cout, shape_feat[1], shape_feat[2] // 2, shape_feat[3] // 2]
+            norm = self._norm(net_norm, shape_feat)
+            if norm is not None:
+                layers.append(norm)
+            layers.append(self._activation(net_act))
+            cin = cout
+            pool = self._pooling(net_pooling, d == 0)
+            if pool is not None:
+                layers.append(pool)
+                shape_feat = [cout, shape_feat[1] // (1 if d == 0 else 2), shape_feat[2] // 2, shape_feat[3] // 2]
+        return nn.Sequential(*layers), shape_feat
+
+    # -- HIP dispatch ---------------------------------------------------------------------------
+    def _feature_params(self):
+        return [self.features[0].weight, self.features[0].bias, self.features[3].weight, self.features[3].bias,
+                self.features[6].weight, self.features[6].bias]
+
+    def _weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self._feature_params())
+
+    def _sync_engine(self, eng) -> None:
+        key = self._weights_key()
+        if getattr(eng, "_owner_key", None) != (id(self), key):
+            eng.set_weights(self._feature_params())
+            eng._owner_key = (id(self), key)
+
+    def _use_hip(self, x) -> bool:
+        if not self._hip_ok or not x.is_cuda:
+            return False
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._feature_params()):
+            return False   # parameter gradients / double backward: torch-ROCm ops (section 8(f)-1)
+        return True
+
+    def embed(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("video_distillation_amd.ConvNet3D.embed has no CPU path: move the clips to a HIP "
+                               "device (the CPU restatement lives in oracle/, for tests only)")
+        if self._use_hip(x):
+            return _EmbedFunction.apply(x, self)
+        out = self.features(x.permute(0, 2, 1, 3, 4))
+        return out.view(out.size(0), -1)
+
+    def forward(self, x):
+        out = self.features(x.permute(0, 2, 1, 3, 4))
+        out = self.logit(self.dropout(self.avg_pool(out)))
+        logits = out.squeeze(3).squeeze(3)
+        return torch.max(logits, 2)[0]
