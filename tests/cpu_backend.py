@@ -1,0 +1,65 @@
+"""CPU stand-in for distill.HipBackend, built on the oracle (TEST INFRASTRUCTURE ONLY).
+
+Lets the trainers' host logic -- class sharding, index sampling, optimiser bookkeeping, the
+collectives -- run under ``gloo`` on a machine without a GPU.  It is never importable from
+the product package."""
+import torch
+
+from oracle import ref_cpu as R
+
+
+class OracleBackend:
+    def __init__(self, net_seeds=None):
+        self.net_seeds = net_seeds
+        self.params = None
+        self.device = torch.device("cpu")
+
+    def new_network(self, seed):
+        s = self.net_seeds[seed] if self.net_seeds is not None else seed
+        return R.init_params(int(s))[:6]
+
+    def set_weights(self, weights):
+        self.params = list(weights) + [None, None]
+
+    def embed_pool(self, pool, index):
+        with torch.no_grad():
+            return R.convnet3d_embed(pool[index], self.params)
+
+    def embed_keep(self, x):
+        xv = x.detach().clone().requires_grad_(True)
+        f = R.convnet3d_embed(xv, self.params)
+        return f.detach(), (xv, f)
+
+    def embed_backward(self, handle, g):
+        xv, f = handle
+        (dx,) = torch.autograd.grad(f, xv, g)
+        return dx
+
+    def dm_loss(self, f_real, f_syn, nclass):
+        d = f_real.shape[1]
+        fr = f_real.view(nclass, -1, d)
+        fs = f_syn.view(nclass, -1, d).detach().clone().requires_grad_(True)
+        loss_c = ((fr.mean(1) - fs.mean(1)) ** 2).sum(1)
+        (g,) = torch.autograd.grad(loss_c.sum(), fs)
+        return loss_c.detach(), g.reshape(f_syn.shape)
+
+    def sgd(self, x, buf, g, lr, mu, first):
+        with torch.no_grad():
+            if first:
+                buf.copy_(g)
+            else:
+                buf.mul_(mu).add_(g)
+            x.sub_(lr * buf)
+
+    def hallucinate(self, static, dynamic, sidx, didx, w, b):
+        self._hal = None
+        return R.hallucinator(static[sidx], dynamic[didx], w, b)
+
+    def hallucinate_backward(self, g_out, static, dynamic, sidx, didx, w, need_static, b=None):
+        st = static.detach().clone().requires_grad_(True)
+        dy = dynamic.detach().clone().requires_grad_(True)
+        wv = w.detach().clone().requires_grad_(True)
+        bv = torch.zeros(3, requires_grad=True)
+        out = R.hallucinator(st[sidx], dy[didx], wv, bv)
+        gs = torch.autograd.grad(out, [st, dy, wv, bv], g_out)
+        return gs[1], (gs[0] if need_static else None), gs[2], gs[3]

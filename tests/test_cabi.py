@@ -1,0 +1,65 @@
+"""The C-ABI shared library loads and exports every symbol include/vd_hip.h declares
+(no compute calls: there is no GPU in the CPU test tier)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "vd_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(vd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from video_distillation_amd import hip
+    assert declared_functions() == sorted(hip.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    from video_distillation_amd import hip
+    if not os.path.exists(hip.LIB_PATH):
+        hip.build()
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    lib.vd_abi_version.restype = ctypes.c_int
+    assert lib.vd_abi_version() == 1
+
+
+def test_params_struct_layout_matches_header():
+    """ctypes mirror of VdConvParams: same field order as the C struct (names must appear in the
+    header in the same sequence) and the size hipcc computes for it."""
+    from video_distillation_amd import hip
+    text = open(os.path.join(ROOT, "include", "vd_hip.h")).read()
+    body = text[text.index("typedef struct VdConvParams {") + len("typedef struct VdConvParams {"):text.index("} VdConvParams;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl or decl.startswith("typedef"):
+            continue
+        decl = re.sub(r"^(const\s+)?[A-Za-z_0-9]+\s*\*?\s*", "", decl, count=1)
+        names += [n.strip().lstrip("*") for n in decl.split(",")]
+    assert names == [f[0] for f in hip.VdConvParams._fields_]
+    assert ctypes.sizeof(hip.VdConvParams) % 8 == 0
+
+
+def test_product_has_no_cpu_fallback():
+    import torch
+    from video_distillation_amd import networks, utils
+    net = networks.ConvNet3D(3, 5, 128, 3, 'relu', 'none', 'maxpooling', 8, (64, 64))
+    with pytest.raises(RuntimeError):
+        net.embed(torch.zeros(1, 8, 3, 64, 64))
+    with pytest.raises(RuntimeError):
+        utils.Conv3DNet()(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 1, 8, 8))
+    # nothing under the product package imports the oracle
+    pkg = os.path.join(ROOT, "video_distillation_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn

@@ -1,0 +1,167 @@
+"""world_size-2 ``gloo`` runs of the DM / s2d trainers' host logic (class sharding, collectives)
+on the CPU with the oracle as compute backend; results must equal the 1-rank run and the
+golden fixtures G3 / G5 (sharding identity)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.cpu_backend import OracleBackend
+from video_distillation_amd import distill
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def randn(seed, *shapes):
+    g = torch.Generator().manual_seed(int(seed))
+    return [torch.randn(*s, generator=g) for s in shapes]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+class _Pool:
+    pass
+
+
+def _g3_setup(rank, world):
+    z = np.load(os.path.join(GOLDEN, "g3_dm_steps.npz"))
+    (syn,) = randn(z["syn_seed"], (3, 8, 3, 64, 64))
+    reals = [randn(z["real_seeds"][it], *[(4, 8, 3, 64, 64)] * 3) for it in range(2)]
+    pool = _Pool(); pool.clips = torch.cat([torch.cat(r) for r in reals]); pool.counts = [4] * 3; pool.offsets = [0, 4, 8]
+    lo, hi = distill.class_range(3, rank, world)
+    tr = distill.DMTrainer(OracleBackend(net_seeds=z["net_seeds"]), pool, 3, 1, 4, lr_img=float(z["lr"]),
+                           momentum=float(z["momentum"]), rank=rank, world=world, image_syn=syn[lo:hi].clone())
+    return z, tr
+
+
+def _g3_run(rank, world):
+    z, tr = _g3_setup(rank, world)
+    orig = distill.sample_real_indices
+    losses = []
+    try:
+        for it in range(2):
+            distill.sample_real_indices = lambda it_, counts, offsets, b, classes, it=it: np.concatenate(
+                [it * 12 + offsets[c] + np.arange(4) for c in classes]).astype(np.int64)
+            losses.append(float(tr.global_loss(tr.step(it))))
+    finally:
+        distill.sample_real_indices = orig
+    return z, losses, tr.gather_syn()
+
+
+def _worker_g3(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z, losses, syn = _g3_run(rank, world)
+        if rank == 0:
+            q.put((losses, syn.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=fn, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return out
+
+
+def test_class_range_partitions():
+    for C, W in ((50, 8), (51, 8), (400, 8), (3, 2), (5, 8)):
+        spans = [distill.class_range(C, r, W) for r in range(W)]
+        assert spans[0][0] == 0 and spans[-1][1] == C
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert [b - a for a, b in [distill.class_range(50, r, 8) for r in range(8)]] == [7, 7, 6, 6, 6, 6, 6, 6]
+
+
+def test_real_batch_sampling_is_sharding_invariant():
+    counts, offsets = [93] * 6, [0, 93, 186, 279, 372, 465]
+    full = distill.sample_real_indices(7, counts, offsets, 64, range(6))
+    parts = np.concatenate([distill.sample_real_indices(7, counts, offsets, 64, range(a, b)) for a, b in ((0, 2), (2, 6))])
+    np.testing.assert_array_equal(full, parts)
+    assert len(set(full[:64])) == 64 and full[:64].max() < 93          # a permutation prefix of class 0
+    assert distill.sample_real_indices(8, counts, offsets, 64, range(6)).tolist() != full.tolist()
+    few = distill.sample_real_indices(1, [3], [0], 8, [0])             # fewer clips than batch_real
+    assert few.shape == (8,) and few.max() < 3
+    assert distill.sample_real_indices(1, counts, offsets, 64, []).shape == (0,)
+
+
+def test_dm_trainer_single_rank_matches_golden():
+    z, losses, syn = _g3_run(0, 1)
+    np.testing.assert_allclose(losses, z["losses"], rtol=1e-5)
+    np.testing.assert_allclose(syn[:, ::2, :, ::4, ::4].numpy(), z["syn2"], rtol=1e-4, atol=1e-5)
+
+
+def test_dm_trainer_two_ranks_gloo_matches_golden():
+    losses, syn = _spawn(_worker_g3, 2)
+    z = np.load(os.path.join(GOLDEN, "g3_dm_steps.npz"))
+    np.testing.assert_allclose(losses, z["losses"], rtol=1e-5)       # all-reduced loss == 1-rank loss
+    np.testing.assert_allclose(syn[:, ::2, :, ::4, ::4], z["syn2"], rtol=1e-4, atol=1e-5)   # all-gathered clips
+
+
+def _g5_run(rank, world):
+    z = np.load(os.path.join(GOLDEN, "g5_s2d_step.npz"))
+    C, vpc, spc, dpc = 3, 1, 2, 2
+    static_syn, dynamic_syn = randn(z["data_seed"], (C * spc, 3, 64, 64), (C, dpc, 8, 1, 64, 64))
+    reals = randn(z["real_seed"], *[(4, 8, 3, 64, 64)] * C)
+    pool = _Pool(); pool.clips = torch.cat(reals); pool.counts = [4] * C; pool.offsets = [0, 4, 8]
+    tr = distill.S2DTrainer(OracleBackend(net_seeds={0: int(z["net_seed"])}), pool, C, vpc, spc, dpc, 4, static_syn,
+                            dynamic_syn, torch.tensor(z["hal_w"]), torch.tensor(z["hal_b"]), lr_dynamic=10.0,
+                            lr_hal=0.01, rank=rank, world=world)
+    orig = distill.sample_real_indices
+    try:
+        distill.sample_real_indices = lambda it_, counts, offsets, b, classes: np.concatenate(
+            [offsets[c] + np.arange(4) for c in classes]).astype(np.int64)
+        loss = tr.step(0, draws=(z["draws_dyn"], z["draws_sta"]))
+    finally:
+        distill.sample_real_indices = orig
+    if world > 1:
+        loss = loss.clone(); dist.all_reduce(loss)
+    return z, float(loss), tr
+
+
+def _worker_g5(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z, loss, tr = _g5_run(rank, world)
+        if rank == 0:
+            q.put((loss, tr.hal_w.numpy(), tr.dynamic.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_s2d_trainer_single_rank_matches_golden():
+    z, loss, tr = _g5_run(0, 1)
+    assert abs(loss / float(z["loss"]) - 1) < 1e-5
+    np.testing.assert_allclose(tr.hal_w.numpy(), z["hal_w_after"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(tr.dynamic.view(3, 2, 8, 1, 64, 64)[:, :, :, :, ::4, ::4].numpy(), z["dynamic_after"], rtol=1e-4, atol=1e-5)
+    s, d = tr.indices(0, draws=(z["draws_dyn"], z["draws_sta"]))
+    np.testing.assert_array_equal(s, z["static_idx"])
+    np.testing.assert_array_equal(d - 2 * np.arange(3), z["dynamic_idx"])      # flattened (class, dpc) rows
+
+
+def test_s2d_trainer_two_ranks_allreduce_hallucinator_grad():
+    loss, hal_w, dyn0 = _spawn(_worker_g5, 2)
+    z = np.load(os.path.join(GOLDEN, "g5_s2d_step.npz"))
+    assert abs(loss / float(z["loss"]) - 1) < 1e-5
+    np.testing.assert_allclose(hal_w, z["hal_w_after"], rtol=1e-5, atol=1e-7)   # shared params: grads summed over ranks
+    np.testing.assert_allclose(dyn0.reshape(2, 2, 8, 1, 64, 64)[:, :, :, :, ::4, ::4], z["dynamic_after"][:2], rtol=1e-4, atol=1e-5)
