@@ -44,7 +44,8 @@ typedef struct VdConvParams {
     const int32_t* tables;        /* a_off / out / tap tables                                 */
     const int32_t* boxes;         /* [nbox][6]                                                */
     const int32_t* gather;        /* [nbox][gather_stride]: LDS slot -> source slot | clip<<24 */
-    int64_t gather_stride;
+    int64_t gather_stride;        /* multiple of 64 (one LDS-DMA wave-instruction = 64 slots)   */
+    const void* zero_slot;        /* 16 zero bytes in device memory (source of zero fill)      */
     int32_t nbox, nclips, ncl;
     int32_t CC, F, H, W, S, NT, MW, MTW;
     int32_t epi, pool_t, relu, n_out, n_stride;

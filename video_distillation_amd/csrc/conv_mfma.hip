@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
     constexpr int H1 = MTW - H0;
-    constexpr int LU = X3 ? 4 : 8;      // patch loads in flight per thread
+    constexpr int LU = 16;              // DMA groups issued back to back per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
 
-    const int gstride = (int)p.gather_stride;
+    const int ngroups = (int)(p.gather_stride >> 6);   // 64-slot DMA groups per patch
+    const int nwaves = nthreads >> 6;
+    const uint4* zslot = reinterpret_cast<const uint4*>(p.zero_slot);
     const int64_t clip_slots = (int64_t)p.CC * p.F * p.H * p.W;
     const int64_t chunk_slots = (int64_t)p.F * p.H * p.W;
 
@@ -103,28 +105,37 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
         __syncthreads();  // previous chunk's fragment reads are done
         // ---- stage the patch of this channel chunk: LU independent 16-byte loads in flight ----
         const uint4* csrc = src + (int64_t)clip0 * clip_slots + (int64_t)cc * chunk_slots;
-        // (the gather rows are padded with -2 = "no LDS slot" to a multiple of 2048 entries)
-        for (int base = tid; base < gstride; base += nthreads * LU) {
-            int e[LU];
-#pragma unroll
-            for (int u = 0; u < LU; ++u) e[u] = gtab[base + u * nthreads];
-            uint4 vh[LU], vl[LU];
+        // LDS-DMA: each wave-instruction moves 64 slots (1 KiB) straight into LDS; the per-lane
+        // SOURCE address comes from the gather table, the destination is lane-linear.  Zero fill
+        // (conv padding, pitch padding, clips beyond the batch) reads a 16-byte zero slot.
+        // (all table entries are consumed BEFORE the first DMA is issued: with an LDS-DMA in flight
+        //  hipcc waits vmcnt(0) at the next use of an ordinary load, which would serialise the DMAs)
+        for (int g0 = wave * LU; g0 < ngroups; g0 += nwaves * LU) {
+            uint32_t off[LU];
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
-                const int ci = e[u] >> 24;
-                const bool ok = (e[u] >= 0) && (clip0 + ci < p.nclips);
-                // 32-bit offset inside this clip group's chunk (ncl * CC*F*H*W slots < 2^28)
-                const uint32_t off = ok ? ((uint32_t)ci * (uint32_t)clip_slots + (uint32_t)(e[u] & 0xFFFFFF)) : 0u;
-                vh[u] = csrc[off];
-                if constexpr (X3) vl[u] = csrc[off + p.src_plane_stride];
-                if (!ok) { vh[u] = make_uint4(0, 0, 0, 0); if constexpr (X3) vl[u] = make_uint4(0, 0, 0, 0); }
+                const int grpi = (g0 + u < ngroups) ? g0 + u : ngroups - 1;
+                const int e = gtab[grpi * 64 + lane];
+                const int ci = e >> 24;
+                const bool ok = (e >= 0) && (clip0 + ci < p.nclips);
+                off[u] = ok ? ((uint32_t)ci * (uint32_t)clip_slots + (uint32_t)(e & 0xFFFFFF)) : 0xFFFFFFFFu;
             }
 #pragma unroll
+            for (int u = 0; u < LU; ++u) asm volatile("" : "+v"(off[u]));   // materialise here, not after a DMA
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
             for (int u = 0; u < LU; ++u) {
-                const int idx = base + u * nthreads;
-                if (e[u] != -2) {
-                    *reinterpret_cast<uint4*>(smem + idx * 16) = vh[u];
-                    if constexpr (X3) *reinterpret_cast<uint4*>(smem + plane_bytes + idx * 16) = vl[u];
+                if (g0 + u < ngroups) {     // wave-uniform
+                    const bool ok = off[u] != 0xFFFFFFFFu;
+                    const uint4* gp = ok ? csrc + off[u] : zslot;
+                    char* dst = smem + (g0 + u) * 1024;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                    if constexpr (X3) {
+                        const uint4* gl = ok ? csrc + off[u] + p.src_plane_stride : zslot;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gl,
+                                                         (__attribute__((address_space(3))) void*)(dst + plane_bytes), 16, 0, 0);
+                    }
                 }
             }
         }

@@ -44,7 +44,9 @@ class _DevPlan:
         p.n_out, p.n_stride = plan.n_out, plan.n_stride
         p.out_clip_stride = plan.out_clip_stride
         p.out_chunk_stride, p.out_t_stride = plan.out_chunk_stride, plan.out_t_stride
-        p.lds_plane_bytes = (plan.lds_slots + 1) * 16
+        p.lds_plane_bytes = int(gt.shape[1]) * 16
+        self.zero = torch.zeros(64, dtype=torch.uint8, device=device)
+        p.zero_slot = self.zero.data_ptr()
         p.prec = prec
         p.wpk = self.wpk.data_ptr(); p.w_plane_stride = self.n_w
         self.params = p

@@ -30,7 +30,7 @@ class VdConvParams(ctypes.Structure):
         ("dst", ctypes.c_void_p), ("dst_plane_stride", ctypes.c_int64),
         ("argmax", ctypes.c_void_p),
         ("type_desc", ctypes.c_void_p), ("tables", ctypes.c_void_p), ("boxes", ctypes.c_void_p),
-        ("gather", ctypes.c_void_p), ("gather_stride", ctypes.c_int64),
+        ("gather", ctypes.c_void_p), ("gather_stride", ctypes.c_int64), ("zero_slot", ctypes.c_void_p),
         ("nbox", ctypes.c_int32), ("nclips", ctypes.c_int32), ("ncl", ctypes.c_int32),
         ("CC", ctypes.c_int32), ("F", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
         ("S", ctypes.c_int32), ("NT", ctypes.c_int32), ("MW", ctypes.c_int32), ("MTW", ctypes.c_int32),

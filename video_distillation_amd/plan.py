@@ -106,8 +106,8 @@ class ConvPlan:
         """int32 [nbox, stride]: for every LDS slot of a box's patch the source slot it is
         filled from, relative to the (clip, channel-chunk) base, with the box-local clip index
         in bits 24..30; -1 = zero fill (conv padding, pitch padding, outside the grid)."""
-        stride = -(-self.lds_slots // 2048) * 2048         # whole passes of 256 threads x 8 loads
-        out = np.full((self.nbox, stride), -2, dtype=np.int64)  # -2: beyond the patch, nothing to write
+        stride = -(-(self.lds_slots + 1) // 64) * 64       # whole LDS-DMA wave-instructions (64 slots)
+        out = -np.ones((self.nbox, stride), dtype=np.int64)
         assert self.F * self.H * self.W < (1 << 24) and self.ncl < 128
         for bi, box in enumerate(self.boxes):
             t = self.types[int(box[0])]
