@@ -32,8 +32,10 @@ extern "C" {
 /* One tile program (see video_distillation_amd/plan.py).  All pointers are device
  * pointers; strides are in the units given. */
 typedef struct VdConvParams {
-    const void* src;              /* 16-byte slots, plane 0                                   */
-    int64_t src_plane_stride;     /* slots between the hi and lo planes (x3 precisions)        */
+    const void* src;              /* 16-bit source, plane 0 (slots are 16 bytes at dword offsets) */
+    int64_t src_plane_stride4;    /* dwords between the hi and lo planes (x3 precisions)       */
+    int64_t src_clip_stride4;     /* dwords per clip                                           */
+    int64_t src_chunk_stride4;    /* dwords per 8-channel chunk                                */
     const void* wpk;              /* packed weights [CC][S][NT][64][8] 16-bit, plane 0        */
     int64_t w_plane_stride;       /* 16-bit elements between hi and lo planes                 */
     const float* bias;            /* [n_out] or NULL                                          */
@@ -47,7 +49,7 @@ typedef struct VdConvParams {
     int64_t gather_stride;        /* multiple of 64 (one LDS-DMA wave-instruction = 64 slots)   */
     const void* zero_slot;        /* 16 zero bytes in device memory (source of zero fill)      */
     int32_t nbox, nclips, ncl;
-    int32_t CC, F, H, W, S, NT, MW, MTW;
+    int32_t CC, S, NT, MW, MTW;
     int32_t epi, pool_t, relu, n_out, n_stride;
     int64_t out_clip_stride;
     int32_t out_chunk_stride, out_t_stride;
@@ -69,11 +71,11 @@ int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, void* out_hi
                     int prec, void* stream);
 
 /* (B,T,3,H,W) fp32 clips (the reference's input layout, networks.py:748) -> first-layer
- * source slots [B][T*3][H][OW][8]: slot = x[b,t,c,h,2*ow-3 .. 2*ow+4], zero padded.
- * clip_index (optional, [nclips]) gathers batch clip b from x[clip_index[b]]: the on-device
- * form of get_images() (distill_baseline.py:84-90) over a pool kept resident in HBM. */
-int vd_pix2slots(const float* x, const int64_t* clip_index, int64_t nclips, int T, int H, int W,
-                 void* out_hi, void* out_lo, int prec, void* stream);
+ * source: 16-bit pixel rows [B][T*3][H][pitch], pitch = roundup8(W+8), row = 3 zeros, the W
+ * pixels, zeros.  clip_index (optional, [nclips]) gathers batch clip b from x[clip_index[b]]:
+ * the on-device form of get_images() (distill_baseline.py:84-90) over a pool resident in HBM. */
+int vd_pix2rows(const float* x, const int64_t* clip_index, int64_t nclips, int T, int H, int W,
+                void* out_hi, void* out_lo, int prec, void* stream);
 
 /* Backward of ReLU + MaxPool3d: scatter the pooled gradient to the arg-max position of the
  * dense conv grid and emit it as channels-last slots (source of the input-gradient pass).

@@ -17,7 +17,8 @@ def pack_weights(plan, w_flat):
 
 
 def run_plan(plan, src, w_flat, bias, nclips, out):
-    """src: float array [nclips, CC, F, H, W, 8]; out: flat float64 array (pre-zeroed).
+    """src: float array [nclips, CC, ...] whose trailing dims flatten to the 16-bit ELEMENTS of one
+    channel chunk (2 per dword); out: flat float64 array (pre-zeroed).
     Returns argmax array (same indexing as out) for pooled epilogues."""
     descs, tables = plan.flat_tables()
     wp = pack_weights(plan, w_flat)                       # [CC,S,NT,64,8]
@@ -25,7 +26,7 @@ def run_plan(plan, src, w_flat, bias, nclips, out):
     col, half = lane & 31, lane >> 5
     arg = {}
     gather = plan.gather_table()
-    src_flat = src.reshape(src.shape[0], src.shape[1], -1, 8)
+    src_flat = src.reshape(src.shape[0], src.shape[1], -1)
     ngroups = -(-nclips // plan.ncl)
     for grp in range(ngroups):
         clip0 = grp * plan.ncl
@@ -47,7 +48,8 @@ def run_plan(plan, src, w_flat, bias, nclips, out):
                     b = clip0 + (e >> 24)
                     if b >= nclips:
                         continue
-                    patch[idx] = src_flat[b, cc, e & 0xFFFFFF]
+                    o2 = 2 * (e & 0xFFFFFF)                   # dword offset -> element offset
+                    patch[idx] = src_flat[b, cc, o2:o2 + 8]
                 # A[row, s, half, j]
                 for s in range(plan.S):
                     for hh in range(2):
@@ -100,13 +102,10 @@ def run_plan(plan, src, w_flat, bias, nclips, out):
     return arg
 
 
-def pix_to_slots(x_btchw):
-    """What vd_pix2slots produces: [B, 1, T*3, H, OW, 8] with slot = x[t,c,h,2ow-3..2ow+4]."""
+def pix_to_rows(x_btchw):
+    """What vd_pix2rows produces: [B, 1, T*3, H, pitch] with 3 leading zero pixels per row."""
     B, T, C, H, W = x_btchw.shape
-    OW = (W + 6 - 7) // 2 + 1
-    xp = np.zeros((B, T, C, H, W + 8))
-    xp[..., 3:3 + W] = x_btchw
-    out = np.zeros((B, 1, T * C, H, OW, 8))
-    for ow in range(OW):
-        out[:, 0, :, :, ow, :] = xp[..., 2 * ow:2 * ow + 8].reshape(B, T * C, H, 8)
+    pitch = P.pix_row_pitch(W)
+    out = np.zeros((B, 1, T * C, H, pitch))
+    out[..., 3:3 + W] = x_btchw.reshape(B, 1, T * C, H, W)
     return out

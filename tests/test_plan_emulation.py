@@ -52,7 +52,7 @@ def test_forward_layer0(net, acts):
     params, x, col = acts
     pl = net["fwd"][0]
     n = 2
-    src = E.pix_to_slots(x[:n].numpy())
+    src = E.pix_to_rows(x[:n].numpy())
     out = np.zeros(n * int(np.prod(pl.out_shape)))
     arg = E.run_plan(pl, src, params[0].numpy().ravel(), params[1].numpy(), n, out)
     got = cl_to_bcthw(out, n, pl.out_shape)

@@ -28,7 +28,7 @@ for prec in precs:
     L = hip.lib(); st = hip.stream_ptr(eng.device)
     g = geo
     import numpy as np
-    n_slots0 = nclips*16*3*112*56
+    n_slots0 = nclips*16*3*112*15
     slots0 = eng._buf("slots0", (eng.planes, n_slots0, 8), torch.int16)
     n1 = nclips*int(np.prod(eng.fwd[0].plan.out_shape[:-1])); act1 = eng._buf("act1", (eng.planes, n1, 8), torch.int16)
     n2 = nclips*int(np.prod(eng.fwd[1].plan.out_shape[:-1])); act2 = eng._buf("act2", (eng.planes, n2, 8), torch.int16)
@@ -42,7 +42,7 @@ for prec in precs:
         return a.elapsed_time(b)/reps
     w = eng._weights
     lo = slots0[1] if eng.planes == 2 else None
-    tp = t(lambda: L.vd_pix2slots(hip.ptr(x), None, ctypes.c_int64(nclips), 16, 112, 112, hip.ptr(slots0[0]), hip.ptr(lo), eng.prec, st))
+    tp = t(lambda: L.vd_pix2rows(hip.ptr(x), None, ctypes.c_int64(nclips), 16, 112, 112, hip.ptr(slots0[0]), hip.ptr(lo), eng.prec, st))
     t0 = t(lambda: eng.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, None, nclips))
     t1 = t(lambda: eng.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, None, nclips))
     t2 = t(lambda: eng.fwd[2].run(act2, n2, w[5], feats.data_ptr(), 0, None, nclips))

@@ -66,26 +66,27 @@ extern "C" int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, v
 }
 
 // ------------------------------------------------------------------------------------------
-// one thread per output slot: (clip, f = t*3+c, h, ow) -> x[clip, t, c, h, 2ow-3 .. 2ow+4]
-__global__ void pix2slots_kernel(const float* __restrict__ x, const int64_t* __restrict__ clip_index, int64_t nslots,
-                                 int rows_per_clip, int H, int W, int OW,
-                                 uint4* __restrict__ hi, uint4* __restrict__ lo, int prec) {
+// one thread per 8 output elements (16 bytes) of a padded 16-bit pixel row:
+// out[row][8j .. 8j+7] = x[row][8j-3 .. 8j+4] (zero outside [0,W))
+__global__ void pix2rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ clip_index, int64_t nchunks,
+                                int rows_per_clip, int W, int cpr,
+                                uint4* __restrict__ hi, uint4* __restrict__ lo, int prec) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nslots) return;
-    const int ow = (int)(i % OW);
-    int64_t row = i / OW;                       // (clip, f, h) flattened == row of x
+    if (i >= nchunks) return;
+    const int j = (int)(i % cpr);
+    int64_t row = i / cpr;                      // (clip, f, h) flattened == row of x
     if (clip_index != nullptr) {                // gather: clip b of the batch is pool clip clip_index[b]
         const int64_t b = row / rows_per_clip;
         row = clip_index[b] * rows_per_clip + (row - b * rows_per_clip);
     }
     const float* xr = x + row * W;
-    const int w0 = 2 * ow - 3;
+    const int w0 = 8 * j - 3;
     uint16_t h16[8], l16[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int ww = w0 + j;
+    for (int k = 0; k < 8; ++k) {
+        const int ww = w0 + k;
         const float v = (ww >= 0 && ww < W) ? xr[ww] : 0.f;
-        split16p(prec, v, h16[j], l16[j]);
+        split16p(prec, v, h16[k], l16[k]);
     }
     uint4 vh, vl;
     vh.x = h16[0] | ((uint32_t)h16[1] << 16); vh.y = h16[2] | ((uint32_t)h16[3] << 16);
@@ -98,14 +99,14 @@ __global__ void pix2slots_kernel(const float* __restrict__ x, const int64_t* __r
     }
 }
 
-extern "C" int vd_pix2slots(const float* x, const int64_t* clip_index, int64_t nclips, int T, int H, int W,
-                            void* out_hi, void* out_lo, int prec, void* stream) {
-    const int OW = (W + 6 - 7) / 2 + 1;
-    const int64_t nslots = nclips * T * 3 * H * OW;
-    if (nslots <= 0) return 0;
+extern "C" int vd_pix2rows(const float* x, const int64_t* clip_index, int64_t nclips, int T, int H, int W,
+                           void* out_hi, void* out_lo, int prec, void* stream) {
+    const int cpr = ((W + 8) + 7) / 8;          // 16-byte chunks per padded row
+    const int64_t nchunks = nclips * T * 3 * H * cpr;
+    if (nchunks <= 0) return 0;
     const int bs = 256;
-    hipLaunchKernelGGL(pix2slots_kernel, dim3((unsigned)((nslots + bs - 1) / bs)), dim3(bs), 0,
-                       reinterpret_cast<hipStream_t>(stream), x, clip_index, nslots, T * 3 * H, H, W, OW, (uint4*)out_hi,
+    hipLaunchKernelGGL(pix2rows_kernel, dim3((unsigned)((nchunks + bs - 1) / bs)), dim3(bs), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, clip_index, nchunks, T * 3 * H, W, cpr, (uint4*)out_hi,
                        (uint4*)out_lo, prec);
     return (int)hipGetLastError();
 }

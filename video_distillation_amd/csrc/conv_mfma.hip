@@ -91,11 +91,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
 
     const int ngroups = (int)(p.gather_stride >> 6);   // 64-slot DMA groups per patch
     const int nwaves = nthreads >> 6;
-    const uint4* zslot = reinterpret_cast<const uint4*>(p.zero_slot);
-    const int64_t clip_slots = (int64_t)p.CC * p.F * p.H * p.W;
-    const int64_t chunk_slots = (int64_t)p.F * p.H * p.W;
-
-    const uint4* src = reinterpret_cast<const uint4*>(p.src);
+    const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);   // dword addressing: a slot may start at any dword
     const uint4* wbase = reinterpret_cast<const uint4*>(p.wpk);
     const int64_t w_lo = p.w_plane_stride >> 3;  // uint4 units
     const int wstep = p.NT * 64;                 // uint4 per K-step
@@ -104,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
     for (int cc = 0; cc < p.CC; ++cc) {
         __syncthreads();  // previous chunk's fragment reads are done
         // ---- stage the patch of this channel chunk: LU independent 16-byte loads in flight ----
-        const uint4* csrc = src + (int64_t)clip0 * clip_slots + (int64_t)cc * chunk_slots;
+        const uint32_t* csrc = src + (int64_t)clip0 * p.src_clip_stride4 + (int64_t)cc * p.src_chunk_stride4;
         // LDS-DMA: each wave-instruction moves 64 slots (1 KiB) straight into LDS; the per-lane
         // SOURCE address comes from the gather table, the destination is lane-linear.  Zero fill
         // (conv padding, pitch padding, clips beyond the batch) reads a 16-byte zero slot.
@@ -118,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
                 const int e = gtab[grpi * 64 + lane];
                 const int ci = e >> 24;
                 const bool ok = (e >= 0) && (clip0 + ci < p.nclips);
-                off[u] = ok ? ((uint32_t)ci * (uint32_t)clip_slots + (uint32_t)(e & 0xFFFFFF)) : 0xFFFFFFFFu;
+                off[u] = ok ? ((uint32_t)ci * (uint32_t)p.src_clip_stride4 + (uint32_t)(e & 0xFFFFFF)) : 0xFFFFFFFFu;
             }
 #pragma unroll
             for (int u = 0; u < LU; ++u) asm volatile("" : "+v"(off[u]));   // materialise here, not after a DMA
@@ -127,12 +124,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
             for (int u = 0; u < LU; ++u) {
                 if (g0 + u < ngroups) {     // wave-uniform
                     const bool ok = off[u] != 0xFFFFFFFFu;
-                    const uint4* gp = ok ? csrc + off[u] : zslot;
+                    const uint32_t* gp = ok ? csrc + off[u] : zslot;
                     char* dst = smem + (g0 + u) * 1024;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
                     if constexpr (X3) {
-                        const uint4* gl = ok ? csrc + off[u] + p.src_plane_stride : zslot;
+                        const uint32_t* gl = ok ? csrc + off[u] + p.src_plane_stride4 : zslot;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gl,
                                                          (__attribute__((address_space(3))) void*)(dst + plane_bytes), 16, 0, 0);
                     }

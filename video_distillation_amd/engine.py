@@ -38,7 +38,8 @@ class _DevPlan:
         p.type_desc = self.type_desc.data_ptr(); p.tables = self.tables.data_ptr(); p.boxes = self.boxes.data_ptr()
         p.gather = self.gather.data_ptr(); p.gather_stride = int(gt.shape[1])
         p.nbox = plan.nbox; p.ncl = plan.ncl
-        p.CC, p.F, p.H, p.W, p.S = plan.CC, plan.F, plan.H, plan.W, plan.S
+        p.CC, p.S = plan.CC, plan.S
+        p.src_clip_stride4, p.src_chunk_stride4 = plan.clip_stride4, plan.chunk_stride4
         p.NT, p.MW, p.MTW = plan.NT, plan.MW, plan.MTW
         p.epi, p.pool_t, p.relu = plan.epi, plan.pool_t, int(plan.relu)
         p.n_out, p.n_stride = plan.n_out, plan.n_stride
@@ -58,10 +59,10 @@ class _DevPlan:
                                             hip.ptr(self.wpk[0]), hip.ptr(lo), self.prec, hip.stream_ptr(w.device)),
                   "vd_pack_weights")
 
-    def run(self, src: torch.Tensor, src_plane_stride: int, bias: Optional[torch.Tensor], dst_ptr: int,
+    def run(self, src: torch.Tensor, src_plane_slots: int, bias: Optional[torch.Tensor], dst_ptr: int,
             dst_plane_stride: int, argmax: Optional[torch.Tensor], nclips: int) -> None:
         p = self.params
-        p.src = src.data_ptr(); p.src_plane_stride = src_plane_stride
+        p.src = src.data_ptr(); p.src_plane_stride4 = src_plane_slots * 4
         p.bias = 0 if bias is None else bias.data_ptr()
         p.dst = dst_ptr; p.dst_plane_stride = dst_plane_stride
         p.argmax = 0 if argmax is None else argmax.data_ptr()
@@ -131,18 +132,18 @@ class EmbedEngine:
         saved = []
         L = hip.lib()
         st = hip.stream_ptr(self.device)
-        OW0 = self.dims[0][7]
+        rowp = P.pix_row_pitch(g.width)
         per1 = int(np.prod(self.fwd[0].plan.out_shape[:-1]))
         per2 = int(np.prod(self.fwd[1].plan.out_shape[:-1]))
         for c0 in range(0, B, self.chunk):
             nb = min(self.chunk, B - c0)
-            n_slots0 = nb * g.frames * 3 * g.height * OW0
+            n_slots0 = nb * g.frames * 3 * g.height * (rowp // 8)      # 16-byte units of the padded pixel rows
             slots0 = self._buf("slots0", (self.planes, n_slots0, 8), torch.int16)
             lo = slots0[1] if self.planes == 2 else None
             xin = x[c0:] if index is None else x
-            hip.check(L.vd_pix2slots(hip.ptr(xin), hip.ptr(None if index is None else index[c0:]),
+            hip.check(L.vd_pix2rows(hip.ptr(xin), hip.ptr(None if index is None else index[c0:]),
                                      ctypes.c_int64(nb), g.frames, g.height, g.width,
-                                     hip.ptr(slots0[0]), hip.ptr(lo), self.prec, st), "vd_pix2slots")
+                                     hip.ptr(slots0[0]), hip.ptr(lo), self.prec, st), "vd_pix2rows")
             n1, n2 = nb * per1, nb * per2
             act1 = self._buf("act1", (self.planes, n1, 8), torch.int16)
             act2 = self._buf("act2", (self.planes, n2, 8), torch.int16)

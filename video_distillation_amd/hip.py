@@ -18,13 +18,14 @@ LIB_PATH = os.path.join(_HERE, "libvd_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("conv_mfma.hip", "aux_kernels.hip")]
 
 PREC = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
-EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_pack_weights", "vd_pix2slots", "vd_unpool_relu_bwd", "vd_dm_loss",
+EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_pack_weights", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_dm_loss",
            "vd_sgd_momentum", "vd_hallucinator_fwd", "vd_hallucinator_bwd", "vd_match_rows_fwd", "vd_match_rows_bwd")
 
 
 class VdConvParams(ctypes.Structure):
     _fields_ = [
-        ("src", ctypes.c_void_p), ("src_plane_stride", ctypes.c_int64),
+        ("src", ctypes.c_void_p), ("src_plane_stride4", ctypes.c_int64),
+        ("src_clip_stride4", ctypes.c_int64), ("src_chunk_stride4", ctypes.c_int64),
         ("wpk", ctypes.c_void_p), ("w_plane_stride", ctypes.c_int64),
         ("bias", ctypes.c_void_p),
         ("dst", ctypes.c_void_p), ("dst_plane_stride", ctypes.c_int64),
@@ -32,8 +33,7 @@ class VdConvParams(ctypes.Structure):
         ("type_desc", ctypes.c_void_p), ("tables", ctypes.c_void_p), ("boxes", ctypes.c_void_p),
         ("gather", ctypes.c_void_p), ("gather_stride", ctypes.c_int64), ("zero_slot", ctypes.c_void_p),
         ("nbox", ctypes.c_int32), ("nclips", ctypes.c_int32), ("ncl", ctypes.c_int32),
-        ("CC", ctypes.c_int32), ("F", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
-        ("S", ctypes.c_int32), ("NT", ctypes.c_int32), ("MW", ctypes.c_int32), ("MTW", ctypes.c_int32),
+        ("CC", ctypes.c_int32), ("S", ctypes.c_int32), ("NT", ctypes.c_int32), ("MW", ctypes.c_int32), ("MTW", ctypes.c_int32),
         ("epi", ctypes.c_int32), ("pool_t", ctypes.c_int32), ("relu", ctypes.c_int32),
         ("n_out", ctypes.c_int32), ("n_stride", ctypes.c_int32),
         ("out_clip_stride", ctypes.c_int64),

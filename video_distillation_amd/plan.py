@@ -83,6 +83,11 @@ class ConvPlan:
     out_chunk_stride: int        # CL: slots per output channel chunk (Fo*Ho*Wo)
     out_shape: Tuple[int, ...]   # logical output grid (for allocation / tests)
     out_t_stride: int = 0        # pool_t == 1: distance between the two outputs of a row group
+    # source addressing in 4-byte units (an LDS slot is filled from 16 bytes at any dword offset)
+    w_step4: int = 4             # dwords between neighbouring w positions (4 = packed slots)
+    row_pitch4: int = 0          # dwords between neighbouring h rows
+    clip_stride4: int = 0        # dwords per clip (all channel chunks)
+    chunk_stride4: int = 0       # dwords per 8-channel chunk
     rows_total: int = 0
     rows_useful: int = 0
     meta: Dict = field(default_factory=dict)
@@ -108,7 +113,7 @@ class ConvPlan:
         in bits 24..30; -1 = zero fill (conv padding, pitch padding, outside the grid)."""
         stride = -(-(self.lds_slots + 1) // 64) * 64       # whole LDS-DMA wave-instructions (64 slots)
         out = -np.ones((self.nbox, stride), dtype=np.int64)
-        assert self.F * self.H * self.W < (1 << 24) and self.ncl < 128
+        assert self.F * self.H * self.row_pitch4 < (1 << 24) and self.ncl < 128
         for bi, box in enumerate(self.boxes):
             t = self.types[int(box[0])]
             f0, h0, w0 = int(box[1]), int(box[2]), int(box[3])
@@ -119,7 +124,7 @@ class ConvPlan:
             sf, sh, sw = f0 + f, h0 + h, w0 + w
             ok = (f < t.pf) & (h < t.ph) & (w < t.pw) & (sf >= 0) & (sf < self.F) & (sh >= 0) & (sh < self.H) \
                 & (sw >= 0) & (sw < self.W)
-            rel = (sf * self.H + sh) * self.W + sw
+            rel = (sf * self.H + sh) * self.row_pitch4 + sw * self.w_step4     # dword offset in the chunk
             out[bi, :idx.size] = np.where(ok, rel | (ci << 24), -1)
         return out.astype(np.int32)
 
@@ -336,7 +341,8 @@ def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps
     # origin: out_index is affine in (a,b,c), so out(ci,a0+a,..) = out(ci,a,..) + [out(0,a0,..)-out(0,0,0,0)].
     widx = widx_fn(CC, S, NT, taps_p, ntaps)
     rows_useful = row_dims[0] * row_dims[1] * row_dims[2]
-    return ConvPlan(name=name, CC=CC, F=F, H=H, W=W, NT=NT, MW=MW, MTW=MTW, S=S, ncl=ncl,
+    return ConvPlan(name=name, CC=CC, F=F, H=H, W=W, row_pitch4=W * 4, chunk_stride4=F * H * W * 4,
+                    clip_stride4=CC * F * H * W * 4, NT=NT, MW=MW, MTW=MTW, S=S, ncl=ncl,
                     boxes=np.asarray(boxes, dtype=np.int32), types=types, widx=widx, epi=epi,
                     pool_t=pool_t, relu=relu, n_out=n_out, n_stride=n_stride,
                     out_clip_stride=out_clip_stride, out_chunk_stride=out_chunk_stride,
@@ -412,10 +418,19 @@ def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: 
                       clip_stride, chunk_stride, out_shape, lds_budget, ncl_options)
 
 
+def pix_row_pitch(w: int) -> int:
+    """Elements per 16-bit pixel row written by vd_pix2rows: 3 leading zeros + W pixels + zero
+    tail, rounded up to a multiple of 8 (16 bytes)."""
+    return -(-(w + 8) // 8) * 8
+
+
 def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_budget: int = 3700,
                      mtw_options=(4,)) -> ConvPlan:
-    """First layer: Conv3d(3->cout) + ReLU + MaxPool(1,2,2) over the 'kw-slot' source made by
-    vd_pix2slots: [clip][t*3+c][h][ow] where a slot holds x[t,c,h,2*ow-3 .. 2*ow+4]."""
+    """First layer: Conv3d(3->cout) + ReLU + MaxPool(1,2,2).  Source = 16-bit pixel rows made by
+    vd_pix2rows: [clip][t*3+c][h][W+8] with 3 zero pixels in front (and >=5 behind), so that the
+    'kw-slot' of output column ow -- x[t,c,h,2*ow-3 .. 2*ow+4], the 7 kernel columns plus one
+    zero-weight tap -- is the 16 bytes at dword offset ow of the row: overlapping windows are
+    read straight out of HBM/L2 by the LDS-DMA, nothing is duplicated in memory."""
     cin = 3
     T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
     Ho, Wo = OH // 2, OW // 2
@@ -452,6 +467,9 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
                       widx_fn, cout, NT, MW, mtw_options, EPI_POOL_CL, 1, True, out_index, None, 0,
                       clip_stride, chunk_stride, (cout // 8, T, Ho, Wo, 8), lds_budget, (1,))
     plan.out_t_stride = Ho * Wo
+    rowp = pix_row_pitch(w_in)
+    plan.w_step4, plan.row_pitch4 = 1, rowp // 2
+    plan.chunk_stride4 = plan.clip_stride4 = t_in * cin * h_in * (rowp // 2)
     return plan
 
 
