@@ -42,6 +42,7 @@ typedef struct VdConvParams {
     void* dst;                    /* POOL_CL: 16-bit slots plane 0; otherwise fp32            */
     int64_t dst_plane_stride;     /* POOL_CL: slots between hi and lo planes                  */
     uint8_t* argmax;              /* pooled epilogues: arg-max byte per output, or NULL        */
+    const int32_t* col_off;       /* ROWS: element offset of column n, or NULL (= n*n_stride)  */
     const int32_t* type_desc;     /* [ntypes][16]                                             */
     const int32_t* tables;        /* a_off / out / tap tables                                 */
     const int32_t* boxes;         /* [nbox][6]                                                */
@@ -55,6 +56,7 @@ typedef struct VdConvParams {
     int32_t out_chunk_stride, out_t_stride;
     int32_t lds_plane_bytes;
     int32_t prec;
+    int32_t dbg;                  /* ablation switches for profiling (0 in production)         */
 } VdConvParams;
 
 int vd_abi_version(void);

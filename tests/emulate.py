@@ -73,7 +73,8 @@ def run_plan(plan, src, w_flat, bias, nclips, out):
                     ci = o // plan.out_clip_stride
                     if clip0 + ci >= nclips:
                         continue
-                    out[base + n[nvalid] * plan.n_stride] = acc[r, nvalid]
+                    coff = plan.col_off[n[nvalid]] if plan.col_off is not None else n[nvalid] * plan.n_stride
+                    out[base + coff] = acc[r, nvalid]
             else:
                 for t in range(mt):
                     for q in range(4):

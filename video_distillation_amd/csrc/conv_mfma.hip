@@ -52,6 +52,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
     constexpr int H1 = MTW - H0;
+    constexpr int AD = (MTW <= 4) ? 2 : 1;              // x1: A-fragment prefetch distance (K-steps)
+    constexpr int DB = X3 ? 2 : (MTW <= 4 ? 2 : 3);   // B-fragment prefetch distance; (DB+1) % (AD+1) == 0
+    static_assert(X3 || (DB + 1) % (AD + 1) == 0, "ring sizes must divide the unroll factor");
     constexpr int LU = 16;              // DMA groups issued back to back per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -101,13 +104,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
     for (int cc = 0; cc < p.CC; ++cc) {
         __syncthreads();  // previous chunk's fragment reads are done
         // ---- stage the patch of this channel chunk: LU independent 16-byte loads in flight ----
+        // first B fragments of this chunk: issued before the patch DMA so both latencies overlap
+        const uint4* wp = wbase + ((int64_t)cc * S * p.NT + wn) * 64 + lane;
+        auto load_b = [&](int s, uint4& bh, uint4& bl) {
+            const int sc = (s < S) ? s : S - 1;
+            bh = wp[(int64_t)sc * wstep];
+            if constexpr (X3) bl = wp[(int64_t)sc * wstep + w_lo];
+        };
+        uint4 bqh[DB + 1], bql[DB + 1];
+#pragma unroll
+        for (int u = 0; u < DB; ++u) {
+            bql[u] = make_uint4(0, 0, 0, 0);
+            load_b(u, bqh[u], bql[u]);
+        }
+        bql[DB] = make_uint4(0, 0, 0, 0);
         const uint32_t* csrc = src + (int64_t)clip0 * p.src_clip_stride4 + (int64_t)cc * p.src_chunk_stride4;
         // LDS-DMA: each wave-instruction moves 64 slots (1 KiB) straight into LDS; the per-lane
         // SOURCE address comes from the gather table, the destination is lane-linear.  Zero fill
         // (conv padding, pitch padding, clips beyond the batch) reads a 16-byte zero slot.
         // (all table entries are consumed BEFORE the first DMA is issued: with an LDS-DMA in flight
         //  hipcc waits vmcnt(0) at the next use of an ordinary load, which would serialise the DMAs)
-        for (int g0 = wave * LU; g0 < ngroups; g0 += nwaves * LU) {
+        for (int g0 = wave * LU; g0 < ngroups && !(p.dbg & 4); g0 += nwaves * LU) {
             uint32_t off[LU];
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
@@ -138,75 +155,90 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
         }
         __syncthreads();
 
-        // ---- K loop over tap pairs: B fragments two steps ahead, A fragments half a step ahead ----
-        const uint4* wp = wbase + ((int64_t)cc * S * p.NT + wn) * 64 + lane;
-        uint4 b0h, b1h, b2h, b0l, b1l, b2l;
-        b0l = b1l = b2l = make_uint4(0, 0, 0, 0);
-        auto load_b = [&](int s, uint4& bh, uint4& bl) {
-            const int sc = (s < S) ? s : S - 1;
-            bh = wp[(int64_t)sc * wstep];
-            if constexpr (X3) bl = wp[(int64_t)sc * wstep + w_lo];
-        };
-        load_b(0, b0h, b0l);
-        load_b(1, b1h, b1l);
-        int tap_cur = lds_tap[half];
-        uint4 A0h[H0], A0l[H0], A1h[H1], A1l[H1];
+        // ---- K loop over tap pairs ---------------------------------------------------------
+        if (p.dbg & 2) continue;
+        // B fragments are fetched DB steps ahead (counted vmcnt), A fragments one full step ahead
+        // (x1: two register sets) or half a step ahead (x3: registers are short).
+        if constexpr (!X3) {
+            // tap offsets live in LDS and are read one step before the A reads that need them
+            auto tap_of = [&](int st) {
+                const int sc = (st < S) ? st : S - 1;
+                return lds_tap[2 * sc + half];
+            };
+            uint4 A[AD + 1][MTW];
 #pragma unroll
-        for (int i = 0; i < H0; ++i) {
-            A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_cur);
-            if constexpr (X3) A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_cur);
-        }
-        auto step = [&](int s, const uint4& bh, const uint4& bl) {
-            const int sn = (s + 1 < S) ? s + 1 : s;
-            const int tap_next = lds_tap[2 * sn + half];
+            for (int d = 0; d < AD; ++d) {
+                const int tp = tap_of(d);
 #pragma unroll
-            for (int i = 0; i < H1; ++i) {
-                A1h[i] = *reinterpret_cast<const uint4*>(smem + a_off[H0 + i] + tap_cur);
-                if constexpr (X3) A1l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[H0 + i] + tap_cur);
+                for (int i = 0; i < MTW; ++i) A[d][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            int tp = tap_of(AD);
+            for (int s = 0; s < S; s += DB + 1) {
+#pragma unroll
+                for (int u = 0; u <= DB; ++u) {
+                    if (s + u >= S) break;
+                    load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
+                    const int tp_next = tap_of(s + u + AD + 1);
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i)
+                        A[(u + AD) % (AD + 1)][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) acc[i] = mfma16<PREC>(A[u % (AD + 1)][i], bqh[u], acc[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    tp = tp_next;
+                }
+            }
+        } else {
+            int tap_cur = lds_tap[half];
+            uint4 A0h[H0], A0l[H0], A1h[H1], A1l[H1];
 #pragma unroll
             for (int i = 0; i < H0; ++i) {
-                if constexpr (X3) {
-                    acc[i] = mfma16<PREC>(A0l[i], bh, acc[i]);
-                    acc[i] = mfma16<PREC>(A0h[i], bl, acc[i]);
-                }
-                acc[i] = mfma16<PREC>(A0h[i], bh, acc[i]);
+                A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_cur);
+                A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_cur);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < S; s += DB + 1) {
 #pragma unroll
-            for (int i = 0; i < H0; ++i) {
-                A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
-                if constexpr (X3) A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_next);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u <= DB; ++u) {
+                    if (s + u >= S) break;
+                    load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
+                    const uint4 bh = bqh[u], bl = bql[u];
+                    const int sn = (s + u + 1 < S) ? s + u + 1 : s + u;
+                    const int tap_next = lds_tap[2 * sn + half];
 #pragma unroll
-            for (int i = 0; i < H1; ++i) {
-                if constexpr (X3) {
-                    acc[H0 + i] = mfma16<PREC>(A1l[i], bh, acc[H0 + i]);
-                    acc[H0 + i] = mfma16<PREC>(A1h[i], bl, acc[H0 + i]);
+                    for (int i = 0; i < H1; ++i) {
+                        A1h[i] = *reinterpret_cast<const uint4*>(smem + a_off[H0 + i] + tap_cur);
+                        A1l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[H0 + i] + tap_cur);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < H0; ++i) {
+                        acc[i] = mfma16<PREC>(A0l[i], bh, acc[i]);
+                        acc[i] = mfma16<PREC>(A0h[i], bl, acc[i]);
+                        acc[i] = mfma16<PREC>(A0h[i], bh, acc[i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < H0; ++i) {
+                        A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
+                        A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_next);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < H1; ++i) {
+                        acc[H0 + i] = mfma16<PREC>(A1l[i], bh, acc[H0 + i]);
+                        acc[H0 + i] = mfma16<PREC>(A1h[i], bl, acc[H0 + i]);
+                        acc[H0 + i] = mfma16<PREC>(A1h[i], bh, acc[H0 + i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    tap_cur = tap_next;
                 }
-                acc[H0 + i] = mfma16<PREC>(A1h[i], bh, acc[H0 + i]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            tap_cur = tap_next;
-        };
-        for (int s = 0; s < S; s += 3) {
-            load_b(s + 2, b2h, b2l);
-            __builtin_amdgcn_sched_barrier(0);
-            step(s, b0h, b0l);
-            if (s + 1 >= S) break;
-            load_b(s + 3, b0h, b0l);
-            __builtin_amdgcn_sched_barrier(0);
-            step(s + 1, b1h, b1l);
-            if (s + 2 >= S) break;
-            load_b(s + 4, b1h, b1l);
-            __builtin_amdgcn_sched_barrier(0);
-            step(s + 2, b2h, b2l);
         }
     }
 
     // ---- epilogue ---------------------------------------------------------------------
+    if (p.dbg & 1) { if (acc[0][0] == 123.456f) reinterpret_cast<float*>(p.dst)[0] = 1.f; return; }
     const int n = wn * 32 + (lane & 31);
     const bool n_ok = n < p.n_out;
     const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
@@ -215,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
 
     if (p.epi == VD_EPI_ROWS) {
         float* dst = reinterpret_cast<float*>(p.dst);
+        const int64_t coff = (p.col_off != nullptr) ? (int64_t)p.col_off[n & 31] : (int64_t)n * p.n_stride;
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
             const int gi = wm * MTW + i;
@@ -225,58 +258,60 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
                 const int64_t idx = out_base + o;
                 float v = acc[i][k] + bias;
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (o >= 0 && n_ok && idx < out_total) dst[idx + (int64_t)n * p.n_stride] = v;
+                if (o >= 0 && n_ok && idx < out_total) dst[idx + coff] = v;
             }
         }
         return;
     }
 
-    // pooled epilogues: registers 8*qh .. 8*qh+7 of this lane are one 2x2x2 row group
+    // pooled epilogues: registers 8*qh .. 8*qh+7 of this lane are one 2x2x2 row group.
+    // max first (bias is per lane and ReLU monotone: relu(max_j(a_j) + b) == max_j relu(a_j + b)),
+    // 32-bit per-lane offsets on top of a 64-bit per-workgroup base.
+    const int64_t lim64 = out_total - out_base;
+    const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
+    const bool feat = (p.epi == VD_EPI_POOL_FEAT);
+    const uint32_t chan = feat ? (uint32_t)n * (uint32_t)p.n_stride
+                               : (uint32_t)(n >> 3) * (uint32_t)p.out_chunk_stride * 8u + (uint32_t)(n & 7);
+    float* dstf = reinterpret_cast<float*>(p.dst) + out_base;
+    uint16_t* dst16 = reinterpret_cast<uint16_t*>(p.dst) + out_base * 8;
+    uint8_t* amx = p.argmax ? p.argmax + (feat ? out_base : out_base * 8) : nullptr;
+    const int nsets = (p.pool_t == 2) ? 1 : 2;
+    const int wsz = (p.pool_t == 2) ? 8 : 4;
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         const int gi = wm * MTW + i;
 #pragma unroll
         for (int qh = 0; qh < 2; ++qh) {
             const int o = o_tab[gi * 4 + half + 2 * qh];
-            if (o < 0) continue;
-            float v[8];
+            if (o < 0 || !n_ok) continue;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v[j] = acc[i][8 * qh + j] + bias;
-                if (p.relu) v[j] = fmaxf(v[j], 0.f);
-            }
-            const int nsets = (p.pool_t == 2) ? 1 : 2;
-            for (int st = 0; st < nsets; ++st) {
-                float mx;
-                int am;
-                if (p.pool_t == 2) {
-                    mx = v[0]; am = 0;
+            for (int st = 0; st < 2; ++st) {
+                if (st >= nsets) break;
+                const int b4 = st * 4;
+                float mx = acc[i][8 * qh + b4];
+                int am = 0;
 #pragma unroll
-                    for (int j = 1; j < 8; ++j) if (v[j] > mx) { mx = v[j]; am = j; }
-                } else {
-                    const int b4 = st * 4;
-                    mx = v[b4]; am = 0;
-#pragma unroll
-                    for (int j = 1; j < 4; ++j) if (v[b4 + j] > mx) { mx = v[b4 + j]; am = j; }
+                for (int j = 1; j < 8; ++j) {
+                    if (j >= wsz) break;
+                    const float v = acc[i][8 * qh + b4 + j];
+                    if (v > mx) { mx = v; am = j; }
                 }
+                mx += bias;
+                if (p.relu) mx = fmaxf(mx, 0.f);
+                const int base = o + st * p.out_t_stride;
+                if (base >= lim) continue;
                 const uint8_t ab = (uint8_t)(am | (mx > 0.f ? 0 : 0x80));
-                const int64_t base = out_base + o + (int64_t)st * p.out_t_stride;
-                if (p.epi == VD_EPI_POOL_FEAT) {
-                    if (base < out_total && n_ok) {
-                        const int64_t idx = base + (int64_t)n * p.n_stride;
-                        reinterpret_cast<float*>(p.dst)[idx] = mx;
-                        if (p.argmax) p.argmax[idx] = ab;
-                    }
+                if (feat) {
+                    const uint32_t idx = (uint32_t)base + chan;
+                    dstf[idx] = mx;
+                    if (amx) amx[idx] = ab;
                 } else {
-                    if (base < out_total && n_ok) {
-                        const int64_t idx = (base + (int64_t)(n >> 3) * p.out_chunk_stride) * 8 + (n & 7);
-                        uint16_t hi, lo;
-                        split16<PREC>(mx, hi, lo);
-                        uint16_t* d16 = reinterpret_cast<uint16_t*>(p.dst);
-                        d16[idx] = hi;
-                        if constexpr (X3) d16[idx + p.dst_plane_stride * 8] = lo;
-                        if (p.argmax) p.argmax[idx] = ab;
-                    }
+                    const uint32_t idx = (uint32_t)base * 8u + chan;
+                    uint16_t hi, lo;
+                    split16<PREC>(mx, hi, lo);
+                    dst16[idx] = hi;
+                    if constexpr (X3) dst16[idx + p.dst_plane_stride * 8] = lo;
+                    if (amx) amx[idx] = ab;
                 }
             }
         }

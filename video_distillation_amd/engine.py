@@ -50,6 +50,8 @@ class _DevPlan:
         p.zero_slot = self.zero.data_ptr()
         p.prec = prec
         p.wpk = self.wpk.data_ptr(); p.w_plane_stride = self.n_w
+        self.col_off = None if plan.col_off is None else torch.from_numpy(plan.col_off.copy()).to(device)
+        p.col_off = 0 if self.col_off is None else self.col_off.data_ptr()
         self.params = p
 
     def pack(self, w: torch.Tensor) -> None:

@@ -29,7 +29,7 @@ class VdConvParams(ctypes.Structure):
         ("wpk", ctypes.c_void_p), ("w_plane_stride", ctypes.c_int64),
         ("bias", ctypes.c_void_p),
         ("dst", ctypes.c_void_p), ("dst_plane_stride", ctypes.c_int64),
-        ("argmax", ctypes.c_void_p),
+        ("argmax", ctypes.c_void_p), ("col_off", ctypes.c_void_p),
         ("type_desc", ctypes.c_void_p), ("tables", ctypes.c_void_p), ("boxes", ctypes.c_void_p),
         ("gather", ctypes.c_void_p), ("gather_stride", ctypes.c_int64), ("zero_slot", ctypes.c_void_p),
         ("nbox", ctypes.c_int32), ("nclips", ctypes.c_int32), ("ncl", ctypes.c_int32),
@@ -38,7 +38,7 @@ class VdConvParams(ctypes.Structure):
         ("n_out", ctypes.c_int32), ("n_stride", ctypes.c_int32),
         ("out_clip_stride", ctypes.c_int64),
         ("out_chunk_stride", ctypes.c_int32), ("out_t_stride", ctypes.c_int32),
-        ("lds_plane_bytes", ctypes.c_int32), ("prec", ctypes.c_int32),
+        ("lds_plane_bytes", ctypes.c_int32), ("prec", ctypes.c_int32), ("dbg", ctypes.c_int32),
     ]
 
 

@@ -88,6 +88,7 @@ class ConvPlan:
     row_pitch4: int = 0          # dwords between neighbouring h rows
     clip_stride4: int = 0        # dwords per clip (all channel chunks)
     chunk_stride4: int = 0       # dwords per 8-channel chunk
+    col_off: Optional[np.ndarray] = None   # EPI_ROWS: element offset of output column n (else n*n_stride)
     rows_total: int = 0
     rows_useful: int = 0
     meta: Dict = field(default_factory=dict)
@@ -540,6 +541,55 @@ def plan_dgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, 
     return plan
 
 
+def plan_dgrad_pix(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, lds_budget: int = 3700,
+                   mtw_options=(7, 8)) -> ConvPlan:
+    """Input gradient of the FIRST layer (cin = 3 pixel channels) with the four stride-2 parity
+    classes merged into the N dimension: one output row = the 2x2 pixel block (t, 2b..2b+1,
+    2c..2c+1), its cin*4 = 12 values are the GEMM columns n = c*4 + ph*2 + pw.  All of them read
+    the same 3x4x4 neighbourhood of dy, so K = 48 taps x cout with structural zeros in B where a
+    tap does not reach a parity.  3x less MFMA work than four N=3 (padded to 32) passes."""
+    assert cin * 4 <= 32 and cout % 8 == 0 and h_in % 2 == 0 and w_in % 2 == 0
+    CC = cout // 8
+    T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
+    taps = [(dt, dh, dw) for dt in range(3) for dh in range(4) for dw in range(4)]
+    rows = (t_in, h_in // 2, w_in // 2)
+    NT, MW = 1, 4
+    col, half = _lane_cols()
+
+    def widx_fn(CC_, S, NT_, taps_p, ntaps):
+        idx = -np.ones((CC_, S, NT_, 64, 8), dtype=np.int64)
+        for s in range(S):
+            for hh in range(2):
+                p = 2 * s + hh
+                if p >= ntaps:
+                    continue
+                dt, dh, dw = taps_p[p]
+                kt = 2 - dt
+                lanes = np.where(half == hh)[0]
+                n = col[lanes]
+                ci, ph, pw = n // 4, (n // 2) % 2, n % 2
+                kh = ph + 5 - 2 * dh          # from oh = b + (dh-1) = (2b+ph+3-kh)/2
+                kw = pw + 5 - 2 * dw
+                ok = (ci < cin) & (kh >= 0) & (kh < KH) & (kw >= 0) & (kw < KW)
+                for cc in range(CC_):
+                    nn = cc * 8 + np.arange(8)
+                    flat = (((nn[None, :] * cin + ci[:, None]) * KT + kt) * KH + kh[:, None]) * KW + kw[:, None]
+                    idx[cc, s, 0, lanes, :] = np.where(ok[:, None], flat, -1)
+        return idx.astype(np.int32)
+
+    clip_stride = t_in * cin * h_in * w_in
+
+    def out_index(ci, a, b, c):
+        return ci * clip_stride + (a * cin * h_in + 2 * b) * w_in + 2 * c
+    max_ncl = 1
+    plan = _make_plan(name, (T, OH, OW), CC, rows, (1, 1, 1), (-1, -1, -1), (1, 1, 1), taps, widx_fn,
+                      cin * 4, NT, MW, mtw_options, EPI_ROWS, 0, False, out_index, None, 0,
+                      clip_stride, 0, (t_in, cin, h_in, w_in), lds_budget, (max_ncl,))
+    n = np.arange(32)
+    plan.col_off = np.where(n < cin * 4, (n // 4) * h_in * w_in + ((n // 2) % 2) * w_in + (n % 2), 0).astype(np.int32)
+    return plan
+
+
 # ----------------------------------------------------------------------------------------
 # whole network
 # ----------------------------------------------------------------------------------------
@@ -588,6 +638,9 @@ def plan_network(geo: NetGeometry, lds_budget: int = 3700) -> Dict[str, object]:
     bwd = []
     for li in range(3):
         cin, cout, t, h, w = dims[li][:5]
+        if li == 0 and h % 2 == 0 and w % 2 == 0:
+            bwd.append([plan_dgrad_pix("bwd0_merged", cin, cout, t, h, w, lds_budget=lds_budget)])
+            continue
         bwd.append([plan_dgrad("bwd%d_%d%d" % (li, ph, pw), cin, cout, t, h, w, ph, pw, pixel_out=(li == 0),
                                lds_budget=lds_budget) for ph, pw in dgrad_classes(h, w)])
     out = {"geo": geo, "dims": dims, "fwd": fwd, "bwd": bwd}
