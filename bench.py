@@ -115,13 +115,15 @@ def main():
         torch.cuda.synchronize()
 
     for it in range(args.warmup):
-        trainer.step(it)
+        trainer.step(it, overlap=True)
+    trainer.sync()
     backend.eng_real.profile = []           # HIP-event pairs around the dominant kernel's launches
     barrier()
     t0 = time.perf_counter()
     losses = []
     for it in range(args.warmup, args.warmup + args.steps):
-        losses.append(trainer.global_loss(trainer.step(it)))
+        losses.append(trainer.global_loss(trainer.step(it, overlap=True)))
+    trainer.sync()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -75,6 +75,14 @@ def fresh_network_weights(seed: int, device) -> List[torch.Tensor]:
     return out
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class HipBackend:
     """Production backend: EmbedEngine (MFMA kernels) + the small HIP kernels."""
 
@@ -86,6 +94,15 @@ class HipBackend:
         self.eng_real = engine.EmbedEngine(geo, prec=prec_real, device=device, chunk=chunk)
         self.eng_syn = self.eng_real if prec_syn == prec_real else engine.EmbedEngine(geo, prec=prec_syn, device=device, chunk=chunk)
         self.num_feat = geo.num_feat
+        # Two HIP streams: the real-clip forward (98.5 % of the FLOPs, large launches) runs on one,
+        # the synthetic-clip forward + backward + optimiser (small launches that cannot fill 256
+        # CUs) on a higher-priority second one, so the small kernels overlap the big ones -- also
+        # across iterations: the backward of step i runs under the real forward of step i+1.
+        self.two_streams = (self.eng_syn is not self.eng_real)
+        if self.two_streams:
+            self.s_real = torch.cuda.Stream(device=self.device)
+            self.s_syn = torch.cuda.Stream(device=self.device, priority=-1)
+        self._ev_real = None
 
     def new_network(self, seed: int):
         return fresh_network_weights(seed, self.device)
@@ -94,6 +111,36 @@ class HipBackend:
         self.eng_real.set_weights(weights)
         if self.eng_syn is not self.eng_real:
             self.eng_syn.set_weights(weights)
+
+    # -- stream plumbing (no-ops for single-stream / CPU test backends) ----------------------
+    def fork(self):
+        """Make both work streams wait for whatever the caller's stream has queued."""
+        if self.two_streams:
+            cur = torch.cuda.current_stream(self.device)
+            self.s_real.wait_stream(cur)
+            self.s_syn.wait_stream(cur)
+
+    def on_real(self):
+        return torch.cuda.stream(self.s_real) if self.two_streams else _NullCtx()
+
+    def on_syn(self):
+        return torch.cuda.stream(self.s_syn) if self.two_streams else _NullCtx()
+
+    def real_to_syn(self, *tensors):
+        """The synthetic-side stream may consume `tensors` produced on the real-side stream."""
+        if self.two_streams:
+            self.s_syn.wait_stream(self.s_real)
+            for t in tensors:
+                t.record_stream(self.s_syn)
+
+    def join(self, *tensors):
+        """The caller's stream waits for both work streams."""
+        if self.two_streams:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.s_real)
+            cur.wait_stream(self.s_syn)
+            for t in tensors:
+                t.record_stream(cur)
 
     def embed_pool(self, pool: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
         return self.eng_real.forward(pool, index=index)
@@ -189,14 +236,40 @@ class DMTrainer:
         self.buf = torch.zeros_like(self.image_syn)
         self.steps_done = 0
 
-    def step(self, it: int) -> torch.Tensor:
+    def step(self, it: int, overlap: bool = False) -> torch.Tensor:
         """One distillation iteration over this rank's classes; returns the rank-local loss sum
-        as a 0-dim device tensor (no host sync)."""
+        as a 0-dim device tensor (no host sync).  With ``overlap`` the work is left in flight on
+        the backend's two streams (the caller must ``sync()`` / ``global_loss()`` before reading
+        results); consecutive steps then overlap: backward(i) runs under the real forward(i+1)."""
         be, ncls = self.be, len(self.classes)
-        be.set_weights(be.new_network(seed=it))
         idx = sample_real_indices(it, self.pool.counts, self.pool.offsets, self.batch_real, self.classes)
         dev = self.image_syn.device
-        f_real = be.embed_pool(self.pool.clips, torch.as_tensor(idx, device=dev))
+        idx_t = torch.as_tensor(idx, device=dev)
+        weights = be.new_network(seed=it)
+        fork, on_real, on_syn = getattr(be, "fork", None), getattr(be, "on_real", _NullCtx), getattr(be, "on_syn", _NullCtx)
+        if fork:
+            fork()
+        if getattr(be, "two_streams", False):
+            for w in weights:
+                w.record_stream(be.s_real)
+                w.record_stream(be.s_syn)
+            with on_real():
+                be.eng_real.set_weights(weights)
+                f_real = be.embed_pool(self.pool.clips, idx_t)
+            with on_syn():
+                be.eng_syn.set_weights(weights)
+                f_syn, handle = be.embed_keep(self.image_syn)
+                be.real_to_syn(f_real)
+                loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
+                grad = be.embed_backward(handle, g_syn)
+                be.sgd(self.image_syn, self.buf, grad, self.lr_img, self.momentum, first=(self.steps_done == 0))
+                loss = loss_c.sum()
+            if not overlap:
+                be.join(loss)
+            self.steps_done += 1
+            return loss
+        be.set_weights(weights)
+        f_real = be.embed_pool(self.pool.clips, idx_t)
         f_syn, handle = be.embed_keep(self.image_syn)
         loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
         grad = be.embed_backward(handle, g_syn)
@@ -206,11 +279,19 @@ class DMTrainer:
 
     def global_loss(self, local_loss: torch.Tensor) -> torch.Tensor:
         """Sum of the per-rank losses (== the reference's ``loss`` before /num_classes)."""
-        if self.world > 1:
-            import torch.distributed as dist
-            local_loss = local_loss.clone()
-            dist.all_reduce(local_loss, op=dist.ReduceOp.SUM)
+        be = self.be
+        ctx = be.on_syn() if getattr(be, "two_streams", False) else _NullCtx()
+        with ctx:
+            if self.world > 1:
+                import torch.distributed as dist
+                local_loss = local_loss.clone()
+                dist.all_reduce(local_loss, op=dist.ReduceOp.SUM)
         return local_loss
+
+    def sync(self) -> None:
+        """Wait (on the caller's stream) for everything the trainer has in flight."""
+        if getattr(self.be, "two_streams", False):
+            self.be.join()
 
     def gather_syn(self) -> torch.Tensor:
         """All synthetic clips in class order on every rank (evaluation / ``images_*.pt``)."""
