@@ -45,7 +45,7 @@ typedef struct VdConvParams {
     const int32_t* col_off;       /* ROWS: element offset of column n, or NULL (= n*n_stride)  */
     const int32_t* type_desc;     /* [ntypes][16]                                             */
     const int32_t* tables;        /* a_off / out / tap tables                                 */
-    const int32_t* boxes;         /* [nbox][6]                                                */
+    const int32_t* boxes;         /* [nbox][8]: a_off / out / tap table offsets, out origin, type */
     const int32_t* gather;        /* [nbox][gather_stride]: LDS slot -> source slot | clip<<24 */
     int64_t gather_stride;        /* multiple of 64 (one LDS-DMA wave-instruction = 64 slots)   */
     const void* zero_slot;        /* 16 zero bytes in device memory (source of zero fill)      */
@@ -57,6 +57,8 @@ typedef struct VdConvParams {
     int32_t lds_plane_bytes;
     int32_t prec;
     int32_t dbg;                  /* ablation switches for profiling (0 in production)         */
+    int32_t reserved0;
+    uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
 } VdConvParams;
 
 int vd_abi_version(void);
@@ -66,6 +68,12 @@ int vd_abi_version(void);
  * ConvNet3D.features (networks.py:757, 768-770, 799) and their autograd backward w.r.t. the
  * input (distill_baseline.py:354, parameters frozen :336-337). */
 int vd_conv_mfma(const VdConvParams* params, void* stream);
+
+/* The same tile program for the FIRST layer's forward over clips without gradient (x1 precisions,
+ * one box type, NT=2 MW=2 MTW=4 S=32, pooled channels-last output, no arg-max): a persistent
+ * kernel, one workgroup per CU, B fragments resident in registers, next patch DMA'd into a second
+ * LDS buffer under the current box's MFMAs.  Same results as vd_conv_mfma. */
+int vd_conv0_persistent(const VdConvParams* params, void* stream);
 
 /* fp32 weights -> MFMA-fragment-ordered 16-bit operands (hi plane, and lo plane for the x3
  * precisions) through the planner's gather table.  n = number of packed elements. */

@@ -1,0 +1,27 @@
+"""Diagnostic: per-workgroup phase timeline (s_memtime) of a forward layer."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+from video_distillation_amd import engine, plan
+nclips = 512
+li = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+geo = plan.NetGeometry(16, 112, 112)
+x = torch.randn(nclips, 16, 3, 112, 112, device="cuda")
+params = [torch.randn(s, device="cuda") * 0.02 for s in [(64,3,3,7,7),(64,),(128,64,3,7,7),(128,),(128,128,3,7,7),(128,)]]
+eng = engine.EmbedEngine(geo, prec="f16", chunk=nclips)
+eng.set_weights(params)
+eng.forward(x); torch.cuda.synchronize()
+dp = eng.fwd[li]
+grid = dp.plan.grid(nclips)
+buf = torch.zeros(grid * 8, dtype=torch.int64, device="cuda")
+dp.params.dbg = 8; dp.params.stamps = buf.data_ptr()
+eng.forward(x); torch.cuda.synchronize()
+dp.params.dbg = 0
+t = buf.cpu().numpy().reshape(grid, 8).astype(np.float64)
+t0 = t[:, 0].min()
+d = np.diff(t[:, :8], axis=1)   # phases: setup, dma-issue, dma-wait, kloop(first chunk + rest), epilogue
+print("grid", grid, "kernel span (cycles of 100MHz*?):", t[:, 7].max() - t0)
+names = ["setup(prologue)", "dma issue", "dma wait+barrier", "K loop (all chunks)", "epi: wait other waves", "epi: max+stage+barrier", "epi: stores issue"]
+for k, nm in enumerate(names):
+    print("%-22s median %8.0f  p10 %8.0f  p90 %8.0f" % (nm, np.median(d[:, k]), np.percentile(d[:, k], 10), np.percentile(d[:, k], 90)))
+print("total per WG median", np.median(t[:, 7] - t[:, 0]))

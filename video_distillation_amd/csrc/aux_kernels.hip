@@ -82,11 +82,25 @@ __global__ void pix2rows_kernel(const float* __restrict__ x, const int64_t* __re
     const float* xr = x + row * W;
     const int w0 = 8 * j - 3;
     uint16_t h16[8], l16[8];
+    if ((W & 3) == 0) {
+        // three aligned 16-byte loads cover x[8j-4 .. 8j+7]; the wanted window is elements 1..8
+        float f[12];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int ww = w0 + k;
-        const float v = (ww >= 0 && ww < W) ? xr[ww] : 0.f;
-        split16p(prec, v, h16[k], l16[k]);
+        for (int q = 0; q < 3; ++q) {
+            const int wq = 8 * j - 4 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wq >= 0 && wq < W) v = *reinterpret_cast<const float4*>(xr + wq);
+            f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) split16p(prec, f[k + 1], h16[k], l16[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ww = w0 + k;
+            const float v = (ww >= 0 && ww < W) ? xr[ww] : 0.f;
+            split16p(prec, v, h16[k], l16[k]);
+        }
     }
     uint4 vh, vl;
     vh.x = h16[0] | ((uint32_t)h16[1] << 16); vh.y = h16[2] | ((uint32_t)h16[3] << 16);

@@ -52,10 +52,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
     constexpr int H1 = MTW - H0;
-    constexpr int AD = (MTW <= 4) ? 2 : 1;              // x1: A-fragment prefetch distance (K-steps)
-    constexpr int DB = X3 ? 2 : (MTW <= 4 ? 2 : 3);   // B-fragment prefetch distance; (DB+1) % (AD+1) == 0
+    constexpr int AD = 1;                               // x1: A-fragment prefetch distance (K-steps)
+    constexpr int DB = X3 ? 2 : 3;                      // B-fragment prefetch distance; (DB+1) % (AD+1) == 0
     static_assert(X3 || (DB + 1) % (AD + 1) == 0, "ring sizes must divide the unroll factor");
-    constexpr int LU = 16;              // DMA groups issued back to back per wave
+    constexpr int LU = (MTW <= 4) ? 14 : 17;   // DMA groups per wave (4 waves x LU x 64 slots >= the plan's patch)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -66,25 +66,63 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
     const int wm = wave / p.NT;
     const int half = lane >> 5;
 
-    const int bid = blockIdx.x;
+    // XCD-aware block order (T1): workgroups are dealt round-robin to the 8 XCDs, so give each XCD a
+    // CONTIGUOUS range of boxes -- neighbouring boxes of a clip share halo rows, which then hit
+    // in that XCD's private L2 instead of being fetched once per XCD.  Bijective for any grid.
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    unsigned long long t_stamp[8];
+    auto stamp = [&](int k) { if (p.dbg & 8) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); t_stamp[k] = t; } };
+    stamp(0);
+    auto finish = [&]() {
+        if ((p.dbg & 8) && tid == 0 && p.stamps != nullptr) {
+            stamp(7);
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)blockIdx.x * 8;
+            for (int k = 0; k < 8; ++k) o[k] = t_stamp[k];
+        }
+    };
     const int grp = bid / p.nbox;
     const int bi = bid - grp * p.nbox;
-    const int32_t* box = p.boxes + bi * 6;
-    const int ty = box[0], out_rel = box[4];
     const int clip0 = grp * p.ncl;
-    const int32_t* desc = p.type_desc + ty * 16;
-    const int32_t* a_tab = p.tables + desc[7];
-    const int32_t* o_tab = p.tables + desc[8];
-    const int32_t* t_tab = p.tables + desc[9];
+    const int ngroups = (int)(p.gather_stride >> 6);   // 64-slot DMA groups per patch
+    const int nwaves = nthreads >> 6;
+
+    // (1) the gather entries of this wave's DMA groups: the longest dependent chain of the prologue,
+    //     so they are requested first; they are the same for every channel chunk and stay in registers.
     const int32_t* gtab = p.gather + (int64_t)bi * p.gather_stride;
+    constexpr bool HOIST = (MTW < 8);   // MTW = 8 has no registers to spare: it re-reads the table per chunk
+    uint32_t goff[HOIST ? LU : 1];
+#pragma unroll
+    for (int u = 0; u < (HOIST ? LU : 1); ++u) {
+        const int gi = wave + u * nwaves;
+        const int e = gtab[((gi < ngroups) ? gi : ngroups - 1) * 64 + lane];
+        const int ci = e >> 24;
+        const bool ok = (e >= 0) && (clip0 + ci < p.nclips);
+        goff[u] = ok ? ((uint32_t)ci * (uint32_t)p.src_clip_stride4 + (uint32_t)(e & 0xFFFFFF)) : 0xFFFFFFFFu;
+    }
+    // (2) one 32-byte row per box: table offsets of its type + output origin (scalar loads)
+    const int32_t* box = p.boxes + bi * 8;
+    const int32_t* a_tab = p.tables + box[0];
+    const int32_t* o_tab = p.tables + box[1];
+    const int32_t* t_tab = p.tables + box[2];
+    const int out_rel = box[3];
 
     const int plane_bytes = p.lds_plane_bytes;
     int* lds_tap = reinterpret_cast<int*>(smem + (X3 ? 2 : 1) * plane_bytes);
+    int* lds_otab = lds_tap + 2 * p.S;
     for (int k = tid; k < 2 * p.S; k += nthreads) lds_tap[k] = t_tab[k];
+    if (p.epi != VD_EPI_ROWS)
+        for (int k = tid; k < p.MW * MTW * 4; k += nthreads) lds_otab[k] = o_tab[k];
 
     int a_off[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
+#pragma unroll
+    for (int u = 0; u < (HOIST ? LU : 1); ++u) asm volatile("" : "+v"(goff[u]));   // consumed before any DMA is in flight
 
     f32x16 acc[MTW];
 #pragma unroll
@@ -92,8 +130,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
 
-    const int ngroups = (int)(p.gather_stride >> 6);   // 64-slot DMA groups per patch
-    const int nwaves = nthreads >> 6;
     const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);   // dword addressing: a slot may start at any dword
     const uint4* wbase = reinterpret_cast<const uint4*>(p.wpk);
@@ -119,42 +155,69 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
         }
         bql[DB] = make_uint4(0, 0, 0, 0);
         const uint32_t* csrc = src + (int64_t)clip0 * p.src_clip_stride4 + (int64_t)cc * p.src_chunk_stride4;
+        if (cc == 0) stamp(1);
         // LDS-DMA: each wave-instruction moves 64 slots (1 KiB) straight into LDS; the per-lane
         // SOURCE address comes from the gather table, the destination is lane-linear.  Zero fill
         // (conv padding, pitch padding, clips beyond the batch) reads a 16-byte zero slot.
         // (all table entries are consumed BEFORE the first DMA is issued: with an LDS-DMA in flight
         //  hipcc waits vmcnt(0) at the next use of an ordinary load, which would serialise the DMAs)
-        for (int g0 = wave * LU; g0 < ngroups && !(p.dbg & 4); g0 += nwaves * LU) {
-            uint32_t off[LU];
+        if (HOIST && !(p.dbg & 4)) {
+            int gi = wave;
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
-                const int grpi = (g0 + u < ngroups) ? g0 + u : ngroups - 1;
-                const int e = gtab[grpi * 64 + lane];
-                const int ci = e >> 24;
-                const bool ok = (e >= 0) && (clip0 + ci < p.nclips);
-                off[u] = ok ? ((uint32_t)ci * (uint32_t)p.src_clip_stride4 + (uint32_t)(e & 0xFFFFFF)) : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < LU; ++u) asm volatile("" : "+v"(off[u]));   // materialise here, not after a DMA
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                if (g0 + u < ngroups) {     // wave-uniform
-                    const bool ok = off[u] != 0xFFFFFFFFu;
-                    const uint32_t* gp = ok ? csrc + off[u] : zslot;
-                    char* dst = smem + (g0 + u) * 1024;
+                asm volatile("" : "+s"(gi));   // keep the per-group scalars (bound test, LDS address) out of SGPR-hungry hoisting
+                if (gi < ngroups) {     // wave-uniform
+                    const bool ok = goff[HOIST ? u : 0] != 0xFFFFFFFFu;
+                    const uint32_t* gp = ok ? csrc + goff[HOIST ? u : 0] : zslot;
+                    char* dst = smem + gi * 1024;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
                     if constexpr (X3) {
-                        const uint32_t* gl = ok ? csrc + off[u] + p.src_plane_stride4 : zslot;
+                        const uint32_t* gl = ok ? csrc + goff[HOIST ? u : 0] + p.src_plane_stride4 : zslot;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gl,
                                                          (__attribute__((address_space(3))) void*)(dst + plane_bytes), 16, 0, 0);
                     }
                 }
+                gi += nwaves;
             }
         }
+        if (!HOIST && !(p.dbg & 4)) {
+            constexpr int LB = 8;
+            for (int g0 = wave; g0 < ngroups; g0 += nwaves * LB) {
+                uint32_t off[LB];
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    const int gi = g0 + u * nwaves;
+                    const int e = gtab[((gi < ngroups) ? gi : ngroups - 1) * 64 + lane];
+                    const int ci = e >> 24;
+                    const bool ok = (e >= 0) && (clip0 + ci < p.nclips);
+                    off[u] = ok ? ((uint32_t)ci * (uint32_t)p.src_clip_stride4 + (uint32_t)(e & 0xFFFFFF)) : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < LB; ++u) asm volatile("" : "+v"(off[u]));   // all consumed before the first DMA
+                int gi = g0;
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    asm volatile("" : "+s"(gi));
+                    if (gi < ngroups) {
+                        const bool ok = off[u] != 0xFFFFFFFFu;
+                        const uint32_t* gp = ok ? csrc + off[u] : zslot;
+                        char* dst = smem + gi * 1024;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                        if constexpr (X3) {
+                            const uint32_t* gl = ok ? csrc + off[u] + p.src_plane_stride4 : zslot;
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gl,
+                                                             (__attribute__((address_space(3))) void*)(dst + plane_bytes), 16, 0, 0);
+                        }
+                    }
+                    gi += nwaves;
+                }
+            }
+        }
+        if (cc == 0) stamp(2);
         __syncthreads();
-
+        if (cc == 0) stamp(3);
         // ---- K loop over tap pairs ---------------------------------------------------------
         if (p.dbg & 2) continue;
         // B fragments are fetched DB steps ahead (counted vmcnt), A fragments one full step ahead
@@ -238,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
     }
 
     // ---- epilogue ---------------------------------------------------------------------
+    stamp(4);
     if (p.dbg & 1) { if (acc[0][0] == 123.456f) reinterpret_cast<float*>(p.dst)[0] = 1.f; return; }
     const int n = wn * 32 + (lane & 31);
     const bool n_ok = n < p.n_out;
@@ -261,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
                 if (o >= 0 && n_ok && idx < out_total) dst[idx + coff] = v;
             }
         }
+        finish();
         return;
     }
 
@@ -276,31 +341,65 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
     uint16_t* dst16 = reinterpret_cast<uint16_t*>(p.dst) + out_base * 8;
     uint8_t* amx = p.argmax ? p.argmax + (feat ? out_base : out_base * 8) : nullptr;
     const int nsets = (p.pool_t == 2) ? 1 : 2;
-    const int wsz = (p.pool_t == 2) ? 8 : 4;
+    // Channels-last outputs without arg-max (the real-clip path): stage the pooled tile through LDS
+    // and write whole 16-byte slots.  (Per-lane 2-byte stores cost one memory instruction per value
+    // and made the epilogue as expensive as the K loop of the first layer.)
+    const bool staged = !feat && amx == nullptr;
+    const int NCH = p.NT * 32;
+    const int Q = p.MW * MTW * 4 * nsets;
+    uint16_t* stg = reinterpret_cast<uint16_t*>(smem);
+    if (staged) __syncthreads();          // every wave is done reading the patch
+    stamp(5);
+    // All register indices below are compile-time constants (a run-time loop bound over acc[]
+    // would turn into select chains): both 4-row halves are reduced unconditionally, pool_t only
+    // decides whether they are merged.
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         const int gi = wm * MTW + i;
 #pragma unroll
         for (int qh = 0; qh < 2; ++qh) {
-            const int o = o_tab[gi * 4 + half + 2 * qh];
+            const int r0 = 8 * qh;
+            if (staged) {
+                float m0 = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 2], acc[i][r0 + 3]));
+                float m1 = fmaxf(fmaxf(acc[i][r0 + 4], acc[i][r0 + 5]), fmaxf(acc[i][r0 + 6], acc[i][r0 + 7]));
+                if (p.pool_t == 2) m0 = fmaxf(m0, m1);
+                m0 += bias; m1 += bias;
+                if (p.relu) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
+                const int q = (gi * 4 + half + 2 * qh) * nsets;
+                uint16_t hi, lo;
+                split16<PREC>(m0, hi, lo);
+                stg[q * NCH + n] = hi;
+                if constexpr (X3) stg[(Q + q) * NCH + n] = lo;
+                if (p.pool_t != 2) {
+                    split16<PREC>(m1, hi, lo);
+                    stg[(q + 1) * NCH + n] = hi;
+                    if constexpr (X3) stg[(Q + q + 1) * NCH + n] = lo;
+                }
+                continue;
+            }
+            const int o = lds_otab[gi * 4 + half + 2 * qh];
             if (o < 0 || !n_ok) continue;
+            float mv[2]; int av[2];
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                if (st >= nsets) break;
-                const int b4 = st * 4;
-                float mx = acc[i][8 * qh + b4];
+                float mx = acc[i][r0 + 4 * st];
                 int am = 0;
 #pragma unroll
-                for (int j = 1; j < 8; ++j) {
-                    if (j >= wsz) break;
-                    const float v = acc[i][8 * qh + b4 + j];
+                for (int j = 1; j < 4; ++j) {
+                    const float v = acc[i][r0 + 4 * st + j];
                     if (v > mx) { mx = v; am = j; }
                 }
-                mx += bias;
+                mv[st] = mx; av[st] = am;
+            }
+            if (p.pool_t == 2 && mv[1] > mv[0]) { mv[0] = mv[1]; av[0] = 4 + av[1]; }   // first maximum wins ties
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                if (st == 1 && p.pool_t == 2) continue;
+                float mx = mv[st] + bias;
                 if (p.relu) mx = fmaxf(mx, 0.f);
                 const int base = o + st * p.out_t_stride;
                 if (base >= lim) continue;
-                const uint8_t ab = (uint8_t)(am | (mx > 0.f ? 0 : 0x80));
+                const uint8_t ab = (uint8_t)(av[st] | (mx > 0.f ? 0 : 0x80));
                 if (feat) {
                     const uint32_t idx = (uint32_t)base + chan;
                     dstf[idx] = mx;
@@ -316,6 +415,195 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
             }
         }
     }
+    if (staged) {
+        __syncthreads();
+        stamp(6);
+        const int cpq_sh = __builtin_ctz(NCH >> 3);        // 16-byte slots per pooled position (4, 8 or 16)
+        const int ns_sh = nsets - 1;
+        uint4* dslots = reinterpret_cast<uint4*>(p.dst) + out_base;
+        for (int item = tid; item < ((Q << cpq_sh)); item += nthreads) {
+            const int q = item >> cpq_sh, cc = item & ((1 << cpq_sh) - 1);
+            const int g = q >> ns_sh, st = q & ns_sh;
+            const int o = lds_otab[g];
+            const int base = o + st * p.out_t_stride;
+            if (o < 0 || base >= lim) continue;
+            const uint32_t slot = (uint32_t)base + (uint32_t)cc * (uint32_t)p.out_chunk_stride;
+            dslots[slot] = *reinterpret_cast<const uint4*>(stg + q * NCH + cc * 8);
+            if constexpr (X3) dslots[slot + p.dst_plane_stride] = *reinterpret_cast<const uint4*>(stg + (Q + q) * NCH + cc * 8);
+        }
+    }
+    finish();
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256, 1) void conv0_persistent_kernel(const VdConvParams p, const int boxes_per_wg) {
+    constexpr int MTW = 4, S = 32, AD = 2, LU = 12;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int half = lane >> 5;
+    const int32_t* a_tab = p.tables + p.boxes[0];
+    const int32_t* o_tab = p.tables + p.boxes[1];
+    const int32_t* t_tab = p.tables + p.boxes[2];
+    const int plane_bytes = p.lds_plane_bytes;
+    const int ngroups = (int)(p.gather_stride >> 6);
+    const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);
+    int* lds_tap = reinterpret_cast<int*>(smem + 2 * plane_bytes);
+    for (int k = tid; k < 2 * S; k += 256) lds_tap[k] = t_tab[k];
+
+    int a_off[MTW], o_idx[MTW][2];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
+        o_idx[i][0] = o_tab[(wm * MTW + i) * 4 + half];
+        o_idx[i][1] = o_tab[(wm * MTW + i) * 4 + half + 2];
+    }
+    // all B fragments of this wave's 32 output channels
+    uint4 breg[S];
+    {
+        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)wn * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) breg[s] = wp[(int64_t)s * 128];
+    }
+    const int n = wn * 32 + (lane & 31);
+    const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
+    const uint32_t chan = (uint32_t)(n >> 3) * (uint32_t)p.out_chunk_stride * 8u + (uint32_t)(n & 7);
+    const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
+
+    const int total = ((p.nclips + p.ncl - 1) / p.ncl) * p.nbox;
+    const int b_lo = blockIdx.x * boxes_per_wg;
+    const int b_hi = (b_lo + boxes_per_wg < total) ? b_lo + boxes_per_wg : total;
+
+    auto issue_dma = [&](int b, int buf) {
+        const int grp = b / p.nbox, bi = b - grp * p.nbox;
+        const int clip0 = grp * p.ncl;
+        const int32_t* gtab = p.gather + (int64_t)bi * p.gather_stride;
+        const uint32_t* csrc = src + (int64_t)clip0 * p.src_clip_stride4;
+        char* base = smem + buf * plane_bytes;
+        for (int g0 = wave * LU; g0 < ngroups; g0 += 4 * LU) {
+            uint32_t off[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int gi = (g0 + u < ngroups) ? g0 + u : ngroups - 1;
+                const int e = gtab[gi * 64 + lane];
+                const int ci = e >> 24;
+                const bool ok = (e >= 0) && (clip0 + ci < p.nclips);
+                off[u] = ok ? ((uint32_t)ci * (uint32_t)p.src_clip_stride4 + (uint32_t)(e & 0xFFFFFF)) : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) asm volatile("" : "+v"(off[u]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                if (g0 + u < ngroups) {
+                    const uint32_t* gp = (off[u] != 0xFFFFFFFFu) ? csrc + off[u] : zslot;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                     (__attribute__((address_space(3))) void*)(base + (g0 + u) * 1024), 16, 0, 0);
+                }
+            }
+        }
+    };
+
+    if (b_lo < b_hi) issue_dma(b_lo, 0);
+    __syncthreads();   // (drains the DMA: vmcnt(0) + barrier) also publishes lds_tap
+
+    for (int b = b_lo; b < b_hi; ++b) {
+        const int buf = (b - b_lo) & 1;
+        if (b + 1 < b_hi) issue_dma(b + 1, buf ^ 1);
+        const char* pb = smem + buf * plane_bytes;
+
+        f32x16 acc[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+        uint4 A[AD + 1][MTW];
+#pragma unroll
+        for (int d = 0; d < AD; ++d) {
+            const int tp = lds_tap[2 * d + half];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) A[d][i] = *reinterpret_cast<const uint4*>(pb + a_off[i] + tp);
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int sn = (s + AD < S) ? s + AD : S - 1;
+            const int tp = lds_tap[2 * sn + half];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) A[(s + AD) % (AD + 1)][i] = *reinterpret_cast<const uint4*>(pb + a_off[i] + tp);
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) acc[i] = mfma16<PREC>(A[s % (AD + 1)][i], breg[s], acc[i]);
+        }
+
+        // epilogue: bias + ReLU + (1,2,2) max-pool, two outputs per 8-row group
+        const int grp = b / p.nbox, bi = b - grp * p.nbox;
+        const int out_rel = p.boxes[bi * 8 + 3];
+        const int64_t out_base = (int64_t)grp * p.ncl * p.out_clip_stride + out_rel;
+        const int64_t lim64 = out_total - out_base;
+        const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
+        uint16_t* dst16 = reinterpret_cast<uint16_t*>(p.dst) + out_base * 8;
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                const int o = o_idx[i][qh];
+                if (o < 0) continue;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const int b4 = 8 * qh + 4 * st;
+                    float mx = fmaxf(fmaxf(acc[i][b4], acc[i][b4 + 1]), fmaxf(acc[i][b4 + 2], acc[i][b4 + 3]));
+                    mx = fmaxf(mx + bias, 0.f);
+                    const int base = o + st * p.out_t_stride;
+                    if (base >= lim) continue;
+                    uint16_t hi, lo;
+                    split16<PREC>(mx, hi, lo);
+                    dst16[(uint32_t)base * 8u + chan] = hi;
+                }
+            }
+        }
+        __syncthreads();   // next patch landed (vmcnt(0)) and everyone is done reading this one
+    }
+}
+
+template <int PREC>
+static int launch_conv0_persistent(const VdConvParams& p, hipStream_t st) {
+    const int total = ((p.nclips + p.ncl - 1) / p.ncl) * p.nbox;
+    if (total <= 0) return 0;
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || ncu <= 0) return e != hipSuccess ? (int)e : -4;
+    }
+    const int per = (total + ncu - 1) / ncu;
+    const int grid = (total + per - 1) / per;
+    const size_t lds = (size_t)2 * p.lds_plane_bytes + (size_t)2 * p.S * sizeof(int) + 16;
+    if (lds > 160 * 1024) return -3;
+    auto kern = conv0_persistent_kernel<PREC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p, per);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vd_conv0_persistent(const VdConvParams* pp, void* stream) {
+    if (pp == nullptr) return -1;
+    const VdConvParams& p = *pp;
+    if (p.NT != 2 || p.MW != 2 || p.MTW != 4 || p.S != 32 || p.CC != 1 || p.epi != VD_EPI_POOL_CL || p.pool_t != 1 ||
+        p.argmax != nullptr || !p.relu)
+        return -2;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p.prec == VD_PREC_F16) return launch_conv0_persistent<VD_PREC_F16>(p, st);
+    if (p.prec == VD_PREC_BF16) return launch_conv0_persistent<VD_PREC_BF16>(p, st);
+    return -2;
 }
 
 template <int PREC, int MTW>
@@ -324,7 +612,7 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     const int groups = (p.nclips + p.ncl - 1) / p.ncl;
     const int64_t grid = (int64_t)groups * p.nbox;
     if (grid <= 0) return 0;
-    const size_t lds = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)2 * p.S * sizeof(int) + 16;
+    const size_t lds = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + p.MW * MTW * 4) * sizeof(int) + 16;
     if (lds > 160 * 1024) return -3;
     auto kern = conv_mfma_kernel<PREC, MTW>;
     static bool attr_set = false;
@@ -343,6 +631,7 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (p.NT * p.MW < 1 || p.NT * p.MW > 4 || p.lds_plane_bytes % 16 != 0) return -2;
     if (p.ncl * 65536 <= 0 || p.S <= 0 || p.CC <= 0) return -2;
+    if (p.MTW < 8 && (p.gather_stride >> 6) > (int64_t)p.NT * p.MW * (p.MTW <= 4 ? 14 : 17)) return -2;   // patch larger than the DMA register budget
 #define VD_DISPATCH(PR)                                                   \
     case PR:                                                              \
         if (p.MTW == 4) return launch<PR, 4>(p, st);                      \

@@ -9,6 +9,7 @@ parameters that are frozen (distill_baseline.py:336-337).
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -26,7 +27,7 @@ class _DevPlan:
         desc, tables = plan.flat_tables()
         self.type_desc = torch.from_numpy(desc.copy()).to(device)
         self.tables = torch.from_numpy(tables.copy()).to(device)
-        self.boxes = torch.from_numpy(plan.boxes.copy()).to(device)
+        self.boxes = torch.from_numpy(plan.device_boxes().copy()).to(device)
         self.widx = torch.from_numpy(plan.widx.reshape(-1).copy()).to(device)
         gt = plan.gather_table()
         self.gather = torch.from_numpy(gt.copy()).to(device)
@@ -53,6 +54,12 @@ class _DevPlan:
         self.col_off = None if plan.col_off is None else torch.from_numpy(plan.col_off.copy()).to(device)
         p.col_off = 0 if self.col_off is None else self.col_off.data_ptr()
         self.params = p
+        # first-layer forward in an x1 precision with a single box type -> persistent kernel
+        # (experimental, off by default: measured slower than the generic kernel)
+        self.persistent_ok = (os.environ.get("VD_PERSISTENT_L0", "0") == "1" and not hip.is_x3(prec)
+                              and plan.epi == P.EPI_POOL_CL and plan.pool_t == 1 and plan.CC == 1
+                              and (plan.NT, plan.MW, plan.MTW, plan.S) == (2, 2, 4, 32) and len(plan.types) == 1
+                              and 2 * p.lds_plane_bytes + 8 * plan.S + 16 <= 160 * 1024)
 
     def pack(self, w: torch.Tensor) -> None:
         assert w.dtype == torch.float32 and w.is_contiguous()
@@ -69,6 +76,10 @@ class _DevPlan:
         p.dst = dst_ptr; p.dst_plane_stride = dst_plane_stride
         p.argmax = 0 if argmax is None else argmax.data_ptr()
         p.nclips = nclips
+        if self.persistent_ok and argmax is None and not p.dbg:
+            hip.check(hip.lib().vd_conv0_persistent(ctypes.byref(p), hip.stream_ptr(src.device)),
+                      "vd_conv0_persistent(%s)" % self.plan.name)
+            return
         hip.check(hip.lib().vd_conv_mfma(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv_mfma(%s)" % self.plan.name)
 
 

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libvd_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("conv_mfma.hip", "aux_kernels.hip")]
 
 PREC = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
-EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_pack_weights", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_dm_loss",
+EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv0_persistent", "vd_pack_weights", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_dm_loss",
            "vd_sgd_momentum", "vd_hallucinator_fwd", "vd_hallucinator_bwd", "vd_match_rows_fwd", "vd_match_rows_bwd")
 
 
@@ -38,7 +38,7 @@ class VdConvParams(ctypes.Structure):
         ("n_out", ctypes.c_int32), ("n_stride", ctypes.c_int32),
         ("out_clip_stride", ctypes.c_int64),
         ("out_chunk_stride", ctypes.c_int32), ("out_t_stride", ctypes.c_int32),
-        ("lds_plane_bytes", ctypes.c_int32), ("prec", ctypes.c_int32), ("dbg", ctypes.c_int32),
+        ("lds_plane_bytes", ctypes.c_int32), ("prec", ctypes.c_int32), ("dbg", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("stamps", ctypes.c_void_p),
     ]
 
 

@@ -129,6 +129,16 @@ class ConvPlan:
             out[bi, :idx.size] = np.where(ok, rel | (ci << 24), -1)
         return out.astype(np.int32)
 
+    def device_boxes(self) -> np.ndarray:
+        """int32 [nbox, 8] rows the kernel reads with one scalar load: offsets of the box type's
+        a_off / out / tap tables inside flat_tables()[1], the output origin, the type id."""
+        descs, _ = self.flat_tables()
+        out = np.zeros((self.nbox, 8), dtype=np.int32)
+        for bi, box in enumerate(self.boxes):
+            ty = int(box[0])
+            out[bi, :5] = (descs[ty][7], descs[ty][8], descs[ty][9], int(box[4]), ty)
+        return out
+
     def flat_tables(self):
         """Serialise box types into (type_desc int32 [ntypes,16], tables int32[...])."""
         descs, chunks, pos = [], [], 0
