@@ -46,11 +46,24 @@ def parse():
     ap.add_argument("--chunk", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-classes", type=int, default=2, help="class terms timed for the CPU baseline")
+    ap.add_argument("--method", default="dm", choices=["dm", "s2d"],
+                    help="dm = distill_baseline.py DM (headline); s2d = DM + static/dynamic memories (config 3)")
     return ap.parse_args()
 
 
 def conv_layer_macs(geo):
     return [d[1] * d[5] * d[6] * d[7] * d[0] * 147 for d in geo.layer_dims()]
+
+
+def pmc_traffic(clips_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md), scaled to this run's clips per launch; None if no PMC pass is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))["conv1_fwd_f16"]
+    return rec["hbm_bytes_per_launch"] * clips_per_launch / rec["clips_per_launch"]
 
 
 def cpu_baseline(args, trainer, backend, it, geo):
@@ -105,8 +118,22 @@ def main():
     c_lo, c_hi = distill.class_range(args.classes, rank, world)
     pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device,
                                       seed=1234 + rank)
-    trainer = distill.DMTrainer(backend, pool, args.classes, args.ipc, args.batch_real, lr_img=1.0, momentum=0.5,
-                                rank=rank, world=world)
+    if args.method == "dm":
+        trainer = distill.DMTrainer(backend, pool, args.classes, args.ipc, args.batch_real, lr_img=1.0, momentum=0.5,
+                                    rank=rank, world=world)
+    else:   # sh/s2d/s2d_DM_ms.sh: vpc 1, spc 2, dpc 2, static frozen, SGD(.95) on dynamic memory + hallucinator
+        gen = torch.Generator(device=device); gen.manual_seed(77)
+        static_syn = torch.randn(args.classes * 2, 3, args.size, args.size, device=device, generator=gen)
+        dynamic_syn = torch.randn(args.classes, 2, args.frames, 1, args.size, args.size, device=device, generator=gen)
+        hal_w = torch.empty(3, 4, 3, 3, 3, device=device).uniform_(-0.096, 0.096, generator=gen)
+        hal_b = torch.empty(3, device=device).uniform_(-0.096, 0.096, generator=gen)
+        trainer = distill.S2DTrainer(backend, pool, args.classes, 1, 2, 2, args.batch_real, static_syn, dynamic_syn,
+                                     hal_w, hal_b, lr_dynamic=1.0, lr_hal=0.01, rank=rank, world=world)
+        trainer.image_syn = trainer.dynamic
+        trainer.global_loss = lambda l: l
+        trainer.sync = lambda: torch.cuda.synchronize()
+        _step = trainer.step
+        trainer.step = lambda it, overlap=False: _step(it)
 
     def barrier():
         if world > 1:
@@ -139,7 +166,7 @@ def main():
         step_flop = 2.0 * sum(macs) * (args.classes * (args.batch_real + args.ipc) + args.classes * args.ipc)
         ms_per_step = dt / args.steps * 1e3
         out = {
-            "metric": "distillation steps/sec (DM, miniUCF101 IPC=%d)" % args.ipc,
+            "metric": "distillation steps/sec (%s, miniUCF101 IPC=%d)" % ("DM" if args.method == "dm" else "DM+Ours s2d", args.ipc),
             "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16" if args.prec_real == "f16" else args.prec_real, "data": "synthetic",
@@ -161,14 +188,14 @@ def main():
             achieved = flop_per_launch / float(np.mean(times)) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<f16,MTW=7> (conv layer 1 fwd, real clips)",
                                "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
-                               "traffic": None, "launches": len(times), "mean_launch_ms": float(np.mean(times)) * 1e3,
+                               "traffic": pmc_traffic(float(np.mean(clips))), "launches": len(times), "mean_launch_ms": float(np.mean(times)) * 1e3,
                                "flop_per_launch": flop_per_launch}
             for lname, li in (("fwd0", 0), ("fwd2", 2)):
                 tt = [a.elapsed_time(b) * 1e-3 for (name, n, a, b) in prof if name == lname]
                 cc = [n for (name, n, a, b) in prof if name == lname]
                 if tt:
                     out["roofline"][lname + "_tflops"] = 2.0 * macs[li] * float(np.mean(cc)) / float(np.mean(tt)) / 1e12
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.method == "dm":
             out["cpu_baseline"] = cpu_baseline(args, trainer, backend, args.warmup + args.steps, geo)
         print(json.dumps(out))
     if world > 1:

@@ -44,7 +44,7 @@ def test_params_struct_layout_matches_header():
         if not decl or decl.startswith("typedef"):
             continue
         decl = re.sub(r"^(const\s+)?[A-Za-z_0-9]+\s*\*?\s*", "", decl, count=1)
-        names += [n.strip().lstrip("*") for n in decl.split(",")]
+        names += [re.sub(r"\[.*\]", "", n.strip().lstrip("*")) for n in decl.split(",")]
     assert names == [f[0] for f in hip.VdConvParams._fields_]
     assert ctypes.sizeof(hip.VdConvParams) % 8 == 0
 

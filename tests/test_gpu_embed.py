@@ -124,3 +124,36 @@ def test_zero_and_single_clip_edge_cases():
     assert _rel(z, want)[0] < 3e-5
     e = eng.forward(torch.zeros(0, 8, 3, 64, 64).cuda())
     assert e.shape == (0, 256)
+
+
+def test_full_size_properties_chunking_gather_and_streams():
+    """Size-independent properties at the benchmark's full clip size (no CPU reference needed):
+    chunking invariance, fused index gather == materialised gather, batch independence,
+    two-stream overlapped trainer == serial trainer (bitwise)."""
+    from video_distillation_amd import distill, engine, plan
+    geo = plan.NetGeometry(16, 112, 112)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    pool = torch.randn(12, 16, 3, 112, 112, device="cuda", generator=g)
+    w = distill.fresh_network_weights(5, "cuda:0")
+    e1 = engine.EmbedEngine(geo, prec="f16", chunk=512); e1.set_weights(w)
+    e2 = engine.EmbedEngine(geo, prec="f16", chunk=5); e2.set_weights(w)      # ragged chunks: 5 + 5 + 2
+    f1 = e1.forward(pool)
+    f2 = e2.forward(pool)
+    assert torch.equal(f1, f2)
+    idx = torch.tensor([7, 0, 11, 3, 3, 9], device="cuda")
+    assert torch.equal(e1.forward(pool, index=idx), f1[idx])                     # gather fused into the first kernel
+    assert torch.equal(e1.forward(pool[4:5]), f1[4:5])                           # clips are independent
+    assert torch.isfinite(f1).all() and float(f1.abs().sum()) > 0
+
+    def run(two_streams):
+        be = distill.HipBackend(geo, "cuda:0", prec_real="f16", prec_syn="f16x3", chunk=512)
+        be.two_streams = be.two_streams and two_streams
+        rp = distill.RealPool(pool, [4, 4, 4], [0, 4, 8])
+        tr = distill.DMTrainer(be, rp, 3, 1, 3, lr_img=0.5)
+        losses = [tr.step(it, overlap=two_streams) for it in range(3)]
+        tr.sync(); torch.cuda.synchronize()
+        return [float(l) for l in losses], tr.image_syn.clone()
+    la, sa = run(False)
+    lb, sb = run(True)
+    assert la == lb and torch.equal(sa, sb)
+    assert la[0] > 0 and not torch.equal(sa, pool[[0, 4, 8]])                    # the step did move the pixels

@@ -18,6 +18,9 @@ dp.params.dbg = 8; dp.params.stamps = buf.data_ptr()
 eng.forward(x); torch.cuda.synchronize()
 dp.params.dbg = 0
 t = buf.cpu().numpy().reshape(grid, 8).astype(np.float64)
+ok = t[:, 0] > 0
+print("valid WGs", ok.sum(), "of", grid)
+t = t[ok]
 t0 = t[:, 0].min()
 d = np.diff(t[:, :8], axis=1)   # phases: setup, dma-issue, dma-wait, kloop(first chunk + rest), epilogue
 print("grid", grid, "kernel span (cycles of 100MHz*?):", t[:, 7].max() - t0)
@@ -25,3 +28,15 @@ names = ["setup(prologue)", "dma issue", "dma wait+barrier", "K loop (all chunks
 for k, nm in enumerate(names):
     print("%-22s median %8.0f  p10 %8.0f  p90 %8.0f" % (nm, np.median(d[:, k]), np.percentile(d[:, k], 10), np.percentile(d[:, k], 90)))
 print("total per WG median", np.median(t[:, 7] - t[:, 0]))
+
+
+ids = np.arange(grid)[ok]
+for x in range(2):
+    sel = (ids % 8) == x
+    tx = t[sel]
+    t0x = tx[:, 0].min(); span = tx[:, 7].max() - t0x
+    res = (tx[:, 7] - tx[:, 0]).sum()
+    st = np.sort(tx[:, 0] - t0x)
+    mid = st[(st > span * 0.3) & (st < span * 0.7)]
+    print("XCD-group %d: span %.0f cycles, concurrent WGs %.1f (%.2f per CU), WG starts / 1000 cycles %.2f" % (
+        x, span, res / span, res / span / 32, len(mid) / (span * 0.4) * 1000))

@@ -428,7 +428,29 @@ __global__ __launch_bounds__(256) void match_rows_fwd_kernel(const float* __rest
                                                               int64_t rows, int len, float* __restrict__ acc) {
     __shared__ float red[16];
     float s_cos = 0.f, s_mse = 0.f, s_dot = 0.f, s_rr = 0.f, s_ss = 0.f;
-    if (len <= 8) {
+    if (len == 1) {
+        // flat sums ('mse' / 'cos' metrics): 16-byte loads, grid-stride
+        const int64_t n4 = rows >> 2;
+        const float4* r4 = reinterpret_cast<const float4*>(gr);
+        const float4* s4 = reinterpret_cast<const float4*>(gs);
+        const bool aligned = ((reinterpret_cast<uintptr_t>(gr) | reinterpret_cast<uintptr_t>(gs)) & 15) == 0;
+        const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+        int64_t done = 0;
+        if (aligned) {
+            for (int64_t i = tid0; i < n4; i += nt) {
+                const float4 x = r4[i], y = s4[i];
+                s_dot += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+                s_rr += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+                s_ss += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+                s_mse += (y.x - x.x) * (y.x - x.x) + (y.y - x.y) * (y.y - x.y) + (y.z - x.z) * (y.z - x.z) + (y.w - x.w) * (y.w - x.w);
+            }
+            done = n4 << 2;
+        }
+        for (int64_t i = done + tid0; i < rows; i += nt) {
+            const float x = gr[i], y = gs[i];
+            s_dot += x * y; s_rr += x * x; s_ss += y * y; s_mse += (y - x) * (y - x);
+        }
+    } else if (len <= 8) {
         // one thread per row
         for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
             float d = 0.f, a = 0.f, b = 0.f, m = 0.f;
@@ -467,8 +489,9 @@ __global__ __launch_bounds__(256) void match_rows_fwd_kernel(const float* __rest
 
 extern "C" int vd_match_rows_fwd(const float* gr, const float* gs, int64_t rows, int len, float* acc, void* stream) {
     if (rows <= 0 || len <= 0) return 0;
-    int64_t blocks = (len <= 8) ? (rows + 255) / 256 : (rows + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    int64_t blocks = (len == 1) ? (rows + 1023) / 1024 : (len <= 8) ? (rows + 255) / 256 : (rows + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(match_rows_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        gr, gs, rows, len, acc);
     return (int)hipGetLastError();

@@ -105,10 +105,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
         goff[u] = ok ? ((uint32_t)ci * (uint32_t)p.src_clip_stride4 + (uint32_t)(e & 0xFFFFFF)) : 0xFFFFFFFFu;
     }
     // (2) one 32-byte row per box: table offsets of its type + output origin (scalar loads)
+    //     (with a single box type the table offsets are launch constants, so nothing in the prologue
+    //      depends on this load: it is only needed for the output origin in the epilogue)
     const int32_t* box = p.boxes + bi * 8;
-    const int32_t* a_tab = p.tables + box[0];
-    const int32_t* o_tab = p.tables + box[1];
-    const int32_t* t_tab = p.tables + box[2];
+    const bool one_type = (p.ntypes == 1);
+    const int32_t* a_tab = p.tables + (one_type ? p.tab_ofs[0] : box[0]);
+    const int32_t* o_tab = p.tables + (one_type ? p.tab_ofs[1] : box[1]);
+    const int32_t* t_tab = p.tables + (one_type ? p.tab_ofs[2] : box[2]);
     const int out_rel = box[3];
 
     const int plane_bytes = p.lds_plane_bytes;
