@@ -59,7 +59,7 @@ typedef struct VdConvParams {
     int32_t dbg;                  /* ablation switches for profiling (0 in production)         */
     int32_t ntypes;               /* number of box types; 1 -> tab_ofs are used for every box     */
     int32_t tab_ofs[3];           /* a_off / out / tap table offsets of box type 0                */
-    int32_t reserved0;
+    int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
 } VdConvParams;
 

@@ -48,7 +48,7 @@ __device__ __forceinline__ void split16(float v, uint16_t& hi, uint16_t& lo) {
 }
 
 template <int PREC, int MTW>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p, const int boxes_per_wg, const int total_boxes) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
     constexpr int H1 = MTW - H0;
@@ -69,15 +69,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
     // XCD-aware block order (T1): workgroups are dealt round-robin to the 8 XCDs, so give each XCD a
     // CONTIGUOUS range of boxes -- neighbouring boxes of a clip share halo rows, which then hit
     // in that XCD's private L2 instead of being fetched once per XCD.  Bijective for any grid.
-    int bid;
+    int wgid;
     {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
         const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
+    // Each workgroup walks `boxes_per_wg` consecutive boxes (launching one workgroup per box is
+    // dispatch-rate bound for the first layer: ~100 000 boxes of ~10 us each per launch).
     unsigned long long t_stamp[8];
     auto stamp = [&](int k) { if (p.dbg & 8) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); t_stamp[k] = t; } };
-    stamp(0);
     auto finish = [&]() {
         if ((p.dbg & 8) && tid == 0 && p.stamps != nullptr) {
             stamp(7);
@@ -85,11 +86,39 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
             for (int k = 0; k < 8; ++k) o[k] = t_stamp[k];
         }
     };
+    const int ngroups = (int)(p.gather_stride >> 6);   // 64-slot DMA groups per patch
+    const int nwaves = nthreads >> 6;
+    const int plane_bytes = p.lds_plane_bytes;
+    int* lds_tap = reinterpret_cast<int*>(smem + (X3 ? 2 : 1) * plane_bytes);
+    int* lds_otab = lds_tap + 2 * p.S;
+    const bool one_type = (p.ntypes == 1);
+    const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);   // dword addressing: a slot may start at any dword
+    const uint4* wbase = reinterpret_cast<const uint4*>(p.wpk);
+    const int64_t w_lo = p.w_plane_stride >> 3;  // uint4 units
+    const int wstep = p.NT * 64;                 // uint4 per K-step
+    const int S = p.S;
+    int a_off[MTW];
+    if (one_type) {   // box-type tables are launch constants: load them once per workgroup
+        const int32_t* a_tab0 = p.tables + p.tab_ofs[0];
+        const int32_t* o_tab0 = p.tables + p.tab_ofs[1];
+        const int32_t* t_tab0 = p.tables + p.tab_ofs[2];
+        for (int k = tid; k < 2 * p.S; k += nthreads) lds_tap[k] = t_tab0[k];
+        if (p.epi != VD_EPI_ROWS)
+            for (int k = tid; k < p.MW * MTW * 4; k += nthreads) lds_otab[k] = o_tab0[k];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) a_off[i] = a_tab0[(wm * MTW + i) * 32 + (lane & 31)];
+    }
+
+  constexpr bool LOOPED = (MTW <= 4);   // only the first layer's instantiations have boxes short enough to need it
+  const int nbit = LOOPED ? boxes_per_wg : 1;
+  for (int bit = 0; bit < nbit; ++bit) {
+    const int bid = wgid * nbit + bit;
+    if (bid >= total_boxes) break;
+    stamp(0);
     const int grp = bid / p.nbox;
     const int bi = bid - grp * p.nbox;
     const int clip0 = grp * p.ncl;
-    const int ngroups = (int)(p.gather_stride >> 6);   // 64-slot DMA groups per patch
-    const int nwaves = nthreads >> 6;
 
     // (1) the gather entries of this wave's DMA groups: the longest dependent chain of the prologue,
     //     so they are requested first; they are the same for every channel chunk and stay in registers.
@@ -108,22 +137,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
     //     (with a single box type the table offsets are launch constants, so nothing in the prologue
     //      depends on this load: it is only needed for the output origin in the epilogue)
     const int32_t* box = p.boxes + bi * 8;
-    const bool one_type = (p.ntypes == 1);
-    const int32_t* a_tab = p.tables + (one_type ? p.tab_ofs[0] : box[0]);
     const int32_t* o_tab = p.tables + (one_type ? p.tab_ofs[1] : box[1]);
-    const int32_t* t_tab = p.tables + (one_type ? p.tab_ofs[2] : box[2]);
     const int out_rel = box[3];
-
-    const int plane_bytes = p.lds_plane_bytes;
-    int* lds_tap = reinterpret_cast<int*>(smem + (X3 ? 2 : 1) * plane_bytes);
-    int* lds_otab = lds_tap + 2 * p.S;
-    for (int k = tid; k < 2 * p.S; k += nthreads) lds_tap[k] = t_tab[k];
-    if (p.epi != VD_EPI_ROWS)
-        for (int k = tid; k < p.MW * MTW * 4; k += nthreads) lds_otab[k] = o_tab[k];
-
-    int a_off[MTW];
+    if (!one_type) {
+        const int32_t* a_tab = p.tables + box[0];
+        const int32_t* t_tab = p.tables + box[2];
+        __syncthreads();   // the previous box's epilogue is done with the LDS tables
+        for (int k = tid; k < 2 * p.S; k += nthreads) lds_tap[k] = t_tab[k];
+        if (p.epi != VD_EPI_ROWS)
+            for (int k = tid; k < p.MW * MTW * 4; k += nthreads) lds_otab[k] = o_tab[k];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
+        for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
+    }
 #pragma unroll
     for (int u = 0; u < (HOIST ? LU : 1); ++u) asm volatile("" : "+v"(goff[u]));   // consumed before any DMA is in flight
 
@@ -132,13 +157,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
-
-    const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);   // dword addressing: a slot may start at any dword
-    const uint4* wbase = reinterpret_cast<const uint4*>(p.wpk);
-    const int64_t w_lo = p.w_plane_stride >> 3;  // uint4 units
-    const int wstep = p.NT * 64;                 // uint4 per K-step
-    const int S = p.S;
 
     for (int cc = 0; cc < p.CC; ++cc) {
         __syncthreads();  // previous chunk's fragment reads are done
@@ -305,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
 
     // ---- epilogue ---------------------------------------------------------------------
     stamp(4);
-    if (p.dbg & 1) { if (acc[0][0] == 123.456f) reinterpret_cast<float*>(p.dst)[0] = 1.f; return; }
+    if (p.dbg & 1) { if (acc[0][0] == 123.456f) reinterpret_cast<float*>(p.dst)[0] = 1.f; continue; }
     const int n = wn * 32 + (lane & 31);
     const bool n_ok = n < p.n_out;
     const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
             }
         }
         finish();
-        return;
+        continue;
     }
 
     // pooled epilogues: registers 8*qh .. 8*qh+7 of this lane are one 2x2x2 row group.
@@ -436,6 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p)
         }
     }
     finish();
+  }   // box loop
 }
 
 template <int PREC>
@@ -613,18 +632,37 @@ template <int PREC, int MTW>
 static int launch(const VdConvParams& p, hipStream_t st) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     const int groups = (p.nclips + p.ncl - 1) / p.ncl;
-    const int64_t grid = (int64_t)groups * p.nbox;
-    if (grid <= 0) return 0;
+    const int64_t total = (int64_t)groups * p.nbox;
+    if (total <= 0) return 0;
     const size_t lds = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + p.MW * MTW * 4) * sizeof(int) + 16;
     if (lds > 160 * 1024) return -3;
     auto kern = conv_mfma_kernel<PREC, MTW>;
     static bool attr_set = false;
+    static int ncu = 0;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
+        int dev = 0;
+        e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || ncu <= 0) return e != hipSuccess ? (int)e : -4;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * p.NT * p.MW), lds, st, p);
+    // resident workgroups per CU: LDS and the register budget of this instantiation (MTW 4: 3 waves
+    // per SIMD, otherwise 2; x3 variants of MTW 4 use more registers -> 2)
+    int occ = (int)((160 * 1024) / lds);
+    const int waves_per_simd = (MTW <= 4 && !X3) ? 3 : 2;
+    const int wg_waves = p.NT * p.MW;
+    const int by_regs = (waves_per_simd * 4) / wg_waves;
+    if (occ > by_regs) occ = by_regs;
+    if (occ < 1) occ = 1;
+    // a few workgroup "generations" keep the tail short while still amortising the dispatch
+    const int64_t slots = (int64_t)ncu * occ;
+    int per = (p.persist > 0 && MTW <= 4) ? (int)((total + slots * p.persist - 1) / (slots * p.persist)) : 1;
+    if (per < 1) per = 1;
+    const int64_t grid = (total + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * p.NT * p.MW), lds, st, p, per, (int)total);
     return (int)hipGetLastError();
 }
 
