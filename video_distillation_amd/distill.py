@@ -250,6 +250,9 @@ class DMTrainer:
         if fork:
             fork()
         if getattr(be, "two_streams", False):
+            # tensors created on the caller's stream but consumed asynchronously on the work streams
+            # must not be recycled by the caching allocator before those streams are done with them
+            idx_t.record_stream(be.s_real)
             for w in weights:
                 w.record_stream(be.s_real)
                 w.record_stream(be.s_syn)
