@@ -184,9 +184,9 @@ extern "C" int vd_unpool_relu_bwd(const float* g, const uint8_t* argmax, int64_t
 // ------------------------------------------------------------------------------------------
 // DM class term: one workgroup per class; threads stride the feature dimension (coalesced
 // rows of the [b][d] matrices), wave-shuffle + LDS reduction of the squared distance.
-__global__ __launch_bounds__(256) void dm_loss_kernel(const float* __restrict__ fr, const float* __restrict__ fs,
-                                                       int nreal, int nsyn, int dim, float* __restrict__ loss,
-                                                       float* __restrict__ gsyn) {
+__global__ __launch_bounds__(1024) void dm_loss_kernel(const float* __restrict__ fr, const float* __restrict__ fs,
+                                                        int nreal, int nsyn, int dim, float* __restrict__ loss,
+                                                        float* __restrict__ gsyn) {
     __shared__ float red[16];
     const int c = blockIdx.x;
     const float* r = fr + (int64_t)c * nreal * dim;
@@ -194,14 +194,23 @@ __global__ __launch_bounds__(256) void dm_loss_kernel(const float* __restrict__ 
     const float inv_r = 1.f / (float)nreal, inv_s = 1.f / (float)nsyn;
     float part = 0.f;
     for (int d = threadIdx.x; d < dim; d += blockDim.x) {
-        float mr = 0.f, ms = 0.f;
-        for (int b = 0; b < nreal; ++b) mr += r[(int64_t)b * dim + d];
-        for (int b = 0; b < nsyn; ++b) ms += s[(int64_t)b * dim + d];
+        // column sums: 8 independent loads in flight per thread (the kernel sits on the critical
+        // path between the real-clip features and the backward pass; it is latency- not bandwidth-bound)
+        float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = 0;
+        for (; b + 8 <= nreal; b += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[k] += r[(int64_t)(b + k) * dim + d];
+        }
+        for (; b < nreal; ++b) m[0] += r[(int64_t)b * dim + d];
+        const float mr = ((m[0] + m[1]) + (m[2] + m[3])) + ((m[4] + m[5]) + (m[6] + m[7]));
+        float ms = 0.f;
+        for (int k = 0; k < nsyn; ++k) ms += s[(int64_t)k * dim + d];
         const float diff = mr * inv_r - ms * inv_s;
         part += diff * diff;
         if (gsyn != nullptr) {
             const float gv = -2.f * diff * inv_s;
-            for (int b = 0; b < nsyn; ++b) gsyn[((int64_t)c * nsyn + b) * dim + d] = gv;
+            for (int k = 0; k < nsyn; ++k) gsyn[((int64_t)c * nsyn + k) * dim + d] = gv;
         }
     }
     const float tot = block_sum(part, red);
@@ -212,7 +221,7 @@ extern "C" int vd_dm_loss(const float* feat_real, const float* feat_syn, int ncl
                           float* loss_per_class, float* g_syn, void* stream) {
     if (nclass <= 0) return 0;
     if (nreal <= 0 || nsyn <= 0 || dim <= 0) return -2;
-    hipLaunchKernelGGL(dm_loss_kernel, dim3(nclass), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), feat_real,
+    hipLaunchKernelGGL(dm_loss_kernel, dim3(nclass), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), feat_real,
                        feat_syn, nreal, nsyn, dim, loss_per_class, g_syn);
     return (int)hipGetLastError();
 }
