@@ -128,6 +128,12 @@ int vd_match_rows_fwd(const float* gr, const float* gs, int64_t rows, int len, f
 int vd_match_rows_bwd(const float* gr, const float* gs, int64_t rows, int len, int mode, const float* acc,
                       const float* gout, float* g_gs, void* stream);
 
+/* Classifier head of ConvNet3D.forward in inference (networks.py:738-745; evaluate_synset's test
+ * passes, utils.py:793-824): AvgPool3d((kt,kh,kw), stride 1) over features (B,C,To,Ho,Wo), dropout
+ * off, 1x1x1 conv (w [K][C], b [K]), squeeze, max over T -> logits (B,K). */
+int vd_head_fwd(const float* feats, const float* w, const float* b, int64_t nclips, int C, int To, int Ho, int Wo,
+                int kt, int kh, int kw, int K, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -204,3 +204,25 @@ def test_g7_evaluate_synset(golden_dir):
         utils.evaluate_synset(0, net, images, torch.arange(C), testloader, args, mode='hallucinator')
     with pytest.raises(SystemExit):
         utils.get_network('NoSuchNet', 3, 10)
+
+
+def test_inference_forward_uses_hip_head(golden_dir):
+    """ConvNet3D.forward under no_grad/eval = HIP features + fused head kernel; must reproduce the
+    reference's logits (fixture G1, both clip sizes) and the torch-op training graph."""
+    from video_distillation_amd import networks
+    z = np.load(os.path.join(golden_dir, "g1_layers.npz"))
+    networks.set_precision(real="f16x3", syn="f16x3")
+    try:
+        for im, fr, key, seedkey in ((64, 8, "logits", "x_seed"), (112, 16, "logits112", "x112_seed")):
+            net = make_net(int(z["seed"]), im=im, frames=fr).cuda().eval()
+            n = 2 if im == 64 else 1
+            (x,) = randn(z[seedkey], (n, fr, 3, im, im))
+            with torch.no_grad():
+                got = net(x.cuda())
+            np.testing.assert_allclose(got.cpu().numpy(), z[key], rtol=2e-4, atol=2e-5)
+            want = net.train(False).__class__.forward  # noqa: F841  (torch-op graph below)
+            with torch.enable_grad():
+                ref = net(x.cuda())                    # grad mode -> torch-ROCm ops
+            np.testing.assert_allclose(got.cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-3, atol=2e-4)
+    finally:
+        networks.set_precision(real="f16", syn="f16x3")

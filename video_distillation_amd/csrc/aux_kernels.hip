@@ -569,4 +569,45 @@ extern "C" int vd_match_rows_bwd(const float* gr, const float* gs, int64_t rows,
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Classifier head of ConvNet3D.forward in eval mode (networks.py:738-745): AvgPool3d(k, stride 1)
+// -> [dropout = identity] -> 1x1x1 conv -> squeeze -> max over T.  One workgroup per clip.
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ feats, const float* __restrict__ w,
+                                                        const float* __restrict__ b, int C, int To, int Ho, int Wo,
+                                                        int kt, int kh, int kw, int K, float* __restrict__ out) {
+    extern __shared__ float pooled[];          // [Tp][C]
+    const int clip = blockIdx.x;
+    const int Tp = To - kt + 1;
+    const float* f = feats + (int64_t)clip * C * To * Ho * Wo;
+    const float inv = 1.f / (float)(kt * kh * kw);
+    for (int i = threadIdx.x; i < Tp * C; i += blockDim.x) {
+        const int c = i % C, t = i / C;
+        float a = 0.f;
+        for (int dt = 0; dt < kt; ++dt)
+            for (int dh = 0; dh < kh; ++dh)
+                for (int dw = 0; dw < kw; ++dw) a += f[((c * To + t + dt) * Ho + dh) * Wo + dw];
+        pooled[t * C + c] = a * inv;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float best = -3.402823466e38f;
+        for (int t = 0; t < Tp; ++t) {
+            float a = b[k];
+            for (int c = 0; c < C; ++c) a += w[k * C + c] * pooled[t * C + c];
+            best = fmaxf(best, a);
+        }
+        out[(int64_t)clip * K + k] = best;
+    }
+}
+
+extern "C" int vd_head_fwd(const float* feats, const float* w, const float* b, int64_t nclips, int C, int To, int Ho,
+                           int Wo, int kt, int kh, int kw, int K, float* out, void* stream) {
+    if (nclips <= 0) return 0;
+    if (Ho - kh + 1 != 1 || Wo - kw + 1 != 1 || To - kt + 1 < 1) return -2;   // forward() squeezes H and W
+    const size_t lds = (size_t)(To - kt + 1) * C * sizeof(float);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)nclips), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       feats, w, b, C, To, Ho, Wo, kt, kh, kw, K, out);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vd_abi_version(void) { return VD_ABI_VERSION; }

@@ -186,7 +186,28 @@ class ConvNet3D(nn.Module):
         out = self.features(x.permute(0, 2, 1, 3, 4))
         return out.view(out.size(0), -1)
 
+    def _infer_hip(self, x):
+        """Inference logits on the HIP path: MFMA features + fused head kernel (avg-pool, 1x1x1
+        conv, max over T).  Used whenever no gradient is being recorded (evaluate_synset's three
+        test passes per evaluation, utils.py:793-824)."""
+        import ctypes
+        from . import hip
+        feats = _EmbedFunction.apply(x.detach(), self)
+        g = P.NetGeometry(x.shape[1], x.shape[3], x.shape[4])
+        d = g.layer_dims()[-1]
+        C, To, Ho, Wo = d[1], d[8], d[9], d[10]
+        kt, kh, kw = self.avg_pool.kernel_size
+        K = self.logit.weight.shape[0]
+        w = self.logit.weight.detach().reshape(K, C).float().contiguous()
+        b = self.logit.bias.detach().float().contiguous()
+        out = torch.empty((x.shape[0], K), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().vd_head_fwd(hip.ptr(feats), hip.ptr(w), hip.ptr(b), ctypes.c_int64(x.shape[0]), C, To, Ho, Wo,
+                                        kt, kh, kw, K, hip.ptr(out), hip.stream_ptr(x.device)), "vd_head_fwd")
+        return out
+
     def forward(self, x):
+        if (self._hip_ok and x.is_cuda and not self.training and not torch.is_grad_enabled()):
+            return self._infer_hip(x)
         out = self.features(x.permute(0, 2, 1, 3, 4))
         out = self.logit(self.dropout(self.avg_pool(out)))
         logits = out.squeeze(3).squeeze(3)
