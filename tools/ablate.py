@@ -11,13 +11,14 @@ params = [torch.randn(s, device="cuda") * 0.02 for s in [(64,3,3,7,7),(64,),(128
 eng = engine.EmbedEngine(geo, prec=prec, chunk=nclips)
 eng.set_weights(params)
 eng.forward(x); torch.cuda.synchronize()
+DBGS = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else (0, 1, 2, 4, 3, 5, 6, 7)
 res = {}
 for rnd in range(3):
-    for dbg in (0, 1, 2, 4, 3, 5, 6, 7):
+    for dbg in DBGS:
         for dp in eng.fwd: dp.params.dbg = dbg
         eng.profile = []
         eng.forward(x); torch.cuda.synchronize()
         for name, n, a, b in eng.profile:
             res.setdefault((name, dbg), []).append(a.elapsed_time(b))
 for name in ("fwd0", "fwd1", "fwd2"):
-    print(name, " ".join("dbg%d=%.2f" % (d, min(res[(name, d)])) for d in (0, 1, 2, 4, 3, 5, 6, 7)))
+    print(name, " ".join("dbg%d=%.2f" % (d, min(res[(name, d)])) for d in DBGS))

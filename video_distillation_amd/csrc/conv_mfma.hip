@@ -19,6 +19,21 @@
 
 #include "../../include/vd_hip.h"
 
+// tuning switches (A/B builds via tools/ab.py; defaults are the shipped configuration)
+#ifndef VD_DB_X1
+#define VD_DB_X1 3
+#endif
+#ifdef VD_NO_SCHED_BARRIER
+#define VD_SCHED_BARRIER()
+#else
+#define VD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifdef VD_SETPRIO
+#define VD_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define VD_PRIO(x)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -53,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
     constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
     constexpr int H1 = MTW - H0;
     constexpr int AD = 1;                               // x1: A-fragment prefetch distance (K-steps)
-    constexpr int DB = X3 ? 2 : 3;                      // B-fragment prefetch distance; (DB+1) % (AD+1) == 0
+    constexpr int DB = X3 ? 2 : VD_DB_X1;               // B-fragment prefetch distance; (DB+1) % (AD+1) == 0
     static_assert(X3 || (DB + 1) % (AD + 1) == 0, "ring sizes must divide the unroll factor");
     constexpr int LU = (MTW <= 4) ? 14 : 17;   // DMA groups per wave (4 waves x LU x 64 slots >= the plan's patch)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
         // first B fragments of this chunk: issued before the patch DMA so both latencies overlap
         const uint4* wp = wbase + ((int64_t)cc * S * p.NT + wn) * 64 + lane;
         auto load_b = [&](int s, uint4& bh, uint4& bl) {
-            const int sc = (s < S) ? s : S - 1;
+            const int sc = (p.dbg & 16) ? 0 : ((s < S) ? s : S - 1);   // dbg 16: always the same (cached) B fragment
             bh = wp[(int64_t)sc * wstep];
             if constexpr (X3) bl = wp[(int64_t)sc * wstep + w_lo];
         };
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
         if constexpr (!X3) {
             // tap offsets live in LDS and are read one step before the A reads that need them
             auto tap_of = [&](int st) {
-                const int sc = (st < S) ? st : S - 1;
+                const int sc = (p.dbg & 32) ? 0 : ((st < S) ? st : S - 1);   // dbg 32: every step reads the same LDS rows
                 return lds_tap[2 * sc + half];
             };
             uint4 A[AD + 1][MTW];
@@ -266,10 +281,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
 #pragma unroll
                     for (int i = 0; i < MTW; ++i)
                         A[(u + AD) % (AD + 1)][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
-                    __builtin_amdgcn_sched_barrier(0);
+                    VD_SCHED_BARRIER();
+                    VD_PRIO(1);
 #pragma unroll
                     for (int i = 0; i < MTW; ++i) acc[i] = mfma16<PREC>(A[u % (AD + 1)][i], bqh[u], acc[i]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    VD_PRIO(0);
+                    VD_SCHED_BARRIER();
                     tp = tp_next;
                 }
             }
