@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--chunk", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-classes", type=int, default=10, help="class terms timed for the CPU baseline")
+    ap.add_argument("--shard", default="auto", choices=["auto", "class", "batch"],
+                    help="multi-GPU decomposition: whole classes per rank, or 1/N of every class's real batch per rank "
+                         "(+ one all-reduce of the per-class feature sums); auto = batch when batch_real %% N == 0")
     ap.add_argument("--method", default="dm", choices=["dm", "s2d"],
                     help="dm = distill_baseline.py DM (headline); s2d = DM + static/dynamic memories (config 3)")
     return ap.parse_args()
@@ -130,11 +133,17 @@ def main():
     geo = plan.NetGeometry(args.frames, args.size, args.size)
     backend = distill.HipBackend(geo, device, prec_real=args.prec_real, prec_syn=args.prec_syn, chunk=args.chunk)
     c_lo, c_hi = distill.class_range(args.classes, rank, world)
-    pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device,
-                                      seed=1234 + rank)
+    shard = args.shard
+    if shard == "auto":
+        shard = "batch" if (world > 1 and args.batch_real % world == 0 and args.method == "dm") else "class"
+    if shard == "batch":   # every rank holds the whole pool (11 GB) and embeds its slice of each class batch
+        pool = distill.RealPool.synthetic(args.classes, list(range(args.classes)), args.pool_per_class, geo, device, seed=1234)
+    else:
+        pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device,
+                                          seed=1234 + rank)
     if args.method == "dm":
         trainer = distill.DMTrainer(backend, pool, args.classes, args.ipc, args.batch_real, lr_img=1.0, momentum=0.5,
-                                    rank=rank, world=world)
+                                    rank=rank, world=world, shard=shard)
     else:   # sh/s2d/s2d_DM_ms.sh: vpc 1, spc 2, dpc 2, static frozen, SGD(.95) on dynamic memory + hallucinator
         gen = torch.Generator(device=device); gen.manual_seed(77)
         static_syn = torch.randn(args.classes * 2, 3, args.size, args.size, device=device, generator=gen)
@@ -188,7 +197,9 @@ def main():
                                    "ConvNet3D depth 3, fresh net per step" % (args.ipc, args.classes, args.batch_real,
                                                                                args.ipc, args.size, args.size, args.frames),
                        "precision": {"real_clips": args.prec_real, "syn_clips": args.prec_syn, "accumulate": "f32"},
-                       "parallelism": "class-sharded x%d (owner-computes, no gradient exchange)" % world,
+                       "parallelism": ("real batch sharded x%d + all-reduce of per-class feature sums (410 KB); synthetic clips "
+                                       "class-owned, no gradient exchange" % world) if trainer.__dict__.get("shard") == "batch" else
+                                      "class-sharded x%d (owner-computes, no gradient exchange)" % world,
                        "pool_per_class": args.pool_per_class},
             "loss_last": float(losses[-1]) / args.classes,
             "step_tflops": step_flop / (dt / args.steps) / 1e12,

@@ -102,6 +102,11 @@ int vd_unpool_relu_bwd(const float* g, const uint8_t* argmax, int64_t nclips, in
 int vd_dm_loss(const float* feat_real, const float* feat_syn, int nclass, int nreal, int nsyn, int dim,
                float* loss_per_class, float* g_syn, void* stream);
 
+/* out[g][d] = scale * sum_b x[g*per+b][d]: per-class partial sums of a rank's slice of the real
+ * batch (torch.mean(output_real, dim=0), distill_baseline.py:351, split over ranks; the partial
+ * sums are exchanged by one RCCL all-reduce). */
+int vd_group_sum(const float* x, int groups, int per, int dim, float scale, float* out, void* stream);
+
 /* torch.optim.SGD(momentum, dampening 0) step on the synthetic pixels
  * (distill_baseline.py:107, 355): buf = first ? g : mu*buf + g ; x -= lr*buf. */
 int vd_sgd_momentum(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, int first,

@@ -43,6 +43,9 @@ class OracleBackend:
         (g,) = torch.autograd.grad(loss_c.sum(), fs)
         return loss_c.detach(), g.reshape(f_syn.shape)
 
+    def group_sum(self, x, groups, per, scale):
+        return x.view(groups, per, -1).sum(1) * scale
+
     def sgd(self, x, buf, g, lr, mu, first):
         with torch.no_grad():
             if first:

@@ -30,19 +30,19 @@ class _Pool:
     pass
 
 
-def _g3_setup(rank, world):
+def _g3_setup(rank, world, shard="class"):
     z = np.load(os.path.join(GOLDEN, "g3_dm_steps.npz"))
     (syn,) = randn(z["syn_seed"], (3, 8, 3, 64, 64))
     reals = [randn(z["real_seeds"][it], *[(4, 8, 3, 64, 64)] * 3) for it in range(2)]
     pool = _Pool(); pool.clips = torch.cat([torch.cat(r) for r in reals]); pool.counts = [4] * 3; pool.offsets = [0, 4, 8]
     lo, hi = distill.class_range(3, rank, world)
     tr = distill.DMTrainer(OracleBackend(net_seeds=z["net_seeds"]), pool, 3, 1, 4, lr_img=float(z["lr"]),
-                           momentum=float(z["momentum"]), rank=rank, world=world, image_syn=syn[lo:hi].clone())
+                           momentum=float(z["momentum"]), rank=rank, world=world, image_syn=syn[lo:hi].clone(), shard=shard)
     return z, tr
 
 
-def _g3_run(rank, world):
-    z, tr = _g3_setup(rank, world)
+def _g3_run(rank, world, shard="class"):
+    z, tr = _g3_setup(rank, world, shard)
     orig = distill.sample_real_indices
     losses = []
     try:
@@ -61,6 +61,18 @@ def _worker_g3(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         z, losses, syn = _g3_run(rank, world)
+        if rank == 0:
+            q.put((losses, syn.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_g3_batch(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z, losses, syn = _g3_run(rank, world, shard="batch")
         if rank == 0:
             q.put((losses, syn.numpy()))
     finally:
@@ -114,6 +126,14 @@ def test_dm_trainer_two_ranks_gloo_matches_golden():
     z = np.load(os.path.join(GOLDEN, "g3_dm_steps.npz"))
     np.testing.assert_allclose(losses, z["losses"], rtol=1e-5)       # all-reduced loss == 1-rank loss
     np.testing.assert_allclose(syn[:, ::2, :, ::4, ::4], z["syn2"], rtol=1e-4, atol=1e-5)   # all-gathered clips
+
+
+def test_dm_trainer_two_ranks_batch_sharded_matches_golden():
+    """Real batch split over ranks + all-reduce of per-class feature sums == the reference step."""
+    losses, syn = _spawn(_worker_g3_batch, 2)
+    z = np.load(os.path.join(GOLDEN, "g3_dm_steps.npz"))
+    np.testing.assert_allclose(losses, z["losses"], rtol=1e-5)
+    np.testing.assert_allclose(syn[:, ::2, :, ::4, ::4], z["syn2"], rtol=1e-4, atol=1e-5)
 
 
 def _g5_run(rank, world):

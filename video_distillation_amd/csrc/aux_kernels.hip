@@ -227,6 +227,32 @@ extern "C" int vd_dm_loss(const float* feat_real, const float* feat_syn, int ncl
 }
 
 // ------------------------------------------------------------------------------------------
+// out[g][d] = scale * sum_{b<per} x[g*per + b][d]  (per-class partial feature sums of a rank's slice
+// of the real batch, exchanged by one all-reduce when the real batch is sharded over ranks)
+__global__ void group_sum_kernel(const float* __restrict__ x, int per, int dim, float scale, float* __restrict__ out) {
+    const int g = blockIdx.y;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= dim) return;
+    const float* r = x + (int64_t)g * per * dim + d;
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 4 <= per; b += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] += r[(int64_t)(b + k) * dim];
+    }
+    for (; b < per; ++b) m[0] += r[(int64_t)b * dim];
+    out[(int64_t)g * dim + d] = ((m[0] + m[1]) + (m[2] + m[3])) * scale;
+}
+
+extern "C" int vd_group_sum(const float* x, int groups, int per, int dim, float scale, float* out, void* stream) {
+    if (groups <= 0 || dim <= 0) return 0;
+    if (per <= 0) return -2;
+    hipLaunchKernelGGL(group_sum_kernel, dim3((dim + 255) / 256, groups), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, per, dim, scale, out);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 __global__ void sgd_momentum_kernel(float* __restrict__ x, float* __restrict__ buf, const float* __restrict__ g,
                                     int64_t n, float lr, float mu, int first) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -160,6 +161,13 @@ class HipBackend:
                                        hip.ptr(g), hip.stream_ptr(self.device)), "vd_dm_loss")
         return loss, g
 
+    def group_sum(self, x: torch.Tensor, groups: int, per: int, scale: float) -> torch.Tensor:
+        hip = self.hip
+        out = torch.empty((groups, x.shape[1]), dtype=torch.float32, device=self.device)
+        hip.check(hip.lib().vd_group_sum(hip.ptr(x), groups, per, x.shape[1], ctypes.c_float(scale), hip.ptr(out),
+                                         hip.stream_ptr(self.device)), "vd_group_sum")
+        return out
+
     def sgd(self, x: torch.Tensor, buf: torch.Tensor, g: torch.Tensor, lr: float, mu: float, first: bool) -> None:
         hip = self.hip
         hip.check(hip.lib().vd_sgd_momentum(hip.ptr(x), hip.ptr(buf), hip.ptr(g), ctypes.c_int64(x.numel()),
@@ -221,7 +229,20 @@ class DMTrainer:
     """Baseline DM (distill_baseline.py DM branch, :292-361) over the classes owned by this rank."""
 
     def __init__(self, backend, pool: RealPool, num_classes: int, ipc: int, batch_real: int, lr_img: float,
-                 momentum: float = 0.5, rank: int = 0, world: int = 1, image_syn: Optional[torch.Tensor] = None):
+                 momentum: float = 0.5, rank: int = 0, world: int = 1, image_syn: Optional[torch.Tensor] = None,
+                 shard: str = "class"):
+        """``shard='class'``: a rank embeds the whole real batch of its own classes (no data-path
+        collective).  ``shard='batch'``: every rank embeds 1/world of EVERY class's real batch and
+        the per-class feature sums (C x D fp32, 410 KB) are all-reduced; the synthetic clips stay
+        class-owned.  The latter balances 50 classes over 8 ranks exactly (6.25 class-equivalents
+        each instead of 7,7,6,...) at the price of one small all-reduce per step; the pool must
+        then hold all classes on every rank."""
+        assert shard in ("class", "batch")
+        # (world == 1 normally has nothing to shard; VD_FORCE_BATCH_SHARD=1 keeps the collective path
+        #  alive on one rank so that it can be smoke-tested on a single-GPU box)
+        self.shard = shard if (world > 1 or os.environ.get("VD_FORCE_BATCH_SHARD") == "1") else "class"
+        if self.shard == "batch":
+            assert batch_real % world == 0, "batch sharding needs batch_real divisible by the number of ranks"
         self.be, self.pool = backend, pool
         self.num_classes, self.ipc, self.batch_real = num_classes, ipc, batch_real
         self.lr_img, self.momentum = float(lr_img), float(momentum)
@@ -242,7 +263,12 @@ class DMTrainer:
         the backend's two streams (the caller must ``sync()`` / ``global_loss()`` before reading
         results); consecutive steps then overlap: backward(i) runs under the real forward(i+1)."""
         be, ncls = self.be, len(self.classes)
-        idx = sample_real_indices(it, self.pool.counts, self.pool.offsets, self.batch_real, self.classes)
+        if self.shard == "batch":
+            per = self.batch_real // self.world
+            idx = sample_real_indices(it, self.pool.counts, self.pool.offsets, self.batch_real, range(self.num_classes))
+            idx = idx.reshape(self.num_classes, self.batch_real)[:, self.rank * per:(self.rank + 1) * per].reshape(-1)
+        else:
+            idx = sample_real_indices(it, self.pool.counts, self.pool.offsets, self.batch_real, self.classes)
         dev = self.image_syn.device
         idx_t = torch.as_tensor(idx, device=dev)
         weights = be.new_network(seed=it)
@@ -258,7 +284,7 @@ class DMTrainer:
                 w.record_stream(be.s_syn)
             with on_real():
                 be.eng_real.set_weights(weights)
-                f_real = be.embed_pool(self.pool.clips, idx_t)
+                f_real = self._real_features(idx_t)
             with on_syn():
                 be.eng_syn.set_weights(weights)
                 f_syn, handle = be.embed_keep(self.image_syn)
@@ -272,13 +298,27 @@ class DMTrainer:
             self.steps_done += 1
             return loss
         be.set_weights(weights)
-        f_real = be.embed_pool(self.pool.clips, idx_t)
+        f_real = self._real_features(idx_t)
         f_syn, handle = be.embed_keep(self.image_syn)
         loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
         grad = be.embed_backward(handle, g_syn)
         be.sgd(self.image_syn, self.buf, grad, self.lr_img, self.momentum, first=(self.steps_done == 0))
         self.steps_done += 1
         return loss_c.sum()
+
+    def _real_features(self, idx_t: torch.Tensor) -> torch.Tensor:
+        """Features of the real clips this rank embeds, in the form dm_loss() consumes: all clips of
+        the owned classes (class sharding), or -- batch sharding -- the all-reduced per-class MEAN
+        feature of the owned classes (one row per class, i.e. a 'batch' of one)."""
+        f = self.be.embed_pool(self.pool.clips, idx_t)
+        if self.shard != "batch":
+            return f
+        import torch.distributed as dist
+        per = self.batch_real // self.world
+        sums = self.be.group_sum(f, self.num_classes, per, 1.0 / self.batch_real)
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        return sums[self.c_lo:self.c_hi].contiguous()
 
     def global_loss(self, local_loss: torch.Tensor) -> torch.Tensor:
         """Sum of the per-rank losses (== the reference's ``loss`` before /num_classes)."""
