@@ -157,3 +157,28 @@ def test_full_size_properties_chunking_gather_and_streams():
     lb, sb = run(True)
     assert la == lb and torch.equal(sa, sb)
     assert la[0] > 0 and not torch.equal(sa, pool[[0, 4, 8]])                    # the step did move the pixels
+
+
+def test_experimental_persistent_first_layer_matches_generic():
+    """vd_conv0_persistent (off by default: measured slower) must stay bit-compatible
+    with the generic tile-program kernel it specialises."""
+    from video_distillation_amd import distill, engine, plan
+    geo = plan.NetGeometry(16, 112, 112)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(3, 16, 3, 112, 112, device="cuda", generator=g)
+    eng = engine.EmbedEngine(geo, prec="f16", chunk=8)
+    eng.set_weights(distill.fresh_network_weights(2, "cuda:0"))
+    ref = eng.forward(x)
+    dp = eng.fwd[0]
+    assert not dp.persistent_ok
+    p = dp.params
+    ok = (dp.plan.epi == 0 and dp.plan.pool_t == 1 and dp.plan.CC == 1 and (dp.plan.NT, dp.plan.MW, dp.plan.MTW, dp.plan.S) == (2, 2, 4, 32)
+          and len(dp.plan.types) == 1 and 2 * p.lds_plane_bytes + 8 * dp.plan.S + 16 <= 160 * 1024)
+    assert ok, "plan no longer matches the persistent kernel's fixed geometry"
+    dp.persistent_ok = True
+    try:
+        got = eng.forward(x)
+    finally:
+        dp.persistent_ok = False
+    torch.cuda.synchronize()
+    assert torch.equal(ref, got)
