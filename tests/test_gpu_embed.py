@@ -182,3 +182,25 @@ def test_experimental_persistent_first_layer_matches_generic():
         dp.persistent_ok = False
     torch.cuda.synchronize()
     assert torch.equal(ref, got)
+
+
+def test_odd_geometry_on_device():
+    """12 x 96 x 80 clips on the GPU: odd conv extents (floor pooling), multi-type box plans, 7 clips per
+    workgroup in the last layer's input-gradient passes."""
+    params = R.init_params(12)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(9, 12, 3, 96, 80, generator=g)
+    gf = torch.randn(9, 384, generator=g)
+    want_f = R.convnet3d_embed(x, params)
+    want_g = _grad_fp64(x, gf, params)
+    eng = _engine((12, 96, 80), "f16x3")
+    eng.set_weights([p.cuda() for p in params])
+    f, sv = eng.forward(x.cuda(), keep=True)
+    dx = eng.backward(sv, gf.cuda())
+    torch.cuda.synchronize()
+    assert f.shape == (9, 384)
+    assert _rel(f, want_f)[0] < 3e-5
+    _grad_check(dx, want_g, "f16x3")
+    eng2 = _engine((12, 96, 80), "f16")
+    eng2.set_weights([p.cuda() for p in params])
+    assert _rel(eng2.forward(x.cuda()), want_f)[0] < 2e-3

@@ -116,3 +116,34 @@ def test_full_resolution_plans_build():
     assert net["fwd"][2].ncl == 2
     for pl in net["fwd"] + [p for l in net["bwd"] for p in l]:
         assert pl.lds_slots * 32 + 4096 <= 160 * 1024
+
+
+def test_odd_geometry_floor_pooling_and_multi_type_boxes():
+    """12 x 96 x 80 clips: conv grids of 12x12x10 and 6x3x3 (odd extents -> floor pooling drops a
+    row/column, ragged edge boxes, several box types per plan, up to 7 clips per workgroup)."""
+    import torch.nn.functional as F
+    geo = P.NetGeometry(12, 96, 80)
+    net = P.plan_network(geo)
+    assert geo.num_feat == 384 and any(len(pl.types) > 1 for l in net["bwd"] for pl in l)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 12, 3, 96, 80, generator=g).double()
+    params = [p.double() for p in R.init_params(5)]
+    col=[]; R.feature_layers(x.permute(0,2,1,3,4), params, collect=col)
+    cl_to, to_cl = cl_to_bcthw, bcthw_to_cl
+    n=2
+    pl=net['fwd'][0]; out=np.zeros(n*int(np.prod(pl.out_shape))); E.run_plan(pl,E.pix_to_rows(x.numpy()),params[0].numpy().ravel(),params[1].numpy(),n,out)
+    np.testing.assert_allclose(cl_to(out,n,pl.out_shape), col[2].numpy(), rtol=1e-9, atol=1e-9)
+    pl=net['fwd'][1]; out=np.zeros(n*int(np.prod(pl.out_shape))); E.run_plan(pl,to_cl(col[2].numpy()),params[2].numpy().ravel(),params[3].numpy(),n,out)
+    np.testing.assert_allclose(cl_to(out,n,pl.out_shape), col[5].numpy(), rtol=1e-9, atol=1e-9)
+    pl=net['fwd'][2]; out=np.zeros(n*geo.num_feat); E.run_plan(pl,to_cl(col[5].numpy()),params[4].numpy().ravel(),params[5].numpy(),n,out)
+    np.testing.assert_allclose(out.reshape(n,-1), col[8].numpy().reshape(n,-1), rtol=1e-9, atol=1e-9)
+    dims=net['dims']
+    for li in range(3):
+        cin,cout,t_,h,w,T,OH,OW=dims[li][:8]
+        dy=torch.randn(1,cout,T,OH,OW,generator=g).double()
+        xin=torch.zeros(1,cin,t_,h,w,dtype=torch.double,requires_grad=True)
+        y=F.conv3d(xin,params[2*li],None,stride=(1,2,2),padding=(1,3,3)); (want,)=torch.autograd.grad(y,xin,dy)
+        out=np.zeros(cin*t_*h*w)
+        for pl in net['bwd'][li]: E.run_plan(pl,to_cl(dy.numpy()),params[2*li].numpy().ravel(),None,1,out)
+        got = out.reshape(1,t_,cin,h,w).transpose(0,2,1,3,4) if li==0 else out.reshape(1,t_,h,w,cin).transpose(0,4,1,2,3)
+        np.testing.assert_allclose(got,want.numpy(),rtol=1e-9,atol=1e-9)
