@@ -33,8 +33,8 @@ import torch
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--classes", type=int, default=50)
     ap.add_argument("--ipc", type=int, default=1)
     ap.add_argument("--batch-real", type=int, default=64)
@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--size", type=int, default=112)
     ap.add_argument("--prec-real", default=os.environ.get("VD_PREC_REAL", "f16"))
     ap.add_argument("--prec-syn", default=os.environ.get("VD_PREC_SYN", "f16x3"))
+    ap.add_argument("--prec-bwd", default=os.environ.get("VD_PREC_BWD", "f16"),
+                    help="operand precision of the input-gradient passes (single-pass fp16 with power-of-two scaling)")
     ap.add_argument("--chunk", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-classes", type=int, default=10, help="class terms timed for the CPU baseline")
@@ -131,7 +133,8 @@ def main():
 
     from video_distillation_amd import distill, plan
     geo = plan.NetGeometry(args.frames, args.size, args.size)
-    backend = distill.HipBackend(geo, device, prec_real=args.prec_real, prec_syn=args.prec_syn, chunk=args.chunk)
+    backend = distill.HipBackend(geo, device, prec_real=args.prec_real, prec_syn=args.prec_syn, chunk=args.chunk,
+                                 prec_bwd=args.prec_bwd)
     c_lo, c_hi = distill.class_range(args.classes, rank, world)
     shard = args.shard
     if shard == "auto":
@@ -196,7 +199,8 @@ def main():
             "config": {"workload": "miniUCF101-shaped DM IPC=%d: C=%d classes x (%d real + %d syn) clips %dx%dx%d, "
                                    "ConvNet3D depth 3, fresh net per step" % (args.ipc, args.classes, args.batch_real,
                                                                                args.ipc, args.size, args.size, args.frames),
-                       "precision": {"real_clips": args.prec_real, "syn_clips": args.prec_syn, "accumulate": "f32"},
+                       "precision": {"real_clips": args.prec_real, "syn_clips_fwd": args.prec_syn, "input_gradient": args.prec_bwd,
+                                     "accumulate": "f32"},
                        "parallelism": ("real batch sharded x%d + all-reduce of per-class feature sums (410 KB); synthetic clips "
                                        "class-owned, no gradient exchange" % world) if trainer.__dict__.get("shard") == "batch" else
                                       "class-sharded x%d (owner-computes, no gradient exchange)" % world,

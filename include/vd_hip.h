@@ -43,6 +43,7 @@ typedef struct VdConvParams {
     int64_t dst_plane_stride;     /* POOL_CL: slots between hi and lo planes                  */
     uint8_t* argmax;              /* pooled epilogues: arg-max byte per output, or NULL        */
     const int32_t* col_off;       /* ROWS: element offset of column n, or NULL (= n*n_stride)  */
+    const float* out_scale;       /* ROWS: device scalar the outputs are multiplied by, or NULL */
     const int32_t* type_desc;     /* [ntypes][16]                                             */
     const int32_t* tables;        /* a_off / out / tap tables                                 */
     const int32_t* boxes;         /* [nbox][8]: a_off / out / tap table offsets, out origin, type */
@@ -92,10 +93,15 @@ int vd_pix2rows(const float* x, const int64_t* clip_index, int64_t nclips, int T
 /* Backward of ReLU + MaxPool3d: scatter the pooled gradient to the arg-max position of the
  * dense conv grid and emit it as channels-last slots (source of the input-gradient pass).
  * g_layout 0: g/argmax indexed [clip][n][pos] (embed features); 1: g [clip][pos][n],
- * argmax as channels-last bytes [clip][n/8][pos][8]. */
+ * argmax as channels-last bytes [clip][n/8][pos][8].
+ * scale (optional device scalar): the gradient is multiplied by scale[0] before the 16-bit split. */
 int vd_unpool_relu_bwd(const float* g, const uint8_t* argmax, int64_t nclips, int C, int To, int Ho, int Wo,
                        int pool_t, int T, int OH, int OW, int g_layout, void* out_hi, void* out_lo,
-                       int prec, void* stream);
+                       int prec, const float* scale, void* stream);
+
+/* out[0] = 2^k with max|g| * 2^k in [target/2, target), out[1] = 2^-k (out[2] is scratch; out has
+ * 4 floats).  Used to keep single-pass fp16 gradient operands inside fp16's exponent range. */
+int vd_absmax_scale(const float* g, int64_t n, float target, float* out, void* stream);
 
 /* DM class term, forward and gradient (distill_baseline.py:351):
  * loss[c] = sum_d (mean_b real[c,b,d] - mean_b syn[c,b,d])^2 ; g_syn = d loss / d syn. */

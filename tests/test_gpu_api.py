@@ -80,7 +80,7 @@ def test_g3_two_dm_steps_trainer(golden_dir):
     from video_distillation_amd import distill, plan
     z = np.load(os.path.join(golden_dir, "g3_dm_steps.npz"))
     geo = plan.NetGeometry(8, 64, 64)
-    be = _FixedNetBackend(distill.HipBackend(geo, "cuda:0", prec_real="f16x3", prec_syn="f16x3"), z["net_seeds"])
+    be = _FixedNetBackend(distill.HipBackend(geo, "cuda:0", prec_real="f16x3", prec_syn="f16x3", prec_bwd="f16x3"), z["net_seeds"])
     (syn,) = randn(z["syn_seed"], (3, 8, 3, 64, 64))
     # pool = the exact real batches of both iterations, class-major: [it][class][4]
     reals = [randn(z["real_seeds"][it], *[(4, 8, 3, 64, 64)] * 3) for it in range(2)]
@@ -130,7 +130,7 @@ def test_g5_s2d_step_trainer(golden_dir):
     z = np.load(os.path.join(golden_dir, "g5_s2d_step.npz"))
     C, vpc, spc, dpc = 3, 1, 2, 2
     geo = plan.NetGeometry(8, 64, 64)
-    be = _FixedNetBackend(distill.HipBackend(geo, "cuda:0", prec_real="f16x3", prec_syn="f16x3"), {0: int(z["net_seed"])})
+    be = _FixedNetBackend(distill.HipBackend(geo, "cuda:0", prec_real="f16x3", prec_syn="f16x3", prec_bwd="f16x3"), {0: int(z["net_seed"])})
     static_syn, dynamic_syn = randn(z["data_seed"], (C * spc, 3, 64, 64), (C, dpc, 8, 1, 64, 64))
     reals = randn(z["real_seed"], *[(4, 8, 3, 64, 64)] * C)
 

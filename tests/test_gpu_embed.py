@@ -207,3 +207,32 @@ def test_odd_geometry_on_device():
     eng2 = _engine((12, 96, 80), "f16")
     eng2.set_weights([p.cuda() for p in params])
     assert _rel(eng2.forward(x.cuda()), want_f)[0] < 2e-3
+
+
+def test_single_pass_fp16_backward_with_dynamic_scaling():
+    """prec_bwd='f16': one MFMA per product in the input-gradient passes, gradients scaled by a power
+    of two per layer (vd_absmax_scale) so they stay inside fp16's exponent range.  Same forward (f16x3)
+    => same arg-max decisions => the difference to the x3 backward is pure operand rounding (~2^-11),
+    also for gradients far below fp16's smallest normal."""
+    from video_distillation_amd import engine, plan
+    params = R.init_params(4)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 8, 3, 64, 64, generator=g)
+    gf = torch.randn(3, 256, generator=g)
+    geo = plan.NetGeometry(8, 64, 64)
+    e3 = engine.EmbedEngine(geo, prec="f16x3"); e3.set_weights([p.cuda() for p in params])
+    e1 = engine.EmbedEngine(geo, prec="f16x3", prec_bwd="f16"); e1.set_weights([p.cuda() for p in params])
+    for mag in (1.0, 1e-7, 1e4):
+        _, s3 = e3.forward(x.cuda(), keep=True)
+        _, s1 = e1.forward(x.cuda(), keep=True)
+        d3 = e3.backward(s3, (gf * mag).cuda())
+        d1 = e1.backward(s1, (gf * mag).cuda())
+        torch.cuda.synchronize()
+        rl2, rmax = _rel(d1, d3)
+        print("f16 bwd vs f16x3 bwd at |g|~%g: rel-l2 %.2e rel-max %.2e" % (mag, rl2, rmax))
+        assert rl2 < 1e-3 and torch.isfinite(d1).all()
+    want = _grad_fp64(x, gf, params)
+    assert _rel(e1.backward(e1.forward(x.cuda(), keep=True)[1], gf.cuda()), want)[0] < 2e-3
+    # the x3 backward is scaled too: a 1e-7 gradient is reproduced as exactly as an O(1) one
+    tiny = e3.backward(e3.forward(x.cuda(), keep=True)[1], (gf * 1e-7).cuda())
+    assert _rel(tiny * 1e7, want)[0] < 1e-3

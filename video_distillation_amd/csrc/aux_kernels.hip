@@ -129,9 +129,11 @@ extern "C" int vd_pix2rows(const float* x, const int64_t* clip_index, int64_t nc
 // Backward of ReLU+MaxPool: one thread per output slot (clip, cc, t, oh, ow) of the dense conv grid.
 __global__ void unpool_relu_bwd_kernel(const float* __restrict__ g, const uint8_t* __restrict__ amax, int64_t nslots,
                                        int C, int To, int Ho, int Wo, int pool_t, int T, int OH, int OW,
-                                       int g_layout, uint4* __restrict__ hi, uint4* __restrict__ lo, int prec) {
+                                       int g_layout, uint4* __restrict__ hi, uint4* __restrict__ lo, int prec,
+                                       const float* __restrict__ scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nslots) return;
+    const float sc = (scale != nullptr) ? scale[0] : 1.f;
     int64_t r = i;
     const int ow = (int)(r % OW); r /= OW;
     const int oh = (int)(r % OH); r /= OH;
@@ -153,7 +155,7 @@ __global__ void unpool_relu_bwd_kernel(const float* __restrict__ g, const uint8_
             int64_t gi, ai;
             if (g_layout == 0) { gi = (clip * C + n) * npos + pos; ai = gi; }
             else { gi = (clip * npos + pos) * C + n; ai = ((clip * CC + cc) * npos + pos) * 8 + e; }
-            if (amax[ai] == (uint8_t)j) v = g[gi];
+            if (amax[ai] == (uint8_t)j) v = g[gi] * sc;
         }
         split16p(prec, v, h16[e], l16[e]);
     }
@@ -170,14 +172,60 @@ __global__ void unpool_relu_bwd_kernel(const float* __restrict__ g, const uint8_
 
 extern "C" int vd_unpool_relu_bwd(const float* g, const uint8_t* argmax, int64_t nclips, int C, int To, int Ho, int Wo,
                                   int pool_t, int T, int OH, int OW, int g_layout, void* out_hi, void* out_lo,
-                                  int prec, void* stream) {
+                                  int prec, const float* scale, void* stream) {
     if (C % 8 != 0 || (pool_t != 1 && pool_t != 2)) return -2;
     const int64_t nslots = nclips * (C / 8) * T * OH * OW;
     if (nslots <= 0) return 0;
     const int bs = 256;
     hipLaunchKernelGGL(unpool_relu_bwd_kernel, dim3((unsigned)((nslots + bs - 1) / bs)), dim3(bs), 0,
                        reinterpret_cast<hipStream_t>(stream), g, argmax, nslots, C, To, Ho, Wo, pool_t, T, OH, OW,
-                       g_layout, (uint4*)out_hi, (uint4*)out_lo, prec);
+                       g_layout, (uint4*)out_hi, (uint4*)out_lo, prec, scale);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Power-of-two scale that brings max|g| to [target/2, target): single-pass fp16 operands keep their
+// 11 bits only inside fp16's narrow exponent range, so gradients are scaled before the 16-bit
+// conversion and the result is multiplied by 1/scale in the fp32 epilogue (exact: powers of two).
+__global__ void absmax_kernel(const float* __restrict__ g, int64_t n, unsigned int* __restrict__ bits) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(g[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, red[i]);
+        atomicMax(bits, __float_as_uint(m));     // non-negative floats order like their bit patterns
+    }
+}
+
+__global__ void scale_from_absmax_kernel(const unsigned int* __restrict__ bits, float target, float* __restrict__ out) {
+    const float m = __uint_as_float(bits[0]);
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+        int e = (int)floorf(log2f(target / m));
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        s = ldexpf(1.f, e);
+    }
+    out[0] = s;
+    out[1] = 1.f / s;
+}
+
+extern "C" int vd_absmax_scale(const float* g, int64_t n, float target, float* out, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    unsigned int* bits = reinterpret_cast<unsigned int*>(out + 2);
+    hipError_t e = hipMemsetAsync(bits, 0, sizeof(unsigned int), st);
+    if (e != hipSuccess) return (int)e;
+    if (n > 0) {
+        int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, n, bits);
+    }
+    hipLaunchKernelGGL(scale_from_absmax_kernel, dim3(1), dim3(1), 0, st, bits, target, out);
     return (int)hipGetLastError();
 }
 

@@ -350,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
     if (p.epi == VD_EPI_ROWS) {
         float* dst = reinterpret_cast<float*>(p.dst);
         const int64_t coff = (p.col_off != nullptr) ? (int64_t)p.col_off[n & 31] : (int64_t)n * p.n_stride;
+        const float osc = (p.out_scale != nullptr) ? p.out_scale[0] : 1.f;
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
             const int gi = wm * MTW + i;
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                 const int row = (k & 3) + 8 * (k >> 2) + 4 * half;
                 const int o = o_tab[gi * 32 + row];
                 const int64_t idx = out_base + o;
-                float v = acc[i][k] + bias;
+                float v = acc[i][k] * osc + bias;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (o >= 0 && n_ok && idx < out_total) dst[idx + coff] = v;
             }

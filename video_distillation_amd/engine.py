@@ -72,8 +72,9 @@ class _DevPlan:
                   "vd_pack_weights")
 
     def run(self, src: torch.Tensor, src_plane_slots: int, bias: Optional[torch.Tensor], dst_ptr: int,
-            dst_plane_stride: int, argmax: Optional[torch.Tensor], nclips: int) -> None:
+            dst_plane_stride: int, argmax: Optional[torch.Tensor], nclips: int, out_scale: Optional[torch.Tensor] = None) -> None:
         p = self.params
+        p.out_scale = 0 if out_scale is None else out_scale.data_ptr()
         p.src = src.data_ptr(); p.src_plane_stride4 = src_plane_slots * 4
         p.bias = 0 if bias is None else bias.data_ptr()
         p.dst = dst_ptr; p.dst_plane_stride = dst_plane_stride
@@ -87,7 +88,8 @@ class _DevPlan:
 
 
 class EmbedEngine:
-    def __init__(self, geo: P.NetGeometry, prec: str = "bf16x3", device="cuda:0", chunk: int = 256):
+    def __init__(self, geo: P.NetGeometry, prec: str = "bf16x3", device="cuda:0", chunk: int = 256,
+                 prec_bwd: Optional[str] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("EmbedEngine needs a HIP device (no CPU fallback)")
         hip.lib()
@@ -100,7 +102,10 @@ class EmbedEngine:
         net = P.plan_network(geo)
         self.dims = net["dims"]
         self.fwd = [_DevPlan(pl, self.device, self.prec) for pl in net["fwd"]]
-        self.bwd = [[_DevPlan(pl, self.device, self.prec) for pl in layer] for layer in net["bwd"]]
+        # operand precision of the input-gradient passes (default: same as the forward)
+        self.prec_bwd = hip.PREC[prec_bwd] if prec_bwd else self.prec
+        self.planes_bwd = 2 if hip.is_x3(self.prec_bwd) else 1
+        self.bwd = [[_DevPlan(pl, self.device, self.prec_bwd) for pl in layer] for layer in net["bwd"]]
         self.num_feat = geo.num_feat
         self._weights: Optional[List[torch.Tensor]] = None
         self._bwd_packed = False
@@ -201,17 +206,26 @@ class EmbedEngine:
             for li, am in ((2, am2), (1, am1), (0, am0)):
                 cin, cout, t, h, w, T, OH, OW, To, Ho, Wo, pt = self.dims[li]
                 nslots = nb * (cout // 8) * T * OH * OW
-                dy = self._buf("dy%d" % li, (self.planes, nslots, 8), torch.int16)
-                lo = dy[1] if self.planes == 2 else None
+                dy = self._buf("dy%d" % li, (self.planes_bwd, nslots, 8), torch.int16)
+                lo = dy[1] if self.planes_bwd == 2 else None
+                sc = inv = None
+                if self.prec_bwd in (hip.PREC["f16"], hip.PREC["f16x3"]):
+                    # fp16 operands (also the hi/lo split ones): bring this layer's gradient into fp16's
+                    # exponent range with an exact power-of-two scale (DM gradients shrink by orders of
+                    # magnitude per layer and would otherwise fall into fp16's subnormals)
+                    scb = self._buf("gscale%d" % li, (4,), torch.float32)
+                    hip.check(L.vd_absmax_scale(hip.ptr(grad), ctypes.c_int64(grad.numel()), ctypes.c_float(1024.0),
+                                                hip.ptr(scb), st), "vd_absmax_scale")
+                    sc, inv = scb, scb[1:]
                 hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am), ctypes.c_int64(nb), cout, To, Ho, Wo, pt,
-                                               T, OH, OW, layout, hip.ptr(dy[0]), hip.ptr(lo), self.prec, st),
+                                               T, OH, OW, layout, hip.ptr(dy[0]), hip.ptr(lo), self.prec_bwd, hip.ptr(sc), st),
                           "vd_unpool_relu_bwd")
                 if li == 0:
                     out = dx[c0:c0 + nb]
                 else:
                     out = self._buf("dx%d" % li, (nb, t, h, w, cin), torch.float32)
                 for dp in self.bwd[li]:
-                    dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb)
+                    dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb, out_scale=inv)
                 grad = out
                 layout = 1
         return dx

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libvd_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("conv_mfma.hip", "aux_kernels.hip")]
 
 PREC = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
-EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv0_persistent", "vd_pack_weights", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_dm_loss",
+EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv0_persistent", "vd_pack_weights", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_absmax_scale", "vd_dm_loss",
            "vd_group_sum", "vd_sgd_momentum", "vd_hallucinator_fwd", "vd_hallucinator_bwd", "vd_match_rows_fwd", "vd_match_rows_bwd", "vd_head_fwd")
 
 
@@ -29,7 +29,7 @@ class VdConvParams(ctypes.Structure):
         ("wpk", ctypes.c_void_p), ("w_plane_stride", ctypes.c_int64),
         ("bias", ctypes.c_void_p),
         ("dst", ctypes.c_void_p), ("dst_plane_stride", ctypes.c_int64),
-        ("argmax", ctypes.c_void_p), ("col_off", ctypes.c_void_p),
+        ("argmax", ctypes.c_void_p), ("col_off", ctypes.c_void_p), ("out_scale", ctypes.c_void_p),
         ("type_desc", ctypes.c_void_p), ("tables", ctypes.c_void_p), ("boxes", ctypes.c_void_p),
         ("gather", ctypes.c_void_p), ("gather_stride", ctypes.c_int64), ("zero_slot", ctypes.c_void_p),
         ("nbox", ctypes.c_int32), ("nclips", ctypes.c_int32), ("ncl", ctypes.c_int32),

@@ -27,15 +27,18 @@ import torch.nn as nn
 
 from . import plan as P
 
-_PRECISION = {"real": os.environ.get("VD_PREC_REAL", "f16"), "syn": os.environ.get("VD_PREC_SYN", "f16x3")}
+_PRECISION = {"real": os.environ.get("VD_PREC_REAL", "f16"), "syn": os.environ.get("VD_PREC_SYN", "f16x3"),
+              "bwd": os.environ.get("VD_PREC_BWD", "f16")}
 _ENGINES: Dict[Tuple, object] = {}
 
 
-def set_precision(real: str = None, syn: str = None) -> None:
-    """Operand precision of the MFMA contraction: ``real`` for inputs without gradient,
-    ``syn`` for inputs that need d/dx.  One of 'bf16', 'f16', 'bf16x3', 'f16x3'."""
+def set_precision(real: str = None, syn: str = None, bwd: str = None) -> None:
+    """Operand precision of the MFMA contraction: ``real`` for the forward of inputs without
+    gradient, ``syn`` for the forward of inputs that need d/dx (its arg-max decisions steer the
+    gradient), ``bwd`` for the input-gradient passes (no discrete decisions: single-pass fp16 with
+    per-layer power-of-two scaling is the default).  One of 'bf16', 'f16', 'bf16x3', 'f16x3'."""
     from . import hip
-    for k, v in (("real", real), ("syn", syn)):
+    for k, v in (("real", real), ("syn", syn), ("bwd", bwd)):
         if v is not None:
             if v not in hip.PREC:
                 raise ValueError("unknown precision %r" % v)
@@ -46,13 +49,14 @@ def get_precision() -> Dict[str, str]:
     return dict(_PRECISION)
 
 
-def get_engine(geo: P.NetGeometry, prec: str, device) -> "object":
+def get_engine(geo: P.NetGeometry, prec: str, device, prec_bwd: str = None) -> "object":
     from . import engine
     device = torch.device(device)
-    key = (geo.frames, geo.height, geo.width, prec, device.index if device.index is not None else torch.cuda.current_device())
+    key = (geo.frames, geo.height, geo.width, prec, prec_bwd,
+           device.index if device.index is not None else torch.cuda.current_device())
     eng = _ENGINES.get(key)
     if eng is None:
-        eng = engine.EmbedEngine(geo, prec=prec, device=device)
+        eng = engine.EmbedEngine(geo, prec=prec, device=device, prec_bwd=prec_bwd)
         _ENGINES[key] = eng
     return eng
 
@@ -65,7 +69,7 @@ class _EmbedFunction(torch.autograd.Function):
         need_grad = ctx.needs_input_grad[0]
         prec = _PRECISION["syn"] if need_grad else _PRECISION["real"]
         geo = P.NetGeometry(x.shape[1], x.shape[3], x.shape[4])
-        eng = get_engine(geo, prec, x.device)
+        eng = get_engine(geo, prec, x.device, _PRECISION["bwd"] if need_grad else None)
         net._sync_engine(eng)
         if need_grad:
             feats, saved = eng.forward(x, keep=True)
