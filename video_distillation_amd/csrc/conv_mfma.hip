@@ -1,16 +1,24 @@
 // Table-driven implicit-GEMM Conv3d for gfx950 (MI355X): v_mfma_f32_32x32x16_{bf16,f16}.
 //
 // One workgroup = one box of output rows (host planner: video_distillation_amd/plan.py).
-//   * the input patch of the box is staged ONCE per 8-channel chunk into LDS (16-byte slots,
-//     zero filled outside the source grid), so every source byte is fetched once per box and
-//     re-used by all taps (147 for the 3x7x7 kernels) out of LDS;
+//   * the input patch of the box is staged ONCE per 8-channel chunk into LDS by LDS-DMA
+//     (global_load_lds_dwordx4: 64 x 16-byte slots per wave-instruction, per-lane source address
+//     from a host-built gather table at dword granularity, zero fill from a 16-byte zero slot), so
+//     every source byte is fetched once per box and re-used by all taps (147 for the 3x7x7
+//     kernels) out of LDS;
 //   * waves split the output channels (NT tiles of 32) and, if N < 128, the rows (MW);
 //     each wave keeps MTW 32x32 fp32 accumulator tiles in registers;
 //   * per K-step (2 taps x 8 channels) a wave issues ONE 1-KiB coalesced load of its
-//     pre-packed B fragment and MTW ds_read_b128 A fragments (bank-conflict-free row maps
-//     are chosen by the planner), then MTW (x1) or 3*MTW (x3 split precision) MFMAs;
+//     pre-packed B fragment (prefetched DB steps ahead, counted vmcnt) and MTW ds_read_b128 A
+//     fragments (one step ahead; bank-conflict-free row maps are chosen by the planner), then
+//     MTW (x1) or 3*MTW (x3 split precision) MFMAs;
 //   * epilogue: bias + ReLU + 2x2x2 / 1x2x2 max-pool with arg-max entirely in-lane (the
-//     planner puts the 8 rows of a pool window into one lane's registers), or plain rows.
+//     planner puts the 8 rows of a pool window into one lane's registers); channels-last outputs
+//     are staged through LDS and stored as whole 16-byte slots; or plain fp32 rows (dgrad);
+//   * workgroups are mapped to boxes XCD-contiguously; for the first layer (short boxes) each
+//     workgroup walks several consecutive boxes.
+// Diagnostics: VdConvParams.dbg bits 0-2 ablate epilogue / K loop / DMA, bit 3 records s_memtime
+// stamps of the workgroup phases (tools/ablate.py, tools/stamps.py); 0 in production.
 //
 // Replaces nn.Conv3d / nn.ReLU / nn.MaxPool3d of ConvNet3D.features (reference
 // networks.py:757, 768-770, 799) and the input-gradient half of their autograd backward.
