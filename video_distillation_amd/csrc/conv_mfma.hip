@@ -287,8 +287,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                     load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
                     const int tp_next = tap_of(s + u + AD + 1);
 #pragma unroll
-                    for (int i = 0; i < MTW; ++i)
+                    for (int i = 0; i < MTW; ++i) {
+                        if (i > 0 && (p.dbg & 64)) { A[(u + AD) % (AD + 1)][i] = A[(u + AD) % (AD + 1)][0]; continue; }   // dbg 64: one LDS read per step
                         A[(u + AD) % (AD + 1)][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
+                    }
                     VD_SCHED_BARRIER();
                     VD_PRIO(1);
 #pragma unroll
