@@ -38,6 +38,7 @@ typedef struct VdConvParams {
     int64_t src_chunk_stride4;    /* dwords per 8-channel chunk                                */
     const void* wpk;              /* packed weights [CC][S][NT][64][8] 16-bit, plane 0        */
     int64_t w_plane_stride;       /* 16-bit elements between hi and lo planes                 */
+    int64_t w_box_stride;         /* 16-bit elements between the B operands of consecutive boxes (0: shared) */
     const float* bias;            /* [n_out] or NULL                                          */
     void* dst;                    /* POOL_CL: 16-bit slots plane 0; otherwise fp32            */
     int64_t dst_plane_stride;     /* POOL_CL: slots between hi and lo planes                  */
@@ -60,6 +61,7 @@ typedef struct VdConvParams {
     int32_t dbg;                  /* ablation switches for profiling (0 in production)         */
     int32_t ntypes;               /* number of box types; 1 -> tab_ofs are used for every box     */
     int32_t tab_ofs[3];           /* a_off / out / tap table offsets of box type 0                */
+    int32_t atomic;               /* ROWS epilogue: accumulate with fp32 atomics                  */
     int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
 } VdConvParams;
@@ -138,6 +140,24 @@ int vd_match_rows_fwd(const float* gr, const float* gs, int64_t rows, int len, f
  * sums in acc as produced by the forward).  gout = upstream scalar gradient. */
 int vd_match_rows_bwd(const float* gr, const float* gs, int64_t rows, int len, int mode, const float* acc,
                       const float* gout, float* g_gs, void* stream);
+
+/* Operand preparation for the weight-gradient tile program (plan.plan_wgrad):
+ *  vd_clip_minor_cl : channels-last slots [plane][clip][C/8][npos][8 ch] -> clip-minor slots
+ *                     [plane][c][ceil(nclips/8)][npos][8 clips] (zero for clips >= nclips);
+ *  vd_clip_minor_pix: fp32 clips (B,T,3,H,W) -> [plane][c][ceil(B/8)][T][H][W][8 clips] 16-bit (hi, lo);
+ *  vd_pack_dy       : dense dy slots [plane][clip][N/8][T][OH][OW][8] -> per-box MFMA B fragments
+ *                     [plane][box][ceil(nclips/8)][S][N/32][64][8], box = block (nt,noh,now) of positions.
+ * planes = 1 or 2 (hi, lo); strides in 16-byte slots. */
+int vd_clip_minor_cl(const void* src, int64_t src_plane_slots, int planes, int64_t nclips, int C, int64_t npos,
+                     void* dst, int64_t dst_plane_slots, void* stream);
+int vd_clip_minor_pix(const float* x, int64_t nclips, int T, int H, int W, void* dst_hi, void* dst_lo, int prec,
+                      void* stream);
+int vd_pack_dy(const void* dy, int64_t dy_plane_slots, int planes, int64_t nclips, int N, int T, int OH, int OW,
+               int nt, int noh, int now, void* dst, int64_t dst_plane_elems, void* stream);
+
+/* db[n] += sum over clips and positions of dy (hi + lo planes) -- Conv3d bias gradient. */
+int vd_bias_grad(const void* dy, int64_t dy_plane_slots, int planes, int64_t nclips, int N, int64_t npos, int prec,
+                 const float* scale_inv, float* db, void* stream);
 
 /* Classifier head of ConvNet3D.forward in inference (networks.py:738-745; evaluate_synset's test
  * passes, utils.py:793-824): AvgPool3d((kt,kh,kw), stride 1) over features (B,C,To,Ho,Wo), dropout

@@ -684,4 +684,173 @@ extern "C" int vd_head_fwd(const float* feats, const float* w, const float* b, i
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight-gradient operand preparation (see plan.plan_wgrad).
+// One thread per (channel chunk cc, clip chunk cb, position): loads the 8 clips' slots (8 channels
+// each), transposes the 8x8 block of 16-bit values in registers, stores 8 slots (8 clips each).
+__global__ void clip_minor_cl_kernel(const uint4* __restrict__ src, int64_t src_plane, int planes, int64_t nclips, int CCh,
+                                     int64_t npos, uint4* __restrict__ dst, int64_t dst_plane, int CCb) {
+    const int64_t total = (int64_t)CCh * CCb * npos;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t pos = i % npos;
+    const int cb = (int)((i / npos) % CCb);
+    const int cc = (int)(i / (npos * CCb));
+    for (int pl = 0; pl < planes; ++pl) {
+        uint16_t m[8][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t clip = (int64_t)cb * 8 + j;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (clip < nclips) v = src[pl * src_plane + (clip * CCh + cc) * npos + pos];
+            m[j][0] = v.x & 0xffff; m[j][1] = v.x >> 16; m[j][2] = v.y & 0xffff; m[j][3] = v.y >> 16;
+            m[j][4] = v.z & 0xffff; m[j][5] = v.z >> 16; m[j][6] = v.w & 0xffff; m[j][7] = v.w >> 16;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint4 o;
+            o.x = m[0][k] | ((uint32_t)m[1][k] << 16); o.y = m[2][k] | ((uint32_t)m[3][k] << 16);
+            o.z = m[4][k] | ((uint32_t)m[5][k] << 16); o.w = m[6][k] | ((uint32_t)m[7][k] << 16);
+            dst[pl * dst_plane + (((int64_t)(cc * 8 + k)) * CCb + cb) * npos + pos] = o;
+        }
+    }
+}
+
+extern "C" int vd_clip_minor_cl(const void* src, int64_t src_plane_slots, int planes, int64_t nclips, int C, int64_t npos,
+                                void* dst, int64_t dst_plane_slots, void* stream) {
+    if (C % 8 != 0 || planes < 1 || planes > 2) return -2;
+    const int CCb = (int)((nclips + 7) / 8);
+    const int64_t total = (int64_t)(C / 8) * CCb * npos;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(clip_minor_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), (const uint4*)src, src_plane_slots, planes, nclips, C / 8, npos,
+                       (uint4*)dst, dst_plane_slots, CCb);
+    return (int)hipGetLastError();
+}
+
+__global__ void clip_minor_pix_kernel(const float* __restrict__ x, int64_t nclips, int T, int HW, uint4* __restrict__ hi,
+                                      uint4* __restrict__ lo, int prec, int CCb) {
+    const int64_t npos = (int64_t)T * HW;
+    const int64_t total = (int64_t)3 * CCb * npos;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t pos = i % npos;
+    const int cb = (int)((i / npos) % CCb);
+    const int c = (int)(i / (npos * CCb));
+    const int64_t t = pos / HW, hw = pos % HW;
+    uint16_t h16[8], l16[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t clip = (int64_t)cb * 8 + j;
+        const float v = (clip < nclips) ? x[((clip * T + t) * 3 + c) * HW + hw] : 0.f;
+        split16p(prec, v, h16[j], l16[j]);
+    }
+    uint4 vh, vl;
+    vh.x = h16[0] | ((uint32_t)h16[1] << 16); vh.y = h16[2] | ((uint32_t)h16[3] << 16);
+    vh.z = h16[4] | ((uint32_t)h16[5] << 16); vh.w = h16[6] | ((uint32_t)h16[7] << 16);
+    hi[i] = vh;
+    if (lo != nullptr) {
+        vl.x = l16[0] | ((uint32_t)l16[1] << 16); vl.y = l16[2] | ((uint32_t)l16[3] << 16);
+        vl.z = l16[4] | ((uint32_t)l16[5] << 16); vl.w = l16[6] | ((uint32_t)l16[7] << 16);
+        lo[i] = vl;
+    }
+}
+
+extern "C" int vd_clip_minor_pix(const float* x, int64_t nclips, int T, int H, int W, void* dst_hi, void* dst_lo, int prec,
+                                 void* stream) {
+    const int CCb = (int)((nclips + 7) / 8);
+    const int64_t total = (int64_t)3 * CCb * T * H * W;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(clip_minor_pix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, nclips, T, H * W, (uint4*)dst_hi, (uint4*)dst_lo, prec, CCb);
+    return (int)hipGetLastError();
+}
+
+// one thread per packed B slot: (plane, box, cb, s, nt, lane) -> 8 clips of dy[pos][n]
+__global__ void pack_dy_kernel(const uint16_t* __restrict__ dy, int64_t dy_plane_elems, int planes, int64_t nclips, int N,
+                               int T, int OH, int OW, int nt, int noh, int now, int S, int CCb, int NT, int nbh, int nbw,
+                               uint4* __restrict__ dst, int64_t dst_plane_slots, int64_t per_plane) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_plane * planes) return;
+    const int pl = (int)(i / per_plane);
+    int64_t r = i - (int64_t)pl * per_plane;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int ntile = (int)(r % NT); r /= NT;
+    const int s = (int)(r % S); r /= S;
+    const int cb = (int)(r % CCb); r /= CCb;
+    const int box = (int)r;
+    const int bw = box % nbw, bh = (box / nbw) % nbh, bt = box / (nbw * nbh);
+    const int pidx = 2 * s + (lane >> 5);
+    const int dow = pidx % now, doh = (pidx / now) % noh, dt = pidx / (now * noh);
+    const int t = bt * nt + dt, oh = bh * noh + doh, ow = bw * now + dow;
+    const int n = ntile * 32 + (lane & 31);
+    uint16_t v[8];
+    const bool inside = (t < T) && (oh < OH) && (ow < OW);
+    const int64_t npos = (int64_t)T * OH * OW;
+    const int64_t pos = ((int64_t)t * OH + oh) * OW + ow;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t clip = (int64_t)cb * 8 + j;
+        v[j] = (inside && clip < nclips) ? dy[pl * dy_plane_elems + ((clip * (N >> 3) + (n >> 3)) * npos + pos) * 8 + (n & 7)] : (uint16_t)0;
+    }
+    uint4 o;
+    o.x = v[0] | ((uint32_t)v[1] << 16); o.y = v[2] | ((uint32_t)v[3] << 16);
+    o.z = v[4] | ((uint32_t)v[5] << 16); o.w = v[6] | ((uint32_t)v[7] << 16);
+    dst[pl * dst_plane_slots + (i - (int64_t)pl * per_plane)] = o;
+}
+
+extern "C" int vd_pack_dy(const void* dy, int64_t dy_plane_slots, int planes, int64_t nclips, int N, int T, int OH, int OW,
+                          int nt, int noh, int now, void* dst, int64_t dst_plane_elems, void* stream) {
+    if (N % 32 != 0 || planes < 1 || planes > 2 || ((nt * noh * now) & 1)) return -2;
+    const int S = nt * noh * now / 2, CCb = (int)((nclips + 7) / 8), NT = N / 32;
+    const int nbt = (T + nt - 1) / nt, nbh = (OH + noh - 1) / noh, nbw = (OW + now - 1) / now;
+    const int64_t per_plane = (int64_t)nbt * nbh * nbw * CCb * S * NT * 64;
+    if (per_plane <= 0) return 0;
+    const int64_t total = per_plane * planes;
+    hipLaunchKernelGGL(pack_dy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const uint16_t*)dy, dy_plane_slots * 8, planes, nclips, N, T, OH, OW, nt, noh, now, S, CCb, NT, nbh, nbw,
+                       (uint4*)dst, dst_plane_elems / 8, per_plane);
+    return (int)hipGetLastError();
+}
+
+// Conv3d bias gradient: one workgroup per 8-channel chunk; threads stride (clip, position).
+__global__ __launch_bounds__(256) void bias_grad_kernel(const uint4* __restrict__ dy, int64_t plane_slots, int planes,
+                                                         int64_t nclips, int CCh, int64_t npos, int prec,
+                                                         const float* __restrict__ scale_inv, float* __restrict__ db) {
+    __shared__ float red[16];
+    const int cc = blockIdx.x;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t total = nclips * npos;
+    for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+        const int64_t clip = i / npos, pos = i - clip * npos;
+        for (int pl = 0; pl < planes; ++pl) {
+            const uint4 v = dy[pl * plane_slots + (clip * CCh + cc) * npos + pos];
+            const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint16_t hbits = (uint16_t)(wds[k >> 1] >> ((k & 1) * 16));
+                float f;
+                if (prec == VD_PREC_BF16 || prec == VD_PREC_BF16X3) f = __uint_as_float((uint32_t)hbits << 16);
+                else f = (float)__builtin_bit_cast(_Float16, hbits);
+                acc[k] += f;
+            }
+        }
+    }
+    const float sc = scale_inv ? scale_inv[0] : 1.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float tot = block_sum(acc[k], red);
+        if (threadIdx.x == 0) db[cc * 8 + k] += tot * sc;
+    }
+}
+
+extern "C" int vd_bias_grad(const void* dy, int64_t dy_plane_slots, int planes, int64_t nclips, int N, int64_t npos, int prec,
+                            const float* scale_inv, float* db, void* stream) {
+    if (N % 8 != 0) return -2;
+    if (nclips <= 0) return 0;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(N / 8), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const uint4*)dy,
+                       dy_plane_slots, planes, nclips, N / 8, npos, prec, scale_inv, db);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vd_abi_version(void) { return VD_ABI_VERSION; }

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
         __syncthreads();  // previous chunk's fragment reads are done
         // ---- stage the patch of this channel chunk: LU independent 16-byte loads in flight ----
         // first B fragments of this chunk: issued before the patch DMA so both latencies overlap
-        const uint4* wp = wbase + ((int64_t)cc * S * p.NT + wn) * 64 + lane;
+        const uint4* wp = wbase + (((int64_t)bi * p.w_box_stride) >> 3) + ((int64_t)cc * S * p.NT + wn) * 64 + lane;
         auto load_b = [&](int s, uint4& bh, uint4& bl) {
             const int sc = (p.dbg & 16) ? 0 : ((s < S) ? s : S - 1);   // dbg 16: always the same (cached) B fragment
             bh = wp[(int64_t)sc * wstep];
@@ -371,7 +371,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                 const int64_t idx = out_base + o;
                 float v = acc[i][k] * osc + bias;
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (o >= 0 && n_ok && idx < out_total) dst[idx + coff] = v;
+                if (o >= 0 && n_ok && idx < out_total) {
+                    if (p.atomic) atomicAdd(&dst[idx + coff], v);   // several boxes add into the same rows (wgrad)
+                    else dst[idx + coff] = v;
+                }
             }
         }
         finish();
@@ -704,6 +707,7 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
 #define VD_DISPATCH(PR)                                                   \
     case PR:                                                              \
         if (p.MTW == 4) return launch<PR, 4>(p, st);                      \
+        if (p.MTW == 5) return launch<PR, 5>(p, st);                      \
         if (p.MTW == 7) return launch<PR, 7>(p, st);                      \
         if (p.MTW == 8) return launch<PR, 8>(p, st);                      \
         return -2;

@@ -28,7 +28,7 @@ class _DevPlan:
         self.type_desc = torch.from_numpy(desc.copy()).to(device)
         self.tables = torch.from_numpy(tables.copy()).to(device)
         self.boxes = torch.from_numpy(plan.device_boxes().copy()).to(device)
-        self.widx = torch.from_numpy(plan.widx.reshape(-1).copy()).to(device)
+        self.widx = torch.from_numpy(plan.widx.reshape(-1).copy()).to(device)   # empty for wgrad plans (B = packed dy)
         gt = plan.gather_table()
         self.gather = torch.from_numpy(gt.copy()).to(device)
         self.n_w = int(self.widx.numel())
@@ -54,6 +54,7 @@ class _DevPlan:
         p.zero_slot = self.zero.data_ptr()
         p.prec = prec
         p.wpk = self.wpk.data_ptr(); p.w_plane_stride = self.n_w
+        p.w_box_stride = plan.w_box_stride; p.atomic = int(plan.atomic)
         self.col_off = None if plan.col_off is None else torch.from_numpy(plan.col_off.copy()).to(device)
         p.col_off = 0 if self.col_off is None else self.col_off.data_ptr()
         self.params = p
@@ -72,9 +73,12 @@ class _DevPlan:
                   "vd_pack_weights")
 
     def run(self, src: torch.Tensor, src_plane_slots: int, bias: Optional[torch.Tensor], dst_ptr: int,
-            dst_plane_stride: int, argmax: Optional[torch.Tensor], nclips: int, out_scale: Optional[torch.Tensor] = None) -> None:
+            dst_plane_stride: int, argmax: Optional[torch.Tensor], nclips: int, out_scale: Optional[torch.Tensor] = None,
+            wpk: Optional[torch.Tensor] = None, w_plane_elems: int = 0) -> None:
         p = self.params
         p.out_scale = 0 if out_scale is None else out_scale.data_ptr()
+        if wpk is not None:     # B operand supplied per call (weight-gradient programs)
+            p.wpk = wpk.data_ptr(); p.w_plane_stride = w_plane_elems
         p.src = src.data_ptr(); p.src_plane_stride4 = src_plane_slots * 4
         p.bias = 0 if bias is None else bias.data_ptr()
         p.dst = dst_ptr; p.dst_plane_stride = dst_plane_stride
@@ -229,3 +233,44 @@ class EmbedEngine:
                 grad = out
                 layout = 1
         return dx
+
+
+class WgradOp:
+    """dW of one Conv3d(k(3,7,7), s(1,2,2), p(1,3,3)) layer for a batch of `nclips` clips, as a tile
+    program of the MFMA kernel (plan.plan_wgrad): x is re-laid out clip-minor, dy is packed into
+    per-box B fragments, boxes of positions accumulate into dW with fp32 atomics."""
+
+    def __init__(self, cin: int, cout: int, t: int, h: int, w: int, nclips: int, prec: str, device):
+        self.cin, self.cout, self.t, self.h, self.w, self.nclips = cin, cout, t, h, w, nclips
+        self.prec = hip.PREC[prec]
+        self.planes = 2 if hip.is_x3(self.prec) else 1
+        self.device = torch.device(device)
+        self.plan = P.plan_wgrad("wgrad", cin, cout, t, h, w, nclips)
+        self.dp = _DevPlan(self.plan, self.device, self.prec)
+        self.T, self.OH, self.OW = self.plan.meta["grid"]
+        self.CCb = self.plan.CC
+        self.npos_in = t * h * w
+        self.xT = torch.empty((self.planes, cin * self.CCb * self.npos_in, 8), dtype=torch.int16, device=self.device)
+        self.bp_elems = self.plan.nbox * self.plan.w_box_stride
+        self.bp = torch.empty((self.planes, self.bp_elems), dtype=torch.int16, device=self.device)
+
+    def run(self, x_src: torch.Tensor, x_is_pixels: bool, x_plane_slots: int, dy: torch.Tensor, dy_plane_slots: int,
+            dw_out: torch.Tensor, out_scale: Optional[torch.Tensor] = None) -> None:
+        """x_src: fp32 clips (B,T,3,H,W) if x_is_pixels else channels-last slots [planes][clip][C/8][npos][8];
+        dy: dense slots [planes][clip][N/8][T][OH][OW][8]; dw_out (cout,cin,3,7,7) fp32 is ACCUMULATED into."""
+        L, st = hip.lib(), hip.stream_ptr(self.device)
+        nb = self.nclips
+        xT_plane = self.xT.shape[1]
+        if x_is_pixels:
+            lo = self.xT[1] if self.planes == 2 else None
+            hip.check(L.vd_clip_minor_pix(hip.ptr(x_src), ctypes.c_int64(nb), self.t, self.h, self.w, hip.ptr(self.xT[0]),
+                                          hip.ptr(lo), self.prec, st), "vd_clip_minor_pix")
+        else:
+            hip.check(L.vd_clip_minor_cl(hip.ptr(x_src), ctypes.c_int64(x_plane_slots), self.planes, ctypes.c_int64(nb), self.cin,
+                                         ctypes.c_int64(self.npos_in), hip.ptr(self.xT), ctypes.c_int64(xT_plane), st),
+                      "vd_clip_minor_cl")
+        nt, noh, now = self.plan.meta["box"]
+        hip.check(L.vd_pack_dy(hip.ptr(dy), ctypes.c_int64(dy_plane_slots), self.planes, ctypes.c_int64(nb), self.cout, self.T,
+                               self.OH, self.OW, nt, noh, now, hip.ptr(self.bp), ctypes.c_int64(self.bp_elems), st), "vd_pack_dy")
+        self.dp.run(self.xT, xT_plane, None, dw_out.data_ptr(), 0, None, self.cin, out_scale=out_scale, wpk=self.bp,
+                    w_plane_elems=self.bp_elems)

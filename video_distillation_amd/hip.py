@@ -19,14 +19,14 @@ SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("conv_mfma.hip", "aux_kernel
 
 PREC = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
 EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv0_persistent", "vd_pack_weights", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_absmax_scale", "vd_dm_loss",
-           "vd_group_sum", "vd_sgd_momentum", "vd_hallucinator_fwd", "vd_hallucinator_bwd", "vd_match_rows_fwd", "vd_match_rows_bwd", "vd_head_fwd")
+           "vd_group_sum", "vd_sgd_momentum", "vd_hallucinator_fwd", "vd_hallucinator_bwd", "vd_match_rows_fwd", "vd_match_rows_bwd", "vd_head_fwd", "vd_clip_minor_cl", "vd_clip_minor_pix", "vd_pack_dy", "vd_bias_grad")
 
 
 class VdConvParams(ctypes.Structure):
     _fields_ = [
         ("src", ctypes.c_void_p), ("src_plane_stride4", ctypes.c_int64),
         ("src_clip_stride4", ctypes.c_int64), ("src_chunk_stride4", ctypes.c_int64),
-        ("wpk", ctypes.c_void_p), ("w_plane_stride", ctypes.c_int64),
+        ("wpk", ctypes.c_void_p), ("w_plane_stride", ctypes.c_int64), ("w_box_stride", ctypes.c_int64),
         ("bias", ctypes.c_void_p),
         ("dst", ctypes.c_void_p), ("dst_plane_stride", ctypes.c_int64),
         ("argmax", ctypes.c_void_p), ("col_off", ctypes.c_void_p), ("out_scale", ctypes.c_void_p),
@@ -38,7 +38,7 @@ class VdConvParams(ctypes.Structure):
         ("n_out", ctypes.c_int32), ("n_stride", ctypes.c_int32),
         ("out_clip_stride", ctypes.c_int64),
         ("out_chunk_stride", ctypes.c_int32), ("out_t_stride", ctypes.c_int32),
-        ("lds_plane_bytes", ctypes.c_int32), ("prec", ctypes.c_int32), ("dbg", ctypes.c_int32), ("ntypes", ctypes.c_int32), ("tab_ofs", ctypes.c_int32 * 3), ("persist", ctypes.c_int32), ("stamps", ctypes.c_void_p),
+        ("lds_plane_bytes", ctypes.c_int32), ("prec", ctypes.c_int32), ("dbg", ctypes.c_int32), ("ntypes", ctypes.c_int32), ("tab_ofs", ctypes.c_int32 * 3), ("atomic", ctypes.c_int32), ("persist", ctypes.c_int32), ("stamps", ctypes.c_void_p),
     ]
 
 

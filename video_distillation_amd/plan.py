@@ -89,6 +89,8 @@ class ConvPlan:
     clip_stride4: int = 0        # dwords per clip (all channel chunks)
     chunk_stride4: int = 0       # dwords per 8-channel chunk
     col_off: Optional[np.ndarray] = None   # EPI_ROWS: element offset of output column n (else n*n_stride)
+    atomic: bool = False         # EPI_ROWS: accumulate with fp32 atomics (several boxes add into the same rows)
+    w_box_stride: int = 0        # 16-bit elements between the packed B operands of consecutive boxes (0 = shared)
     rows_total: int = 0
     rows_useful: int = 0
     meta: Dict = field(default_factory=dict)
@@ -598,6 +600,102 @@ def plan_dgrad_pix(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: i
     n = np.arange(32)
     plan.col_off = np.where(n < cin * 4, (n // 4) * h_in * w_in + ((n // 2) % 2) * w_in + (n % 2), 0).astype(np.int32)
     return plan
+
+
+def plan_wgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, nclips: int,
+               lds_budget: int = 3700, block=(2, 4, 14)) -> ConvPlan:
+    """Weight gradient of Conv3d(cin->cout, k(3,7,7), s(1,2,2), p(1,3,3)) as a tile program of the SAME
+    kernel, with the roles of the operands rotated:
+
+        dW[n, c, tap] = sum_{clip, pos} dy[clip, pos, n] * x[clip, c, pos*stride + tap]
+
+      * a 'clip' of the program is one INPUT CHANNEL c; its output rows are the 147 taps;
+      * the K loop runs over (position in a block) x (8 clips per slot): the source is x in a
+        clip-minor layout [c][clip/8][t][h][w][8 clips] (vd_clip_minor), the 'channel chunks' are
+        the clip chunks, the program's taps are the block's positions (stride-2 offsets);
+      * a box is a block of output positions; every box of a channel adds into the same 147 x cout
+        rows (fp32 atomics), and its B operand -- dy of its positions, packed per box by
+        vd_pack_dy -- sits at box * w_box_stride.
+    The A address stays  a_off[row = tap] + tap_off[step position]  (both additive in the patch)."""
+    assert cout % 32 == 0
+    T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
+    nt, noh, now = block
+    nt, noh, now = min(nt, T), min(noh, OH), min(now, OW)
+    if (nt * noh * now) % 2:
+        now += 1                                  # K steps take position pairs; the extra column is masked by zero dy
+    CCb = -(-nclips // 8)
+    NT = cout // 32
+    MW = 1
+    MTW = 5                                      # 147 taps -> 5 row tiles of 32
+    pf, ph, pw = nt + 2, 2 * (noh - 1) + 7, 2 * (now - 1) + 7
+    positions = [(dt, doh, dow) for dt in range(nt) for doh in range(noh) for dow in range(now)]
+    S = len(positions) // 2
+    best = None
+    rows_tap = [(kt, kh, kw) for kt in range(KT) for kh in range(KH) for kw in range(KW)]
+    for dph in range(0, 16):
+        pitch_h = pw + dph
+        for dpf in range(0, 16):
+            pitch_f = ph * pitch_h + dpf
+            pitch_c = pf * pitch_f
+            if pitch_c > lds_budget * 1.12 and best is not None:
+                continue
+            a_off = np.zeros(MTW * 32, dtype=np.int64)
+            for r, (kt, kh, kw) in enumerate(rows_tap):
+                a_off[r] = kt * pitch_f + kh * pitch_h + kw
+            cyc = float(np.mean([_conflict_cycles(a_off[t * 32:(t + 1) * 32]) for t in range(MTW)]))
+            key = (round(cyc, 3), pitch_c)
+            if best is None or key < best[0]:
+                out = -np.ones(MTW * 32, dtype=np.int64)
+                out[:len(rows_tap)] = np.arange(len(rows_tap))
+                tap_off = np.array([(dt * pitch_f + 2 * doh * pitch_h + 2 * dow) * SLOT_BYTES for dt, doh, dow in positions])
+                best = (key, BoxType(pf, ph, pw, pitch_h, pitch_f, pitch_c, MTW, (a_off * SLOT_BYTES).astype(np.int32),
+                                     out.astype(np.int32), tap_off.astype(np.int32), cyc))
+            if cyc <= 4.0 + 1e-9:
+                break
+        if best[0][0] <= 4.0 + 1e-9:
+            break
+    bt = best[1]
+    boxes, blocks = [], []
+    for t0 in range(0, T, nt):
+        for oh0 in range(0, OH, noh):
+            for ow0 in range(0, OW, now):
+                boxes.append([0, t0 - 1, 2 * oh0 - 3, 2 * ow0 - 3, 0, 0])
+                blocks.append((t0, oh0, ow0))
+    plan = ConvPlan(name=name, CC=CCb, F=t_in, H=h_in, W=w_in, row_pitch4=w_in * 4, chunk_stride4=t_in * h_in * w_in * 4,
+                    clip_stride4=CCb * t_in * h_in * w_in * 4, NT=NT, MW=MW, MTW=MTW, S=S, ncl=1,
+                    boxes=np.asarray(boxes, dtype=np.int32), types=[bt], widx=np.zeros((0,), dtype=np.int32),
+                    epi=EPI_ROWS, pool_t=0, relu=False, n_out=cout, n_stride=cin * KT * KH * KW,
+                    out_clip_stride=KT * KH * KW, out_chunk_stride=0, out_shape=(cout, cin, KT, KH, KW),
+                    rows_total=len(boxes) * MTW * 32, rows_useful=len(boxes) * len(rows_tap), meta={"box": (nt, noh, now)})
+    plan.atomic = True
+    plan.w_box_stride = CCb * S * NT * 64 * 8
+    plan.meta.update({"blocks": blocks, "positions": positions, "grid": (T, OH, OW), "nclips": nclips, "cout": cout})
+    return plan
+
+
+def wgrad_pack_index(plan: ConvPlan) -> np.ndarray:
+    """Gather table of vd_pack_dy's output for tests: [nbox, CCb, S, NT, 64, 8] -> (clip, t, oh, ow, n)
+    flat index into dy[clip][t][oh][ow][n] (channels-last logical order) or -1."""
+    T, OH, OW = plan.meta["grid"]
+    nclips, cout = plan.meta["nclips"], plan.meta["cout"]
+    positions = plan.meta["positions"]
+    lane = np.arange(64); col, half = lane & 31, lane >> 5
+    out = -np.ones((plan.nbox, plan.CC, plan.S, plan.NT, 64, 8), dtype=np.int64)
+    for bi, (t0, oh0, ow0) in enumerate(plan.meta["blocks"]):
+        for s in range(plan.S):
+            for hh in range(2):
+                dt, doh, dow = positions[2 * s + hh]
+                t, oh, ow = t0 + dt, oh0 + doh, ow0 + dow
+                if t >= T or oh >= OH or ow >= OW:
+                    continue
+                lanes = np.where(half == hh)[0]
+                for nt in range(plan.NT):
+                    n = nt * 32 + col[lanes]
+                    for cb in range(plan.CC):
+                        clip = cb * 8 + np.arange(8)
+                        flat = (((clip[None, :] * T + t) * OH + oh) * OW + ow) * cout + n[:, None]
+                        out[bi, cb, s, nt, lanes, :] = np.where(clip[None, :] < nclips, flat, -1)
+    return out
 
 
 # ----------------------------------------------------------------------------------------
