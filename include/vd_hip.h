@@ -165,6 +165,23 @@ int vd_bias_grad(const void* dy, int64_t dy_plane_slots, int planes, int64_t ncl
 int vd_head_fwd(const float* feats, const float* w, const float* b, int64_t nclips, int C, int To, int Ho, int Wo,
                 int kt, int kh, int kw, int K, float* out, void* stream);
 
+/* Training half of evaluate_synset / epoch('train') (utils.py:765-792, 852-853):
+ *  vd_standardize     : out = (x - mean(x)) / std(x), batch-global scalars, unbiased std (:770); scratch2 = 2 doubles;
+ *  vd_head_train_fwd  : avg-pool, dropout (mask (B,C,Tp) holding 0 or 1/(1-p), or NULL), 1x1x1 conv, max over T;
+ *                       also returns the dropped tensor (B,Tp,C) and the arg-max frame per (clip, class);
+ *  vd_ce_loss         : nn.CrossEntropyLoss (mean): per-clip losses and d(mean loss)/d logits;
+ *  vd_head_train_bwd  : gradients of the head: g_w [K][C], g_b [K] (accumulated, fp32 atomics), g_feats (B,C,To,Ho,Wo);
+ *  vd_sgd_momentum_wd : torch.optim.SGD(momentum, weight_decay) step. */
+int vd_standardize(const float* x, int64_t n, double* scratch2, float* out, void* stream);
+int vd_head_train_fwd(const float* feats, const float* mask, const float* w, const float* b, int64_t nclips, int C, int To,
+                      int Ho, int Wo, int kt, int kh, int kw, int K, float* dropped, float* logits, int32_t* amax_t, void* stream);
+int vd_ce_loss(const float* logits, const int64_t* labels, int B, int K, float* loss_per_clip, float* dlogits, void* stream);
+int vd_head_train_bwd(const float* dlogits, const int32_t* amax_t, const float* dropped, const float* mask, const float* w,
+                      int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K, float* g_w, float* g_b,
+                      float* g_feats, void* stream);
+int vd_sgd_momentum_wd(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, float wd, int first,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

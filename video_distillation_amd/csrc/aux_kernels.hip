@@ -853,4 +853,186 @@ extern "C" int vd_bias_grad(const void* dy, int64_t dy_plane_slots, int planes, 
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Training half of the classifier head + loss + optimiser (evaluate_synset / epoch('train'),
+// reference utils.py:765-792, 852): one workgroup per clip, everything per clip fits LDS.
+//   pooled[t'][c] = mean over the (kt,kh,kw) window of feats;  dropped = pooled * mask (mask already
+//   holds 0 or 1/(1-p));  z[t'][k] = b[k] + sum_c w[k][c] * dropped[t'][c];  logits[k] = max_t' z.
+__global__ __launch_bounds__(256) void head_train_fwd_kernel(const float* __restrict__ feats, const float* __restrict__ mask,
+                                                              const float* __restrict__ w, const float* __restrict__ b,
+                                                              int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K,
+                                                              float* __restrict__ dropped_out, float* __restrict__ logits,
+                                                              int32_t* __restrict__ amax_t) {
+    extern __shared__ float pooled[];          // [Tp][C]
+    const int clip = blockIdx.x;
+    const int Tp = To - kt + 1;
+    const float* f = feats + (int64_t)clip * C * To * Ho * Wo;
+    const float inv = 1.f / (float)(kt * kh * kw);
+    for (int i = threadIdx.x; i < Tp * C; i += blockDim.x) {
+        const int c = i % C, t = i / C;
+        float a = 0.f;
+        for (int dt = 0; dt < kt; ++dt)
+            for (int dh = 0; dh < kh; ++dh)
+                for (int dw = 0; dw < kw; ++dw) a += f[((c * To + t + dt) * Ho + dh) * Wo + dw];
+        a *= inv;
+        if (mask != nullptr) a *= mask[((int64_t)clip * C + c) * Tp + t];     // mask layout (B, C, Tp) like the pooled tensor
+        pooled[t * C + c] = a;
+        dropped_out[((int64_t)clip * Tp + t) * C + c] = a;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float best = -3.402823466e38f;
+        int bt = 0;
+        for (int t = 0; t < Tp; ++t) {
+            float a = b[k];
+            for (int c = 0; c < C; ++c) a += w[k * C + c] * pooled[t * C + c];
+            if (a > best) { best = a; bt = t; }
+        }
+        logits[(int64_t)clip * K + k] = best;
+        amax_t[(int64_t)clip * K + k] = bt;
+    }
+}
+
+extern "C" int vd_head_train_fwd(const float* feats, const float* mask, const float* w, const float* b, int64_t nclips, int C,
+                                 int To, int Ho, int Wo, int kt, int kh, int kw, int K, float* dropped, float* logits,
+                                 int32_t* amax_t, void* stream) {
+    if (nclips <= 0) return 0;
+    if (Ho - kh + 1 != 1 || Wo - kw + 1 != 1 || To - kt + 1 < 1) return -2;
+    const size_t lds = (size_t)(To - kt + 1) * C * sizeof(float);
+    hipLaunchKernelGGL(head_train_fwd_kernel, dim3((unsigned)nclips), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       feats, mask, w, b, C, To, Ho, Wo, kt, kh, kw, K, dropped, logits, amax_t);
+    return (int)hipGetLastError();
+}
+
+// Mean cross-entropy over the batch and its gradient w.r.t. the logits: one workgroup per clip.
+__global__ __launch_bounds__(64) void ce_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int B,
+                                                      int K, float* __restrict__ loss_per_clip, float* __restrict__ dlogits) {
+    const int clip = blockIdx.x, lane = threadIdx.x;
+    const float* z = logits + (int64_t)clip * K;
+    float m = -3.402823466e38f;
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, z[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float sum = 0.f;
+    for (int k = lane; k < K; k += 64) sum += __expf(z[k] - m);
+    sum = wave_sum(sum);
+    const int y = (int)labels[clip];
+    const float lse = m + __logf(sum);
+    if (lane == 0) loss_per_clip[clip] = lse - z[y];
+    const float invB = 1.f / (float)B;
+    for (int k = lane; k < K; k += 64) dlogits[(int64_t)clip * K + k] = (__expf(z[k] - lse) - (k == y ? 1.f : 0.f)) * invB;
+}
+
+extern "C" int vd_ce_loss(const float* logits, const int64_t* labels, int B, int K, float* loss_per_clip, float* dlogits,
+                          void* stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), logits, labels, B, K,
+                       loss_per_clip, dlogits);
+    return (int)hipGetLastError();
+}
+
+// Backward of the head: dlogits (B,K) routed to the arg-max frame; gradients of the 1x1x1 conv
+// (atomics into g_w [K][C], g_b [K]) and of the features (B,C,To,Ho,Wo) through dropout and avg-pool.
+__global__ __launch_bounds__(256) void head_train_bwd_kernel(const float* __restrict__ dlogits, const int32_t* __restrict__ amax_t,
+                                                              const float* __restrict__ dropped, const float* __restrict__ mask,
+                                                              const float* __restrict__ w, int C, int To, int Ho, int Wo, int kt,
+                                                              int kh, int kw, int K, float* __restrict__ g_w,
+                                                              float* __restrict__ g_b, float* __restrict__ g_feats) {
+    extern __shared__ float dp[];              // [Tp][C] gradient w.r.t. the dropped/pooled tensor
+    const int clip = blockIdx.x;
+    const int Tp = To - kt + 1;
+    const float* dl = dlogits + (int64_t)clip * K;
+    const int32_t* am = amax_t + (int64_t)clip * K;
+    for (int i = threadIdx.x; i < Tp * C; i += blockDim.x) {
+        const int c = i % C, t = i / C;
+        float a = 0.f;
+        for (int k = 0; k < K; ++k) if (am[k] == t) a += dl[k] * w[k * C + c];
+        if (mask != nullptr) a *= mask[((int64_t)clip * C + c) * Tp + t];
+        dp[t * C + c] = a;
+    }
+    for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+        const int c = i % C, k = i / C;
+        atomicAdd(&g_w[i], dl[k] * dropped[((int64_t)clip * Tp + am[k]) * C + c]);
+    }
+    for (int k = threadIdx.x; k < K; k += blockDim.x) atomicAdd(&g_b[k], dl[k]);
+    __syncthreads();
+    const float inv = 1.f / (float)(kt * kh * kw);
+    float* gf = g_feats + (int64_t)clip * C * To * Ho * Wo;
+    for (int i = threadIdx.x; i < C * To * Ho * Wo; i += blockDim.x) {
+        const int x = i % Wo, y = (i / Wo) % Ho, t = (i / (Wo * Ho)) % To, c = i / (Wo * Ho * To);
+        // windows (stride 1) containing (t,y,x): t' in [t-kt+1, t], and the single h'/w' window covers all y,x
+        float a = 0.f;
+        for (int tp = t - kt + 1; tp <= t; ++tp) if (tp >= 0 && tp < Tp) a += dp[tp * C + c];
+        (void)x; (void)y;
+        gf[i] = a * inv;
+    }
+}
+
+extern "C" int vd_head_train_bwd(const float* dlogits, const int32_t* amax_t, const float* dropped, const float* mask,
+                                 const float* w, int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K,
+                                 float* g_w, float* g_b, float* g_feats, void* stream) {
+    if (nclips <= 0) return 0;
+    if (Ho - kh + 1 != 1 || Wo - kw + 1 != 1 || To - kt + 1 < 1) return -2;
+    const size_t lds = (size_t)(To - kt + 1) * C * sizeof(float);
+    hipLaunchKernelGGL(head_train_bwd_kernel, dim3((unsigned)nclips), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       dlogits, amax_t, dropped, mask, w, C, To, Ho, Wo, kt, kh, kw, K, g_w, g_b, g_feats);
+    return (int)hipGetLastError();
+}
+
+// torch.optim.SGD(momentum, weight_decay): g' = g + wd*p; buf = first ? g' : mu*buf + g'; p -= lr*buf.
+__global__ void sgd_wd_kernel(float* __restrict__ x, float* __restrict__ buf, const float* __restrict__ g, int64_t n, float lr,
+                              float mu, float wd, int first) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float p = x[i];
+        const float gv = g[i] + wd * p;
+        const float bnew = first ? gv : buf[i] * mu + gv;
+        buf[i] = bnew;
+        x[i] = p - lr * bnew;
+    }
+}
+
+extern "C" int vd_sgd_momentum_wd(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, float wd,
+                                  int first, void* stream) {
+    if (n <= 0) return 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(sgd_wd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, buf, g, n,
+                       lr, momentum, wd, first);
+    return (int)hipGetLastError();
+}
+
+// Batch-global standardisation of epoch() (utils.py:770): out = (x - mean(x)) / std(x), unbiased std.
+__global__ void sum_sumsq_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ acc) {
+    __shared__ float red[16];
+    float s = 0.f, q = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        s += v; q += v * v;
+    }
+    const float ts = block_sum(s, red);
+    const float tq = block_sum(q, red);
+    if (threadIdx.x == 0) { atomicAdd(&acc[0], (double)ts); atomicAdd(&acc[1], (double)tq); }
+}
+
+__global__ void standardize_kernel(const float* __restrict__ x, int64_t n, const double* __restrict__ acc, float* __restrict__ out) {
+    const double mean = acc[0] / (double)n;
+    const double var = (acc[1] - (double)n * mean * mean) / (double)(n - 1);
+    const float m = (float)mean, inv = (float)(1.0 / sqrt(var));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (x[i] - m) * inv;
+}
+
+extern "C" int vd_standardize(const float* x, int64_t n, double* scratch2, float* out, void* stream) {
+    if (n < 2) return -2;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(scratch2, 0, 2 * sizeof(double), st);
+    if (e != hipSuccess) return (int)e;
+    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sum_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, scratch2);
+    hipLaunchKernelGGL(standardize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, scratch2, out);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vd_abi_version(void) { return VD_ABI_VERSION; }

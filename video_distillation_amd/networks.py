@@ -11,10 +11,11 @@ Execution
     ``EmbedEngine``; the gradient w.r.t. ``x`` comes from the HIP input-gradient passes.
     Clips that carry no gradient (the real batches) use the fast operand precision, clips
     that do (the synthetic ones) the split precision (see ``set_precision``).
-  * anything that needs parameter gradients or double backward (``forward`` during
-    ``evaluate_synset``, DC / MTT callers using ``create_graph=True``) runs the same graph
-    through torch-ROCm ops; the HIP weight-gradient kernels are the next scope row
-    (SURVEY.md section 8(f)-1).
+  * ``hip_train_step`` -- one ``epoch('train')`` iteration of ``evaluate_synset`` (forward, CE
+    loss, all parameter gradients, SGD with momentum / weight decay) on the HIP path
+    (train.TrainEngine: weight gradients are tile programs of the same MFMA kernel).
+  * callers that need double backward (DC / MTT with ``create_graph=True``) or a custom loss on
+    parameter gradients run the same graph through torch-ROCm ops.
 There is no CPU compute path: ``embed`` on a CPU tensor raises.
 """
 from __future__ import annotations
@@ -28,17 +29,19 @@ import torch.nn as nn
 from . import plan as P
 
 _PRECISION = {"real": os.environ.get("VD_PREC_REAL", "f16"), "syn": os.environ.get("VD_PREC_SYN", "f16x3"),
-              "bwd": os.environ.get("VD_PREC_BWD", "f16")}
+              "bwd": os.environ.get("VD_PREC_BWD", "f16"),
+              "train": os.environ.get("VD_PREC_TRAIN", "f16x3"), "train_bwd": os.environ.get("VD_PREC_TRAIN_BWD", "f16x3")}
 _ENGINES: Dict[Tuple, object] = {}
 
 
-def set_precision(real: str = None, syn: str = None, bwd: str = None) -> None:
+def set_precision(real: str = None, syn: str = None, bwd: str = None, train: str = None, train_bwd: str = None) -> None:
     """Operand precision of the MFMA contraction: ``real`` for the forward of inputs without
     gradient, ``syn`` for the forward of inputs that need d/dx (its arg-max decisions steer the
     gradient), ``bwd`` for the input-gradient passes (no discrete decisions: single-pass fp16 with
-    per-layer power-of-two scaling is the default).  One of 'bf16', 'f16', 'bf16x3', 'f16x3'."""
+    per-layer power-of-two scaling is the default); ``train`` / ``train_bwd`` for the forward and
+    the gradient passes of ``hip_train_step``.  One of 'bf16', 'f16', 'bf16x3', 'f16x3'."""
     from . import hip
-    for k, v in (("real", real), ("syn", syn), ("bwd", bwd)):
+    for k, v in (("real", real), ("syn", syn), ("bwd", bwd), ("train", train), ("train_bwd", train_bwd)):
         if v is not None:
             if v not in hip.PREC:
                 raise ValueError("unknown precision %r" % v)
@@ -208,6 +211,58 @@ class ConvNet3D(nn.Module):
         hip.check(hip.lib().vd_head_fwd(hip.ptr(feats), hip.ptr(w), hip.ptr(b), ctypes.c_int64(x.shape[0]), C, To, Ho, Wo,
                                         kt, kh, kw, K, hip.ptr(out), hip.stream_ptr(x.device)), "vd_head_fwd")
         return out
+
+    # -- training step on the HIP path (utils.epoch 'train' dispatches here) ----------------------
+    def hip_trainable(self, x, optimizer, criterion) -> bool:
+        """True when (net, optimiser, loss) is the combination ``evaluate_synset`` builds
+        (utils.py:852-853): plain SGD with momentum / weight decay over exactly this module's
+        parameters and mean cross-entropy."""
+        if not (self._hip_ok and x.is_cuda and x.dim() == 5 and x.shape[2] == 3):
+            return False
+        if type(optimizer) is not torch.optim.SGD or len(optimizer.param_groups) != 1:
+            return False
+        g = optimizer.param_groups[0]
+        if g.get("nesterov") or g.get("dampening", 0) != 0 or g.get("maximize"):
+            return False
+        mine = list(self.parameters())
+        if len(g["params"]) != len(mine) or any(a is not b for a, b in zip(g["params"], mine)):
+            return False
+        if any((not p.is_cuda) or p.dtype != torch.float32 or not p.is_contiguous() for p in mine):
+            return False
+        return (type(criterion) is nn.CrossEntropyLoss and criterion.weight is None and criterion.reduction == "mean"
+                and getattr(criterion, "label_smoothing", 0.0) == 0.0)
+
+    def _train_engine(self, x):
+        from . import train
+        key = ("train", x.shape[1], x.shape[3], x.shape[4], _PRECISION["train"], _PRECISION["train_bwd"],
+               x.device.index if x.device.index is not None else torch.cuda.current_device())
+        te = _ENGINES.get(key)
+        if te is None:
+            te = train.TrainEngine(P.NetGeometry(x.shape[1], x.shape[3], x.shape[4]), self.logit.weight.shape[0],
+                                   self.avg_pool.kernel_size, x.device, prec=_PRECISION["train"],
+                                   prec_bwd=_PRECISION["train_bwd"])
+            _ENGINES[key] = te
+        return te
+
+    def hip_train_step(self, x, labels, optimizer):
+        """forward + CrossEntropyLoss + backward + ``optimizer.step()`` for one batch, on the HIP
+        path.  ``x`` is the (already standardised) batch (B,T,3,H,W).  Momentum buffers live in
+        ``optimizer.state`` exactly where torch keeps them.  Returns (logits, loss)."""
+        te = self._train_engine(x)
+        params = list(self.parameters())
+        mask = None
+        if self.training and self.dropout.p > 0:
+            keep = 1.0 - self.dropout.p
+            mask = torch.bernoulli(torch.full((x.shape[0], te.C, te.Tp), keep, device=x.device)) / keep
+        loss, logits, grads = te.loss_and_grads(x, labels, params, mask)
+        grp = optimizer.param_groups[0]
+        bufs = [optimizer.state[p].get("momentum_buffer") for p in params]
+        new = te.sgd_step([p.data for p in params], grads, bufs, float(grp["lr"]), float(grp["momentum"]),
+                          float(grp["weight_decay"]))
+        for p, b in zip(params, new):
+            optimizer.state[p]["momentum_buffer"] = b
+            torch.autograd.graph.increment_version(p)
+        return logits, loss
 
     def forward(self, x):
         if (self._hip_ok and x.is_cuda and not self.training and not torch.is_grad_enabled()):

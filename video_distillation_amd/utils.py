@@ -277,6 +277,14 @@ def get_eval_pool(eval_mode, model, model_eval):
 # ------------------------------------------------------------------------------------------
 # evaluate_synset / epoch
 # ------------------------------------------------------------------------------------------
+def _standardize(img):
+    """(img - img.mean()) / img.std() (utils.py:770); HIP kernel for device tensors."""
+    if img.is_cuda:
+        from . import train
+        return train.standardize(img)
+    return (img - img.mean()) / img.std()
+
+
 def epoch(mode, dataloader, net, optimizer, criterion, args):
     """``epoch`` (utils.py:752-844): one training pass, or THREE test passes (test clips resample
     their start frame on every read); batch-global standardisation with the unbiased std."""
@@ -292,11 +300,15 @@ def epoch(mode, dataloader, net, optimizer, criterion, args):
             img = datum[0].float().to(args.device)
             if 'Video' in args.model:
                 img = img[:, :, :, 24:-24, 24:-24]
-            img = (img - img.mean()) / img.std()
+            img = _standardize(img)
             lab = datum[1].long().to(args.device)
             n_b = lab.shape[0]
-            output = net(img)
-            loss = criterion(output, lab)
+            hip_step = (mode == 'train' and hasattr(net, 'hip_trainable') and net.hip_trainable(img, optimizer, criterion))
+            if hip_step:    # forward + loss + backward + optimizer.step() on the HIP path
+                output, loss = net.hip_train_step(img, lab, optimizer)
+            else:
+                output = net(img)
+                loss = criterion(output, lab)
             out_np, lab_np = output.detach().cpu().numpy(), lab.cpu().numpy()
             matched = np.equal(np.argmax(out_np, axis=-1), lab_np)
             order = np.argsort(out_np, axis=-1)
@@ -313,7 +325,7 @@ def epoch(mode, dataloader, net, optimizer, criterion, args):
             loss_avg += loss.item() * n_b
             acc_avg += np.sum(matched)
             num_exp += n_b
-            if mode == 'train':
+            if mode == 'train' and not hip_step:
                 optimizer.zero_grad()
                 loss.backward()
                 optimizer.step()
