@@ -817,22 +817,22 @@ extern "C" int vd_pack_dy(const void* dy, int64_t dy_plane_slots, int planes, in
 __global__ __launch_bounds__(256) void bias_grad_kernel(const uint4* __restrict__ dy, int64_t plane_slots, int planes,
                                                          int64_t nclips, int CCh, int64_t npos, int prec,
                                                          const float* __restrict__ scale_inv, float* __restrict__ db) {
+    // grid (N/8, clips, position blocks): every workgroup reduces a contiguous run of slots of one
+    // (clip, channel chunk) and adds its 8 partial sums with fp32 atomics.
     __shared__ float red[16];
     const int cc = blockIdx.x;
+    const int64_t clip = blockIdx.y;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int64_t total = nclips * npos;
-    for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
-        const int64_t clip = i / npos, pos = i - clip * npos;
-        for (int pl = 0; pl < planes; ++pl) {
-            const uint4 v = dy[pl * plane_slots + (clip * CCh + cc) * npos + pos];
+    const bool bf = (prec == VD_PREC_BF16 || prec == VD_PREC_BF16X3);
+    for (int pl = 0; pl < planes; ++pl) {
+        const uint4* base = dy + pl * plane_slots + (clip * CCh + cc) * npos;
+        for (int64_t pos = (int64_t)blockIdx.z * blockDim.x + threadIdx.x; pos < npos; pos += (int64_t)gridDim.z * blockDim.x) {
+            const uint4 v = base[pos];
             const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint16_t hbits = (uint16_t)(wds[k >> 1] >> ((k & 1) * 16));
-                float f;
-                if (prec == VD_PREC_BF16 || prec == VD_PREC_BF16X3) f = __uint_as_float((uint32_t)hbits << 16);
-                else f = (float)__builtin_bit_cast(_Float16, hbits);
-                acc[k] += f;
+                acc[k] += bf ? __uint_as_float((uint32_t)hbits << 16) : (float)__builtin_bit_cast(_Float16, hbits);
             }
         }
     }
@@ -840,16 +840,18 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const uint4* __restrict_
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const float tot = block_sum(acc[k], red);
-        if (threadIdx.x == 0) db[cc * 8 + k] += tot * sc;
+        if (threadIdx.x == 0) atomicAdd(&db[cc * 8 + k], tot * sc);
     }
 }
 
 extern "C" int vd_bias_grad(const void* dy, int64_t dy_plane_slots, int planes, int64_t nclips, int N, int64_t npos, int prec,
                             const float* scale_inv, float* db, void* stream) {
-    if (N % 8 != 0) return -2;
+    if (N % 8 != 0 || nclips > 65535) return -2;
     if (nclips <= 0) return 0;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(N / 8), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const uint4*)dy,
-                       dy_plane_slots, planes, nclips, N / 8, npos, prec, scale_inv, db);
+    int zb = (int)((npos + 256 * 8 - 1) / (256 * 8));
+    if (zb > 64) zb = 64;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(N / 8, (unsigned)nclips, zb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const uint4*)dy, dy_plane_slots, planes, nclips, N / 8, npos, prec, scale_inv, db);
     return (int)hipGetLastError();
 }
 
