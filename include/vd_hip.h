@@ -62,6 +62,9 @@ typedef struct VdConvParams {
     int32_t ntypes;               /* number of box types; 1 -> tab_ofs are used for every box     */
     int32_t tab_ofs[3];           /* a_off / out / tap table offsets of box type 0                */
     int32_t atomic;               /* ROWS epilogue: accumulate with fp32 atomics                  */
+    int32_t select;               /* pooled epilogues: argmax is an INPUT, emit the selected row (0 if ReLU-dead) */
+    int32_t src_split_cc;         /* >0: channel chunks >= this come from a second tensor ...     */
+    int64_t src_split_off4;       /* ... that starts this many dwords after src (same strides)    */
     int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
 } VdConvParams;
@@ -179,6 +182,14 @@ int vd_ce_loss(const float* logits, const int64_t* labels, int B, int K, float* 
 int vd_head_train_bwd(const float* dlogits, const int32_t* amax_t, const float* dropped, const float* mask, const float* w,
                       int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K, float* g_w, float* g_b,
                       float* g_feats, void* stream);
+/* Second-order pass through the head for gradient matching (DC: match_loss(gw_syn, gw_real).backward() with
+ * gw_syn = autograd.grad(CE(net(x)), params, create_graph=True), upstream DC loop / distill_baseline.py:250):
+ * adjoints of the head's parameter gradients (v_w, v_b) and of the feature gradient (gbar_feats) -> adjoint of
+ * the features (abar_feats), through the CE Hessian and the saved arg-max frames / dropout mask. */
+int vd_head_second_order(const float* logits, const float* dlogits, const int32_t* amax_t, const float* dropped,
+                         const float* mask, const float* w, const float* v_w, const float* v_b, const float* gbar_feats,
+                         int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K, float* abar_feats,
+                         void* stream);
 int vd_sgd_momentum_wd(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, float wd, int first,
                        void* stream);
 

@@ -981,6 +981,95 @@ extern "C" int vd_head_train_bwd(const float* dlogits, const int32_t* amax_t, co
     return (int)hipGetLastError();
 }
 
+// Second-order pass through the head (gradient matching, d match_loss / d pixels): given the
+// adjoints of the head's parameter gradients (v_w [K][C], v_b [K]) and of the feature gradient
+// (gbar_feats, (B,C,To,Ho,Wo)), produce the adjoint of the features.  With p = softmax(logits),
+// dlog = (p - onehot)/B, t*_k the arg-max frame of class k:
+//   dlogbar[k]  = sum_c w[k][c] * m*avgpool(gbar_feats)[t*_k][c] + sum_c v_w[k][c] * dropped[t*_k][c] + v_b[k]
+//   logitbar[k] = p[k] * (dlogbar[k] - <p, dlogbar>) / B                       (Hessian of the mean CE)
+//   dropbar[t][c] = sum_{k: t*_k = t} (w[k][c] * logitbar[k] + v_w[k][c] * dlog[k])
+//   abar_feats = avgpool^T (m * dropbar)
+__global__ __launch_bounds__(256) void head_second_order_kernel(
+    const float* __restrict__ logits, const float* __restrict__ dlogits, const int32_t* __restrict__ amax_t,
+    const float* __restrict__ dropped, const float* __restrict__ mask, const float* __restrict__ w,
+    const float* __restrict__ v_w, const float* __restrict__ v_b, const float* __restrict__ gbar_feats, int B, int C, int To,
+    int Ho, int Wo, int kt, int kh, int kw, int K, float* __restrict__ abar_feats) {
+    extern __shared__ float sm[];
+    const int Tp = To - kt + 1;
+    float* u = sm;                   // [Tp][C]  m * avgpool(gbar_feats), later m * dropbar
+    float* dlb = sm + Tp * C;        // [K] dlogbar, then logitbar
+    float* pk = dlb + K;             // [K] softmax
+    __shared__ float red[16];
+    const int clip = blockIdx.x;
+    const float inv = 1.f / (float)(kt * kh * kw);
+    const float* gb = gbar_feats + (int64_t)clip * C * To * Ho * Wo;
+    for (int i = threadIdx.x; i < Tp * C; i += blockDim.x) {
+        const int c = i % C, t = i / C;
+        float a = 0.f;
+        for (int dt = 0; dt < kt; ++dt)
+            for (int dh = 0; dh < kh; ++dh)
+                for (int dw = 0; dw < kw; ++dw) a += gb[((c * To + t + dt) * Ho + dh) * Wo + dw];
+        a *= inv;
+        if (mask != nullptr) a *= mask[((int64_t)clip * C + c) * Tp + t];
+        u[i] = a;
+    }
+    const float* z = logits + (int64_t)clip * K;
+    float m = -3.402823466e38f;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, z[k]);
+    float ssum = 0.f;
+    for (int k = 0; k < K; ++k) ssum += __expf(z[k] - m);
+    __syncthreads();
+    const int32_t* am = amax_t + (int64_t)clip * K;
+    const float* dl = dlogits + (int64_t)clip * K;
+    float part = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const int t = am[k];
+        const float* dr = dropped + ((int64_t)clip * Tp + t) * C;
+        float a = v_b[k];
+        for (int c = 0; c < C; ++c) a += w[k * C + c] * u[t * C + c] + v_w[k * C + c] * dr[c];
+        const float p = __expf(z[k] - m) / ssum;
+        dlb[k] = a;
+        pk[k] = p;
+        part += p * a;
+    }
+    __shared__ float dot_s;
+    const float dot0 = block_sum(part, red);       // valid in thread 0 only
+    if (threadIdx.x == 0) dot_s = dot0;
+    __syncthreads();
+    const float dot = dot_s;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) dlb[k] = pk[k] * (dlb[k] - dot) / (float)B;
+    __syncthreads();
+    for (int i = threadIdx.x; i < Tp * C; i += blockDim.x) {
+        const int c = i % C, t = i / C;
+        float a = 0.f;
+        for (int k = 0; k < K; ++k)
+            if (am[k] == t) a += w[k * C + c] * dlb[k] + v_w[k * C + c] * dl[k];
+        if (mask != nullptr) a *= mask[((int64_t)clip * C + c) * Tp + t];
+        u[i] = a;
+    }
+    __syncthreads();
+    float* out = abar_feats + (int64_t)clip * C * To * Ho * Wo;
+    for (int i = threadIdx.x; i < C * To * Ho * Wo; i += blockDim.x) {
+        const int t = (i / (Wo * Ho)) % To, c = i / (Wo * Ho * To);
+        float a = 0.f;
+        for (int tp = t - kt + 1; tp <= t; ++tp) if (tp >= 0 && tp < Tp) a += u[tp * C + c];
+        out[i] = a * inv;
+    }
+}
+
+extern "C" int vd_head_second_order(const float* logits, const float* dlogits, const int32_t* amax_t, const float* dropped,
+                                    const float* mask, const float* w, const float* v_w, const float* v_b,
+                                    const float* gbar_feats, int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw,
+                                    int K, float* abar_feats, void* stream) {
+    if (nclips <= 0) return 0;
+    if (Ho - kh + 1 != 1 || Wo - kw + 1 != 1 || To - kt + 1 < 1) return -2;
+    const size_t lds = ((size_t)(To - kt + 1) * C + 2 * (size_t)K) * sizeof(float);
+    hipLaunchKernelGGL(head_second_order_kernel, dim3((unsigned)nclips), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       logits, dlogits, amax_t, dropped, mask, w, v_w, v_b, gbar_feats, (int)nclips, C, To, Ho, Wo, kt, kh, kw, K,
+                       abar_feats);
+    return (int)hipGetLastError();
+}
+
 // torch.optim.SGD(momentum, weight_decay): g' = g + wd*p; buf = first ? g' : mu*buf + g'; p -= lr*buf.
 __global__ void sgd_wd_kernel(float* __restrict__ x, float* __restrict__ buf, const float* __restrict__ g, int64_t n, float lr,
                               float mu, float wd, int first) {

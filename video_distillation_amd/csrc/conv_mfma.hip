@@ -198,7 +198,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
             load_b(u, bqh[u], bql[u]);
         }
         bql[DB] = make_uint4(0, 0, 0, 0);
-        const uint32_t* csrc = src + (int64_t)clip0 * p.src_clip_stride4 + (int64_t)cc * p.src_chunk_stride4;
+        // channel chunks >= src_split_cc live in a second tensor of the same shape (K-concatenated operands
+        // of the second-order passes): its distance from the first one is src_split_off4 dwords
+        const uint32_t* csrc = src + (int64_t)clip0 * p.src_clip_stride4 +
+                               ((p.src_split_cc > 0 && cc >= p.src_split_cc)
+                                    ? p.src_split_off4 + (int64_t)(cc - p.src_split_cc) * p.src_chunk_stride4
+                                    : (int64_t)cc * p.src_chunk_stride4);
         if (cc == 0) stamp(1);
         // LDS-DMA: each wave-instruction moves 64 slots (1 KiB) straight into LDS; the per-lane
         // SOURCE address comes from the gather table, the destination is lane-linear.  Zero fill
@@ -431,6 +436,32 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
             }
             const int o = lds_otab[gi * 4 + half + 2 * qh];
             if (o < 0 || !n_ok) continue;
+            if (p.select) {
+                // the arg-max bytes are an INPUT: emit the accumulator row a previous forward selected
+                // (0 where that forward's ReLU was dead) -- the adjoint of vd_unpool_relu_bwd
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    if (st == 1 && p.pool_t == 2) continue;
+                    const int base = o + st * p.out_t_stride;
+                    if (base >= lim) continue;
+                    const uint32_t idx = feat ? (uint32_t)base + chan : (uint32_t)base * 8u + chan;
+                    const int ab = amx[idx];
+                    const int jsel = (p.pool_t == 2) ? (ab & 7) : (4 * st + (ab & 3));
+                    float v = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v = (j == jsel) ? acc[i][r0 + j] : v;
+                    v = (ab & 0x80) ? 0.f : v + bias;
+                    if (feat) {
+                        dstf[idx] = v;
+                    } else {
+                        uint16_t hi, lo;
+                        split16<PREC>(v, hi, lo);
+                        dst16[idx] = hi;
+                        if constexpr (X3) dst16[idx + p.dst_plane_stride * 8] = lo;
+                    }
+                }
+                continue;
+            }
             float mv[2]; int av[2];
 #pragma unroll
             for (int st = 0; st < 2; ++st) {

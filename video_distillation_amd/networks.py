@@ -30,18 +30,20 @@ from . import plan as P
 
 _PRECISION = {"real": os.environ.get("VD_PREC_REAL", "f16"), "syn": os.environ.get("VD_PREC_SYN", "f16x3"),
               "bwd": os.environ.get("VD_PREC_BWD", "f16"),
-              "train": os.environ.get("VD_PREC_TRAIN", "f16x3"), "train_bwd": os.environ.get("VD_PREC_TRAIN_BWD", "f16x3")}
+              "train": os.environ.get("VD_PREC_TRAIN", "f16x3"), "train_bwd": os.environ.get("VD_PREC_TRAIN_BWD", "f16x3"),
+              "match": os.environ.get("VD_PREC_MATCH", "bf16x3")}
 _ENGINES: Dict[Tuple, object] = {}
 
 
-def set_precision(real: str = None, syn: str = None, bwd: str = None, train: str = None, train_bwd: str = None) -> None:
+def set_precision(real: str = None, syn: str = None, bwd: str = None, train: str = None, train_bwd: str = None,
+                  match: str = None) -> None:
     """Operand precision of the MFMA contraction: ``real`` for the forward of inputs without
     gradient, ``syn`` for the forward of inputs that need d/dx (its arg-max decisions steer the
     gradient), ``bwd`` for the input-gradient passes (no discrete decisions: single-pass fp16 with
     per-layer power-of-two scaling is the default); ``train`` / ``train_bwd`` for the forward and
     the gradient passes of ``hip_train_step``.  One of 'bf16', 'f16', 'bf16x3', 'f16x3'."""
     from . import hip
-    for k, v in (("real", real), ("syn", syn), ("bwd", bwd), ("train", train), ("train_bwd", train_bwd)):
+    for k, v in (("real", real), ("syn", syn), ("bwd", bwd), ("train", train), ("train_bwd", train_bwd), ("match", match)):
         if v is not None:
             if v not in hip.PREC:
                 raise ValueError("unknown precision %r" % v)
@@ -91,6 +93,28 @@ class _EmbedFunction(torch.autograd.Function):
             raise RuntimeError("ConvNet3D parameters changed between embed() and backward()")
         net._sync_engine(eng)
         return eng.backward(ctx.saved, g), None
+
+
+class _ParamGradFunction(torch.autograd.Function):
+    """(loss, logits, dCE/dparams...) = f(x); backward = HIP second-order pass (train.GradMatchEngine.vjp)."""
+
+    @staticmethod
+    def forward(ctx, x, labels, mask, net):
+        te = net._gm_engine(x)
+        loss, logits, g, state = te.param_grads(x, labels, list(net.parameters()), mask)
+        ctx.te, ctx.state, ctx.net = te, state, net
+        ctx.wkey = tuple((p.data_ptr(), p._version) for p in net.parameters())
+        loss = loss.detach()
+        ctx.mark_non_differentiable(loss, logits)
+        return (loss, logits) + tuple(g)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, _gl, _glog, *v):
+        net = ctx.net
+        if tuple((p.data_ptr(), p._version) for p in net.parameters()) != ctx.wkey:
+            raise RuntimeError("ConvNet3D parameters changed between param_grads() and backward()")
+        return ctx.te.vjp(ctx.state, v, list(net.parameters())), None, None, None
 
 
 class ConvNet3D(nn.Module):
@@ -244,17 +268,51 @@ class ConvNet3D(nn.Module):
             _ENGINES[key] = te
         return te
 
+    def _gm_engine(self, x):
+        from . import train
+        key = ("gm", x.shape[1], x.shape[3], x.shape[4], _PRECISION["match"],
+               x.device.index if x.device.index is not None else torch.cuda.current_device())
+        te = _ENGINES.get(key)
+        if te is None:
+            te = train.GradMatchEngine(P.NetGeometry(x.shape[1], x.shape[3], x.shape[4]), self.logit.weight.shape[0],
+                                       self.avg_pool.kernel_size, x.device, prec=_PRECISION["match"])
+            _ENGINES[key] = te
+        return te
+
+    def _dropout_mask(self, x, te):
+        if self.training and self.dropout.p > 0:
+            keep = 1.0 - self.dropout.p
+            return torch.bernoulli(torch.full((x.shape[0], te.C, te.Tp), keep, device=x.device)) / keep
+        return None
+
+    def param_grads(self, x, labels, create_graph: bool = False, mask=None):
+        """``torch.autograd.grad(CrossEntropyLoss()(net(x), labels), net.parameters(), create_graph=...)``
+        on the HIP path (gradient matching: upstream DC loop).  Returns
+        (loss, [8 gradients in parameters() order]).  With ``create_graph`` the gradients are
+        differentiable w.r.t. ``x`` (needed for ``match_loss(gw_syn, gw_real).backward()``): forward
+        mode of that second derivative is the HIP second-order pass of train.GradMatchEngine.
+        ``mask`` (B,128,T') overrides the dropout draw of train mode."""
+        if not (self._hip_ok and x.is_cuda):
+            raise RuntimeError("ConvNet3D.param_grads: HIP tensors and the ConvNet3D of get_network only (no CPU path)")
+        if create_graph:
+            te = self._gm_engine(x)
+            if mask is None:
+                mask = self._dropout_mask(x, te)
+            out = _ParamGradFunction.apply(x, labels, mask, self)
+            return out[0], list(out[2:])
+        te = self._train_engine(x)
+        if mask is None:
+            mask = self._dropout_mask(x, te)
+        loss, _, g = te.loss_and_grads(x, labels, list(self.parameters()), mask)
+        return loss, [t.clone() for t in g]
+
     def hip_train_step(self, x, labels, optimizer):
         """forward + CrossEntropyLoss + backward + ``optimizer.step()`` for one batch, on the HIP
         path.  ``x`` is the (already standardised) batch (B,T,3,H,W).  Momentum buffers live in
         ``optimizer.state`` exactly where torch keeps them.  Returns (logits, loss)."""
         te = self._train_engine(x)
         params = list(self.parameters())
-        mask = None
-        if self.training and self.dropout.p > 0:
-            keep = 1.0 - self.dropout.p
-            mask = torch.bernoulli(torch.full((x.shape[0], te.C, te.Tp), keep, device=x.device)) / keep
-        loss, logits, grads = te.loss_and_grads(x, labels, params, mask)
+        loss, logits, grads = te.loss_and_grads(x, labels, params, self._dropout_mask(x, te))
         grp = optimizer.param_groups[0]
         bufs = [optimizer.state[p].get("momentum_buffer") for p in params]
         new = te.sgd_step([p.data for p in params], grads, bufs, float(grp["lr"]), float(grp["momentum"]),

@@ -20,7 +20,7 @@ import torch
 
 from . import hip
 from . import plan as P
-from .engine import EmbedEngine, WgradOp
+from .engine import EmbedEngine, WgradOp, _DevPlan
 
 
 def standardize(x: torch.Tensor) -> torch.Tensor:
@@ -73,10 +73,11 @@ class TrainEngine:
 
     # ------------------------------------------------------------------------------------
     def loss_and_grads(self, x: torch.Tensor, labels: torch.Tensor, params: Sequence[torch.Tensor],
-                       mask: Optional[torch.Tensor] = None):
+                       mask: Optional[torch.Tensor] = None, state: Optional[dict] = None):
         """x (B,T,3,H,W) fp32 (already standardised), labels (B,) int64, params = the 8 network
         tensors in ``parameters()`` order, mask (B,C,Tp) dropout multipliers or None.
-        Returns (mean CE loss [device scalar], logits (B,K), [8 gradient tensors])."""
+        Returns (mean CE loss [device scalar], logits (B,K), [8 gradient tensors]).  ``state`` (a dict)
+        receives what a second-order pass needs (GradMatchEngine)."""
         eng, L, st = self.eng, hip.lib(), hip.stream_ptr(self.device)
         B = int(x.shape[0])
         x = x.detach().to(torch.float32).contiguous()
@@ -144,6 +145,9 @@ class TrainEngine:
                 for dp in eng.bwd[li]:
                     dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb, out_scale=inv)
                 grad, layout = out, 1
+        if state is not None:
+            state.update(nb=nb, am=(am0, am1, am2), dropped=dropped, logits=logits, dlog=dlog, amt=amt, mask=mask,
+                         wl=wl, act_plane=act_plane, x=x)
         return loss_c.mean(), logits, g
 
     # ------------------------------------------------------------------------------------
@@ -163,3 +167,120 @@ class TrainEngine:
                       "vd_sgd_momentum_wd")
             out.append(b)
         return out
+
+
+class GradMatchEngine(TrainEngine):
+    """Parameter gradients of CE(net(x)) that stay differentiable w.r.t. the clips x -- the
+    ``torch.autograd.grad(loss, params, create_graph=True)`` of gradient matching (upstream DC
+    loop; distill_baseline.py:250 for the reference's DC/MTT callers) -- and the vector-Jacobian
+    product that ``match_loss(gw_syn, gw_real).backward()`` needs: d <v, gw(x)> / dx.
+
+    With a_l the layer inputs, dz_l the gradients at the conv outputs, P_l the (fixed) ReLU +
+    arg-max selection of layer l and V_l = v for the weights of layer l, the adjoint sweep is
+      up:    dzbar_l = conv(a_l, V_l) + vb_l + conv(gbar_l, W_l),  gbar_{l+1} = P_l dzbar_l
+      head:  second-order pass through avg-pool / dropout / logit conv / max over T / CE Hessian
+      down:  abar_l = convT(P_l^T abar_{l+1}, W_l) + convT(dz_l, V_l)
+    Every conv is a tile program of the MFMA kernel: the two convs of the upward sweep are one
+    program with K-concatenated operands ([a_l | gbar_l] x [V_l | W_l], ``src_split_cc``) and the
+    ``select`` epilogue; the second convT of the downward sweep accumulates with fp32 atomics.
+    Operands are bf16 hi+lo pairs (bf16x3): adjoints span many orders of magnitude."""
+
+    def __init__(self, geo: P.NetGeometry, num_classes: int, pool_kernel, device, prec: str = "bf16x3"):
+        if not prec.startswith("bf16"):
+            raise ValueError("GradMatchEngine: bf16 / bf16x3 operands only (no per-tensor scaling of the adjoints)")
+        super().__init__(geo, num_classes, pool_kernel, device, prec=prec, prec_bwd=prec)
+        eng = self.eng
+        self.sel = [_DevPlan(eng.fwd[0].plan, self.device, eng.prec)]
+        for li in (1, 2):
+            cin, cout, t, h, w = eng.dims[li][:5]
+            pl = P.plan_forward_cl("sel%d" % li, 2 * cin, cout, t, h, w, eng.dims[li][11], feat_out=(li == 2))
+            dp = _DevPlan(pl, self.device, eng.prec)
+            dp.params.src_split_cc = cin // 8
+            dp.params.src_clip_stride4 = pl.clip_stride4 // 2      # each of the two source tensors holds cin channels per clip
+            self.sel.append(dp)
+        for dp in self.sel:
+            dp.params.select = 1
+        self.bwdV = [[_DevPlan(dp.plan, self.device, eng.prec_bwd) for dp in layer] for layer in eng.bwd]
+        for layer in self.bwdV:
+            for dp in layer:
+                dp.params.atomic = 1
+
+    def param_grads(self, x, labels, params, mask=None):
+        """-> (loss, logits, [8 gradient tensors], state); state feeds ``vjp``."""
+        eng = self.eng
+        keep_ws, eng._ws = eng._ws, {}
+        state = {}
+        try:
+            loss, logits, g = self.loss_and_grads(x, labels, params, mask, state=state)
+            g = [t.clone() for t in g]
+        finally:
+            state["ws"], eng._ws = eng._ws, keep_ws
+        return loss, logits, g, state
+
+    def vjp(self, state: dict, v: Sequence[Optional[torch.Tensor]], params: Sequence[torch.Tensor]) -> torch.Tensor:
+        """d (sum_i <v_i, g_i(x)>) / dx for the ``param_grads`` call that produced ``state``."""
+        eng, L, st = self.eng, hip.lib(), hip.stream_ptr(self.device)
+        geo = self.geo
+        nb = state["nb"]
+        am = state["am"]
+        W = [p.detach().to(self.device, torch.float32).contiguous() for p in params]
+        V = [torch.zeros_like(w) if t is None else t.detach().to(self.device, torch.float32).contiguous().view_as(w)
+             for t, w in zip(v, W)]
+        keep_ws, eng._ws = eng._ws, state["ws"]
+        try:
+            for li in range(3):
+                for dp in eng.bwd[li]:
+                    dp.pack(W[2 * li])
+                for dp in self.bwdV[li]:
+                    dp.pack(V[2 * li])
+            self.sel[0].pack(V[0])
+            for li in (1, 2):
+                self.sel[li].pack(torch.cat([V[2 * li], W[2 * li]], dim=1).contiguous())
+            rowp = P.pix_row_pitch(geo.width)
+            n_slots0 = nb * geo.frames * 3 * geo.height * (rowp // 8)
+            per1 = int(np.prod(eng.fwd[0].plan.out_shape[:-1]))
+            per2 = int(np.prod(eng.fwd[1].plan.out_shape[:-1]))
+            n1, n2 = nb * per1, nb * per2
+            slots0 = eng._buf("slots0", (eng.planes, n_slots0, 8), torch.int16)
+            act1 = eng._buf("act1", (eng.planes, n1, 8), torch.int16)
+            act2 = eng._buf("act2", (eng.planes, n2, 8), torch.int16)
+            gbar1 = eng._buf("gbar1", (eng.planes, n1, 8), torch.int16)
+            gbar2 = eng._buf("gbar2", (eng.planes, n2, 8), torch.int16)
+            gbar3 = torch.empty((nb, eng.num_feat), dtype=torch.float32, device=self.device)
+            # ---- upward sweep -------------------------------------------------------------
+            self.sel[0].run(slots0, n_slots0, V[1], gbar1.data_ptr(), n1, am[0], nb)
+            for dp, a, gb in ((self.sel[1], act1, gbar1), (self.sel[2], act2, gbar2)):
+                off = gb.data_ptr() - a.data_ptr()
+                assert off % 4 == 0
+                dp.params.src_split_off4 = off // 4
+            self.sel[1].run(act1, n1, V[3], gbar2.data_ptr(), n2, am[1], nb)
+            self.sel[2].run(act2, n2, V[5], gbar3.data_ptr(), 0, am[2], nb)
+            # ---- head -----------------------------------------------------------------------
+            kt, kh, kw = self.pool_kernel
+            abar = torch.empty((nb, eng.num_feat), dtype=torch.float32, device=self.device)
+            vw = V[6].reshape(self.K, self.C).contiguous()
+            hip.check(L.vd_head_second_order(hip.ptr(state["logits"]), hip.ptr(state["dlog"]), hip.ptr(state["amt"]),
+                                             hip.ptr(state["dropped"]), hip.ptr(state["mask"]), hip.ptr(state["wl"]), hip.ptr(vw),
+                                             hip.ptr(V[7]), hip.ptr(gbar3), ctypes.c_int64(nb), self.C, self.To, self.Ho, self.Wo,
+                                             kt, kh, kw, self.K, hip.ptr(abar), st), "vd_head_second_order")
+            # ---- downward sweep -------------------------------------------------------------
+            dx = torch.empty((nb, geo.frames, geo.channel, geo.height, geo.width), dtype=torch.float32, device=self.device)
+            grad, layout = abar, 0
+            for li in (2, 1, 0):
+                cin, cout, t, h, w, T, OH, OW, To, Ho, Wo, pt = eng.dims[li]
+                nslots = nb * (cout // 8) * T * OH * OW
+                dy = eng._buf("dy%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)       # dz_l of the first-order pass
+                zb = eng._buf("zb%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)
+                lo = zb[1] if eng.planes_bwd == 2 else None
+                hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout, To, Ho, Wo, pt, T, OH,
+                                               OW, layout, hip.ptr(zb[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(None), st),
+                          "vd_unpool_relu_bwd")
+                out = dx if li == 0 else eng._buf("ax%d" % li, (nb, t, h, w, cin), torch.float32)
+                for dp in eng.bwd[li]:
+                    dp.run(zb, nslots, None, out.data_ptr(), 0, None, nb)
+                for dp in self.bwdV[li]:
+                    dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb)
+                grad, layout = out, 1
+        finally:
+            eng._ws = keep_ws
+        return dx
