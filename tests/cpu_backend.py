@@ -66,3 +66,43 @@ class OracleBackend:
         out = R.hallucinator(st[sidx], dy[didx], wv, bv)
         gs = torch.autograd.grad(out, [st, dy, wv, bv], g_out)
         return gs[1], (gs[0] if need_static else None), gs[2], gs[3]
+
+
+class _OracleNet(torch.nn.Module):
+    """The 8 ConvNet3D tensors as a module (parameters() order of the reference), oracle forward."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.ps = torch.nn.ParameterList([torch.nn.Parameter(p.detach().clone()) for p in params])
+        self.dropout = torch.nn.Dropout(0.5)
+
+    def forward(self, x):
+        return R.convnet3d_logits(x, list(self.ps), training=self.training and self.dropout.p > 0, p_drop=self.dropout.p)
+
+
+class OracleGMOps:
+    """CPU stand-in for distill.HipGMOps (gradient matching), built on the oracle."""
+
+    def __init__(self, dis_metric="ours"):
+        self.dis_metric = dis_metric
+
+    def make_net(self, params, geo, num_classes):
+        return _OracleNet(params).train()
+
+    def param_grads(self, net, x, labels, create_graph):
+        loss = torch.nn.functional.cross_entropy(net(x), labels)
+        return list(torch.autograd.grad(loss, list(net.parameters()), create_graph=create_graph))
+
+    def match_loss(self, gw_syn, gw_real):
+        return R.match_loss(gw_syn, gw_real, self.dis_metric)
+
+    sgd = OracleBackend.sgd
+
+    def train_epoch(self, net, images, labels, optimizer, batch_train):
+        # one un-shuffled pass (the tests use a single batch), batch-global standardisation as epoch() does
+        for i in range(0, images.shape[0], batch_train):
+            img = R.standardise_batch(images[i:i + batch_train])
+            loss = torch.nn.functional.cross_entropy(net(img), labels[i:i + batch_train])
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()

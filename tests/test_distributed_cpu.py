@@ -185,3 +185,49 @@ def test_s2d_trainer_two_ranks_allreduce_hallucinator_grad():
     assert abs(loss / float(z["loss"]) - 1) < 1e-5
     np.testing.assert_allclose(hal_w, z["hal_w_after"], rtol=1e-5, atol=1e-7)   # shared params: grads summed over ranks
     np.testing.assert_allclose(dyn0.reshape(2, 2, 8, 1, 64, 64)[:, :, :, :, ::4, ::4], z["dynamic_after"][:2], rtol=1e-4, atol=1e-5)
+
+
+# ---- gradient matching (DC) trainer: class sharding identity ------------------------------------
+
+def _gm_run(rank, world, outer_loop=1, inner_loop=1, steps=2):
+    from tests.cpu_backend import OracleGMOps
+    from video_distillation_amd import plan
+    C, ipc = 2, 1
+    geo = plan.NetGeometry(8, 64, 64)
+    g = torch.Generator().manual_seed(4242)
+    clips = torch.randn(C * 3, 8, 3, 64, 64, generator=g)
+    pool = distill.RealPool(clips, [3] * C, [0, 3])
+    lo, hi = distill.class_range(C, rank, world)
+    syn = torch.stack([clips[0], clips[3]])[lo:hi].clone()
+    tr = distill.GMTrainer(OracleGMOps("ours"), pool, geo, C, ipc, batch_real=2, lr_img=0.1, lr_net=0.01, rank=rank,
+                           world=world, image_syn=syn, outer_loop=outer_loop, inner_loop=inner_loop, dropout_p=0.0)
+    losses = [float(tr.global_loss(tr.step(it))) for it in range(steps)]
+    return losses, tr.gather_syn()
+
+
+def _worker_gm(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        losses, syn = _gm_run(rank, world, outer_loop=2, inner_loop=1, steps=1)
+        if rank == 0:
+            q.put((losses, syn.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gm_trainer_class_sharding_identity_two_ranks_gloo():
+    """Two ranks owning one class each (outer loop 2: one all-gather + network update in between)
+    reproduce the single-rank run: summed loss and gathered synthetic clips."""
+    torch.set_num_threads(4)
+    want_l, want_s = _gm_run(0, 1, outer_loop=2, inner_loop=1, steps=1)
+    got_l, got_s = _spawn(_worker_gm, 2)
+    np.testing.assert_allclose(got_l, want_l, rtol=1e-5)
+    np.testing.assert_allclose(got_s, want_s.numpy(), rtol=1e-4, atol=5e-5)   # thread-count dependent summation order
+    assert want_l[0] > 0 and not np.allclose(want_s.numpy()[0], _gm_run(0, 1, steps=0)[1].numpy()[0])
+
+
+def test_gm_trainer_momentum_and_fresh_network_per_iteration():
+    losses, syn = _gm_run(0, 1, steps=2)
+    assert len(losses) == 2 and all(np.isfinite(losses)) and losses[0] != losses[1]

@@ -243,3 +243,32 @@ def test_param_grads_autograd_surface_and_match_loss():
     print("match_loss %.6f vs %.6f, d/dx per-clip rel-l2" % (float(loss), float(want)), ["%.1e" % e for e in per])
     assert abs(float(loss) - float(want)) / abs(float(want)) < 1e-3
     assert min(per) < 1e-3 and max(per) < 5e-2
+
+
+def test_g9_gradient_matching_vs_reference_golden(golden_dir):
+    """Fixture G9 (generated from the reference's get_network / match_loss composed the upstream-DC way):
+    loss and d loss / d syn of one class term, all three metrics, through net.param_grads + utils.match_loss."""
+    from video_distillation_amd import networks, utils
+    z = np.load(os.path.join(golden_dir, "g9_grad_match.npz"))
+    C, lab = int(z["C"]), int(z["label"])
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    real = torch.randn(3, 8, 3, 64, 64, generator=g)
+    syn = torch.randn(2, 8, 3, 64, 64, generator=g)
+    torch.manual_seed(int(z["net_seed"]))
+    net = networks.ConvNet3D(3, C, 128, 3, 'relu', 'none', 'maxpooling', frames=8, im_size=(64, 64)).cuda().train()
+    net.dropout.p = 0.0
+    lab_r, lab_s = torch.full((3,), lab).cuda(), torch.full((2,), lab).cuda()
+    _, gw_real = net.param_grads(real.cuda(), lab_r)
+    np.testing.assert_allclose([float(t.double().abs().sum()) for t in gw_real], z["gw_real_l1"], rtol=2e-3)
+    for metric in ("ours", "mse", "cos"):
+        args = types.SimpleNamespace(device="cuda", dis_metric=metric)
+        xs = syn.cuda().requires_grad_(True)
+        _, gw_syn = net.param_grads(xs, lab_s, create_graph=True)
+        loss = utils.match_loss(gw_syn, [t.detach() for t in gw_real], args)
+        (gx,) = torch.autograd.grad(loss, xs)
+        rel = abs(float(loss) - float(z["loss_" + metric])) / abs(float(z["loss_" + metric]))
+        got = gx[0] if metric == "ours" else gx[:, 3]
+        gerr = _rel(got, torch.tensor(z["grad_" + metric]).double())
+        print("G9 %s: loss rel %.1e, grad rel-l2 %.1e" % (metric, rel, gerr))
+        assert rel < 1e-3                       # north_star bar on the loss
+        assert gerr < 2e-2                      # arg-max flips allowed (fp32 reference vs bf16x3), see above

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import ref_cpu as R
 
@@ -214,3 +215,24 @@ def test_g7_evaluate_training_curve(golden_dir):
 def test_flop_count_matches_baseline_md():
     assert abs(R.dm_step_flops(50, 64, 1, 16, 112, 112) - 36.31e12) / 36.31e12 < 1e-3
     assert abs(R.dm_step_flops(50, 64, 1, 8, 64, 64) - 5.85e12) / 5.85e12 < 1e-3
+
+
+def test_g9_gradient_matching_class_term(golden_dir):
+    """Upstream-DC class term composed from the reference's get_network / match_loss (fixture G9):
+    the oracle's double backward must reproduce loss and d loss / d syn for all three metrics."""
+    z = load(golden_dir, "g9_grad_match.npz")
+    C, lab = int(z["C"]), int(z["label"])
+    real, syn = randn(z["data_seed"], (3, 8, 3, 64, 64), (2, 8, 3, 64, 64))
+    params = [p.requires_grad_(True) for p in R.init_params(int(z["net_seed"]), 3, C)]
+    lab_r, lab_s = torch.full((3,), lab), torch.full((2,), lab)
+    gw_real = [t.detach() for t in torch.autograd.grad(F.cross_entropy(R.convnet3d_logits(real, params), lab_r), params)]
+    np.testing.assert_allclose([float(t.double().abs().sum()) for t in gw_real], z["gw_real_l1"], rtol=1e-4)
+    for metric in ("ours", "mse", "cos"):
+        xs = syn.clone().requires_grad_(True)
+        gw_syn = torch.autograd.grad(F.cross_entropy(R.convnet3d_logits(xs, params), lab_s), params, create_graph=True)
+        loss = R.match_loss(list(gw_syn), gw_real, metric)
+        (g,) = torch.autograd.grad(loss, xs)
+        close(loss, z["loss_" + metric], rtol=2e-4)
+        got = g[0] if metric == "ours" else g[:, 3]
+        want = torch.tensor(z["grad_" + metric])
+        assert float((got - want).norm() / want.norm()) < 2e-3, metric     # same arithmetic, different summation order

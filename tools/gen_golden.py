@@ -274,15 +274,47 @@ def g7(networks, utils):
         logit_w_after=net_out.logit.weight.detach().reshape(C, -1)[:, :16])
 
 
+def g9(networks, utils):
+    # gradient-matching class term the way the upstream DC loop composes it from the reference's own
+    # get_network / match_loss (the reference's DC branch is never executed for video):
+    # gw_real detached, gw_syn with create_graph=True, match_loss, backward to the synthetic clips.
+    args = _Args(); args.device = 'cpu'
+    C = 4
+    net = make_net(networks, 91, C, 64, 8).train()
+    net.dropout.p = 0.0
+    g = torch.Generator().manual_seed(901)
+    real = torch.randn(3, 8, 3, 64, 64, generator=g); syn = torch.randn(2, 8, 3, 64, 64, generator=g)
+    lab_r = torch.full((3,), 2, dtype=torch.long); lab_s = torch.full((2,), 2, dtype=torch.long)
+    crit = torch.nn.CrossEntropyLoss()
+    params = list(net.parameters())
+    gw_real = [t.detach().clone() for t in torch.autograd.grad(crit(net(real), lab_r), params)]
+    rec = {"net_seed": 91, "data_seed": 901, "C": C, "label": 2,
+           "gw_real_l1": np.array([float(t.double().abs().sum()) for t in gw_real])}
+    for metric in ("ours", "mse", "cos"):
+        args.dis_metric = metric
+        xs = syn.clone().requires_grad_(True)
+        gw_syn = torch.autograd.grad(crit(net(xs), lab_s), params, create_graph=True)
+        loss = utils.match_loss(gw_syn, gw_real, args)
+        loss.backward()
+        rec["loss_" + metric] = loss.detach()
+        rec["grad_l1_" + metric] = np.array([float(xs.grad[b].double().abs().sum()) for b in range(2)])
+        # one full clip for 'ours' (1.5 MB), a frame of each clip for the others
+        rec["grad_" + metric] = xs.grad[0] if metric == "ours" else xs.grad[:, 3]
+        if metric == "ours":
+            rec["gw_syn_l1"] = np.array([float(t.detach().double().abs().sum()) for t in gw_syn])
+    npz("g9_grad_match.npz", **rec)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     networks, utils = import_reference()
-    g1(networks)
-    g2_g3(networks)
-    g4_g5(networks, utils)
-    g6(networks, utils)
-    g7(networks, utils)
+    only = set(sys.argv[1:])
+    for name, fn in (("g1", lambda: g1(networks)), ("g2", lambda: g2_g3(networks)), ("g4", lambda: g4_g5(networks, utils)),
+                     ("g6", lambda: g6(networks, utils)), ("g7", lambda: g7(networks, utils)),
+                     ("g9", lambda: g9(networks, utils))):
+        if not only or name in only:
+            fn()
 
 
 if __name__ == "__main__":

@@ -423,3 +423,140 @@ class S2DTrainer:
         self.steps_done += 1
         self.last_grads = (g_dyn, g_w, g_b)
         return loss_c.sum()
+
+
+# ------------------------------------------------------------------------------------------------
+# Gradient matching (DC): SURVEY section 8(f)-2, config 4
+# ------------------------------------------------------------------------------------------------
+def fresh_full_network(seed: int, num_classes: int, device) -> List[torch.Tensor]:
+    """All 8 ConvNet3D tensors (feature stack + 1x1x1 logit conv), PyTorch default init, drawn on
+    the device from a seed shared by all ranks (``fresh_network_weights`` plus the head)."""
+    out = fresh_network_weights(seed, device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed) + (1 << 20))
+    bound = 1.0 / math.sqrt(128.0)
+    for shp in ((num_classes, 128, 1, 1, 1), (num_classes,)):
+        out.append(torch.empty(shp, device=device, dtype=torch.float32).uniform_(-bound, bound, generator=gen))
+    return out
+
+
+class HipGMOps:
+    """The device operations of the gradient-matching loop, on the HIP path."""
+
+    def __init__(self, device, dis_metric: str = "ours"):
+        import types
+        from . import hip
+        self.hip, self.device = hip, torch.device(device)
+        self.args = types.SimpleNamespace(device=self.device, dis_metric=dis_metric)
+
+    def make_net(self, params: Sequence[torch.Tensor], geo: P.NetGeometry, num_classes: int):
+        from . import networks
+        net = networks.ConvNet3D(3, num_classes, 128, 3, 'relu', 'none', 'maxpooling', frames=geo.frames,
+                                 im_size=(geo.height, geo.width))
+        net = net.to(self.device)
+        with torch.no_grad():
+            for p, w in zip(net.parameters(), params):
+                p.copy_(w)
+        return net.train()
+
+    def param_grads(self, net, x, labels, create_graph: bool):
+        return net.param_grads(x, labels, create_graph=create_graph)[1]
+
+    def match_loss(self, gw_syn, gw_real):
+        from . import utils
+        return utils.match_loss(gw_syn, gw_real, self.args)
+
+    def sgd(self, x, buf, g, lr, mu, first):
+        hip = self.hip
+        hip.check(hip.lib().vd_sgd_momentum(hip.ptr(x), hip.ptr(buf), hip.ptr(g), ctypes.c_int64(x.numel()), ctypes.c_float(lr),
+                                            ctypes.c_float(mu), int(first), hip.stream_ptr(self.device)), "vd_sgd_momentum")
+
+    def train_epoch(self, net, images, labels, optimizer, batch_train: int):
+        import types
+        from . import utils
+        args = types.SimpleNamespace(device=self.device, model="ConvNet3D", eval_mode="SS")
+        loader = torch.utils.data.DataLoader(utils.TensorDataset(images, labels), batch_size=batch_train, shuffle=True,
+                                             num_workers=0)
+        return utils.epoch('train', loader, net, optimizer, torch.nn.CrossEntropyLoss().to(self.device), args)
+
+
+class GMTrainer:
+    """Gradient matching over the classes owned by this rank, in the structure of the upstream DC
+    loop the reference's ``--method DC`` arguments / ``get_loops`` / ``match_loss`` belong to
+    (distill_baseline.py:22-26, 370-379; utils.py:634-709; the loop body itself is absent from the
+    reference):
+
+        net <- fresh network;  for ol in range(outer_loop):
+            for every class c:  gw_real = dCE/dparams on a real batch (detached)
+                                gw_syn  = dCE/dparams on the class's synthetic clips (create_graph)
+                                loss   += match_loss(gw_syn, gw_real)
+            pixels <- SGD(lr_img, momentum .5) on d loss / d pixels
+            (unless last) train net on the synthetic set for inner_loop epochs, SGD(lr_net, m .5)
+
+    Pixel gradients are class-disjoint, so classes shard over ranks with no gradient exchange; the
+    network update needs every rank's synthetic clips (all-gather), after which all ranks take the
+    same deterministic training step."""
+
+    def __init__(self, ops, pool: RealPool, geo: P.NetGeometry, num_classes: int, ipc: int, batch_real: int, lr_img: float,
+                 lr_net: float = 0.01, momentum: float = 0.5, rank: int = 0, world: int = 1,
+                 image_syn: Optional[torch.Tensor] = None, outer_loop: int = 1, inner_loop: int = 1, batch_train: int = 256,
+                 dropout_p: Optional[float] = None):
+        self.ops, self.pool, self.geo = ops, pool, geo
+        self.num_classes, self.ipc, self.batch_real = num_classes, ipc, batch_real
+        self.lr_img, self.lr_net, self.momentum = float(lr_img), float(lr_net), float(momentum)
+        self.rank, self.world = rank, world
+        self.outer_loop, self.inner_loop, self.batch_train = int(outer_loop), int(inner_loop), int(batch_train)
+        self.dropout_p = dropout_p
+        self.c_lo, self.c_hi = class_range(num_classes, rank, world)
+        self.classes = list(range(self.c_lo, self.c_hi))
+        if image_syn is None:
+            idx = np.concatenate([pool.offsets[c] + np.arange(ipc) % pool.counts[c] for c in self.classes]) \
+                if self.classes else np.zeros(0, dtype=np.int64)
+            image_syn = pool.clips[torch.as_tensor(idx, device=pool.clips.device, dtype=torch.int64)].clone()
+        self.image_syn = image_syn.contiguous()
+        self.buf = torch.zeros_like(self.image_syn)
+        self.steps_done = 0
+
+    def step(self, it: int) -> torch.Tensor:
+        """One ``for it`` iteration; returns the rank-local matching loss summed over the outer loop."""
+        ops, dev = self.ops, self.image_syn.device
+        net = ops.make_net(fresh_full_network(it, self.num_classes, dev), self.geo, self.num_classes)
+        if self.dropout_p is not None:
+            net.dropout.p = float(self.dropout_p)
+        for p in net.parameters():
+            p.requires_grad_(True)
+        opt_net = torch.optim.SGD(net.parameters(), lr=self.lr_net, momentum=0.5)
+        total = torch.zeros((), device=dev)
+        for ol in range(self.outer_loop):
+            idx = sample_real_indices(it * self.outer_loop + ol, self.pool.counts, self.pool.offsets, self.batch_real, self.classes)
+            idx_t = torch.as_tensor(idx, device=dev).reshape(len(self.classes), -1)
+            g_img = torch.zeros_like(self.image_syn)
+            for k, c in enumerate(self.classes):
+                real = self.pool.clips[idx_t[k]]
+                lab_r = torch.full((real.shape[0],), c, dtype=torch.int64, device=dev)
+                lab_s = torch.full((self.ipc,), c, dtype=torch.int64, device=dev)
+                gw_real = [t.detach() for t in ops.param_grads(net, real, lab_r, False)]
+                syn = self.image_syn[k * self.ipc:(k + 1) * self.ipc].detach().clone().requires_grad_(True)
+                gw_syn = ops.param_grads(net, syn, lab_s, True)
+                loss = ops.match_loss(gw_syn, gw_real)
+                (g,) = torch.autograd.grad(loss, syn)
+                g_img[k * self.ipc:(k + 1) * self.ipc] = g
+                total = total + loss.detach()
+            ops.sgd(self.image_syn, self.buf, g_img, self.lr_img, self.momentum, first=(self.steps_done == 0))
+            self.steps_done += 1
+            if ol == self.outer_loop - 1:
+                break
+            syn_all = self.gather_syn().detach().clone()
+            lab_all = torch.arange(self.num_classes, device=dev).repeat_interleave(self.ipc)
+            for _ in range(self.inner_loop):
+                ops.train_epoch(net, syn_all, lab_all, opt_net, self.batch_train)
+        return total
+
+    def global_loss(self, local_loss: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            import torch.distributed as dist
+            local_loss = local_loss.clone()
+            dist.all_reduce(local_loss, op=dist.ReduceOp.SUM)
+        return local_loss
+
+    gather_syn = DMTrainer.gather_syn
