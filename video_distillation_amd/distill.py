@@ -500,8 +500,9 @@ class GMTrainer:
     def __init__(self, ops, pool: RealPool, geo: P.NetGeometry, num_classes: int, ipc: int, batch_real: int, lr_img: float,
                  lr_net: float = 0.01, momentum: float = 0.5, rank: int = 0, world: int = 1,
                  image_syn: Optional[torch.Tensor] = None, outer_loop: int = 1, inner_loop: int = 1, batch_train: int = 256,
-                 dropout_p: Optional[float] = None):
+                 dropout_p: Optional[float] = None, net_init=None):
         self.ops, self.pool, self.geo = ops, pool, geo
+        self.net_init = net_init        # it -> 8 tensors; default: fresh_full_network(it) drawn on the device
         self.num_classes, self.ipc, self.batch_real = num_classes, ipc, batch_real
         self.lr_img, self.lr_net, self.momentum = float(lr_img), float(lr_net), float(momentum)
         self.rank, self.world = rank, world
@@ -520,7 +521,8 @@ class GMTrainer:
     def step(self, it: int) -> torch.Tensor:
         """One ``for it`` iteration; returns the rank-local matching loss summed over the outer loop."""
         ops, dev = self.ops, self.image_syn.device
-        net = ops.make_net(fresh_full_network(it, self.num_classes, dev), self.geo, self.num_classes)
+        params = self.net_init(it) if self.net_init is not None else fresh_full_network(it, self.num_classes, dev)
+        net = ops.make_net([p.to(dev) for p in params], self.geo, self.num_classes)
         if self.dropout_p is not None:
             net.dropout.p = float(self.dropout_p)
         for p in net.parameters():
