@@ -51,8 +51,10 @@ def parse():
     ap.add_argument("--shard", default="auto", choices=["auto", "class", "batch"],
                     help="multi-GPU decomposition: whole classes per rank, or 1/N of every class's real batch per rank "
                          "(+ one all-reduce of the per-class feature sums); auto = batch when batch_real %% N == 0")
-    ap.add_argument("--method", default="dm", choices=["dm", "s2d"],
-                    help="dm = distill_baseline.py DM (headline); s2d = DM + static/dynamic memories (config 3)")
+    ap.add_argument("--method", default="dm", choices=["dm", "s2d", "dc"],
+                    help="dm = distill_baseline.py DM (headline); s2d = DM + static/dynamic memories (config 3); "
+                         "dc = gradient matching with match_loss (config 4: use --classes 51 --ipc 5)")
+    ap.add_argument("--dis-metric", default="ours", choices=["ours", "mse", "cos"], help="match_loss metric of --method dc")
     return ap.parse_args()
 
 
@@ -144,6 +146,8 @@ def main():
     else:
         pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device,
                                           seed=1234 + rank)
+    if args.method == "dc":
+        return bench_dc(args, distill, geo, pool, device, rank, world)
     if args.method == "dm":
         trainer = distill.DMTrainer(backend, pool, args.classes, args.ipc, args.batch_real, lr_img=1.0, momentum=0.5,
                                     rank=rank, world=world, shard=shard)
@@ -227,6 +231,51 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.method == "dm":
             out["cpu_baseline"] = cpu_baseline(args, trainer, backend, args.warmup + args.steps, geo)
         print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_dc(args, distill, geo, pool, device, rank, world):
+    """Secondary line: gradient matching, one step = one `for it` iteration of
+    distill.GMTrainer with get_loops(ipc) (ipc 1 / 5 -> outer 1, inner 1: no network update inside)."""
+    from video_distillation_amd import utils
+    outer, inner = utils.get_loops(args.ipc)
+    ops = distill.HipGMOps(device, args.dis_metric)
+    trainer = distill.GMTrainer(ops, pool, geo, args.classes, args.ipc, args.batch_real, lr_img=0.1, rank=rank, world=world,
+                                outer_loop=outer, inner_loop=inner)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+    for it in range(args.warmup):
+        trainer.step(it)
+    barrier()
+    t0 = time.perf_counter()
+    losses = [trainer.global_loss(trainer.step(it)) for it in range(args.warmup, args.warmup + args.steps)]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    if rank == 0:
+        from video_distillation_amd import networks
+        print(json.dumps({
+            "metric": "distillation steps/sec (DC gradient matching '%s', IPC=%d)" % (args.dis_metric, args.ipc),
+            "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": networks.get_precision()["match"], "data": "synthetic",
+            "config": {"workload": "gradient matching: C=%d classes x (%d real + %d syn) clips %dx%dx%d, fresh net per step, "
+                                   "outer_loop %d inner_loop %d" % (args.classes, args.batch_real, args.ipc, args.size, args.size,
+                                                                    args.frames, outer, inner),
+                       "precision": networks.get_precision(),
+                       "parallelism": "class-sharded x%d (owner-computes, no gradient exchange)" % world},
+            "loss_last": float(losses[-1]) / args.classes}))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
