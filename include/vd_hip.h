@@ -185,11 +185,13 @@ int vd_head_train_bwd(const float* dlogits, const int32_t* amax_t, const float* 
 /* Second-order pass through the head for gradient matching (DC: match_loss(gw_syn, gw_real).backward() with
  * gw_syn = autograd.grad(CE(net(x)), params, create_graph=True), upstream DC loop / distill_baseline.py:250):
  * adjoints of the head's parameter gradients (v_w, v_b) and of the feature gradient (gbar_feats) -> adjoint of
- * the features (abar_feats), through the CE Hessian and the saved arg-max frames / dropout mask. */
+ * the features (abar_feats), through the CE Hessian and the saved arg-max frames / dropout mask.  wbar [K][C] /
+ * bbar [K] (optional, accumulated with fp32 atomics): adjoint of the head's own parameters -- the head rows of
+ * the Hessian-vector product MTT's unrolled inner loop needs (distill_baseline.py:250-252). */
 int vd_head_second_order(const float* logits, const float* dlogits, const int32_t* amax_t, const float* dropped,
                          const float* mask, const float* w, const float* v_w, const float* v_b, const float* gbar_feats,
                          int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K, float* abar_feats,
-                         void* stream);
+                         float* wbar, float* bbar, void* stream);
 int vd_sgd_momentum_wd(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, float wd, int first,
                        void* stream);
 

@@ -309,3 +309,32 @@ def test_gm_trainer_hip_matches_oracle_trainer():
           "update/pixel norm %.2e" % float((want_s0 - syn0).norm() / syn0.norm()))
     assert max(per) < 5e-2
     assert torch.isfinite(got_s).all() and _rel(got_s, want_s.double()) < 5e-2
+
+
+@pytest.mark.parametrize("B,K,use_mask", [(1, 4, False), (3, 5, True)])
+def test_hessian_vector_product_matches_fp64(B, K, use_mask):
+    """param_adjoint=True: d <v, dCE/dparams> / d params (H v, MTT's unrolled inner loop) vs fp64."""
+    from video_distillation_amd import plan, train
+    T, H, W = 8, 64, 64
+    g = torch.Generator().manual_seed(B * 7 + K)
+    x = R.standardise_batch(torch.randn(B, T, 3, H, W, generator=g))
+    labels = torch.randint(0, K, (B,), generator=g)
+    params = R.init_params(700 + K, 3, K)
+    te = train.GradMatchEngine(plan.NetGeometry(T, H, W), K, (2, 1, 1), "cuda:0")
+    mask = (torch.rand(B, te.C, te.Tp, generator=g) < 0.5).float() * 2.0 if use_mask else None
+    v = [torch.randn(p.shape, generator=g) for p in params]
+    xr = x.double().clone().requires_grad_(True)
+    p64 = [p.double().requires_grad_(True) for p in params]
+    m = None if mask is None else mask.double()[:, :, :, None, None]
+    gw = torch.autograd.grad(F.cross_entropy(R.convnet3d_logits(xr, p64, drop_mask=m), labels), p64, create_graph=True)
+    s = sum((a * b.double()).sum() for a, b in zip(gw, v))
+    want = torch.autograd.grad(s, [xr] + p64)
+    pc = [p.cuda() for p in params]
+    _, _, gw_hip, state = te.param_grads(x.cuda(), labels.cuda(), pc, None if mask is None else mask.cuda())
+    dx, hv = te.vjp(state, [t.cuda() for t in v], pc, param_adjoint=True)
+    torch.cuda.synchronize()
+    e_first = max(_rel(a_, r_.detach()) for a_, r_ in zip(gw_hip, gw))
+    errs = [_rel(dx, want[0])] + [_rel(a_, r_) for a_, r_ in zip(hv, want[1:])]
+    print("H v rel-l2 (dx, 8 params):", " ".join("%.1e" % e for e in errs), "| first-order %.1e" % e_first)
+    tol = 2e-4 if e_first < 1e-4 else min(5e-2, 10 * e_first)      # arg-max flip in this batch: see above
+    assert max(errs) < tol, errs

@@ -993,7 +993,8 @@ __global__ __launch_bounds__(256) void head_second_order_kernel(
     const float* __restrict__ logits, const float* __restrict__ dlogits, const int32_t* __restrict__ amax_t,
     const float* __restrict__ dropped, const float* __restrict__ mask, const float* __restrict__ w,
     const float* __restrict__ v_w, const float* __restrict__ v_b, const float* __restrict__ gbar_feats, int B, int C, int To,
-    int Ho, int Wo, int kt, int kh, int kw, int K, float* __restrict__ abar_feats) {
+    int Ho, int Wo, int kt, int kh, int kw, int K, float* __restrict__ abar_feats, float* __restrict__ wbar,
+    float* __restrict__ bbar) {
     extern __shared__ float sm[];
     const int Tp = To - kt + 1;
     float* u = sm;                   // [Tp][C]  m * avgpool(gbar_feats), later m * dropbar
@@ -1039,6 +1040,17 @@ __global__ __launch_bounds__(256) void head_second_order_kernel(
     const float dot = dot_s;
     for (int k = threadIdx.x; k < K; k += blockDim.x) dlb[k] = pk[k] * (dlb[k] - dot) / (float)B;
     __syncthreads();
+    if (wbar != nullptr) {
+        // adjoint of the logit conv's own parameters (Hessian-vector product for MTT):
+        //   wbar[k][c] += dlog[k] * (m*avgpool(gbar))[t*_k][c] + logitbar[k] * dropped[t*_k][c];  bbar[k] += logitbar[k]
+        for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+            const int c = i % C, k = i / C;
+            const int t = am[k];
+            atomicAdd(&wbar[i], dl[k] * u[t * C + c] + dlb[k] * dropped[((int64_t)clip * Tp + t) * C + c]);
+        }
+        for (int k = threadIdx.x; k < K; k += blockDim.x) atomicAdd(&bbar[k], dlb[k]);
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < Tp * C; i += blockDim.x) {
         const int c = i % C, t = i / C;
         float a = 0.f;
@@ -1060,13 +1072,13 @@ __global__ __launch_bounds__(256) void head_second_order_kernel(
 extern "C" int vd_head_second_order(const float* logits, const float* dlogits, const int32_t* amax_t, const float* dropped,
                                     const float* mask, const float* w, const float* v_w, const float* v_b,
                                     const float* gbar_feats, int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw,
-                                    int K, float* abar_feats, void* stream) {
+                                    int K, float* abar_feats, float* wbar, float* bbar, void* stream) {
     if (nclips <= 0) return 0;
     if (Ho - kh + 1 != 1 || Wo - kw + 1 != 1 || To - kt + 1 < 1) return -2;
     const size_t lds = ((size_t)(To - kt + 1) * C + 2 * (size_t)K) * sizeof(float);
     hipLaunchKernelGGL(head_second_order_kernel, dim3((unsigned)nclips), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
                        logits, dlogits, amax_t, dropped, mask, w, v_w, v_b, gbar_feats, (int)nclips, C, To, Ho, Wo, kt, kh, kw, K,
-                       abar_feats);
+                       abar_feats, wbar, bbar);
     return (int)hipGetLastError();
 }
 

@@ -217,8 +217,11 @@ class GradMatchEngine(TrainEngine):
             state["ws"], eng._ws = eng._ws, keep_ws
         return loss, logits, g, state
 
-    def vjp(self, state: dict, v: Sequence[Optional[torch.Tensor]], params: Sequence[torch.Tensor]) -> torch.Tensor:
-        """d (sum_i <v_i, g_i(x)>) / dx for the ``param_grads`` call that produced ``state``."""
+    def vjp(self, state: dict, v: Sequence[Optional[torch.Tensor]], params: Sequence[torch.Tensor],
+            param_adjoint: bool = False):
+        """d (sum_i <v_i, g_i(x)>) / dx for the ``param_grads`` call that produced ``state``.  With
+        ``param_adjoint`` also d (sum_i <v_i, g_i>) / d params -- the Hessian-vector product H v of the
+        CE loss w.r.t. the parameters (MTT's unrolled inner loop) -- returned as (dx, [8 tensors])."""
         eng, L, st = self.eng, hip.lib(), hip.stream_ptr(self.device)
         geo = self.geo
         nb = state["nb"]
@@ -247,6 +250,13 @@ class GradMatchEngine(TrainEngine):
             gbar1 = eng._buf("gbar1", (eng.planes, n1, 8), torch.int16)
             gbar2 = eng._buf("gbar2", (eng.planes, n2, 8), torch.int16)
             gbar3 = torch.empty((nb, eng.num_feat), dtype=torch.float32, device=self.device)
+            hv = None
+            if param_adjoint:
+                hflat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=self.device)
+                hv, o = [], 0
+                for shp, n in zip(self.shapes, self.sizes):
+                    hv.append(hflat[o:o + n].view(*shp))
+                    o += n
             # ---- upward sweep -------------------------------------------------------------
             self.sel[0].run(slots0, n_slots0, V[1], gbar1.data_ptr(), n1, am[0], nb)
             for dp, a, gb in ((self.sel[1], act1, gbar1), (self.sel[2], act2, gbar2)):
@@ -262,7 +272,8 @@ class GradMatchEngine(TrainEngine):
             hip.check(L.vd_head_second_order(hip.ptr(state["logits"]), hip.ptr(state["dlog"]), hip.ptr(state["amt"]),
                                              hip.ptr(state["dropped"]), hip.ptr(state["mask"]), hip.ptr(state["wl"]), hip.ptr(vw),
                                              hip.ptr(V[7]), hip.ptr(gbar3), ctypes.c_int64(nb), self.C, self.To, self.Ho, self.Wo,
-                                             kt, kh, kw, self.K, hip.ptr(abar), st), "vd_head_second_order")
+                                             kt, kh, kw, self.K, hip.ptr(abar), hip.ptr(hv[6] if hv else None),
+                                             hip.ptr(hv[7] if hv else None), st), "vd_head_second_order")
             # ---- downward sweep -------------------------------------------------------------
             dx = torch.empty((nb, geo.frames, geo.channel, geo.height, geo.width), dtype=torch.float32, device=self.device)
             grad, layout = abar, 0
@@ -280,7 +291,19 @@ class GradMatchEngine(TrainEngine):
                     dp.run(zb, nslots, None, out.data_ptr(), 0, None, nb)
                 for dp in self.bwdV[li]:
                     dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb)
+                if hv:
+                    # parameter side: z_l = conv(a_l, W_l) + b_l carries zbar_l, and g_{a_l} = convT(dz_l, W_l) carries gbar_l
+                    op = self._wgrad(li, nb)
+                    hip.check(L.vd_bias_grad(hip.ptr(zb), ctypes.c_int64(nslots), eng.planes_bwd, ctypes.c_int64(nb), cout,
+                                             ctypes.c_int64(T * OH * OW), eng.prec_bwd, hip.ptr(None), hip.ptr(hv[2 * li + 1]), st),
+                              "vd_bias_grad")
+                    if li == 0:
+                        op.run(state["x"], True, 0, zb, nslots, hv[0])
+                    else:
+                        a_l, g_l, n_l = (act1, gbar1, n1) if li == 1 else (act2, gbar2, n2)
+                        op.run(a_l, False, n_l, zb, nslots, hv[2 * li])
+                        op.run(g_l, False, n_l, dy, nslots, hv[2 * li])
                 grad, layout = out, 1
         finally:
             eng._ws = keep_ws
-        return dx
+        return (dx, hv) if param_adjoint else dx
