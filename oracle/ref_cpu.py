@@ -248,6 +248,45 @@ def train_epochs(params: List[torch.Tensor], images: torch.Tensor, labels: torch
     return {"loss": losses, "acc": accs, "lr": lrs, "params": [p.detach() for p in params]}
 
 
+def flatten_params(params: Sequence[torch.Tensor]) -> torch.Tensor:
+    """``torch.cat([p.reshape(-1) for p in params])`` -- ReparamModule's flat parameter
+    (reparam_module.py:51), parameters() order."""
+    return torch.cat([p.reshape(-1) for p in params], 0)
+
+
+def unflatten_params(flat: torch.Tensor, channel: int = 3, num_classes: int = 50) -> List[torch.Tensor]:
+    out, o = [], 0
+    for shp in param_shapes(channel, num_classes):
+        n = int(np.prod(shp))
+        out.append(flat[o:o + n].view(shp))
+        o += n
+    return out
+
+
+def mtt_step(start: Sequence[torch.Tensor], target: Sequence[torch.Tensor], image_syn: torch.Tensor,
+             label_syn: torch.Tensor, syn_lr: float, index_chunks: Sequence[torch.Tensor],
+             drop_masks: Optional[Sequence[torch.Tensor]] = None, dtype=torch.float32):
+    """One MTT iteration (distill_baseline.py:213-262): ``len(index_chunks)`` unrolled student steps
+    theta <- theta - syn_lr * dCE/dtheta on the given synthetic batches (create_graph), then
+    grand_loss = |theta_N - target|^2 / |theta_0 - target|^2; returns (grand_loss, d/d image_syn,
+    d/d syn_lr)."""
+    num_classes = start[6].shape[0]
+    x = image_syn.detach().to(dtype).clone().requires_grad_(True)
+    lr = torch.tensor(float(syn_lr), dtype=dtype, requires_grad=True)
+    theta0 = flatten_params([p.detach().to(dtype) for p in start])
+    tgt = flatten_params([p.detach().to(dtype) for p in target])
+    theta = theta0.clone().requires_grad_(True)
+    for s, idx in enumerate(index_chunks):
+        m = None if drop_masks is None else drop_masks[s].to(dtype)[:, :, :, None, None]
+        logits = convnet3d_logits(x[idx], unflatten_params(theta, 3, num_classes), drop_mask=m)
+        ce = F.cross_entropy(logits, label_syn[idx])
+        (g,) = torch.autograd.grad(ce, theta, create_graph=True)
+        theta = theta - lr * g
+    grand = ((theta - tgt) ** 2).sum() / ((theta0 - tgt) ** 2).sum()
+    gx, glr = torch.autograd.grad(grand, [x, lr])
+    return grand.detach(), gx, glr
+
+
 def dm_step_flops(num_classes: int, batch_real: int, ipc: int, frames: int, h: int, w: int) -> float:
     """Algorithmic FLOPs of one DM step as BASELINE.md section 3 counts them: every tap incl.
     zero padding, forward for every clip plus one input-gradient pass per synthetic clip."""

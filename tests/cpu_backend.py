@@ -106,3 +106,22 @@ class OracleGMOps:
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()
+
+
+class OracleMTTOps:
+    """CPU stand-in for distill.HipMTTOps: per-step double backward with torch autograd (fp32)."""
+
+    def grads(self, params, x, labels):
+        xv = x.detach().clone().requires_grad_(True)
+        pv = [p.detach().clone().requires_grad_(True) for p in params]
+        ce = torch.nn.functional.cross_entropy(R.convnet3d_logits(xv, pv), labels)
+        g = torch.autograd.grad(ce, pv, create_graph=True)
+        return [t.detach() for t in g], (xv, pv, g)
+
+    def hvp(self, handle, v):
+        xv, pv, g = handle
+        s = sum((a * b).sum() for a, b in zip(g, v))
+        out = torch.autograd.grad(s, [xv] + pv)
+        return out[0], list(out[1:])
+
+    sgd = OracleBackend.sgd

@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from oracle import ref_cpu as R
 from tests.cpu_backend import OracleBackend
 from video_distillation_amd import distill
 
@@ -231,3 +232,58 @@ def test_gm_trainer_class_sharding_identity_two_ranks_gloo():
 def test_gm_trainer_momentum_and_fresh_network_per_iteration():
     losses, syn = _gm_run(0, 1, steps=2)
     assert len(losses) == 2 and all(np.isfinite(losses)) and losses[0] != losses[1]
+
+
+# ---- MTT trainer: explicit reverse sweep vs autograd through the unrolled loop; batch sharding ----
+
+def _mtt_setup(rank=0, world=1):
+    from tests.cpu_backend import OracleMTTOps
+    z = np.load(os.path.join(GOLDEN, "g10_mtt_step.npz"))
+    C, n_syn = int(z["C"]), int(z["n_syn"])
+    start = R.init_params(int(z["net_seed"]), 3, C)
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    target = [p + 0.02 * p.abs().mean() * torch.randn(p.shape, generator=g) for p in start]
+    image_syn = torch.randn(n_syn, 8, 3, 64, 64, generator=g)
+    tr = distill.MTTTrainer(OracleMTTOps(), C, image_syn.clone(), torch.tensor(z["labels"]), float(z["syn_lr"]), lr_img=100.0,
+                            lr_lr=1e-5, syn_steps=int(z["syn_steps"]), batch_syn=int(z["batch_syn"]), expert_epochs=1,
+                            max_start_epoch=1, rank=rank, world=world)
+    return z, tr, [start, target], [torch.tensor(i) for i in z["indices"]], image_syn
+
+
+def test_mtt_trainer_reverse_sweep_matches_reference_golden():
+    """Fixture G10 (reference ReparamModule + autograd): grand loss, d/d image_syn, d/d syn_lr from the
+    trainer's explicit reverse sweep; then the optimiser bookkeeping of the update."""
+    z, tr, traj, chunks, image_syn = _mtt_setup()
+    grand = tr.step(0, traj, start_epoch=0, index_chunks=chunks)
+    g_img, g_lr = tr.last_grads
+    assert abs(grand - float(z["grand_loss"])) / float(z["grand_loss"]) < 1e-4
+    assert abs(g_lr - float(z["grad_lr"])) / abs(float(z["grad_lr"])) < 2e-3
+    want = torch.tensor(z["grad_img"])
+    assert float((g_img[:, ::2, :, ::2, ::2] - want).norm() / want.norm()) < 2e-3
+    np.testing.assert_allclose(tr.image_syn.numpy(), (image_syn - 100.0 * g_img).numpy(), rtol=1e-5, atol=1e-6)   # first step: buf = g
+    assert abs(tr.syn_lr - max(float(z["syn_lr"]) - 1e-5 * g_lr, 0.001)) < 1e-9
+
+
+def _worker_mtt(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z, tr, traj, chunks, _ = _mtt_setup(rank, world)
+        grand = tr.step(0, traj, start_epoch=0, index_chunks=chunks)
+        if rank == 0:
+            q.put((grand, tr.last_grads[0].numpy(), tr.last_grads[1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mtt_trainer_batch_sharded_two_ranks_gloo():
+    """Each student step's synthetic batch split over 2 ranks + all-reduce of the flat gradient and of
+    the Hessian-vector product == the single-rank iteration."""
+    z, tr, traj, chunks, _ = _mtt_setup()
+    want = tr.step(0, traj, start_epoch=0, index_chunks=chunks, update=False)
+    grand, g_img, g_lr = _spawn(_worker_mtt, 2)
+    assert abs(grand - want) / want < 1e-5
+    assert abs(g_lr - tr.last_grads[1]) / abs(g_lr) < 1e-3
+    ref = tr.last_grads[0].numpy()
+    assert np.linalg.norm(g_img - ref) / np.linalg.norm(ref) < 1e-3

@@ -338,3 +338,32 @@ def test_hessian_vector_product_matches_fp64(B, K, use_mask):
     print("H v rel-l2 (dx, 8 params):", " ".join("%.1e" % e for e in errs), "| first-order %.1e" % e_first)
     tol = 2e-4 if e_first < 1e-4 else min(5e-2, 10 * e_first)      # arg-max flip in this batch: see above
     assert max(errs) < tol, errs
+
+
+def test_g10_mtt_step_on_hip_vs_reference_golden(golden_dir):
+    """distill.MTTTrainer with the HIP ops vs fixture G10 (one MTT iteration run with the REFERENCE's
+    ReparamModule + autograd): grand loss, d/d syn_lr, d/d image_syn."""
+    from video_distillation_amd import distill, plan
+    z = np.load(os.path.join(golden_dir, "g10_mtt_step.npz"))
+    C, n_syn = int(z["C"]), int(z["n_syn"])
+    start = R.init_params(int(z["net_seed"]), 3, C)
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    target = [p + 0.02 * p.abs().mean() * torch.randn(p.shape, generator=g) for p in start]
+    image_syn = torch.randn(n_syn, 8, 3, 64, 64, generator=g)
+    ops = distill.HipMTTOps(plan.NetGeometry(8, 64, 64), C, "cuda:0", dropout_p=0.0)
+    tr = distill.MTTTrainer(ops, C, image_syn.clone().cuda(), torch.tensor(z["labels"]).cuda(), float(z["syn_lr"]), lr_img=100.0,
+                            lr_lr=1e-5, syn_steps=int(z["syn_steps"]), batch_syn=int(z["batch_syn"]), expert_epochs=1,
+                            max_start_epoch=1)
+    grand = tr.step(0, [start, target], start_epoch=0, index_chunks=[torch.tensor(i) for i in z["indices"]])
+    g_img, g_lr = tr.last_grads
+    want = torch.tensor(z["grad_img"]).double()
+    per = [_rel(g_img[b, ::2, :, ::2, ::2], want[b]) for b in range(n_syn)]
+    print("G10 grand loss %.6f vs %.6f, d/dlr %.5e vs %.5e, d/dx per-clip rel-l2 %s"
+          % (grand, float(z["grand_loss"]), g_lr, float(z["grad_lr"]), ["%.1e" % e for e in per]))
+    assert abs(grand - float(z["grand_loss"])) / float(z["grand_loss"]) < 1e-3
+    assert abs(g_lr - float(z["grad_lr"])) / abs(float(z["grad_lr"])) < 1e-2
+    assert max(per) < 5e-2 and sorted(per)[len(per) // 2] < 2e-3       # arg-max flips confined to single clips
+    got_l1 = [float(g_img[b].double().abs().sum()) for b in range(n_syn)]
+    np.testing.assert_allclose(got_l1, z["grad_l1"], rtol=2e-2)
+    # optimiser bookkeeping on the device
+    np.testing.assert_allclose(tr.image_syn.cpu().numpy(), (image_syn - 100.0 * g_img.cpu()).numpy(), rtol=1e-5, atol=1e-6)

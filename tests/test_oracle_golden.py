@@ -236,3 +236,25 @@ def test_g9_gradient_matching_class_term(golden_dir):
         got = g[0] if metric == "ours" else g[:, 3]
         want = torch.tensor(z["grad_" + metric])
         assert float((got - want).norm() / want.norm()) < 2e-3, metric     # same arithmetic, different summation order
+
+
+def _g10_inputs(z):
+    C, n_syn = int(z["C"]), int(z["n_syn"])
+    start = R.init_params(int(z["net_seed"]), 3, C)
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    target = [p + 0.02 * p.abs().mean() * torch.randn(p.shape, generator=g) for p in start]
+    image_syn = torch.randn(n_syn, 8, 3, 64, 64, generator=g)
+    return start, target, image_syn, torch.tensor(z["labels"]), [torch.tensor(i) for i in z["indices"]]
+
+
+def test_g10_mtt_step(golden_dir):
+    """One MTT iteration re-stated around the reference's ReparamModule (fixture G10)."""
+    z = load(golden_dir, "g10_mtt_step.npz")
+    start, target, image_syn, labels, chunks = _g10_inputs(z)
+    np.testing.assert_allclose(float(R.flatten_params(target).double().abs().sum()), float(z["target_l1"]), rtol=1e-6)
+    grand, gx, glr = R.mtt_step(start, target, image_syn, labels, float(z["syn_lr"]), chunks)
+    close(grand, z["grand_loss"], rtol=1e-4)
+    close(glr, z["grad_lr"], rtol=2e-3)
+    np.testing.assert_allclose([float(gx[b].double().abs().sum()) for b in range(gx.shape[0])], z["grad_l1"], rtol=2e-3)
+    want = torch.tensor(z["grad_img"])
+    assert float((gx[:, ::2, :, ::2, ::2] - want).norm() / want.norm()) < 2e-3

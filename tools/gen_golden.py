@@ -305,6 +305,54 @@ def g9(networks, utils):
     npz("g9_grad_match.npz", **rec)
 
 
+def g10(networks, utils):
+    # one MTT iteration (distill_baseline.py:192-275) re-stated around the reference's ReparamModule /
+    # ConvNet3D: unrolled student steps with create_graph, normalised parameter distance, backward to the
+    # synthetic clips and to syn_lr.  Expert trajectory = seeded start + a seeded perturbation.
+    sys.path.insert(0, REF)
+    from reparam_module import ReparamModule
+    C, n_syn, syn_steps, batch_syn = 3, 4, 2, 2
+    net = make_net(networks, 101, C, 64, 8)
+    net.dropout.p = 0.0
+    starting = [p.detach().clone() for p in net.parameters()]
+    g = torch.Generator().manual_seed(1001)
+    target = [p + 0.02 * p.abs().mean() * torch.randn(p.shape, generator=g) for p in starting]
+    image_syn = torch.randn(n_syn, 8, 3, 64, 64, generator=g).requires_grad_(True)
+    label_syn = torch.tensor([0, 1, 2, 0])
+    syn_lr = torch.tensor(0.01).requires_grad_(True)
+    student_net = ReparamModule(net)
+    student_net.train()
+    num_params = sum([np.prod(p.size()) for p in (student_net.parameters())])
+    target_params = torch.cat([p.reshape(-1) for p in target], 0)
+    student_params = [torch.cat([p.reshape(-1) for p in starting], 0).requires_grad_(True)]
+    starting_params = torch.cat([p.reshape(-1) for p in starting], 0)
+    criterion = torch.nn.CrossEntropyLoss()
+    torch.manual_seed(1011)
+    indices_chunks, used = [], []
+    for step in range(syn_steps):
+        if not indices_chunks:
+            indices = torch.randperm(len(image_syn))
+            indices_chunks = list(torch.split(indices, batch_syn))
+        these = indices_chunks.pop()
+        used.append(these.clone())
+        out = student_net(image_syn[these], flat_param=student_params[-1])
+        ce = criterion(out, label_syn[these])
+        grad = torch.autograd.grad(ce, student_params[-1], create_graph=True)[0]
+        student_params.append(student_params[-1] - syn_lr * grad)
+    param_loss = torch.nn.functional.mse_loss(student_params[-1], target_params, reduction="sum")
+    param_dist = torch.nn.functional.mse_loss(starting_params, target_params, reduction="sum")
+    param_loss = param_loss / num_params
+    param_dist = param_dist / num_params
+    grand_loss = param_loss / param_dist
+    grand_loss.backward()
+    npz("g10_mtt_step.npz", net_seed=101, data_seed=1001, C=C, n_syn=n_syn, syn_steps=syn_steps, batch_syn=batch_syn,
+        labels=label_syn, indices=torch.stack(used), syn_lr=0.01, grand_loss=grand_loss.detach(),
+        grad_lr=syn_lr.grad, grad_l1=np.array([float(image_syn.grad[b].double().abs().sum()) for b in range(n_syn)]),
+        grad_img=image_syn.grad[:, ::2, :, ::2, ::2],
+        final_l1=float(student_params[-1].detach().double().abs().sum()),
+        target_l1=float(target_params.double().abs().sum()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -312,7 +360,7 @@ def main():
     only = set(sys.argv[1:])
     for name, fn in (("g1", lambda: g1(networks)), ("g2", lambda: g2_g3(networks)), ("g4", lambda: g4_g5(networks, utils)),
                      ("g6", lambda: g6(networks, utils)), ("g7", lambda: g7(networks, utils)),
-                     ("g9", lambda: g9(networks, utils))):
+                     ("g9", lambda: g9(networks, utils)), ("g10", lambda: g10(networks, utils))):
         if not only or name in only:
             fn()
 

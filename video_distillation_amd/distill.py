@@ -562,3 +562,148 @@ class GMTrainer:
         return local_loss
 
     gather_syn = DMTrainer.gather_syn
+
+
+# ------------------------------------------------------------------------------------------------
+# Trajectory matching (MTT): SURVEY section 8(f)-3, config 5
+# ------------------------------------------------------------------------------------------------
+FULL_SHAPES = lambda k: PARAM_SHAPES + ((k, 128, 1, 1, 1), (k,))     # noqa: E731
+
+
+def flatten_params(params: Sequence[torch.Tensor]) -> torch.Tensor:
+    """ReparamModule's flat parameter (reparam_module.py:51): parameters() order, concatenated."""
+    return torch.cat([p.reshape(-1) for p in params], 0)
+
+
+def unflatten_params(flat: torch.Tensor, num_classes: int) -> List[torch.Tensor]:
+    out, o = [], 0
+    for shp in FULL_SHAPES(num_classes):
+        n = int(np.prod(shp))
+        out.append(flat[o:o + n].view(shp))
+        o += n
+    return out
+
+
+class HipMTTOps:
+    """Device operations of the unrolled student loop on the HIP path (train.GradMatchEngine)."""
+
+    def __init__(self, geo: P.NetGeometry, num_classes: int, device, dropout_p: float = 0.5):
+        from . import hip, networks, train
+        self.hip, self.device = hip, torch.device(device)
+        pool = (2, 2, 2) if geo.height > 64 else (2, 1, 1)          # networks.py:733
+        self.te = train.GradMatchEngine(geo, num_classes, pool, device, prec=networks.get_precision()["match"])
+        self.dropout_p = float(dropout_p)
+
+    def grads(self, params, x, labels):
+        """-> ([8 gradients of the mean CE], handle for hvp)."""
+        te, mask = self.te, None
+        if self.dropout_p > 0:
+            keep = 1.0 - self.dropout_p
+            mask = torch.bernoulli(torch.full((x.shape[0], te.C, te.Tp), keep, device=self.device)) / keep
+        _, _, g, state = te.param_grads(x, labels, params, mask)
+        return g, (state, [p for p in params])
+
+    def hvp(self, handle, v):
+        """-> (d <v, g> / dx, [d <v, g> / dparams])."""
+        state, params = handle
+        return self.te.vjp(state, v, params, param_adjoint=True)
+
+    sgd = HipGMOps.sgd
+
+
+class MTTTrainer:
+    """One MTT iteration (distill_baseline.py:192-275): ``syn_steps`` unrolled student updates
+    theta_{s+1} = theta_s - syn_lr * dCE(x_s; theta_s)/dtheta from an expert's start epoch, the
+    normalised distance to the expert's parameters ``expert_epochs`` later, and its gradient w.r.t.
+    the synthetic clips and syn_lr.  The reverse sweep is explicit (no autograd tape):
+
+        thetabar_N = 2 (theta_N - target) / |theta_0 - target|^2
+        for s = N-1 .. 0:   v = -syn_lr * thetabar_{s+1};  lrbar -= <thetabar_{s+1}, g_s>
+                            (xbar_s, Hv) = second-order pass of step s with adjoint v
+                            thetabar_s = thetabar_{s+1} + Hv
+
+    All per-step state (activations, arg-max, first-order gradients at the conv outputs) of the
+    unrolled loop stays resident in HBM between the forward and the reverse sweep.
+    Multi-GPU: the synthetic batch of every student step is split over ranks (what the reference's
+    DataParallel does, :238-241); the flat parameter gradient and the Hessian-vector product are
+    all-reduced per inner step (2 x 14.6 MB), pixel gradients are rank-disjoint and summed once."""
+
+    def __init__(self, ops, num_classes: int, image_syn: torch.Tensor, label_syn: torch.Tensor, syn_lr: float,
+                 lr_img: float, lr_lr: float, syn_steps: int, batch_syn: int, expert_epochs: int, max_start_epoch: int,
+                 momentum: float = 0.5, rank: int = 0, world: int = 1):
+        self.ops, self.num_classes = ops, num_classes
+        self.image_syn, self.label_syn = image_syn.contiguous(), label_syn
+        self.buf = torch.zeros_like(self.image_syn)
+        self.syn_lr, self.lr_buf = float(syn_lr), 0.0
+        self.lr_img, self.lr_lr, self.momentum = float(lr_img), float(lr_lr), float(momentum)
+        self.syn_steps, self.batch_syn = int(syn_steps), int(batch_syn)
+        self.expert_epochs, self.max_start_epoch = int(expert_epochs), int(max_start_epoch)
+        self.rank, self.world = rank, world
+        self.steps_done = 0
+        self.last_grads = None
+
+    def _allreduce(self, tensors):
+        if self.world > 1:
+            import torch.distributed as dist
+            flat = flatten_params(tensors)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            return unflatten_params(flat, self.num_classes)
+        return tensors
+
+    def step(self, it: int, trajectory, start_epoch: Optional[int] = None, index_chunks=None, update: bool = True):
+        """``trajectory``: one expert (list over epochs of the 8 parameter tensors, as stored in
+        ``replay_buffer_N.pt``, buffer.py:75-104).  Returns the grand loss (python float)."""
+        dev = self.image_syn.device
+        rng = np.random.default_rng([it, 17])
+        if start_epoch is None:
+            start_epoch = int(rng.integers(0, self.max_start_epoch))
+        start = [p.to(dev, torch.float32) for p in trajectory[start_epoch]]
+        target = flatten_params([p.to(dev, torch.float32) for p in trajectory[start_epoch + self.expert_epochs]])
+        if index_chunks is None:            # torch.randperm + split + pop() of distill_baseline.py:226-233, seeded per iteration
+            index_chunks, pending = [], []
+            for _ in range(self.syn_steps):
+                if not pending:
+                    perm = torch.as_tensor(rng.permutation(self.image_syn.shape[0]))
+                    pending = list(torch.split(perm, self.batch_syn))
+                index_chunks.append(pending.pop())
+        theta0 = flatten_params(start)
+        theta = theta0.clone()
+        tape = []
+        for idx in index_chunks:
+            idx = idx.to(dev)
+            mine = idx[self.rank::self.world] if self.world > 1 else idx       # this rank's share of the batch
+            share = float(mine.numel()) / float(idx.numel())
+            params = unflatten_params(theta, self.num_classes)
+            if mine.numel():
+                g, handle = self.ops.grads(params, self.image_syn[mine], self.label_syn.to(dev)[mine])
+                g = [t * share for t in g]
+            else:
+                g, handle = [torch.zeros_like(p) for p in params], None
+            g = flatten_params(self._allreduce(g))
+            tape.append((mine, share, handle, g))
+            theta = theta - self.syn_lr * g
+        dist0 = float(((theta0 - target) ** 2).sum())
+        grand = float(((theta - target) ** 2).sum()) / dist0
+        # ---- reverse sweep ---------------------------------------------------------------------
+        tbar = 2.0 * (theta - target) / dist0
+        g_img = torch.zeros_like(self.image_syn)
+        g_lr = 0.0
+        for mine, share, handle, g in reversed(tape):
+            g_lr -= float((tbar * g).sum())
+            if handle is not None:
+                v = unflatten_params(tbar * (-self.syn_lr * share), self.num_classes)
+                dx, hv = self.ops.hvp(handle, v)
+                g_img.index_add_(0, mine, dx)
+            else:
+                hv = [torch.zeros_like(p) for p in unflatten_params(tbar, self.num_classes)]
+            tbar = tbar + flatten_params(self._allreduce(hv))
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(g_img, op=dist.ReduceOp.SUM)
+        self.last_grads = (g_img, g_lr)
+        if update:
+            self.ops.sgd(self.image_syn, self.buf, g_img, self.lr_img, self.momentum, first=(self.steps_done == 0))
+            self.lr_buf = g_lr if self.steps_done == 0 else self.momentum * self.lr_buf + g_lr     # optimizer_lr: SGD(lr_lr, .5)
+            self.syn_lr = max(self.syn_lr - self.lr_lr * self.lr_buf, 0.001)                       # .clip(min=0.001), :269
+            self.steps_done += 1
+        return grand
