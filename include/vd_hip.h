@@ -182,6 +182,10 @@ int vd_ce_loss(const float* logits, const int64_t* labels, int B, int K, float* 
 int vd_head_train_bwd(const float* dlogits, const int32_t* amax_t, const float* dropped, const float* mask, const float* w,
                       int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K, float* g_w, float* g_b,
                       float* g_feats, void* stream);
+/* Re-split 16-bit operand elements between the hi/lo formats (f16 pairs <-> bf16 pairs); lo pointers optional. */
+int vd_resplit_slots(const void* src_hi, const void* src_lo, int64_t n_elems, int src_prec, void* dst_hi, void* dst_lo,
+                     int dst_prec, void* stream);
+
 /* Second-order pass through the head for gradient matching (DC: match_loss(gw_syn, gw_real).backward() with
  * gw_syn = autograd.grad(CE(net(x)), params, create_graph=True), upstream DC loop / distill_baseline.py:250):
  * adjoints of the head's parameter gradients (v_w, v_b) and of the feature gradient (gbar_feats) -> adjoint of

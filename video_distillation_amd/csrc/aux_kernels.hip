@@ -981,6 +981,34 @@ extern "C" int vd_head_train_bwd(const float* dlogits, const int32_t* amax_t, co
     return (int)hipGetLastError();
 }
 
+// Re-split 16-bit operand slots from one hi/lo format to another (f16 pairs <-> bf16 pairs): the
+// gradient-matching engine takes its pooling decisions from an f16x3 forward (rounding error like
+// fp32's) and runs the adjoint sweeps on bf16 pairs (fp32's exponent range).
+__global__ void resplit_kernel(const uint16_t* __restrict__ shi, const uint16_t* __restrict__ slo, int64_t n, int sprec,
+                               uint16_t* __restrict__ dhi, uint16_t* __restrict__ dlo, int dprec) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool sbf = (sprec == VD_PREC_BF16 || sprec == VD_PREC_BF16X3);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = sbf ? __uint_as_float((uint32_t)shi[i] << 16) : (float)__builtin_bit_cast(_Float16, shi[i]);
+        if (slo != nullptr) v += sbf ? __uint_as_float((uint32_t)slo[i] << 16) : (float)__builtin_bit_cast(_Float16, slo[i]);
+        uint16_t hi, lo;
+        split16p(dprec, v, hi, lo);
+        dhi[i] = hi;
+        if (dlo != nullptr) dlo[i] = lo;
+    }
+}
+
+extern "C" int vd_resplit_slots(const void* src_hi, const void* src_lo, int64_t n_elems, int src_prec, void* dst_hi, void* dst_lo,
+                                int dst_prec, void* stream) {
+    if (n_elems <= 0) return 0;
+    int64_t blocks = (n_elems + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(resplit_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const uint16_t*)src_hi, (const uint16_t*)src_lo, n_elems, src_prec, (uint16_t*)dst_hi, (uint16_t*)dst_lo,
+                       dst_prec);
+    return (int)hipGetLastError();
+}
+
 // Second-order pass through the head (gradient matching, d match_loss / d pixels): given the
 // adjoints of the head's parameter gradients (v_w [K][C], v_b [K]) and of the feature gradient
 // (gbar_feats, (B,C,To,Ho,Wo)), produce the adjoint of the features.  With p = softmax(logits),

@@ -258,7 +258,7 @@ class ConvNet3D(nn.Module):
 
     def _train_engine(self, x):
         from . import train
-        key = ("train", x.shape[1], x.shape[3], x.shape[4], _PRECISION["train"], _PRECISION["train_bwd"],
+        key = ("train", x.shape[1], x.shape[3], x.shape[4], self.logit.weight.shape[0], _PRECISION["train"], _PRECISION["train_bwd"],
                x.device.index if x.device.index is not None else torch.cuda.current_device())
         te = _ENGINES.get(key)
         if te is None:
@@ -270,7 +270,7 @@ class ConvNet3D(nn.Module):
 
     def _gm_engine(self, x):
         from . import train
-        key = ("gm", x.shape[1], x.shape[3], x.shape[4], _PRECISION["match"],
+        key = ("gm", x.shape[1], x.shape[3], x.shape[4], self.logit.weight.shape[0], _PRECISION["match"],
                x.device.index if x.device.index is not None else torch.cuda.current_device())
         te = _ENGINES.get(key)
         if te is None:

@@ -71,6 +71,12 @@ class TrainEngine:
             o += n
         return out
 
+    def _forward(self, x, params):
+        """Forward with kept activations ("act1"/"act2" in the engine workspace) and arg-max bytes."""
+        feats, saved = self.eng.forward(x, keep=True)
+        (_, nb, am0, am1, am2), = saved
+        return feats, nb, (am0, am1, am2)
+
     # ------------------------------------------------------------------------------------
     def loss_and_grads(self, x: torch.Tensor, labels: torch.Tensor, params: Sequence[torch.Tensor],
                        mask: Optional[torch.Tensor] = None, state: Optional[dict] = None):
@@ -86,8 +92,7 @@ class TrainEngine:
         for li in (1, 2):
             for dp in eng.bwd[li]:
                 dp.pack(eng._weights[2 * li])
-        feats, saved = eng.forward(x, keep=True)
-        (_, nb, am0, am1, am2), = saved
+        feats, nb, (am0, am1, am2) = self._forward(x, params)
         per1 = int(np.prod(eng.fwd[0].plan.out_shape[:-1]))
         per2 = int(np.prod(eng.fwd[1].plan.out_shape[:-1]))
         acts = [None, eng._buf("act1", (eng.planes, nb * per1, 8), torch.int16),
@@ -200,10 +205,37 @@ class GradMatchEngine(TrainEngine):
             self.sel.append(dp)
         for dp in self.sel:
             dp.params.select = 1
+        # the pooling decisions come from an f16x3 forward (operand error ~4e-7, like fp32's own rounding;
+        # bf16 pairs are exact to ~1e-5 only and flip near-tied windows far more often than the reference)
+        self.eng_fwd = EmbedEngine(geo, prec="f16x3", device=device, chunk=1 << 30)
         self.bwdV = [[_DevPlan(dp.plan, self.device, eng.prec_bwd) for dp in layer] for layer in eng.bwd]
         for layer in self.bwdV:
             for dp in layer:
                 dp.params.atomic = 1
+
+    def _forward(self, x, params):
+        eng, ef, L, st = self.eng, self.eng_fwd, hip.lib(), hip.stream_ptr(self.device)
+        ef.set_weights(params[:6])
+        keep_ws, ef._ws = ef._ws, {}
+        try:
+            feats, saved = ef.forward(x, keep=True)
+            (_, nb, am0, am1, am2), = saved
+            g = self.geo
+            per1 = int(np.prod(eng.fwd[0].plan.out_shape[:-1]))
+            per2 = int(np.prod(eng.fwd[1].plan.out_shape[:-1]))
+            for name, n in (("act1", nb * per1), ("act2", nb * per2)):
+                src = ef._buf(name, (2, n, 8), torch.int16)
+                dst = eng._buf(name, (eng.planes, n, 8), torch.int16)
+                hip.check(L.vd_resplit_slots(hip.ptr(src[0]), hip.ptr(src[1]), ctypes.c_int64(n * 8), ef.prec, hip.ptr(dst[0]),
+                                             hip.ptr(dst[1] if eng.planes == 2 else None), eng.prec, st), "vd_resplit_slots")
+            rowp = P.pix_row_pitch(g.width)
+            n_slots0 = nb * g.frames * 3 * g.height * (rowp // 8)
+            slots0 = eng._buf("slots0", (eng.planes, n_slots0, 8), torch.int16)
+            hip.check(L.vd_pix2rows(hip.ptr(x), hip.ptr(None), ctypes.c_int64(nb), g.frames, g.height, g.width, hip.ptr(slots0[0]),
+                                     hip.ptr(slots0[1] if eng.planes == 2 else None), eng.prec, st), "vd_pix2rows")
+        finally:
+            ef._ws = keep_ws
+        return feats, nb, (am0, am1, am2)
 
     def param_grads(self, x, labels, params, mask=None):
         """-> (loss, logits, [8 gradient tensors], state); state feeds ``vjp``."""
