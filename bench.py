@@ -51,9 +51,12 @@ def parse():
     ap.add_argument("--shard", default="auto", choices=["auto", "class", "batch"],
                     help="multi-GPU decomposition: whole classes per rank, or 1/N of every class's real batch per rank "
                          "(+ one all-reduce of the per-class feature sums); auto = batch when batch_real %% N == 0")
-    ap.add_argument("--method", default="dm", choices=["dm", "s2d", "dc"],
+    ap.add_argument("--syn-steps", type=int, default=10, help="--method mtt: unrolled student steps (sh/baseline/MTT.sh)")
+    ap.add_argument("--batch-syn", type=int, default=256, help="--method mtt: synthetic clips per student step")
+    ap.add_argument("--method", default="dm", choices=["dm", "s2d", "dc", "mtt"],
                     help="dm = distill_baseline.py DM (headline); s2d = DM + static/dynamic memories (config 3); "
-                         "dc = gradient matching with match_loss (config 4: use --classes 51 --ipc 5)")
+                         "dc = gradient matching with match_loss (config 4: use --classes 51 --ipc 5); "
+                         "mtt = trajectory matching (config 5: use --classes 400 --frames 8 --size 64)")
     ap.add_argument("--dis-metric", default="ours", choices=["ours", "mse", "cos"], help="match_loss metric of --method dc")
     return ap.parse_args()
 
@@ -148,6 +151,8 @@ def main():
                                           seed=1234 + rank)
     if args.method == "dc":
         return bench_dc(args, distill, geo, pool, device, rank, world)
+    if args.method == "mtt":
+        return bench_mtt(args, distill, geo, pool, device, rank, world)
     if args.method == "dm":
         trainer = distill.DMTrainer(backend, pool, args.classes, args.ipc, args.batch_real, lr_img=1.0, momentum=0.5,
                                     rank=rank, world=world, shard=shard)
@@ -276,6 +281,57 @@ def bench_dc(args, distill, geo, pool, device, rank, world):
                        "precision": networks.get_precision(),
                        "parallelism": "class-sharded x%d (owner-computes, no gradient exchange)" % world},
             "loss_last": float(losses[-1]) / args.classes}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_mtt(args, distill, geo, pool, device, rank, world):
+    """Secondary line: one MTT iteration = syn_steps unrolled student steps on
+    batch_syn synthetic clips + the reverse sweep to the pixels and syn_lr; expert buffer = random-walk
+    parameter lists (11 epochs) shared by all ranks; every step's batch is split over the ranks."""
+    from video_distillation_amd import networks
+    C = args.classes
+    gen = torch.Generator(device=device); gen.manual_seed(99)
+    image_syn = torch.randn(C * args.ipc, args.frames, 3, args.size, args.size, device=device, generator=gen)
+    label_syn = torch.arange(C, device=device).repeat_interleave(args.ipc)
+    traj = [distill.fresh_full_network(5, C, device)]
+    for e in range(11):
+        traj.append([p + 0.01 * p.abs().mean() * torch.randn(p.shape, device=device, generator=gen) for p in traj[-1]])
+    ops = distill.HipMTTOps(geo, C, device, dropout_p=0.5)
+    tr = distill.MTTTrainer(ops, C, image_syn, label_syn, syn_lr=0.01, lr_img=1.0, lr_lr=1e-6, syn_steps=args.syn_steps,
+                            batch_syn=min(args.batch_syn, C * args.ipc), expert_epochs=1, max_start_epoch=10, rank=rank, world=world)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+    for it in range(args.warmup):
+        tr.step(it, traj)
+    barrier()
+    t0 = time.perf_counter()
+    losses = [tr.step(it, traj) for it in range(args.warmup, args.warmup + args.steps)]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "distillation steps/sec (MTT, syn_steps=%d)" % args.syn_steps,
+            "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": networks.get_precision()["match"], "data": "synthetic",
+            "config": {"workload": "trajectory matching: C=%d classes, %d synthetic clips %dx%dx%d, syn_steps %d x batch_syn %d, "
+                                   "expert_epochs 1, synthetic random-walk expert buffer" % (
+                                       C, C * args.ipc, args.size, args.size, args.frames, args.syn_steps, tr.batch_syn),
+                       "precision": networks.get_precision(),
+                       "parallelism": "student batch split x%d, all-reduce of flat gradient + Hessian-vector product per inner step" % world},
+            "grand_loss_last": float(losses[-1]), "syn_lr": tr.syn_lr}))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

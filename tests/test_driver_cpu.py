@@ -48,3 +48,21 @@ def test_dm_driver_runs_and_logs_reference_keys(tmp_path):
     order = torch.argsort(labels, stable=True)
     first = clips[order][[0, per, 2 * per]]
     assert not torch.equal(tr.image_syn, first) and float((tr.image_syn - first).abs().max()) < 1.0
+
+
+def test_expert_buffer_format_roundtrip(tmp_path):
+    """replay_buffer_N.pt: list[expert] of list[epoch] of the 8 parameter tensors; first free N;
+    loader concatenates all files and asserts when none exists (distill_baseline.py:116-133)."""
+    import pytest
+    from oracle import ref_cpu as R
+    traj = [[R.init_params(s + e, 3, 4) for e in range(3)] for s in (10, 20)]
+    p0 = checkpoint.save_expert_buffer(str(tmp_path), traj[:1])
+    p1 = checkpoint.save_expert_buffer(str(tmp_path), traj[1:])
+    assert os.path.basename(p0) == "replay_buffer_0.pt" and os.path.basename(p1) == "replay_buffer_1.pt"
+    raw = torch.load(p0)
+    assert isinstance(raw, list) and len(raw) == 1 and len(raw[0]) == 3 and len(raw[0][0]) == 8
+    assert [tuple(t.shape) for t in raw[0][0]] == [tuple(s) for s in R.param_shapes(3, 4)]
+    both = checkpoint.load_expert_buffers(str(tmp_path))
+    assert len(both) == 2 and torch.equal(both[1][2][6], traj[1][2][6])
+    with pytest.raises(AssertionError):
+        checkpoint.load_expert_buffers(os.path.join(tmp_path, "nope"))

@@ -59,3 +59,59 @@ def load_hallucinators(path: str):
     if not out:
         raise KeyError("no '{i}.encoder.weight' keys in %s" % path)
     return out
+
+
+# ---- expert trajectories for MTT (buffer.py:75-104; distill_baseline.py:113-135, 203-216) -------
+def save_expert_buffer(save_dir: str, trajectories) -> str:
+    """``replay_buffer_{n}.pt``: list over experts of list over epochs of the 8 parameter tensors
+    (CPU, parameters() order); n = first free index, as buffer.py:97-101."""
+    os.makedirs(save_dir, exist_ok=True)
+    n = 0
+    while os.path.exists(os.path.join(save_dir, "replay_buffer_{}.pt".format(n))):
+        n += 1
+    path = os.path.join(save_dir, "replay_buffer_{}.pt".format(n))
+    torch.save([[[p.detach().cpu() for p in ep] for ep in traj] for traj in trajectories], path)
+    return path
+
+
+def load_expert_buffers(buffer_dir: str, max_files: int = None):
+    """All ``replay_buffer_*.pt`` of a directory, concatenated (distill_baseline.py:116-133);
+    raises AssertionError like the reference when none is found."""
+    files, n = [], 0
+    while os.path.exists(os.path.join(buffer_dir, "replay_buffer_{}.pt".format(n))):
+        files.append(os.path.join(buffer_dir, "replay_buffer_{}.pt".format(n)))
+        n += 1
+    if n == 0:
+        raise AssertionError("No buffers detected at {}".format(buffer_dir))
+    if max_files is not None:
+        files = files[:max_files]
+    out = []
+    for f in files:
+        out += torch.load(f, map_location="cpu")
+    return out
+
+
+def train_expert_trajectories(net_factory, trainloader, args, num_experts: int, train_epochs: int, lr_teacher: float = 0.01,
+                              mom: float = 0.0, l2: float = 0.0, decay: bool = False):
+    """The producer loop of buffer.py:64-95 (with ``args.eval_mode`` defined): every
+    expert is a fresh network trained with SGD through ``utils.epoch('train')`` -- i.e. the HIP
+    train step -- recording the parameters before training and after every epoch."""
+    from . import utils
+    criterion = torch.nn.CrossEntropyLoss().to(args.device)
+    if not hasattr(args, "eval_mode"):
+        args.eval_mode = "SS"
+    trajectories = []
+    for _ in range(num_experts):
+        net = net_factory().to(args.device)
+        net.train()
+        lr = lr_teacher
+        opt = torch.optim.SGD(net.parameters(), lr=lr, momentum=mom, weight_decay=l2)
+        stamps = [[p.detach().cpu() for p in net.parameters()]]
+        for e in range(train_epochs):
+            utils.epoch("train", trainloader, net, opt, criterion, args)
+            stamps.append([p.detach().cpu() for p in net.parameters()])
+            if decay and e == train_epochs // 2 + 1:
+                lr *= 0.1
+                opt = torch.optim.SGD(net.parameters(), lr=lr, momentum=mom, weight_decay=l2)
+        trajectories.append(stamps)
+    return trajectories
