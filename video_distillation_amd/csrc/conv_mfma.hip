@@ -70,9 +70,12 @@ __device__ __forceinline__ void split16(float v, uint16_t& hi, uint16_t& lo) {
     }
 }
 
-template <int PREC, int MTW>
+// SO = second-order variant: split sources + select epilogue (gradient matching / MTT); a separate
+// instantiation so that the extra parameters cost the hot forward / dgrad programs no scalar registers.
+template <int PREC, int MTW, bool SO = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p, const int boxes_per_wg, const int total_boxes) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
+    constexpr bool EXT = SO || MTW == 5;
     constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
     constexpr int H1 = MTW - H0;
     constexpr int AD = 1;                               // x1: A-fragment prefetch distance (K-steps)
@@ -185,7 +188,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
         __syncthreads();  // previous chunk's fragment reads are done
         // ---- stage the patch of this channel chunk: LU independent 16-byte loads in flight ----
         // first B fragments of this chunk: issued before the patch DMA so both latencies overlap
-        const uint4* wp = wbase + (((int64_t)bi * p.w_box_stride) >> 3) + ((int64_t)cc * S * p.NT + wn) * 64 + lane;
+        // (per-box B operands and atomic accumulation exist only in the weight-gradient (MTW 5) and
+        //  second-order instantiations: two scalar registers the hot programs do not pay for)
+        const uint4* wp = wbase + (EXT ? (((int64_t)bi * p.w_box_stride) >> 3) : (int64_t)0) + ((int64_t)cc * S * p.NT + wn) * 64 + lane;
         auto load_b = [&](int s, uint4& bh, uint4& bl) {
             const int sc = (p.dbg & 16) ? 0 : ((s < S) ? s : S - 1);   // dbg 16: always the same (cached) B fragment
             bh = wp[(int64_t)sc * wstep];
@@ -200,10 +205,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
         bql[DB] = make_uint4(0, 0, 0, 0);
         // channel chunks >= src_split_cc live in a second tensor of the same shape (K-concatenated operands
         // of the second-order passes): its distance from the first one is src_split_off4 dwords
-        const uint32_t* csrc = src + (int64_t)clip0 * p.src_clip_stride4 +
-                               ((p.src_split_cc > 0 && cc >= p.src_split_cc)
-                                    ? p.src_split_off4 + (int64_t)(cc - p.src_split_cc) * p.src_chunk_stride4
-                                    : (int64_t)cc * p.src_chunk_stride4);
+        const uint32_t* csrc = src + (int64_t)clip0 * p.src_clip_stride4 + (int64_t)cc * p.src_chunk_stride4;
+        if constexpr (SO) {
+            if (p.src_split_cc > 0 && cc >= p.src_split_cc)
+                csrc = src + (int64_t)clip0 * p.src_clip_stride4 + p.src_split_off4 +
+                       (int64_t)(cc - p.src_split_cc) * p.src_chunk_stride4;
+        }
         if (cc == 0) stamp(1);
         // LDS-DMA: each wave-instruction moves 64 slots (1 KiB) straight into LDS; the per-lane
         // SOURCE address comes from the gather table, the destination is lane-linear.  Zero fill
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                 float v = acc[i][k] * osc + bias;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (o >= 0 && n_ok && idx < out_total) {
-                    if (p.atomic) atomicAdd(&dst[idx + coff], v);   // several boxes add into the same rows (wgrad)
+                    if (EXT && p.atomic) atomicAdd(&dst[idx + coff], v);   // several boxes add into the same rows (wgrad)
                     else dst[idx + coff] = v;
                 }
             }
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
             }
             const int o = lds_otab[gi * 4 + half + 2 * qh];
             if (o < 0 || !n_ok) continue;
-            if (p.select) {
+            if (SO && p.select) {
                 // the arg-max bytes are an INPUT: emit the accumulator row a previous forward selected
                 // (0 where that forward's ReLU was dead) -- the adjoint of vd_unpool_relu_bwd
 #pragma unroll
@@ -690,7 +697,7 @@ extern "C" int vd_conv0_persistent(const VdConvParams* pp, void* stream) {
     return -2;
 }
 
-template <int PREC, int MTW>
+template <int PREC, int MTW, bool SO = false>
 static int launch(const VdConvParams& p, hipStream_t st) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     const int groups = (p.nclips + p.ncl - 1) / p.ncl;
@@ -698,7 +705,7 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     if (total <= 0) return 0;
     const size_t lds = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + p.MW * MTW * 4) * sizeof(int) + 16;
     if (lds > 160 * 1024) return -3;
-    auto kern = conv_mfma_kernel<PREC, MTW>;
+    auto kern = conv_mfma_kernel<PREC, MTW, SO>;
     static bool attr_set = false;
     static int ncu = 0;
     if (!attr_set) {
@@ -735,6 +742,14 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     if (p.NT * p.MW < 1 || p.NT * p.MW > 4 || p.lds_plane_bytes % 16 != 0) return -2;
     if (p.ncl * 65536 <= 0 || p.S <= 0 || p.CC <= 0) return -2;
     if (p.MTW < 8 && (p.gather_stride >> 6) > (int64_t)p.NT * p.MW * (p.MTW <= 4 ? 14 : 17)) return -2;   // patch larger than the DMA register budget
+    if (p.MTW != 5 && (p.atomic || p.w_box_stride != 0 || p.select || p.src_split_cc > 0)) {
+        // second-order programs (and accumulating dgrad launches): bf16 pairs only (train.GradMatchEngine)
+        if (p.prec != VD_PREC_BF16X3) return -2;
+        if (p.MTW == 4) return launch<VD_PREC_BF16X3, 4, true>(p, st);
+        if (p.MTW == 7) return launch<VD_PREC_BF16X3, 7, true>(p, st);
+        if (p.MTW == 8) return launch<VD_PREC_BF16X3, 8, true>(p, st);
+        return -2;
+    }
 #define VD_DISPATCH(PR)                                                   \
     case PR:                                                              \
         if (p.MTW == 4) return launch<PR, 4>(p, st);                      \

@@ -191,8 +191,8 @@ class GradMatchEngine(TrainEngine):
     Operands are bf16 hi+lo pairs (bf16x3): adjoints span many orders of magnitude."""
 
     def __init__(self, geo: P.NetGeometry, num_classes: int, pool_kernel, device, prec: str = "bf16x3"):
-        if not prec.startswith("bf16"):
-            raise ValueError("GradMatchEngine: bf16 / bf16x3 operands only (no per-tensor scaling of the adjoints)")
+        if prec != "bf16x3":
+            raise ValueError("GradMatchEngine: bf16x3 operands only (adjoints span fp32's exponent range and are not scaled)")
         super().__init__(geo, num_classes, pool_kernel, device, prec=prec, prec_bwd=prec)
         eng = self.eng
         self.sel = [_DevPlan(eng.fwd[0].plan, self.device, eng.prec)]
