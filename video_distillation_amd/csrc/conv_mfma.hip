@@ -72,24 +72,32 @@ __device__ __forceinline__ void split16(float v, uint16_t& hi, uint16_t& lo) {
 
 // SO = second-order variant: split sources + select epilogue (gradient matching / MTT); a separate
 // instantiation so that the extra parameters cost the hot forward / dgrad programs no scalar registers.
-template <int PREC, int MTW, bool SO = false>
+// NTW = N tiles (of 32 output channels) per wave: with 2, an A fragment read from LDS feeds two MFMAs,
+// which halves the LDS read traffic per MFMA (the co-critical resource of the NTW = 1 layout).
+template <int PREC, int MTW, bool SO = false, int NTW = 1>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p, const int boxes_per_wg, const int total_boxes) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     constexpr bool EXT = SO || MTW == 5;
+    constexpr int TILES = MTW * NTW;                    // accumulator tiles per wave
     constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
     constexpr int H1 = MTW - H0;
     constexpr int AD = 1;                               // x1: A-fragment prefetch distance (K-steps)
     constexpr int DB = X3 ? 2 : VD_DB_X1;               // B-fragment prefetch distance; (DB+1) % (AD+1) == 0
     static_assert(X3 || (DB + 1) % (AD + 1) == 0, "ring sizes must divide the unroll factor");
-    constexpr int LU = (MTW <= 4) ? 14 : 17;   // DMA groups per wave (4 waves x LU x 64 slots >= the plan's patch)
+    constexpr int LU = (TILES <= 4) ? 14 : 17;   // DMA groups per wave (4 waves x LU x 64 slots >= the plan's patch)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave % p.NT;
-    const int wm = wave / p.NT;
+    const int ncols = p.NT / NTW;                      // wave columns; p.NT counts all N tiles
+    const int wn = wave % ncols;
+    const int wm = wave / ncols;
+    // NTW = 2: boxes of 7 M tiles run on 2 wave rows x 4 tiles; the wave row that owns the padding tile
+    // skips its LDS reads and MFMAs (the MFMA pipe of its SIMD is then free for the co-resident workgroup)
+    bool short_row = false;
+    if constexpr (NTW == 2) short_row = p.mt_valid > 0 && (wm + 1) * MTW > p.mt_valid;
     const int half = lane >> 5;
 
     // XCD-aware block order (T1): workgroups are dealt round-robin to the 8 XCDs, so give each XCD a
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
         for (int i = 0; i < MTW; ++i) a_off[i] = a_tab0[(wm * MTW + i) * 32 + (lane & 31)];
     }
 
-  constexpr bool LOOPED = (MTW <= 4);   // only the first layer's instantiations have boxes short enough to need it
+  constexpr bool LOOPED = (TILES <= 4);   // only the first layer's instantiations have boxes short enough to need it
   const int nbit = LOOPED ? boxes_per_wg : 1;
   for (int bit = 0; bit < nbit; ++bit) {
     const int bid = wgid * nbit + bit;
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
     // (1) the gather entries of this wave's DMA groups: the longest dependent chain of the prologue,
     //     so they are requested first; they are the same for every channel chunk and stay in registers.
     const int32_t* gtab = p.gather + (int64_t)bi * p.gather_stride;
-    constexpr bool HOIST = (MTW < 8);   // MTW = 8 has no registers to spare: it re-reads the table per chunk
+    constexpr bool HOIST = (TILES < 8);   // MTW = 8 has no registers to spare: it re-reads the table per chunk
     uint32_t goff[HOIST ? LU : 1];
 #pragma unroll
     for (int u = 0; u < (HOIST ? LU : 1); ++u) {
@@ -178,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
 #pragma unroll
     for (int u = 0; u < (HOIST ? LU : 1); ++u) asm volatile("" : "+v"(goff[u]));   // consumed before any DMA is in flight
 
-    f32x16 acc[MTW];
+    f32x16 acc[TILES];      // [j * MTW + i]: N tile j of this wave, M tile i
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
+    for (int i = 0; i < TILES; ++i)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
 
@@ -190,19 +198,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
         // first B fragments of this chunk: issued before the patch DMA so both latencies overlap
         // (per-box B operands and atomic accumulation exist only in the weight-gradient (MTW 5) and
         //  second-order instantiations: two scalar registers the hot programs do not pay for)
-        const uint4* wp = wbase + (EXT ? (((int64_t)bi * p.w_box_stride) >> 3) : (int64_t)0) + ((int64_t)cc * S * p.NT + wn) * 64 + lane;
-        auto load_b = [&](int s, uint4& bh, uint4& bl) {
+        const uint4* wp = wbase + (EXT ? (((int64_t)bi * p.w_box_stride) >> 3) : (int64_t)0) + ((int64_t)cc * S * p.NT + wn * NTW) * 64 + lane;
+        auto load_b = [&](int s, uint4* bh, uint4* bl) {
             const int sc = (p.dbg & 16) ? 0 : ((s < S) ? s : S - 1);   // dbg 16: always the same (cached) B fragment
-            bh = wp[(int64_t)sc * wstep];
-            if constexpr (X3) bl = wp[(int64_t)sc * wstep + w_lo];
-        };
-        uint4 bqh[DB + 1], bql[DB + 1];
 #pragma unroll
-        for (int u = 0; u < DB; ++u) {
-            bql[u] = make_uint4(0, 0, 0, 0);
-            load_b(u, bqh[u], bql[u]);
-        }
-        bql[DB] = make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < NTW; ++j) {
+                bh[j] = wp[(int64_t)sc * wstep + j * 64];
+                if constexpr (X3) bl[j] = wp[(int64_t)sc * wstep + j * 64 + w_lo];
+            }
+        };
+        uint4 bqh[DB + 1][NTW], bql[DB + 1][NTW];
+#pragma unroll
+        for (int u = 0; u <= DB; ++u)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) bql[u][j] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < DB; ++u) load_b(u, bqh[u], bql[u]);
         // channel chunks >= src_split_cc live in a second tensor of the same shape (K-concatenated operands
         // of the second-order passes): its distance from the first one is src_split_off4 dwords
         const uint32_t* csrc = src + (int64_t)clip0 * p.src_clip_stride4 + (int64_t)cc * p.src_chunk_stride4;
@@ -301,12 +312,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
 #pragma unroll
                     for (int i = 0; i < MTW; ++i) {
                         if (i > 0 && (p.dbg & 64)) { A[(u + AD) % (AD + 1)][i] = A[(u + AD) % (AD + 1)][0]; continue; }   // dbg 64: one LDS read per step
+                        if (NTW == 2 && i == MTW - 1 && short_row) continue;
                         A[(u + AD) % (AD + 1)][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
                     }
                     VD_SCHED_BARRIER();
                     VD_PRIO(1);
 #pragma unroll
-                    for (int i = 0; i < MTW; ++i) acc[i] = mfma16<PREC>(A[u % (AD + 1)][i], bqh[u], acc[i]);
+                    for (int i = 0; i < MTW; ++i) {
+                        if (NTW == 2 && i == MTW - 1 && short_row) continue;
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+                            acc[j * MTW + i] = mfma16<PREC>(A[u % (AD + 1)][i], bqh[u][j], acc[j * MTW + i]);
+                    }
                     VD_PRIO(0);
                     VD_SCHED_BARRIER();
                     tp = tp_next;
@@ -325,7 +342,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                 for (int u = 0; u <= DB; ++u) {
                     if (s + u >= S) break;
                     load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
-                    const uint4 bh = bqh[u], bl = bql[u];
+                    uint4 bh[NTW], bl[NTW];
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) { bh[j] = bqh[u][j]; bl[j] = bql[u][j]; }
                     const int sn = (s + u + 1 < S) ? s + u + 1 : s + u;
                     const int tap_next = lds_tap[2 * sn + half];
 #pragma unroll
@@ -335,11 +354,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < H0; ++i) {
-                        acc[i] = mfma16<PREC>(A0l[i], bh, acc[i]);
-                        acc[i] = mfma16<PREC>(A0h[i], bl, acc[i]);
-                        acc[i] = mfma16<PREC>(A0h[i], bh, acc[i]);
-                    }
+                    for (int i = 0; i < H0; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j) {
+                            acc[j * MTW + i] = mfma16<PREC>(A0l[i], bh[j], acc[j * MTW + i]);
+                            acc[j * MTW + i] = mfma16<PREC>(A0h[i], bl[j], acc[j * MTW + i]);
+                            acc[j * MTW + i] = mfma16<PREC>(A0h[i], bh[j], acc[j * MTW + i]);
+                        }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < H0; ++i) {
@@ -349,9 +370,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < H1; ++i) {
-                        acc[H0 + i] = mfma16<PREC>(A1l[i], bh, acc[H0 + i]);
-                        acc[H0 + i] = mfma16<PREC>(A1h[i], bl, acc[H0 + i]);
-                        acc[H0 + i] = mfma16<PREC>(A1h[i], bh, acc[H0 + i]);
+                        if (NTW == 2 && i == H1 - 1 && short_row) continue;
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j) {
+                            acc[j * MTW + H0 + i] = mfma16<PREC>(A1l[i], bh[j], acc[j * MTW + H0 + i]);
+                            acc[j * MTW + H0 + i] = mfma16<PREC>(A1h[i], bl[j], acc[j * MTW + H0 + i]);
+                            acc[j * MTW + H0 + i] = mfma16<PREC>(A1h[i], bh[j], acc[j * MTW + H0 + i]);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     tap_cur = tap_next;
@@ -363,16 +388,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
     // ---- epilogue ---------------------------------------------------------------------
     stamp(4);
     if (p.dbg & 1) { if (acc[0][0] == 123.456f) reinterpret_cast<float*>(p.dst)[0] = 1.f; continue; }
-    const int n = wn * 32 + (lane & 31);
-    const bool n_ok = n < p.n_out;
-    const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
     const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
     const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
 
     if (p.epi == VD_EPI_ROWS) {
         float* dst = reinterpret_cast<float*>(p.dst);
-        const int64_t coff = (p.col_off != nullptr) ? (int64_t)p.col_off[n & 31] : (int64_t)n * p.n_stride;
         const float osc = (p.out_scale != nullptr) ? p.out_scale[0] : 1.f;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int n = (wn * NTW + j) * 32 + (lane & 31);
+        const bool n_ok = n < p.n_out;
+        const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+        const int64_t coff = (p.col_off != nullptr) ? (int64_t)p.col_off[n & 31] : (int64_t)n * p.n_stride;
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
             const int gi = wm * MTW + i;
@@ -381,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                 const int row = (k & 3) + 8 * (k >> 2) + 4 * half;
                 const int o = o_tab[gi * 32 + row];
                 const int64_t idx = out_base + o;
-                float v = acc[i][k] * osc + bias;
+                float v = acc[j * MTW + i][k] * osc + bias;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (o >= 0 && n_ok && idx < out_total) {
                     if (EXT && p.atomic) atomicAdd(&dst[idx + coff], v);   // several boxes add into the same rows (wgrad)
@@ -389,6 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                 }
             }
         }
+      }
         finish();
         continue;
     }
@@ -399,8 +427,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
     const int64_t lim64 = out_total - out_base;
     const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
     const bool feat = (p.epi == VD_EPI_POOL_FEAT);
-    const uint32_t chan = feat ? (uint32_t)n * (uint32_t)p.n_stride
-                               : (uint32_t)(n >> 3) * (uint32_t)p.out_chunk_stride * 8u + (uint32_t)(n & 7);
     float* dstf = reinterpret_cast<float*>(p.dst) + out_base;
     uint16_t* dst16 = reinterpret_cast<uint16_t*>(p.dst) + out_base * 8;
     uint8_t* amx = p.argmax ? p.argmax + (feat ? out_base : out_base * 8) : nullptr;
@@ -418,14 +444,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
     // would turn into select chains): both 4-row halves are reduced unconditionally, pool_t only
     // decides whether they are merged.
 #pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int n = (wn * NTW + j) * 32 + (lane & 31);
+    const bool n_ok = n < p.n_out;
+    const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+    const uint32_t chan = feat ? (uint32_t)n * (uint32_t)p.n_stride
+                               : (uint32_t)(n >> 3) * (uint32_t)p.out_chunk_stride * 8u + (uint32_t)(n & 7);
+    f32x16* accj = acc + j * MTW;
+#pragma unroll
     for (int i = 0; i < MTW; ++i) {
         const int gi = wm * MTW + i;
 #pragma unroll
         for (int qh = 0; qh < 2; ++qh) {
             const int r0 = 8 * qh;
             if (staged) {
-                float m0 = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 2], acc[i][r0 + 3]));
-                float m1 = fmaxf(fmaxf(acc[i][r0 + 4], acc[i][r0 + 5]), fmaxf(acc[i][r0 + 6], acc[i][r0 + 7]));
+                float m0 = fmaxf(fmaxf(accj[i][r0], accj[i][r0 + 1]), fmaxf(accj[i][r0 + 2], accj[i][r0 + 3]));
+                float m1 = fmaxf(fmaxf(accj[i][r0 + 4], accj[i][r0 + 5]), fmaxf(accj[i][r0 + 6], accj[i][r0 + 7]));
                 if (p.pool_t == 2) m0 = fmaxf(m0, m1);
                 m0 += bias; m1 += bias;
                 if (p.relu) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
@@ -456,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                     const int jsel = (p.pool_t == 2) ? (ab & 7) : (4 * st + (ab & 3));
                     float v = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v = (j == jsel) ? acc[i][r0 + j] : v;
+                    for (int j = 0; j < 8; ++j) v = (j == jsel) ? accj[i][r0 + j] : v;
                     v = (ab & 0x80) ? 0.f : v + bias;
                     if (feat) {
                         dstf[idx] = v;
@@ -472,11 +506,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
             float mv[2]; int av[2];
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                float mx = acc[i][r0 + 4 * st];
+                float mx = accj[i][r0 + 4 * st];
                 int am = 0;
 #pragma unroll
                 for (int j = 1; j < 4; ++j) {
-                    const float v = acc[i][r0 + 4 * st + j];
+                    const float v = accj[i][r0 + 4 * st + j];
                     if (v > mx) { mx = v; am = j; }
                 }
                 mv[st] = mx; av[st] = am;
@@ -505,6 +539,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
             }
         }
     }
+  }   // N tiles of this wave
     if (staged) {
         __syncthreads();
         stamp(6);
@@ -697,7 +732,7 @@ extern "C" int vd_conv0_persistent(const VdConvParams* pp, void* stream) {
     return -2;
 }
 
-template <int PREC, int MTW, bool SO = false>
+template <int PREC, int MTW, bool SO = false, int NTW = 1>
 static int launch(const VdConvParams& p, hipStream_t st) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     const int groups = (p.nclips + p.ncl - 1) / p.ncl;
@@ -705,7 +740,9 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     if (total <= 0) return 0;
     const size_t lds = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + p.MW * MTW * 4) * sizeof(int) + 16;
     if (lds > 160 * 1024) return -3;
-    auto kern = conv_mfma_kernel<PREC, MTW, SO>;
+    auto kern = conv_mfma_kernel<PREC, MTW, SO, NTW>;
+    if (p.NT % NTW != 0) return -2;
+    const int ncols = p.NT / NTW;
     static bool attr_set = false;
     static int ncu = 0;
     if (!attr_set) {
@@ -721,17 +758,17 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     // resident workgroups per CU: LDS and the register budget of this instantiation (MTW 4: 3 waves
     // per SIMD, otherwise 2; x3 variants of MTW 4 use more registers -> 2)
     int occ = (int)((160 * 1024) / lds);
-    const int waves_per_simd = (MTW <= 4 && !X3) ? 3 : 2;
-    const int wg_waves = p.NT * p.MW;
+    const int waves_per_simd = (MTW * NTW <= 4 && !X3) ? 3 : 2;
+    const int wg_waves = ncols * p.MW;
     const int by_regs = (waves_per_simd * 4) / wg_waves;
     if (occ > by_regs) occ = by_regs;
     if (occ < 1) occ = 1;
     // a few workgroup "generations" keep the tail short while still amortising the dispatch
     const int64_t slots = (int64_t)ncu * occ;
-    int per = (p.persist > 0 && MTW <= 4) ? (int)((total + slots * p.persist - 1) / (slots * p.persist)) : 1;
+    int per = (p.persist > 0 && MTW * NTW <= 4) ? (int)((total + slots * p.persist - 1) / (slots * p.persist)) : 1;
     if (per < 1) per = 1;
     const int64_t grid = (total + per - 1) / per;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * p.NT * p.MW), lds, st, p, per, (int)total);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * ncols * p.MW), lds, st, p, per, (int)total);
     return (int)hipGetLastError();
 }
 
@@ -739,9 +776,23 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     if (pp == nullptr) return -1;
     const VdConvParams& p = *pp;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (p.NT * p.MW < 1 || p.NT * p.MW > 4 || p.lds_plane_bytes % 16 != 0) return -2;
+    const int ntw = p.NTW > 0 ? p.NTW : 1;
+    if (p.NT % ntw != 0) return -2;
+    const int wgw = (p.NT / ntw) * p.MW;
+    if (wgw < 1 || wgw > 4 || p.lds_plane_bytes % 16 != 0) return -2;
     if (p.ncl * 65536 <= 0 || p.S <= 0 || p.CC <= 0) return -2;
-    if (p.MTW < 8 && (p.gather_stride >> 6) > (int64_t)p.NT * p.MW * (p.MTW <= 4 ? 14 : 17)) return -2;   // patch larger than the DMA register budget
+    if (p.MTW * ntw < 8 && (p.gather_stride >> 6) > (int64_t)wgw * (p.MTW * ntw <= 4 ? 14 : 17)) return -2;   // patch larger than the DMA register budget
+    if (ntw == 2) {     // two N tiles per wave: forward / dgrad programs with 4 M tiles per wave (x1 and x3 operand formats)
+        if (p.MTW != 4 || p.select || p.src_split_cc > 0 || p.atomic || p.w_box_stride != 0) return -2;
+        switch (p.prec) {
+            case VD_PREC_BF16: return launch<VD_PREC_BF16, 4, false, 2>(p, st);
+            case VD_PREC_F16: return launch<VD_PREC_F16, 4, false, 2>(p, st);
+            case VD_PREC_BF16X3: return launch<VD_PREC_BF16X3, 4, false, 2>(p, st);
+            case VD_PREC_F16X3: return launch<VD_PREC_F16X3, 4, false, 2>(p, st);
+            default: return -2;
+        }
+    }
+    if (ntw != 1) return -2;
     if (p.MTW != 5 && (p.atomic || p.w_box_stride != 0 || p.select || p.src_split_cc > 0)) {
         // second-order programs (and accumulating dgrad launches): bf16 pairs only (train.GradMatchEngine)
         if (p.prec != VD_PREC_BF16X3) return -2;

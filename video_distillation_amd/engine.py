@@ -41,7 +41,9 @@ class _DevPlan:
         p.nbox = plan.nbox; p.ncl = plan.ncl
         p.CC, p.S = plan.CC, plan.S
         p.src_clip_stride4, p.src_chunk_stride4 = plan.clip_stride4, plan.chunk_stride4
-        p.NT, p.MW, p.MTW = plan.NT, plan.MW, plan.MTW
+        p.NT, p.MW, p.MTW, p.NTW = plan.NT, plan.MW, plan.MTW, plan.NTW
+        mt_max = max(t.mt for t in plan.types)
+        p.mt_valid = mt_max if (plan.NTW == 2 and mt_max < plan.MW * plan.MTW and os.environ.get("VD_SKIP_PAD", "1") == "1") else 0
         p.epi, p.pool_t, p.relu = plan.epi, plan.pool_t, int(plan.relu)
         p.n_out, p.n_stride = plan.n_out, plan.n_stride
         p.out_clip_stride = plan.out_clip_stride
@@ -103,7 +105,9 @@ class EmbedEngine:
         self.planes = 2 if hip.is_x3(self.prec) else 1
         self.device = torch.device(device)
         self.chunk = int(chunk)
-        net = P.plan_network(geo)
+        # two N tiles per wave (half the LDS reads per MFMA) for the layer-1/2 forward programs
+        self.ntw = int(os.environ.get("VD_NTW", "2"))
+        net = P.plan_network(geo, ntw=self.ntw)
         self.dims = net["dims"]
         self.fwd = [_DevPlan(pl, self.device, self.prec) for pl in net["fwd"]]
         # operand precision of the input-gradient passes (default: same as the forward)

@@ -91,6 +91,7 @@ class ConvPlan:
     col_off: Optional[np.ndarray] = None   # EPI_ROWS: element offset of output column n (else n*n_stride)
     atomic: bool = False         # EPI_ROWS: accumulate with fp32 atomics (several boxes add into the same rows)
     w_box_stride: int = 0        # 16-bit elements between the packed B operands of consecutive boxes (0 = shared)
+    NTW: int = 1                 # N tiles per wave: wave grid = (NT / NTW) columns x MW rows
     rows_total: int = 0
     rows_useful: int = 0
     meta: Dict = field(default_factory=dict)
@@ -101,7 +102,7 @@ class ConvPlan:
 
     @property
     def threads(self) -> int:
-        return 64 * self.NT * self.MW
+        return 64 * (self.NT // self.NTW) * self.MW
 
     @property
     def lds_slots(self) -> int:
@@ -376,17 +377,22 @@ def _lane_cols():
 
 
 def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, pool_t: int,
-                    feat_out: bool, lds_budget: int = 3700, mtw_options=(7, 8)) -> ConvPlan:
+                    feat_out: bool, lds_budget: int = 3700, mtw_options=(7, 8), ntw: int = 1) -> ConvPlan:
     """Forward Conv3d(cin->cout) + ReLU + MaxPool(pool_t,2,2) over a channels-last chunked
-    source [clip][cin/8][t][h][w] (slots of 8 channels)."""
+    source [clip][cin/8][t][h][w] (slots of 8 channels).  ``ntw`` = N tiles per wave: with 2 the
+    workgroup is 2 wave columns x 2 wave rows of 4 M tiles x 2 N tiles, and every A fragment read
+    from LDS feeds two MFMAs."""
     assert cin % 8 == 0 and cout % 32 == 0
+    if ntw == 2:
+        assert cout == 128
+        mtw_options = (4,)
     CC = cin // 8
     T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
     To, Ho, Wo = T // pool_t, OH // 2, OW // 2
     rows = (To * pool_t, Ho * 2, Wo * 2)           # conv rows that survive floor pooling
     taps = [(kt, kh, kw) for kt in range(KT) for kh in range(KH) for kw in range(KW)]
     NT = cout // 32
-    MW = max(1, 4 // NT)
+    MW = max(1, 4 // (NT // ntw))
     col, half = _lane_cols()
 
     def widx_fn(CC_, S, NT_, taps_p, ntaps):
@@ -426,9 +432,11 @@ def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: 
         out_shape = (cout // 8, To, Ho, Wo, 8)
     max_ncl = max(1, (8 * 32 * MW) // (rows[0] * rows[1] * rows[2]))
     ncl_options = sorted({1, max_ncl} | {n for n in (2, 4, 8) if n <= max_ncl})
-    return _make_plan(name, (t_in, h_in, w_in), CC, rows, (2, 2, 2), (-1, -3, -3), (1, 2, 2), taps,
+    plan = _make_plan(name, (t_in, h_in, w_in), CC, rows, (2, 2, 2), (-1, -3, -3), (1, 2, 2), taps,
                       widx_fn, cout, NT, MW, mtw_options, epi, pool_t, True, out_index, None, n_stride,
                       clip_stride, chunk_stride, out_shape, lds_budget, ncl_options)
+    plan.NTW = ntw
+    return plan
 
 
 def pix_row_pitch(w: int) -> int:
@@ -730,10 +738,10 @@ class NetGeometry:
 _PLAN_CACHE: Dict[Tuple, Dict[str, object]] = {}
 
 
-def plan_network(geo: NetGeometry, lds_budget: int = 3700) -> Dict[str, object]:
+def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1) -> Dict[str, object]:
     """All tile programs of one ConvNet3D geometry: forward L0..L2 and the input-gradient
-    passes (one per parity class per layer)."""
-    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget)
+    passes (one per parity class per layer).  ``ntw`` = N tiles per wave of the layer-1/2 forward programs."""
+    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw)
     if key in _PLAN_CACHE:
         return _PLAN_CACHE[key]
     dims = geo.layer_dims()
@@ -741,8 +749,15 @@ def plan_network(geo: NetGeometry, lds_budget: int = 3700) -> Dict[str, object]:
     fwd = [plan_forward_pix("fwd0", dims[0][1], dims[0][2], dims[0][3], dims[0][4], lds_budget)]
     for li in (1, 2):
         cin, cout, t, h, w = dims[li][:5]
-        fwd.append(plan_forward_cl("fwd%d" % li, cin, cout, t, h, w, dims[li][11], feat_out=(li == 2),
-                                   lds_budget=lds_budget))
+        pl = plan_forward_cl("fwd%d" % li, cin, cout, t, h, w, dims[li][11], feat_out=(li == 2), lds_budget=lds_budget)
+        if ntw == 2 and cout == 128:
+            # two N tiles per wave halve the LDS reads per MFMA (measured +20 % on layer 2), but the workgroup then
+            # has 8 M tiles: only worth it where the boxes fill them (layer 1's 7-tile boxes would pad 1/8)
+            pl2 = plan_forward_cl("fwd%d" % li, cin, cout, t, h, w, dims[li][11], feat_out=(li == 2), lds_budget=lds_budget,
+                                  ntw=2)
+            if pl2.rows_total <= pl.rows_total:
+                pl = pl2
+        fwd.append(pl)
     bwd = []
     for li in range(3):
         cin, cout, t, h, w = dims[li][:5]
