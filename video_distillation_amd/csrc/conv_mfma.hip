@@ -150,8 +150,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
     const int bid = wgid * nbit + bit;
     if (bid >= total_boxes) break;
     stamp(0);
-    const int grp = bid / p.nbox;
-    const int bi = bid - grp * p.nbox;
+    int grp = bid / p.nbox;
+    int bi = bid - grp * p.nbox;
+    if constexpr (EXT) {
+        // weight-gradient programs: every box has its own B operand (packed dy, MBs), shared by all clip
+        // groups (= input channels).  Box-major order makes the workgroups resident on an XCD stream the
+        // SAME B concurrently, so it is fetched into that L2 once instead of once per channel.
+        if (p.w_box_stride != 0) {
+            const int ngrp = total_boxes / p.nbox;
+            bi = bid / ngrp;
+            grp = bid - bi * ngrp;
+        }
+    }
     const int clip0 = grp * p.ncl;
 
     // (1) the gather entries of this wave's DMA groups: the longest dependent chain of the prologue,
