@@ -249,7 +249,8 @@ class WgradOp:
         self.prec = hip.PREC[prec]
         self.planes = 2 if hip.is_x3(self.prec) else 1
         self.device = torch.device(device)
-        self.plan = P.plan_wgrad("wgrad", cin, cout, t, h, w, nclips)
+        blk = os.environ.get("VD_WG_BLOCK")
+        self.plan = P.plan_wgrad("wgrad", cin, cout, t, h, w, nclips, block=tuple(int(v) for v in blk.split(",")) if blk else None)
         self.dp = _DevPlan(self.plan, self.device, self.prec)
         self.T, self.OH, self.OW = self.plan.meta["grid"]
         self.CCb = self.plan.CC

@@ -610,8 +610,31 @@ def plan_dgrad_pix(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: i
     return plan
 
 
+WGRAD_BLOCKS = ((8, 4, 4), (4, 4, 14), (8, 2, 14), (4, 7, 7), (2, 7, 14), (4, 2, 14), (2, 4, 14), (2, 2, 14), (1, 4, 14), (1, 2, 14))
+
+
 def plan_wgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, nclips: int,
-               lds_budget: int = 3700, block=(2, 4, 14)) -> ConvPlan:
+               lds_budget: int = 3700, block=None) -> ConvPlan:
+    if block is None:
+        # the largest block of positions (= K steps per staged patch, and fewest atomic passes over dW) whose
+        # patch fits the LDS budget and the DMA-group budget of the workgroup (cout/32 waves x 17 groups of 64 slots)
+        best = None
+        for cand in WGRAD_BLOCKS:
+            pl = _plan_wgrad(name, cin, cout, t_in, h_in, w_in, nclips, lds_budget, cand)
+            bt = pl.types[0]
+            groups = -(-bt.pitch_c // 64)
+            if bt.pitch_c > lds_budget or groups > (cout // 32) * 17:
+                continue
+            key = (pl.nbox, -pl.S)
+            if best is None or key < best[0]:
+                best = (key, pl)
+        assert best is not None, "no weight-gradient block fits"
+        return best[1]
+    return _plan_wgrad(name, cin, cout, t_in, h_in, w_in, nclips, lds_budget, block)
+
+
+def _plan_wgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, nclips: int,
+                lds_budget: int, block) -> ConvPlan:
     """Weight gradient of Conv3d(cin->cout, k(3,7,7), s(1,2,2), p(1,3,3)) as a tile program of the SAME
     kernel, with the roles of the operands rotated:
 
