@@ -166,9 +166,12 @@ def test_experimental_persistent_first_layer_matches_generic():
     geo = plan.NetGeometry(16, 112, 112)
     g = torch.Generator(device="cuda").manual_seed(11)
     x = torch.randn(3, 16, 3, 112, 112, device="cuda", generator=g)
-    eng = engine.EmbedEngine(geo, prec="f16", chunk=8)
+    eng = engine.EmbedEngine(geo, prec="f16", chunk=8, ntw0=1)      # the persistent kernel is fixed to the 2x2-wave layout
     eng.set_weights(distill.fresh_network_weights(2, "cuda:0"))
     ref = eng.forward(x)
+    eng2 = engine.EmbedEngine(geo, prec="f16", chunk=8, ntw0=2)     # default layout: 1 wave column x 4 wave rows, 2 N tiles per wave
+    eng2.set_weights(distill.fresh_network_weights(2, "cuda:0"))
+    assert eng2.fwd[0].plan.NTW == 2 and torch.equal(ref, eng2.forward(x))   # same K order per output: bitwise equal
     dp = eng.fwd[0]
     assert not dp.persistent_ok
     p = dp.params

@@ -793,12 +793,12 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     if (p.ncl * 65536 <= 0 || p.S <= 0 || p.CC <= 0) return -2;
     if (p.MTW * ntw < 8 && (p.gather_stride >> 6) > (int64_t)wgw * (p.MTW * ntw <= 4 ? 14 : 17)) return -2;   // patch larger than the DMA register budget
     if (ntw == 2) {     // two N tiles per wave: forward / dgrad programs with 4 M tiles per wave (x1 and x3 operand formats)
-        if (p.MTW != 4 || p.select || p.src_split_cc > 0 || p.atomic || p.w_box_stride != 0) return -2;
+        if ((p.MTW != 4 && p.MTW != 2) || p.select || p.src_split_cc > 0 || p.atomic || p.w_box_stride != 0) return -2;
         switch (p.prec) {
-            case VD_PREC_BF16: return launch<VD_PREC_BF16, 4, false, 2>(p, st);
-            case VD_PREC_F16: return launch<VD_PREC_F16, 4, false, 2>(p, st);
-            case VD_PREC_BF16X3: return launch<VD_PREC_BF16X3, 4, false, 2>(p, st);
-            case VD_PREC_F16X3: return launch<VD_PREC_F16X3, 4, false, 2>(p, st);
+            case VD_PREC_BF16: return p.MTW == 4 ? launch<VD_PREC_BF16, 4, false, 2>(p, st) : launch<VD_PREC_BF16, 2, false, 2>(p, st);
+            case VD_PREC_F16: return p.MTW == 4 ? launch<VD_PREC_F16, 4, false, 2>(p, st) : launch<VD_PREC_F16, 2, false, 2>(p, st);
+            case VD_PREC_BF16X3: return p.MTW == 4 ? launch<VD_PREC_BF16X3, 4, false, 2>(p, st) : launch<VD_PREC_BF16X3, 2, false, 2>(p, st);
+            case VD_PREC_F16X3: return p.MTW == 4 ? launch<VD_PREC_F16X3, 4, false, 2>(p, st) : launch<VD_PREC_F16X3, 2, false, 2>(p, st);
             default: return -2;
         }
     }

@@ -95,7 +95,7 @@ class _DevPlan:
 
 class EmbedEngine:
     def __init__(self, geo: P.NetGeometry, prec: str = "bf16x3", device="cuda:0", chunk: int = 256,
-                 prec_bwd: Optional[str] = None):
+                 prec_bwd: Optional[str] = None, ntw0: Optional[int] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("EmbedEngine needs a HIP device (no CPU fallback)")
         hip.lib()
@@ -105,9 +105,12 @@ class EmbedEngine:
         self.planes = 2 if hip.is_x3(self.prec) else 1
         self.device = torch.device(device)
         self.chunk = int(chunk)
-        # two N tiles per wave (half the LDS reads per MFMA) for the layer-1/2 forward programs
+        # two N tiles per wave (half the LDS reads per MFMA): layer-1/2 forward programs whose boxes fill 8 M
+        # tiles, and the first layer in the single-pass formats (measured: x1 +7 %, x3 -6 % -> x3 keeps one)
         self.ntw = int(os.environ.get("VD_NTW", "2"))
-        net = P.plan_network(geo, ntw=self.ntw)
+        if ntw0 is None:
+            ntw0 = int(os.environ.get("VD_NTW0", "1" if (hip.is_x3(self.prec) or self.ntw != 2) else "2"))
+        net = P.plan_network(geo, ntw=self.ntw, ntw0=ntw0)
         self.dims = net["dims"]
         self.fwd = [_DevPlan(pl, self.device, self.prec) for pl in net["fwd"]]
         # operand precision of the input-gradient passes (default: same as the forward)

@@ -22,6 +22,8 @@ import itertools
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 
 SLOT_BYTES = 16
@@ -446,7 +448,7 @@ def pix_row_pitch(w: int) -> int:
 
 
 def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_budget: int = 3700,
-                     mtw_options=(4,)) -> ConvPlan:
+                     mtw_options=(4,), ntw: int = 1) -> ConvPlan:
     """First layer: Conv3d(3->cout) + ReLU + MaxPool(1,2,2).  Source = 16-bit pixel rows made by
     vd_pix2rows: [clip][t*3+c][h][W+8] with 3 zero pixels in front (and >=5 behind), so that the
     'kw-slot' of output column ow -- x[t,c,h,2*ow-3 .. 2*ow+4], the 7 kernel columns plus one
@@ -459,7 +461,10 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
     rows = (T, Ho * 2, Wo * 2)
     taps = [(kt * cin + c, kh, 0) for kt in range(KT) for c in range(cin) for kh in range(KH)]
     NT = cout // 32
-    MW = max(1, 4 // NT)
+    MW = max(1, 4 // (NT // ntw))
+    if ntw == 2:                 # one wave column of 2 N tiles, 4 wave rows of 2 M tiles: same 8-tile box
+        assert NT == 2
+        mtw_options = (2,)
     col, half = _lane_cols()
 
     def widx_fn(CC_, S, NT_, taps_p, ntaps):
@@ -488,6 +493,7 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
                       widx_fn, cout, NT, MW, mtw_options, EPI_POOL_CL, 1, True, out_index, None, 0,
                       clip_stride, chunk_stride, (cout // 8, T, Ho, Wo, 8), lds_budget, (1,))
     plan.out_t_stride = Ho * Wo
+    plan.NTW = ntw
     rowp = pix_row_pitch(w_in)
     plan.w_step4, plan.row_pitch4 = 1, rowp // 2
     plan.chunk_stride4 = plan.clip_stride4 = t_in * cin * h_in * (rowp // 2)
@@ -761,15 +767,16 @@ class NetGeometry:
 _PLAN_CACHE: Dict[Tuple, Dict[str, object]] = {}
 
 
-def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1) -> Dict[str, object]:
+def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: int = 1) -> Dict[str, object]:
     """All tile programs of one ConvNet3D geometry: forward L0..L2 and the input-gradient
-    passes (one per parity class per layer).  ``ntw`` = N tiles per wave of the layer-1/2 forward programs."""
-    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw)
+    passes (one per parity class per layer).  ``ntw`` / ``ntw0`` = N tiles per wave of the layer-1/2
+    and of the first-layer forward programs."""
+    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw, ntw0)
     if key in _PLAN_CACHE:
         return _PLAN_CACHE[key]
     dims = geo.layer_dims()
     assert geo.channel == 3 and geo.pools_t[0] == 1, "first layer planner assumes RGB clips and (1,2,2) pooling"
-    fwd = [plan_forward_pix("fwd0", dims[0][1], dims[0][2], dims[0][3], dims[0][4], lds_budget)]
+    fwd = [plan_forward_pix("fwd0", dims[0][1], dims[0][2], dims[0][3], dims[0][4], lds_budget, ntw=ntw0)]
     for li in (1, 2):
         cin, cout, t, h, w = dims[li][:5]
         pl = plan_forward_cl("fwd%d" % li, cin, cout, t, h, w, dims[li][11], feat_out=(li == 2), lds_budget=lds_budget)
