@@ -213,7 +213,10 @@ def main():
                        "parallelism": ("real batch sharded x%d + all-reduce of per-class feature sums (410 KB); synthetic clips "
                                        "class-owned, no gradient exchange" % world) if trainer.__dict__.get("shard") == "batch" else
                                       "class-sharded x%d (owner-computes, no gradient exchange)" % world,
-                       "pool_per_class": args.pool_per_class},
+                       "pool_per_class": args.pool_per_class,
+                       "real_pool": "resident in HBM: fp32 clips + the same clips converted once to the first layer's 16-bit pixel "
+                                    "rows; a real batch is an index list (get_images + cast of the reference), no per-step "
+                                    "conversion" if backend.resident_rows else "resident in HBM as fp32, converted per step"},
             "loss_last": float(losses[-1]) / args.classes,
             "step_tflops": step_flop / (dt / args.steps) / 1e12,
             "step_frac_of_mfma_peak": step_flop / (dt / args.steps) / 2.5e15,

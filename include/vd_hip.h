@@ -66,6 +66,7 @@ typedef struct VdConvParams {
     int32_t src_split_cc;         /* >0: channel chunks >= this come from a second tensor ...     */
     int64_t src_split_off4;       /* ... that starts this many dwords after src (same strides)    */
     int32_t NTW;                  /* N tiles per wave (0/1: one; 2: an A fragment feeds two MFMAs; wave columns = NT / NTW) */
+    const int64_t* clip_index;    /* first-layer programs (ncl = 1): source clip of batch clip b is src + clip_index[b]*clip stride (NULL: b) */
     int32_t mt_valid;             /* NTW = 2: M tiles per box that carry rows (< MW*MTW: the last wave row skips its padding tile); 0 = all */
     int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */

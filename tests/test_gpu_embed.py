@@ -239,3 +239,24 @@ def test_single_pass_fp16_backward_with_dynamic_scaling():
     # the x3 backward is scaled too: a 1e-7 gradient is reproduced as exactly as an O(1) one
     tiny = e3.backward(e3.forward(x.cuda(), keep=True)[1], (gf * 1e-7).cuda())
     assert _rel(tiny * 1e7, want)[0] < 1e-3
+
+
+def test_resident_pool_rows_equal_per_step_conversion():
+    """Batches read through an index out of the pool converted once to 16-bit pixel rows (HipBackend's
+    default for the real clips) == converting the gathered fp32 clips every step (bitwise), both layouts
+    of the first-layer program; the two-stream trainer gives the same step either way."""
+    from video_distillation_amd import distill, engine, plan
+    geo = plan.NetGeometry(16, 112, 112)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    pool = torch.randn(10, 16, 3, 112, 112, device="cuda", generator=g)
+    idx = torch.tensor([7, 0, 3, 3, 9, 1, 2], device="cuda")
+    w = distill.fresh_network_weights(4, "cuda:0")
+    for prec, ntw0 in (("f16", 2), ("f16", 1), ("f16x3", 1)):
+        eng = engine.EmbedEngine(geo, prec=prec, chunk=4, ntw0=ntw0)
+        eng.set_weights(w)
+        rows = eng.pool_rows(pool, step=4)
+        a = eng.forward(pool, index=idx)
+        b = eng.forward(pool, index=idx, rows=rows)
+        c = eng.forward(pool[idx])
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and torch.equal(a, c), (prec, ntw0)

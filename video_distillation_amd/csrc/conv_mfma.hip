@@ -227,6 +227,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
         // channel chunks >= src_split_cc live in a second tensor of the same shape (K-concatenated operands
         // of the second-order passes): its distance from the first one is src_split_off4 dwords
         const uint32_t* csrc = src + (int64_t)clip0 * p.src_clip_stride4 + (int64_t)cc * p.src_chunk_stride4;
+        if constexpr (TILES <= 4) {
+            // first-layer programs (one clip per box) may read their clip through an index: the real pool is kept
+            // resident as 16-bit pixel rows and a batch is just a list of pool indices (get_images, distill_baseline.py:84-90)
+            if (p.clip_index != nullptr) csrc = src + p.clip_index[clip0] * (int64_t)p.src_clip_stride4;
+        }
         if constexpr (SO) {
             if (p.src_split_cc > 0 && cc >= p.src_split_cc)
                 csrc = src + (int64_t)clip0 * p.src_clip_stride4 + p.src_split_off4 +
@@ -792,6 +797,7 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     if (wgw < 1 || wgw > 4 || p.lds_plane_bytes % 16 != 0) return -2;
     if (p.ncl * 65536 <= 0 || p.S <= 0 || p.CC <= 0) return -2;
     if (p.MTW * ntw < 8 && (p.gather_stride >> 6) > (int64_t)wgw * (p.MTW * ntw <= 4 ? 14 : 17)) return -2;   // patch larger than the DMA register budget
+    if (p.clip_index != nullptr && (p.ncl != 1 || p.CC != 1 || p.MTW * ntw > 4)) return -2;
     if (ntw == 2) {     // two N tiles per wave: forward / dgrad programs with 4 M tiles per wave (x1 and x3 operand formats)
         if ((p.MTW != 4 && p.MTW != 2) || p.select || p.src_split_cc > 0 || p.atomic || p.w_box_stride != 0) return -2;
         switch (p.prec) {

@@ -76,8 +76,9 @@ class _DevPlan:
 
     def run(self, src: torch.Tensor, src_plane_slots: int, bias: Optional[torch.Tensor], dst_ptr: int,
             dst_plane_stride: int, argmax: Optional[torch.Tensor], nclips: int, out_scale: Optional[torch.Tensor] = None,
-            wpk: Optional[torch.Tensor] = None, w_plane_elems: int = 0) -> None:
+            wpk: Optional[torch.Tensor] = None, w_plane_elems: int = 0, clip_index: Optional[torch.Tensor] = None) -> None:
         p = self.params
+        p.clip_index = 0 if clip_index is None else clip_index.data_ptr()
         p.out_scale = 0 if out_scale is None else out_scale.data_ptr()
         if wpk is not None:     # B operand supplied per call (weight-gradient programs)
             p.wpk = wpk.data_ptr(); p.w_plane_stride = w_plane_elems
@@ -148,7 +149,25 @@ class EmbedEngine:
             self._bwd_packed = True
 
     # ------------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor, keep: bool = False, index: Optional[torch.Tensor] = None):
+    def pool_rows(self, pool: torch.Tensor, step: int = 256) -> torch.Tensor:
+        """The whole (static) clip pool converted ONCE to this engine's first-layer operand format
+        (16-bit pixel rows, [planes][N * slots per clip][8]); ``forward(..., rows=)`` then reads batches
+        straight out of it through the index -- no per-step conversion of the real clips."""
+        g = self.geo
+        N = int(pool.shape[0])
+        rowp = P.pix_row_pitch(g.width)
+        per = g.frames * 3 * g.height * (rowp // 8)
+        rows = torch.empty((self.planes, N * per, 8), dtype=torch.int16, device=self.device)
+        L, st = hip.lib(), hip.stream_ptr(self.device)
+        for i in range(0, N, step):
+            nb = min(step, N - i)
+            lo = rows[1, i * per:] if self.planes == 2 else None
+            hip.check(L.vd_pix2rows(hip.ptr(pool[i:]), hip.ptr(None), ctypes.c_int64(nb), g.frames, g.height, g.width,
+                                     hip.ptr(rows[0, i * per:]), hip.ptr(lo), self.prec, st), "vd_pix2rows")
+        return rows
+
+    def forward(self, x: torch.Tensor, keep: bool = False, index: Optional[torch.Tensor] = None,
+                rows: Optional[torch.Tensor] = None):
         """x (B,T,3,H,W) fp32 on the device -> features (B, num_feat) fp32.  With ``keep`` the
         pooling arg-max of every layer is retained and returned as a handle for ``backward``
         (several forwards may be outstanding before their backwards, as in the reference's
@@ -170,12 +189,17 @@ class EmbedEngine:
         for c0 in range(0, B, self.chunk):
             nb = min(self.chunk, B - c0)
             n_slots0 = nb * g.frames * 3 * g.height * (rowp // 8)      # 16-byte units of the padded pixel rows
-            slots0 = self._buf("slots0", (self.planes, n_slots0, 8), torch.int16)
-            lo = slots0[1] if self.planes == 2 else None
-            xin = x[c0:] if index is None else x
-            hip.check(L.vd_pix2rows(hip.ptr(xin), hip.ptr(None if index is None else index[c0:]),
-                                     ctypes.c_int64(nb), g.frames, g.height, g.width,
-                                     hip.ptr(slots0[0]), hip.ptr(lo), self.prec, st), "vd_pix2rows")
+            cidx = None
+            if rows is not None:      # batch = index into the resident, already converted pool
+                assert index is not None and rows.shape[0] == self.planes
+                slots0, n_slots0, cidx = rows, int(rows.shape[1]), index[c0:]
+            else:
+                slots0 = self._buf("slots0", (self.planes, n_slots0, 8), torch.int16)
+                lo = slots0[1] if self.planes == 2 else None
+                xin = x[c0:] if index is None else x
+                hip.check(L.vd_pix2rows(hip.ptr(xin), hip.ptr(None if index is None else index[c0:]),
+                                         ctypes.c_int64(nb), g.frames, g.height, g.width,
+                                         hip.ptr(slots0[0]), hip.ptr(lo), self.prec, st), "vd_pix2rows")
             n1, n2 = nb * per1, nb * per2
             act1 = self._buf("act1", (self.planes, n1, 8), torch.int16)
             act2 = self._buf("act2", (self.planes, n2, 8), torch.int16)
@@ -188,7 +212,7 @@ class EmbedEngine:
             prof = self.profile
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if prof is not None else None
             if ev: ev[0].record()
-            self.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, am0, nb)
+            self.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, am0, nb, clip_index=cidx)
             if ev: ev[1].record()
             self.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, am1, nb)
             if ev: ev[2].record()
