@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--prec-syn", default=os.environ.get("VD_PREC_SYN", "f16x3"))
     ap.add_argument("--prec-bwd", default=os.environ.get("VD_PREC_BWD", "f16"),
                     help="operand precision of the input-gradient passes (single-pass fp16 with power-of-two scaling)")
-    ap.add_argument("--chunk", type=int, default=512)
+    ap.add_argument("--chunk", type=int, default=3200, help="real clips per launch (all of a single-GPU step by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-classes", type=int, default=10, help="class terms timed for the CPU baseline")
     ap.add_argument("--shard", default="auto", choices=["auto", "class", "batch"],

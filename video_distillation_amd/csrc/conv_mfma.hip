@@ -74,11 +74,15 @@ __device__ __forceinline__ void split16(float v, uint16_t& hi, uint16_t& lo) {
 // instantiation so that the extra parameters cost the hot forward / dgrad programs no scalar registers.
 // NTW = N tiles (of 32 output channels) per wave: with 2, an A fragment read from LDS feeds two MFMAs,
 // which halves the LDS read traffic per MFMA (the co-critical resource of the NTW = 1 layout).
-template <int PREC, int MTW, bool SO = false, int NTW = 1>
+// BAL = 1 (with NTW = 2, MTW = 3): boxes of 7 M tiles on 2 x 2 waves -- every wave owns 3 M tiles x 2 N
+// tiles plus ONE N tile of the seventh M tile: 7 MFMAs per K step for 4 A-fragment reads (instead of 7).
+template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p, const int boxes_per_wg, const int total_boxes) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     constexpr bool EXT = SO || MTW == 5;
-    constexpr int TILES = MTW * NTW;                    // accumulator tiles per wave
+    constexpr int TILES = MTW * NTW + BAL;              // accumulator tiles per wave
+    constexpr int MA = MTW + BAL;                       // M tiles (A fragments per K step) a wave touches
+    static_assert(BAL == 0 || (NTW == 2 && !X3 && !SO), "balanced layout: single-pass formats, two N tiles per wave");
     constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
     constexpr int H1 = MTW - H0;
     constexpr int AD = 1;                               // x1: A-fragment prefetch distance (K-steps)
@@ -132,16 +136,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
     const int64_t w_lo = p.w_plane_stride >> 3;  // uint4 units
     const int wstep = p.NT * 64;                 // uint4 per K-step
     const int S = p.S;
-    int a_off[MTW];
+    int a_off[MA];
+    const int mt_tot = p.MW * MTW + BAL;               // M tiles of the workgroup
+    auto tile_of = [&](int i) { return (BAL && i == MTW) ? p.MW * MTW : wm * MTW + i; };
     if (one_type) {   // box-type tables are launch constants: load them once per workgroup
         const int32_t* a_tab0 = p.tables + p.tab_ofs[0];
         const int32_t* o_tab0 = p.tables + p.tab_ofs[1];
         const int32_t* t_tab0 = p.tables + p.tab_ofs[2];
         for (int k = tid; k < 2 * p.S; k += nthreads) lds_tap[k] = t_tab0[k];
         if (p.epi != VD_EPI_ROWS)
-            for (int k = tid; k < p.MW * MTW * 4; k += nthreads) lds_otab[k] = o_tab0[k];
+            for (int k = tid; k < mt_tot * 4; k += nthreads) lds_otab[k] = o_tab0[k];
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) a_off[i] = a_tab0[(wm * MTW + i) * 32 + (lane & 31)];
+        for (int i = 0; i < MA; ++i) a_off[i] = a_tab0[tile_of(i) * 32 + (lane & 31)];
     }
 
   constexpr bool LOOPED = (TILES <= 4);   // only the first layer's instantiations have boxes short enough to need it
@@ -189,9 +195,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
         __syncthreads();   // the previous box's epilogue is done with the LDS tables
         for (int k = tid; k < 2 * p.S; k += nthreads) lds_tap[k] = t_tab[k];
         if (p.epi != VD_EPI_ROWS)
-            for (int k = tid; k < p.MW * MTW * 4; k += nthreads) lds_otab[k] = o_tab[k];
+            for (int k = tid; k < mt_tot * 4; k += nthreads) lds_otab[k] = o_tab[k];
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
+        for (int i = 0; i < MA; ++i) a_off[i] = a_tab[tile_of(i) * 32 + (lane & 31)];
     }
 #pragma unroll
     for (int u = 0; u < (HOIST ? LU : 1); ++u) asm volatile("" : "+v"(goff[u]));   // consumed before any DMA is in flight
@@ -310,12 +316,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                 const int sc = (p.dbg & 32) ? 0 : ((st < S) ? st : S - 1);   // dbg 32: every step reads the same LDS rows
                 return lds_tap[2 * sc + half];
             };
-            uint4 A[AD + 1][MTW];
+            uint4 A[AD + 1][MA];
 #pragma unroll
             for (int d = 0; d < AD; ++d) {
                 const int tp = tap_of(d);
 #pragma unroll
-                for (int i = 0; i < MTW; ++i) A[d][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
+                for (int i = 0; i < MA; ++i) A[d][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
             }
             int tp = tap_of(AD);
             for (int s = 0; s < S; s += DB + 1) {
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                     load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
                     const int tp_next = tap_of(s + u + AD + 1);
 #pragma unroll
-                    for (int i = 0; i < MTW; ++i) {
+                    for (int i = 0; i < MA; ++i) {
                         if (i > 0 && (p.dbg & 64)) { A[(u + AD) % (AD + 1)][i] = A[(u + AD) % (AD + 1)][0]; continue; }   // dbg 64: one LDS read per step
                         if (NTW == 2 && i == MTW - 1 && short_row) continue;
                         A[(u + AD) % (AD + 1)][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
@@ -338,6 +344,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
 #pragma unroll
                         for (int j = 0; j < NTW; ++j)
                             acc[j * MTW + i] = mfma16<PREC>(A[u % (AD + 1)][i], bqh[u][j], acc[j * MTW + i]);
+                    }
+                    if constexpr (BAL) {   // seventh M tile: this wave's single N tile of it (wave row picks which)
+                        uint4 bx = bqh[u][0];
+                        if (wm) bx = bqh[u][1];
+                        acc[MTW * NTW] = mfma16<PREC>(A[u % (AD + 1)][MTW], bx, acc[MTW * NTW]);
                     }
                     VD_PRIO(0);
                     VD_SCHED_BARRIER();
@@ -410,20 +421,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
         float* dst = reinterpret_cast<float*>(p.dst);
         const float osc = (p.out_scale != nullptr) ? p.out_scale[0] : 1.f;
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const int n = (wn * NTW + j) * 32 + (lane & 31);
+      for (int j = 0; j < NTW + BAL; ++j) {
+        const bool ex = BAL && j == NTW;                     // the extra (seventh-tile) accumulator of a balanced wave
+        const int n = (wn * NTW + (ex ? wm : j)) * 32 + (lane & 31);
         const bool n_ok = n < p.n_out;
         const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
         const int64_t coff = (p.col_off != nullptr) ? (int64_t)p.col_off[n & 31] : (int64_t)n * p.n_stride;
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
-            const int gi = wm * MTW + i;
+            if (ex && i > 0) continue;
+            const int gi = ex ? p.MW * MTW : wm * MTW + i;
+            const f32x16& at = acc[ex ? MTW * NTW : j * MTW + i];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int row = (k & 3) + 8 * (k >> 2) + 4 * half;
                 const int o = o_tab[gi * 32 + row];
                 const int64_t idx = out_base + o;
-                float v = acc[j * MTW + i][k] * osc + bias;
+                float v = at[k] * osc + bias;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (o >= 0 && n_ok && idx < out_total) {
                     if (EXT && p.atomic) atomicAdd(&dst[idx + coff], v);   // several boxes add into the same rows (wgrad)
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
     // and made the epilogue as expensive as the K loop of the first layer.)
     const bool staged = !feat && amx == nullptr;
     const int NCH = p.NT * 32;
-    const int Q = p.MW * MTW * 4 * nsets;
+    const int Q = mt_tot * 4 * nsets;
     uint16_t* stg = reinterpret_cast<uint16_t*>(smem);
     if (staged) __syncthreads();          // every wave is done reading the patch
     stamp(5);
@@ -459,22 +473,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
     // would turn into select chains): both 4-row halves are reduced unconditionally, pool_t only
     // decides whether they are merged.
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const int n = (wn * NTW + j) * 32 + (lane & 31);
+  for (int j = 0; j < NTW + BAL; ++j) {
+    const bool ex = BAL && j == NTW;
+    const int n = (wn * NTW + (ex ? wm : j)) * 32 + (lane & 31);
     const bool n_ok = n < p.n_out;
     const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
     const uint32_t chan = feat ? (uint32_t)n * (uint32_t)p.n_stride
                                : (uint32_t)(n >> 3) * (uint32_t)p.out_chunk_stride * 8u + (uint32_t)(n & 7);
-    f32x16* accj = acc + j * MTW;
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
-        const int gi = wm * MTW + i;
+        if (ex && i > 0) continue;
+        const int gi = ex ? p.MW * MTW : wm * MTW + i;
+        const f32x16& at = acc[ex ? MTW * NTW : j * MTW + i];
 #pragma unroll
         for (int qh = 0; qh < 2; ++qh) {
             const int r0 = 8 * qh;
             if (staged) {
-                float m0 = fmaxf(fmaxf(accj[i][r0], accj[i][r0 + 1]), fmaxf(accj[i][r0 + 2], accj[i][r0 + 3]));
-                float m1 = fmaxf(fmaxf(accj[i][r0 + 4], accj[i][r0 + 5]), fmaxf(accj[i][r0 + 6], accj[i][r0 + 7]));
+                float m0 = fmaxf(fmaxf(at[r0], at[r0 + 1]), fmaxf(at[r0 + 2], at[r0 + 3]));
+                float m1 = fmaxf(fmaxf(at[r0 + 4], at[r0 + 5]), fmaxf(at[r0 + 6], at[r0 + 7]));
                 if (p.pool_t == 2) m0 = fmaxf(m0, m1);
                 m0 += bias; m1 += bias;
                 if (p.relu) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
                     const int jsel = (p.pool_t == 2) ? (ab & 7) : (4 * st + (ab & 3));
                     float v = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v = (j == jsel) ? accj[i][r0 + j] : v;
+                    for (int j = 0; j < 8; ++j) v = (j == jsel) ? at[r0 + j] : v;
                     v = (ab & 0x80) ? 0.f : v + bias;
                     if (feat) {
                         dstf[idx] = v;
@@ -521,11 +537,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p,
             float mv[2]; int av[2];
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                float mx = accj[i][r0 + 4 * st];
+                float mx = at[r0 + 4 * st];
                 int am = 0;
 #pragma unroll
                 for (int j = 1; j < 4; ++j) {
-                    const float v = accj[i][r0 + 4 * st + j];
+                    const float v = at[r0 + 4 * st + j];
                     if (v > mx) { mx = v; am = j; }
                 }
                 mv[st] = mx; av[st] = am;
@@ -747,15 +763,15 @@ extern "C" int vd_conv0_persistent(const VdConvParams* pp, void* stream) {
     return -2;
 }
 
-template <int PREC, int MTW, bool SO = false, int NTW = 1>
+template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0>
 static int launch(const VdConvParams& p, hipStream_t st) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     const int groups = (p.nclips + p.ncl - 1) / p.ncl;
     const int64_t total = (int64_t)groups * p.nbox;
     if (total <= 0) return 0;
-    const size_t lds = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + p.MW * MTW * 4) * sizeof(int) + 16;
+    const size_t lds = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + (p.MW * MTW + BAL) * 4) * sizeof(int) + 16;
     if (lds > 160 * 1024) return -3;
-    auto kern = conv_mfma_kernel<PREC, MTW, SO, NTW>;
+    auto kern = conv_mfma_kernel<PREC, MTW, SO, NTW, BAL>;
     if (p.NT % NTW != 0) return -2;
     const int ncols = p.NT / NTW;
     static bool attr_set = false;
@@ -773,7 +789,7 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     // resident workgroups per CU: LDS and the register budget of this instantiation (MTW 4: 3 waves
     // per SIMD, otherwise 2; x3 variants of MTW 4 use more registers -> 2)
     int occ = (int)((160 * 1024) / lds);
-    const int waves_per_simd = (MTW * NTW <= 4 && !X3) ? 3 : 2;
+    const int waves_per_simd = (MTW * NTW + BAL <= 4 && !X3) ? 3 : 2;
     const int wg_waves = ncols * p.MW;
     const int by_regs = (waves_per_simd * 4) / wg_waves;
     if (occ > by_regs) occ = by_regs;
@@ -798,6 +814,13 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     if (p.ncl * 65536 <= 0 || p.S <= 0 || p.CC <= 0) return -2;
     if (p.MTW * ntw < 8 && (p.gather_stride >> 6) > (int64_t)wgw * (p.MTW * ntw <= 4 ? 14 : 17)) return -2;   // patch larger than the DMA register budget
     if (p.clip_index != nullptr && (p.ncl != 1 || p.CC != 1 || p.MTW * ntw > 4)) return -2;
+    if (ntw == 2 && p.MTW == 3) {   // balanced 7-tile layout (2 x 2 waves), single-pass formats
+        if (p.MW != 2 || p.NT != 4 || p.select || p.src_split_cc > 0 || p.atomic || p.w_box_stride != 0) return -2;
+        if ((p.gather_stride >> 6) > (int64_t)4 * 17) return -2;
+        if (p.prec == VD_PREC_F16) return launch<VD_PREC_F16, 3, false, 2, 1>(p, st);
+        if (p.prec == VD_PREC_BF16) return launch<VD_PREC_BF16, 3, false, 2, 1>(p, st);
+        return -2;
+    }
     if (ntw == 2) {     // two N tiles per wave: forward / dgrad programs with 4 M tiles per wave (x1 and x3 operand formats)
         if ((p.MTW != 4 && p.MTW != 2) || p.select || p.src_split_cc > 0 || p.atomic || p.w_box_stride != 0) return -2;
         switch (p.prec) {

@@ -111,7 +111,8 @@ class EmbedEngine:
         self.ntw = int(os.environ.get("VD_NTW", "2"))
         if ntw0 is None:
             ntw0 = int(os.environ.get("VD_NTW0", "1" if (hip.is_x3(self.prec) or self.ntw != 2) else "2"))
-        net = P.plan_network(geo, ntw=self.ntw, ntw0=ntw0)
+        bal = (self.ntw == 2 and not hip.is_x3(self.prec) and os.environ.get("VD_BALANCED", "1") == "1")
+        net = P.plan_network(geo, ntw=self.ntw, ntw0=ntw0, balanced=bal)
         self.dims = net["dims"]
         self.fwd = [_DevPlan(pl, self.device, self.prec) for pl in net["fwd"]]
         # operand precision of the input-gradient passes (default: same as the forward)

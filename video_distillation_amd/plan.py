@@ -19,6 +19,7 @@ p(1,3,3) -> ReLU -> MaxPool3d) but nothing below is copied from it.
 from __future__ import annotations
 
 import itertools
+import dataclasses
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -767,11 +768,11 @@ class NetGeometry:
 _PLAN_CACHE: Dict[Tuple, Dict[str, object]] = {}
 
 
-def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: int = 1) -> Dict[str, object]:
+def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: int = 1, balanced: bool = False) -> Dict[str, object]:
     """All tile programs of one ConvNet3D geometry: forward L0..L2 and the input-gradient
     passes (one per parity class per layer).  ``ntw`` / ``ntw0`` = N tiles per wave of the layer-1/2
     and of the first-layer forward programs."""
-    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw, ntw0)
+    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw, ntw0, balanced)
     if key in _PLAN_CACHE:
         return _PLAN_CACHE[key]
     dims = geo.layer_dims()
@@ -787,6 +788,10 @@ def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: i
                                   ntw=2)
             if pl2.rows_total <= pl.rows_total:
                 pl = pl2
+            elif balanced and (pl.NT, pl.MW, pl.MTW) == (4, 1, 7) and all(t.mt == 7 for t in pl.types):
+                # 7-tile boxes: same tables, but executed by 2 x 2 waves of 3 M tiles x 2 N tiles + one N tile of the
+                # seventh M tile each (kernel template BAL): 7 MFMAs per K step for 4 A reads instead of 7
+                pl = dataclasses.replace(pl, MW=2, MTW=3, NTW=2, meta=dict(pl.meta, balanced=1))
         fwd.append(pl)
     bwd = []
     for li in range(3):
