@@ -227,7 +227,9 @@ def main():
             clips = [n for (name, n, a, b) in prof if name == "fwd1"]
             flop_per_launch = 2.0 * macs[1] * float(np.mean(clips))
             achieved = flop_per_launch / float(np.mean(times)) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<f16,MTW=7> (conv layer 1 fwd, real clips)",
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<%s, 3, false, 2, 1> = PREC %s, balanced 7-tile layout (conv layer 1 fwd, real clips)" % (
+                                   {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}[args.prec_real], args.prec_real)
+                               if not args.prec_real.endswith("x3") else "conv_mfma_kernel<%s, 7> (conv layer 1 fwd, real clips)" % args.prec_real,
                                "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
                                "traffic": pmc_traffic(float(np.mean(clips))), "launches": len(times), "mean_launch_ms": float(np.mean(times)) * 1e3,
                                "flop_per_launch": flop_per_launch}
