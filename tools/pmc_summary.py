@@ -9,24 +9,24 @@ fetch_csv, write_csv, clips, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), s
 
 
 def per_kernel(path, counter):
-    acc = defaultdict(list)
-    for row in csv.DictReader(open(path)):
+    """(kernel name, grid) -> values, plus the keys in order of first dispatch."""
+    acc, order = defaultdict(list), []
+    for row in sorted(csv.DictReader(open(path)), key=lambda r: int(r["Dispatch_Id"])):
         if row["Counter_Name"] != counter:
             continue
-        acc[(row["Kernel_Name"], int(row["Grid_Size"]))].append(float(row["Counter_Value"]))
-    return acc
+        key = (row["Kernel_Name"], int(row["Grid_Size"]))
+        if key not in acc:
+            order.append(key)
+        acc[key].append(float(row["Counter_Value"]))
+    return acc, order
 
 
-f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
-names = {"pix2rows": "pix2rows_f16"}
+(f, order), (w, _) = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
 res = {}
-conv = sorted([k for k in f if k[0].startswith("void conv_mfma_kernel")], key=lambda k: -k[1])
-# the three forward launches of run_l1.py, largest grid first: layer 0, layer 1, layer 2
-labels = ["conv0_fwd_f16", "conv1_fwd_f16", "conv2_fwd_f16"]
-for key in f:
-    if key[0].startswith("pix2rows_kernel"):
-        conv.insert(0, key); labels.insert(0, "pix2rows_f16")
-for key, label in zip(conv, labels):
+# run_l1.py launches, in dispatch order: pix2rows, then the forward programs of layers 0, 1, 2
+keys = [k for k in order if k[0].startswith("pix2rows_kernel")][:1] + [k for k in order if k[0].startswith("void conv_mfma_kernel")][:3]
+labels = ["pix2rows_f16", "conv0_fwd_f16", "conv1_fwd_f16", "conv2_fwd_f16"]
+for key, label in zip(keys, labels):
     fv = sum(f[key]) / len(f[key])
     wv = sum(w[key]) / len(w[key]) if key in w else 0.0
     res[label] = {"kernel": key[0].split("(")[0], "grid": key[1], "clips_per_launch": clips, "FETCH_SIZE_KB": fv, "WRITE_SIZE_KB": wv,

@@ -14,7 +14,7 @@ prof() {  # name, then the program and its arguments
   cp $(ls $OUT/$name/*/*kernel_stats.csv | head -1) $OUT/${name}_kernel_stats.csv
 }
 prof bench python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline
-tail -1 $OUT/bench.log > $OUT/bench_1gpu_under_rocprof.json
+grep '"metric"' $OUT/bench.log | tail -1 > $OUT/bench_1gpu_under_rocprof.json
 VD_SKIP_TORCH=1 prof train_step python3 $ROOT/tools/bench_train.py 50
 prof dc python3 $ROOT/bench.py --method dc --classes 8 --ipc 5 --steps 2 --warmup 1
 prof mtt python3 $ROOT/bench.py --method mtt --classes 400 --frames 8 --size 64 --pool-per-class 1 --steps 2 --warmup 1
