@@ -72,12 +72,19 @@ __device__ __forceinline__ void split16(float v, uint16_t& hi, uint16_t& lo) {
 
 // SO = second-order variant: split sources + select epilogue (gradient matching / MTT); a separate
 // instantiation so that the extra parameters cost the hot forward / dgrad programs no scalar registers.
+// minimum waves per SIMD the register allocation must allow: the short first-layer programs (<= 4 accumulator
+// tiles, single-pass formats) hide their per-box latencies with more resident workgroups
+#ifndef VD_OCC_SMALL
+#define VD_OCC_SMALL 2
+#endif
+#define VD_OCC(PREC, MTW, NTW, BAL) \
+    ((((MTW) * (NTW) + (BAL)) <= 4 && ((PREC) == VD_PREC_BF16 || (PREC) == VD_PREC_F16)) ? VD_OCC_SMALL : 2)
 // NTW = N tiles (of 32 output channels) per wave: with 2, an A fragment read from LDS feeds two MFMAs,
 // which halves the LDS read traffic per MFMA (the co-critical resource of the NTW = 1 layout).
 // BAL = 1 (with NTW = 2, MTW = 3): boxes of 7 M tiles on 2 x 2 waves -- every wave owns 3 M tiles x 2 N
 // tiles plus ONE N tile of the seventh M tile: 7 MFMAs per K step for 4 A-fragment reads (instead of 7).
 template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const VdConvParams p, const int boxes_per_wg, const int total_boxes) {
+__global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_kernel(const VdConvParams p, const int boxes_per_wg, const int total_boxes) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     constexpr bool EXT = SO || MTW == 5;
     constexpr int TILES = MTW * NTW + BAL;              // accumulator tiles per wave
@@ -789,7 +796,7 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     // resident workgroups per CU: LDS and the register budget of this instantiation (MTW 4: 3 waves
     // per SIMD, otherwise 2; x3 variants of MTW 4 use more registers -> 2)
     int occ = (int)((160 * 1024) / lds);
-    const int waves_per_simd = (MTW * NTW + BAL <= 4 && !X3) ? 3 : 2;
+    const int waves_per_simd = VD_OCC(PREC, MTW, NTW, BAL);
     const int wg_waves = ncols * p.MW;
     const int by_regs = (waves_per_simd * 4) / wg_waves;
     if (occ > by_regs) occ = by_regs;

@@ -777,7 +777,8 @@ def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: i
         return _PLAN_CACHE[key]
     dims = geo.layer_dims()
     assert geo.channel == 3 and geo.pools_t[0] == 1, "first layer planner assumes RGB clips and (1,2,2) pooling"
-    fwd = [plan_forward_pix("fwd0", dims[0][1], dims[0][2], dims[0][3], dims[0][4], lds_budget, ntw=ntw0)]
+    fwd = [plan_forward_pix("fwd0", dims[0][1], dims[0][2], dims[0][3], dims[0][4],
+                            int(os.environ.get("VD_L0_BUDGET", lds_budget)), ntw=ntw0)]
     for li in (1, 2):
         cin, cout, t, h, w = dims[li][:5]
         pl = plan_forward_cl("fwd%d" % li, cin, cout, t, h, w, dims[li][11], feat_out=(li == 2), lds_budget=lds_budget)
