@@ -226,3 +226,45 @@ def test_inference_forward_uses_hip_head(golden_dir):
             np.testing.assert_allclose(got.cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-3, atol=2e-4)
     finally:
         networks.set_precision(real="f16", syn="f16x3")
+
+
+def test_g11_evaluate_synset_multi_static_on_hip(golden_dir):
+    """evaluate_synset(mode='multi-static') on the device: MultiStaticSharedDataset composes every item with the
+    HIP hallucinator, every batch takes the HIP train step; the reference's per-epoch losses (fixture G11)."""
+    import random
+    from video_distillation_amd import utils
+    z = np.load(os.path.join(golden_dir, "g11_multi_static_eval.npz"))
+    C, n_test = int(z["C"]), int(z["n_test"])
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    static = torch.randn(C * 2, 3, 64, 64, generator=g)
+    dynamic = torch.randn(C, 2, 8, 1, 64, 64, generator=g)
+    test_x = torch.randn(n_test, 8, 3, 64, 64, generator=g)
+    hals = []
+    for k in range(2):
+        h = utils.Conv3DNet(img_size=64)
+        h.load_state_dict({"encoder.weight": torch.tensor(z["hal_w"][k]), "encoder.bias": torch.tensor(z["hal_b"][k])})
+        hals.append(h.cuda())
+    net = make_net(int(z["net_seed"]), num_classes=C)
+    net.dropout.p = 0.0
+    args = types.SimpleNamespace(device="cuda", lr_net=float(z["lr_net"]), epoch_eval_train=int(z["epochs"]),
+                                 batch_train=256, model="ConvNet3D", eval_mode="SS")
+    testloader = torch.utils.data.DataLoader(utils.TensorDataset(test_x, torch.arange(n_test) % C), batch_size=4)
+    losses, orig_epoch = [], utils.epoch
+
+    def spy(mode, *a):
+        out = orig_epoch(mode, *a)
+        if mode == 'train':
+            losses.append(out[0])
+        return out
+    utils.epoch = spy
+    torch.manual_seed(int(z["rng_seed"])); random.seed(int(z["rng_seed"]))
+    try:
+        net_out, acc_train, acc_test, _ = utils.evaluate_synset(0, net, (static.cuda(), dynamic.cuda(), hals), None, testloader,
+                                                                args, mode='multi-static')
+    finally:
+        utils.epoch = orig_epoch
+    print("multi-static train losses", losses, "golden", z["train_loss"])
+    np.testing.assert_allclose(losses, z["train_loss"], rtol=1e-3)
+    assert abs(acc_train - float(z["acc_train"])) < 1e-6
+    l1 = np.array([float(p.double().abs().sum()) for p in net_out.parameters()])
+    np.testing.assert_allclose(l1, z["params_after_l1"], rtol=1e-4)

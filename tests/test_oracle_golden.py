@@ -258,3 +258,46 @@ def test_g10_mtt_step(golden_dir):
     np.testing.assert_allclose([float(gx[b].double().abs().sum()) for b in range(gx.shape[0])], z["grad_l1"], rtol=2e-3)
     want = torch.tensor(z["grad_img"])
     assert float((gx[:, ::2, :, ::2, ::2] - want).norm() / want.norm()) < 2e-3
+
+
+def test_g11_evaluate_synset_multi_static(golden_dir):
+    """evaluate_synset(mode='multi-static') of the reference (fixture G11): per-item random choice of static
+    image / dynamic memory / hallucinator (python `random`), loader shuffle from torch's global RNG."""
+    import random
+    z = load(golden_dir, "g11_multi_static_eval.npz")
+    C, n_test, epochs, lr = int(z["C"]), int(z["n_test"]), int(z["epochs"]), float(z["lr_net"])
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    static = torch.randn(C * 2, 3, 64, 64, generator=g)
+    dynamic = torch.randn(C, 2, 8, 1, 64, 64, generator=g)
+    hal_w, hal_b = torch.tensor(z["hal_w"]), torch.tensor(z["hal_b"])
+
+    class Items(torch.utils.data.Dataset):      # utils.py:462-496 restated for spc/C == 2
+        def __len__(self):
+            return C
+
+        def __getitem__(self, index):
+            s_idx = random.randint(0, 1) + index * 2
+            d_idx = random.randint(0, 1)
+            h = random.randint(0, 1)
+            return R.hallucinator(static[s_idx][None], dynamic[index, d_idx][None], hal_w[h], hal_b[h])[0], index
+    params = [p.requires_grad_(True) for p in R.init_params(int(z["net_seed"]), 3, C)]
+    torch.manual_seed(int(z["rng_seed"])); random.seed(int(z["rng_seed"]))
+    loader = torch.utils.data.DataLoader(Items(), batch_size=256, shuffle=True)
+    bufs, losses, accs = [None] * 8, [], []
+    for ep in range(epochs + 1):
+        for img, lab in loader:
+            logits = R.convnet3d_logits(R.standardise_batch(img.float()), params)
+            loss = F.cross_entropy(logits, lab)
+            grads = torch.autograd.grad(loss, params)
+            with torch.no_grad():
+                for i, (p, gr) in enumerate(zip(params, grads)):
+                    gr = gr + 0.0005 * p
+                    bufs[i] = gr.clone() if bufs[i] is None else bufs[i] * 0.9 + gr
+                    p -= lr * bufs[i]
+            losses.append(float(loss)); accs.append(float((logits.argmax(1) == lab).float().mean()))
+        if ep == epochs // 2 + 1:
+            lr *= 0.1
+            bufs = [None] * 8
+    np.testing.assert_allclose(losses, z["train_loss"], rtol=2e-4)
+    np.testing.assert_allclose(accs, z["train_acc"], atol=1e-6)
+    np.testing.assert_allclose([float(p.double().abs().sum()) for p in params], z["params_after_l1"], rtol=1e-5)

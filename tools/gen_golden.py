@@ -353,6 +353,50 @@ def g10(networks, utils):
         target_l1=float(target_params.double().abs().sum()))
 
 
+def g11(networks, utils):
+    # evaluate_synset(mode='multi-static') (utils.py:848-886 with MultiStaticSharedDataset :462-496 and two
+    # Conv3DNet hallucinators :1178-1197): python `random` picks (static, dynamic, hallucinator) per item,
+    # torch's global RNG shuffles the loader; dropout disabled.
+    C, n_test = 3, 6
+    args = _Args()
+    args.device = 'cpu'; args.lr_net = 0.01; args.epoch_eval_train = 2; args.batch_train = 256
+    args.model = 'ConvNet3D'; args.eval_mode = 'SS'
+    g = torch.Generator().manual_seed(1101)
+    static = torch.randn(C * 2, 3, 64, 64, generator=g)
+    dynamic = torch.randn(C, 2, 8, 1, 64, 64, generator=g)
+    test_x = torch.randn(n_test, 8, 3, 64, 64, generator=g)
+    test_y = torch.arange(n_test) % C
+    hals = []
+    for k in range(2):
+        torch.manual_seed(1110 + k)
+        hals.append(utils.Conv3DNet(img_size=64))
+    testloader = torch.utils.data.DataLoader(utils.TensorDataset(test_x, test_y), batch_size=4, shuffle=False)
+    net = make_net(networks, 111, C, 64, 8)
+    net.dropout.p = 0.0
+    torch.manual_seed(1121); random.seed(1121); np.random.seed(1121)
+    rec = []
+    orig_epoch = utils.epoch
+
+    def spy(mode, loader, net_, opt, crit, a):
+        out = orig_epoch(mode, loader, net_, opt, crit, a)
+        rec.append((mode, out[0], out[1]))
+        return out
+    utils.epoch = spy
+    try:
+        with torch.no_grad():
+            pass
+        net_out, acc_train, acc_test, acc_per = utils.evaluate_synset(0, net, (static, dynamic, hals), None, testloader, args,
+                                                                      mode='multi-static')
+    finally:
+        utils.epoch = orig_epoch
+    train = [(l, a) for m, l, a in rec if m == 'train']
+    npz("g11_multi_static_eval.npz", net_seed=111, data_seed=1101, hal_seeds=np.array([1110, 1111]), rng_seed=1121, C=C,
+        n_test=n_test, lr_net=0.01, epochs=2, train_loss=np.array([t[0] for t in train]),
+        train_acc=np.array([t[1] for t in train]), acc_train=acc_train, acc_test=acc_test,
+        hal_w=torch.stack([h.encoder.weight.detach() for h in hals]), hal_b=torch.stack([h.encoder.bias.detach() for h in hals]),
+        params_after_l1=np.array([float(p.double().abs().sum()) for p in net_out.parameters()]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -360,7 +404,8 @@ def main():
     only = set(sys.argv[1:])
     for name, fn in (("g1", lambda: g1(networks)), ("g2", lambda: g2_g3(networks)), ("g4", lambda: g4_g5(networks, utils)),
                      ("g6", lambda: g6(networks, utils)), ("g7", lambda: g7(networks, utils)),
-                     ("g9", lambda: g9(networks, utils)), ("g10", lambda: g10(networks, utils))):
+                     ("g9", lambda: g9(networks, utils)), ("g10", lambda: g10(networks, utils)),
+                     ("g11", lambda: g11(networks, utils))):
         if not only or name in only:
             fn()
 
