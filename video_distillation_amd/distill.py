@@ -103,8 +103,9 @@ class HipBackend:
         # across iterations: the backward of step i runs under the real forward of step i+1.
         self.two_streams = (self.eng_syn is not self.eng_real)
         if self.two_streams:
-            self.s_real = torch.cuda.Stream(device=self.device)
-            self.s_syn = torch.cuda.Stream(device=self.device, priority=-1)
+            pr, ps = (int(v) for v in os.environ.get("VD_STREAM_PRIO", "0,-1").split(","))
+            self.s_real = torch.cuda.Stream(device=self.device, priority=pr)
+            self.s_syn = torch.cuda.Stream(device=self.device, priority=ps)
         self._ev_real = None
         self.resident_rows = os.environ.get("VD_RESIDENT_ROWS", "1") == "1"
         self._pool_rows = None
