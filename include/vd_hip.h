@@ -202,6 +202,26 @@ int vd_head_second_order(const float* logits, const float* dlogits, const int32_
 int vd_sgd_momentum_wd(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, float wd, int first,
                        void* stream);
 
+/* ---- Serialised tile programs: the torch-free, Python-free way to run a layer ------------------------------
+ * A program blob is written offline by the planner (engine.export_program(plan) / tools/export_programs.py) for
+ * one layer geometry; it replaces what nn.Conv3d/nn.ReLU/nn.MaxPool3d's constructors hold in the reference
+ * (networks.py:792-814) plus the launch geometry.  The handle owns only the program's small device tables and the
+ * packed-weight buffer; sources, weights, bias, outputs and arg-max are caller-owned device memory.
+ *  vd_program_load         : parse + upload (prec = VD_PREC_*); returns 0 and *out, or <0 / a hipError_t;
+ *  vd_program_pack_weights : fp32 Conv3d weight (device) -> this program's MFMA B fragments;
+ *  vd_program_run          : launch for nclips clips (src_plane_slots / dst_plane_stride as in VdConvParams;
+ *                            clip_index optional, first-layer programs only);
+ *  vd_program_info         : 0 boxes per clip group, 1 packed weight elements per plane, 2 planes,
+ *                            3 output clip stride, 4 output channels;
+ *  vd_program_free         : release the handle. */
+typedef struct VdProgram VdProgram;
+int vd_program_load(const void* blob, int64_t nbytes, int prec, VdProgram** out);
+int vd_program_pack_weights(VdProgram* prog, const float* w, void* stream);
+int vd_program_run(VdProgram* prog, const void* src, int64_t src_plane_slots, const float* bias, void* dst,
+                   int64_t dst_plane_stride, uint8_t* argmax, const int64_t* clip_index, int nclips, void* stream);
+int64_t vd_program_info(const VdProgram* prog, int what);
+void vd_program_free(VdProgram* prog);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,44 @@
+"""The hot path driven WITHOUT Python or torch in the loop: examples/embed_forward.cpp is compiled against
+include/vd_hip.h + libvd_hip.so, loads the serialised tile programs (vd_program_load) and runs
+ConvNet3D.embed through the C ABI; its output must equal the engine's (same kernels) and match the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("prec,x3,tol", [("f16", False, 2e-3), ("f16x3", True, 3e-5)])
+def test_c_driver_runs_embed_through_the_c_abi(tmp_path, prec, x3, tol):
+    from video_distillation_amd import engine, hip, plan
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import export_programs
+    T, H, W, B = 8, 64, 64, 5
+    d = str(tmp_path)
+    export_programs.export(d, T, H, W, x3=x3)
+    params = R.init_params(21)[:6]
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(B, T, 3, H, W, generator=g)
+    np.concatenate([p.numpy().reshape(-1) for p in params]).astype(np.float32).tofile(os.path.join(d, "weights.bin"))
+    x.numpy().astype(np.float32).tofile(os.path.join(d, "clips.bin"))
+    exe = os.path.join(d, "embed_forward")
+    libdir = os.path.dirname(hip.LIB_PATH)
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-o", exe, os.path.join(ROOT, "examples", "embed_forward.cpp"),
+                    "-L" + libdir, "-lvd_hip", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([exe, d, str(B), str(T), str(H), str(W), str(hip.PREC[prec])], check=True, capture_output=True, text=True)
+    print(out.stdout.strip())
+    feats = torch.from_numpy(np.fromfile(os.path.join(d, "feats.bin"), dtype=np.float32).reshape(B, -1))
+    want = R.convnet3d_embed(x, params)
+    rel = float((feats - want).norm() / want.norm())
+    print("C driver vs oracle rel-l2 %.2e (%s)" % (rel, prec))
+    assert feats.shape == want.shape and rel < tol
+    eng = engine.EmbedEngine(plan.NetGeometry(T, H, W), prec=prec, chunk=B)
+    eng.set_weights([p.cuda() for p in params])
+    assert torch.equal(eng.forward(x.cuda()).cpu(), feats)        # same programs, same kernels: bitwise

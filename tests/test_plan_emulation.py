@@ -147,3 +147,22 @@ def test_odd_geometry_floor_pooling_and_multi_type_boxes():
         for pl in net['bwd'][li]: E.run_plan(pl,to_cl(dy.numpy()),params[2*li].numpy().ravel(),None,1,out)
         got = out.reshape(1,t_,cin,h,w).transpose(0,2,1,3,4) if li==0 else out.reshape(1,t_,h,w,cin).transpose(0,4,1,2,3)
         np.testing.assert_allclose(got,want.numpy(),rtol=1e-9,atol=1e-9)
+
+
+def test_exported_program_blob_layout():
+    """plan.export_program: 40 int64 header words + the int32 arrays whose lengths the header lists
+    (what vd_program_load in csrc/program.hip parses)."""
+    from video_distillation_amd import plan as P
+    net = P.plan_network(P.NetGeometry(8, 64, 64), ntw=2, ntw0=2, balanced=True)
+    for pl in net["fwd"] + [net["bwd"][1][0]]:
+        blob = P.export_program(pl)
+        h = np.frombuffer(blob[:P.PROGRAM_HEADER_WORDS * 8], dtype=np.int64)
+        assert blob[:8] == P.PROGRAM_MAGIC
+        assert (h[1], h[2], h[3], h[4], h[5], h[6]) == (pl.CC, pl.S, pl.NT, pl.MW, pl.MTW, pl.NTW)
+        n_int = int(h[28:34].sum())
+        assert len(blob) == P.PROGRAM_HEADER_WORDS * 8 + 4 * n_int
+        ints = np.frombuffer(blob[P.PROGRAM_HEADER_WORDS * 8:], dtype=np.int32)
+        o = int(h[28] + h[29] + h[30])
+        np.testing.assert_array_equal(ints[o:o + int(h[31])], pl.gather_table().reshape(-1))
+        np.testing.assert_array_equal(ints[o + int(h[31]):o + int(h[31]) + int(h[32])], pl.widx.reshape(-1))
+        assert h[22] == pl.ncl and h[23] == pl.nbox and h[24] == pl.gather_table().shape[1]

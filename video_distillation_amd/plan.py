@@ -159,6 +159,31 @@ class ConvPlan:
 
 # ----------------------------------------------------------------------------------------
 # bank-conflict model for the A-fragment reads
+PROGRAM_MAGIC = b"VDPROG01"
+PROGRAM_HEADER_WORDS = 40
+
+
+def export_program(plan: "ConvPlan", persist: int = 4) -> bytes:
+    """Serialise a tile program for ``vd_program_load`` (include/vd_hip.h): 40 int64 header words
+    followed by the int32 arrays type_desc | tables | boxes | gather | widx | col_off."""
+    desc, tables = plan.flat_tables()
+    boxes = plan.device_boxes().reshape(-1)
+    gt = plan.gather_table()
+    widx = plan.widx.reshape(-1).astype(np.int32)
+    col = np.zeros(0, dtype=np.int32) if plan.col_off is None else plan.col_off.astype(np.int32).reshape(-1)
+    mt_max = max(t.mt for t in plan.types)
+    h = np.zeros(PROGRAM_HEADER_WORDS, dtype=np.int64)
+    h[0] = np.frombuffer(PROGRAM_MAGIC, dtype=np.int64)[0]
+    h[1:28] = [plan.CC, plan.S, plan.NT, plan.MW, plan.MTW, plan.NTW, plan.epi, plan.pool_t, int(plan.relu), plan.n_out,
+               plan.n_stride, plan.out_clip_stride, plan.out_chunk_stride, plan.out_t_stride, int(gt.shape[1]) * 16,
+               len(plan.types), int(desc[0][7]), int(desc[0][8]), int(desc[0][9]), int(plan.atomic), plan.w_box_stride,
+               plan.ncl, plan.nbox, int(gt.shape[1]), plan.clip_stride4, plan.chunk_stride4,
+               mt_max if (plan.NTW == 2 and mt_max < plan.MW * plan.MTW) else 0]
+    h[28:35] = [desc.size, tables.size, boxes.size, gt.size, widx.size, col.size, persist]
+    arrays = [desc.reshape(-1), tables, boxes, gt.reshape(-1), widx, col]
+    return h.tobytes() + b"".join(np.ascontiguousarray(a, dtype=np.int32).tobytes() for a in arrays)
+
+
 # ----------------------------------------------------------------------------------------
 def _conflict_cycles(slots_per_row: np.ndarray) -> float:
     """Average LDS cycles per ds_read_b128 wave-instruction (4 = conflict-free) for one MFMA
