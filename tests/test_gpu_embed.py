@@ -260,3 +260,30 @@ def test_resident_pool_rows_equal_per_step_conversion():
         c = eng.forward(pool[idx])
         torch.cuda.synchronize()
         assert torch.equal(a, b) and torch.equal(a, c), (prec, ntw0)
+
+
+@pytest.mark.parametrize("geom", [(8, 112, 112), (16, 64, 64), (16, 128, 128), (4, 64, 96), (8, 80, 112)])
+def test_other_geometries_forward_and_input_gradient(geom):
+    """The planner picks wave layouts per geometry (two N tiles per wave where boxes fill 8 M tiles, the balanced
+    7-tile layout, multi-type box plans at odd extents): forward in both operand classes and the input gradient
+    against the oracle on clip sizes other than the two the configs use."""
+    T, H, W = geom
+    params = R.init_params(31)
+    g = torch.Generator().manual_seed(T * H + W)
+    x = torch.randn(3, T, 3, H, W, generator=g)
+    want = R.convnet3d_embed(x, params)
+    gf = torch.randn(want.shape, generator=g)
+    for prec in ("f16", "f16x3"):
+        eng = _engine(geom, prec)
+        eng.set_weights([p.cuda() for p in params])
+        got = eng.forward(x.cuda())
+        rel = _rel(got, want)[0]
+        lay = [(pl.plan.NTW, pl.plan.MW, pl.plan.MTW) for pl in eng.fwd]
+        print(geom, prec, "layouts (NTW,MW,MTW)", lay, "fwd rel-l2 %.2e" % rel)
+        assert got.shape == want.shape and rel < TOL[prec]
+    f, sv = eng.forward(x.cuda(), keep=True)
+    dx = eng.backward(sv, gf.cuda())
+    torch.cuda.synchronize()
+    per = [_rel(dx[i], _grad_fp64(x[i:i + 1], gf[i:i + 1], params)[0])[0] for i in range(3)]
+    print("   input gradient per-clip rel-l2 vs fp64:", ["%.1e" % v for v in per])
+    assert sum(v < 1e-4 for v in per) >= 2 and max(per) < 3e-2       # arg-max flips confined to single clips
