@@ -42,7 +42,7 @@ def bcthw_to_cl(a):
 def test_plans_cover_and_fit(net):
     for pl in net["fwd"] + [p for l in net["bwd"] for p in l]:
         assert pl.lds_slots * 16 * 2 + 4096 <= 160 * 1024, pl.name  # hi+lo planes must fit LDS
-        assert pl.MTW in (4, 7, 8) and pl.threads in (64, 128, 256)
+        assert pl.MTW in (2, 3, 4, 7, 8) and pl.threads in (64, 128, 256)
         for t in pl.types:
             assert t.a_off.min() >= 0 and (t.a_off.max() + t.tap_off.max()) // 16 < pl.ncl * t.pitch_c + 1
             assert t.a_off.size == pl.MW * pl.MTW * 32

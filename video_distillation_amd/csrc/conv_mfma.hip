@@ -842,6 +842,7 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     if (p.MTW != 5 && (p.atomic || p.w_box_stride != 0 || p.select || p.src_split_cc > 0)) {
         // second-order programs (and accumulating dgrad launches): bf16 pairs only (train.GradMatchEngine)
         if (p.prec != VD_PREC_BF16X3) return -2;
+        if (p.MTW == 2) return launch<VD_PREC_BF16X3, 2, true>(p, st);
         if (p.MTW == 4) return launch<VD_PREC_BF16X3, 4, true>(p, st);
         if (p.MTW == 7) return launch<VD_PREC_BF16X3, 7, true>(p, st);
         if (p.MTW == 8) return launch<VD_PREC_BF16X3, 8, true>(p, st);
@@ -849,6 +850,7 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     }
 #define VD_DISPATCH(PR)                                                   \
     case PR:                                                              \
+        if (p.MTW == 2) return launch<PR, 2>(p, st);                      \
         if (p.MTW == 4) return launch<PR, 4>(p, st);                      \
         if (p.MTW == 5) return launch<PR, 5>(p, st);                      \
         if (p.MTW == 7) return launch<PR, 7>(p, st);                      \

@@ -333,13 +333,16 @@ def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps
             rows_max = (MW * MTW * 32) // ncl
             if rows_max < group[0] * group[1] * group[2]:
                 continue
+            # programs with <= 4 accumulator tiles per wave run the box-walking instantiation, whose DMA register
+            # budget is 14 groups of 64 slots per wave
+            budget = lds_budget if MTW > 4 else min(lds_budget, (NT * MW * 14 * 64 * 100) // 112 - 64)
 
             def slot_fn(na, nb, nc, ncl=ncl):
                 e = ext(na, nb, nc)
                 return int(ncl * e[0] * e[1] * e[2] * 1.06) + 16
 
             try:
-                box = force_box or _choose_box(row_dims, group, rows_max, slot_fn, lds_budget)
+                box = force_box or _choose_box(row_dims, group, rows_max, slot_fn, budget)
             except ValueError:
                 continue
             nbox = -(-row_dims[0] // box[0]) * -(-row_dims[1] // box[1]) * -(-row_dims[2] // box[2])
@@ -405,7 +408,7 @@ def _lane_cols():
 
 
 def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, pool_t: int,
-                    feat_out: bool, lds_budget: int = 3700, mtw_options=(7, 8), ntw: int = 1) -> ConvPlan:
+                    feat_out: bool, lds_budget: int = 3700, mtw_options=(7, 8, 4, 2), ntw: int = 1) -> ConvPlan:
     """Forward Conv3d(cin->cout) + ReLU + MaxPool(pool_t,2,2) over a channels-last chunked
     source [clip][cin/8][t][h][w] (slots of 8 channels).  ``ntw`` = N tiles per wave: with 2 the
     workgroup is 2 wave columns x 2 wave rows of 4 M tiles x 2 N tiles, and every A fragment read
@@ -532,7 +535,7 @@ def dgrad_classes(h: int, w: int):
 
 
 def plan_dgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, ph: int, pw: int,
-               pixel_out: bool, lds_budget: int = 3700, mtw_options=(7, 8)) -> ConvPlan:
+               pixel_out: bool, lds_budget: int = 3700, mtw_options=(7, 8, 4, 2)) -> ConvPlan:
     """Input gradient of Conv3d(cin->cout, k(3,7,7), s(1,2,2), p(1,3,3)) for the input positions
     (t, 2b+ph, 2c+pw).  Source: dense dy on the conv grid, channels-last chunks of cout.
     dx[t,h,w,ci] = sum_{kt,kh,kw,n} dy[t+1-kt, (h+3-kh)/2, (w+3-kw)/2, n] * W[n,ci,kt,kh,kw]."""
