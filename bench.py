@@ -57,6 +57,9 @@ def parse():
                     help="dm = distill_baseline.py DM (headline); s2d = DM + static/dynamic memories (config 3); "
                          "dc = gradient matching with match_loss (config 4: use --classes 51 --ipc 5); "
                          "mtt = trajectory matching (config 5: use --classes 400 --frames 8 --size 64)")
+    ap.add_argument("--eval-epochs", type=int, default=0,
+                    help="after the timed steps, run evaluate_synset on the synthetic clips for this many epochs (HIP train "
+                         "step + HIP inference, SURVEY 8(d): eval top-1 beside the metric) and report it under 'eval'")
     ap.add_argument("--dis-metric", default="ours", choices=["ours", "mse", "cos"], help="match_loss metric of --method dc")
     return ap.parse_args()
 
@@ -238,6 +241,8 @@ def main():
                 cc = [n for (name, n, a, b) in prof if name == lname]
                 if tt:
                     out["roofline"][lname + "_tflops"] = 2.0 * macs[li] * float(np.mean(cc)) / float(np.mean(tt)) / 1e12
+        if args.eval_epochs > 0 and args.method == "dm":
+            out["eval"] = run_eval(args, trainer, pool, device)
         if world == 1 and not args.no_cpu_baseline and args.method == "dm":
             out["cpu_baseline"] = cpu_baseline(args, trainer, backend, args.warmup + args.steps, geo)
         print(json.dumps(out))
@@ -245,6 +250,31 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_eval(args, trainer, pool, device):
+    """evaluate_synset (utils.py:848-886) on the current synthetic clips: a fresh ConvNet3D trained for
+    --eval-epochs epochs with the HIP train step, tested (3 passes, HIP inference) on 4 held-out pool clips per
+    class.  The pool is synthetic noise, so the accuracy is chance level by construction; the timing is the point."""
+    import types
+    from video_distillation_amd import utils
+    C = args.classes
+    syn = trainer.gather_syn().detach().clone()
+    labels = torch.arange(C, device=device).repeat_interleave(args.ipc)
+    idx = torch.as_tensor([pool.offsets[c] + pool.counts[c] - 1 - k for c in range(C) for k in range(4)], device=device)
+    test = utils.TensorDataset(pool.clips[idx], torch.arange(C, device=device).repeat_interleave(4))
+    loader = torch.utils.data.DataLoader(test, batch_size=64, shuffle=False)
+    eargs = types.SimpleNamespace(device=device, lr_net=0.01, epoch_eval_train=args.eval_epochs, batch_train=256,
+                                  model="ConvNet3D", eval_mode="SS")
+    net = utils.get_network("ConvNet3D", 3, C, (args.size, args.size), frames=args.frames, dist=False).to(device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, acc_train, acc_test, _ = utils.evaluate_synset(0, net, syn, labels, loader, eargs, mode="none")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"epochs": args.eval_epochs + 1, "seconds": dt, "ms_per_epoch": dt / (args.eval_epochs + 1) * 1e3,
+            "acc_train": float(acc_train), "acc_test": float(acc_test), "test_clips": int(idx.numel()),
+            "note": "synthetic noise pool: test accuracy is chance by construction"}
 
 
 def bench_dc(args, distill, geo, pool, device, rank, world):
