@@ -460,6 +460,7 @@ class HipGMOps:
         from . import hip
         self.hip, self.device = hip, torch.device(device)
         self.args = types.SimpleNamespace(device=self.device, dis_metric=dis_metric)
+        self._side = None
 
     def make_net(self, params: Sequence[torch.Tensor], geo: P.NetGeometry, num_classes: int):
         from . import networks
@@ -473,6 +474,23 @@ class HipGMOps:
 
     def param_grads(self, net, x, labels, create_graph: bool):
         return net.param_grads(x, labels, create_graph=create_graph)[1]
+
+    def param_grads_async(self, net, x, labels):
+        """First-order parameter gradients of a REAL batch on a side stream: the real batch of the next class
+        is independent of the synthetic-clip passes of the current one, and neither fills the GPU alone
+        (64-clip launches / 5-clip launches), so the trainer overlaps them.  Returns (gradients, event)."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            g = [t.detach() for t in net.param_grads(x, labels, create_graph=False)[1]]
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        for t in g + [x, labels]:
+            t.record_stream(self._side)
+            t.record_stream(main)
+        return g, ev
 
     def match_loss(self, gw_syn, gw_real):
         from . import utils
@@ -545,11 +563,23 @@ class GMTrainer:
             idx = sample_real_indices(it * self.outer_loop + ol, self.pool.counts, self.pool.offsets, self.batch_real, self.classes)
             idx_t = torch.as_tensor(idx, device=dev).reshape(len(self.classes), -1)
             g_img = torch.zeros_like(self.image_syn)
-            for k, c in enumerate(self.classes):
+            overlap = hasattr(ops, "param_grads_async") and os.environ.get("VD_GM_OVERLAP", "1") == "1"
+
+            def real_side(k):
+                c = self.classes[k]
                 real = self.pool.clips[idx_t[k]]
                 lab_r = torch.full((real.shape[0],), c, dtype=torch.int64, device=dev)
+                if overlap:
+                    return ops.param_grads_async(net, real, lab_r)
+                return [t.detach() for t in ops.param_grads(net, real, lab_r, False)], None
+            pending = real_side(0) if self.classes else None
+            for k, c in enumerate(self.classes):
+                gw_real, ready = pending
+                if k + 1 < len(self.classes):
+                    pending = real_side(k + 1)          # runs under this class's synthetic-clip passes
+                if ready is not None:
+                    torch.cuda.current_stream(dev).wait_event(ready)
                 lab_s = torch.full((self.ipc,), c, dtype=torch.int64, device=dev)
-                gw_real = [t.detach() for t in ops.param_grads(net, real, lab_r, False)]
                 syn = self.image_syn[k * self.ipc:(k + 1) * self.ipc].detach().clone().requires_grad_(True)
                 gw_syn = ops.param_grads(net, syn, lab_s, True)
                 loss = ops.match_loss(gw_syn, gw_real)
