@@ -294,6 +294,7 @@ def epoch(mode, dataloader, net, optimizer, criterion, args):
     criterion = criterion.to(args.device)
     net.train() if mode == 'train' else net.eval()
     correct_per_class = defaultdict(list)
+    stat_loss, stat_match, stat_lab, stat_topk = [], [], [], {3: [], 5: []}
     passes = 1 if mode == 'train' else 3
     for _ in range(passes):
         for datum in dataloader:
@@ -309,28 +310,31 @@ def epoch(mode, dataloader, net, optimizer, criterion, args):
             else:
                 output = net(img)
                 loss = criterion(output, lab)
-            out_np, lab_np = output.detach().cpu().numpy(), lab.cpu().numpy()
-            matched = np.equal(np.argmax(out_np, axis=-1), lab_np)
-            order = np.argsort(out_np, axis=-1)
-            for k, name in ((1, 'top1'), (3, 'top3'), (5, 'top5')):
-                hit = np.sum([lab_np[i] in order[i, -k:] for i in range(n_b)])
-                if name == 'top1' and mode != 'train':
-                    top1_acc_avg += hit
-                elif name == 'top3' and mode != 'train':
-                    top3_acc_avg += hit
-                elif name == 'top5':
-                    top5_acc_avg += hit
-            for y, c in zip(lab_np.tolist(), matched.tolist()):
-                correct_per_class[y].append(c)
-            loss_avg += loss.item() * n_b
-            acc_avg += np.sum(matched)
+            # statistics stay on the device; one host transfer per epoch instead of one per batch
+            with torch.no_grad():
+                out_d = output.detach()
+                order = torch.argsort(out_d, dim=-1)
+                matched = out_d.argmax(dim=-1) == lab          # np.argmax semantics: first maximum
+                stat_loss.append(loss.detach().reshape(1) * n_b)
+                stat_match.append(matched)
+                stat_lab.append(lab)
+                for k in (3, 5):
+                    stat_topk[k].append((order[:, -k:] == lab[:, None]).any(dim=1).sum().reshape(1))
             num_exp += n_b
             if mode == 'train' and not hip_step:
                 optimizer.zero_grad()
                 loss.backward()
                 optimizer.step()
-    loss_avg /= num_exp
-    acc_avg /= num_exp
+    matched = torch.cat(stat_match).cpu().numpy()
+    labs = torch.cat(stat_lab).cpu().numpy()
+    loss_avg = float(torch.cat(stat_loss).sum().cpu()) / num_exp
+    acc_avg = float(np.sum(matched)) / num_exp
+    top5_acc_avg = float(torch.cat(stat_topk[5]).sum().cpu())
+    if mode != 'train':
+        top1_acc_avg = float(np.sum(matched))
+        top3_acc_avg = float(torch.cat(stat_topk[3]).sum().cpu())
+    for y, c in zip(labs.tolist(), matched.tolist()):
+        correct_per_class[y].append(c)
     top_acc_avg = [acc_avg, top1_acc_avg / num_exp, top3_acc_avg / num_exp, top5_acc_avg / num_exp]
     per_class = dict(correct_per_class)
     per_class = [np.mean(per_class[i]) if i in per_class else None for i in range(len(per_class))]
