@@ -334,7 +334,7 @@ def bench_mtt(args, distill, geo, pool, device, rank, world):
     traj = [distill.fresh_full_network(5, C, device)]
     for e in range(11):
         traj.append([p + 0.01 * p.abs().mean() * torch.randn(p.shape, device=device, generator=gen) for p in traj[-1]])
-    ops = distill.HipMTTOps(geo, C, device, dropout_p=0.5)
+    ops = distill.HipMTTOps(geo, C, device, dropout_p=0.5, batch_hint=min(args.batch_syn, C * args.ipc) // max(world, 1))
     tr = distill.MTTTrainer(ops, C, image_syn, label_syn, syn_lr=0.01, lr_img=1.0, lr_lr=1e-6, syn_steps=args.syn_steps,
                             batch_syn=min(args.batch_syn, C * args.ipc), expert_epochs=1, max_start_epoch=10, rank=rank, world=world)
 

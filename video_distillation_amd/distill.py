@@ -629,11 +629,13 @@ def unflatten_params(flat: torch.Tensor, num_classes: int) -> List[torch.Tensor]
 class HipMTTOps:
     """Device operations of the unrolled student loop on the HIP path (train.GradMatchEngine)."""
 
-    def __init__(self, geo: P.NetGeometry, num_classes: int, device, dropout_p: float = 0.5):
+    def __init__(self, geo: P.NetGeometry, num_classes: int, device, dropout_p: float = 0.5,
+                 batch_hint: Optional[int] = None):
         from . import hip, networks, train
         self.hip, self.device = hip, torch.device(device)
         pool = (2, 2, 2) if geo.height > 64 else (2, 1, 1)          # networks.py:733
-        self.te = train.GradMatchEngine(geo, num_classes, pool, device, prec=networks.get_precision()["match"])
+        self.te = train.GradMatchEngine(geo, num_classes, pool, device, prec=networks.get_precision()["match"],
+                                        batch_hint=batch_hint)
         self.dropout_p = float(dropout_p)
 
     def grads(self, params, x, labels):

@@ -96,7 +96,7 @@ class _DevPlan:
 
 class EmbedEngine:
     def __init__(self, geo: P.NetGeometry, prec: str = "bf16x3", device="cuda:0", chunk: int = 256,
-                 prec_bwd: Optional[str] = None, ntw0: Optional[int] = None):
+                 prec_bwd: Optional[str] = None, ntw0: Optional[int] = None, batch_hint: Optional[int] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("EmbedEngine needs a HIP device (no CPU fallback)")
         hip.lib()
@@ -112,7 +112,8 @@ class EmbedEngine:
         if ntw0 is None:
             ntw0 = int(os.environ.get("VD_NTW0", "1" if (hip.is_x3(self.prec) or self.ntw != 2) else "2"))
         bal = (self.ntw == 2 and not hip.is_x3(self.prec) and os.environ.get("VD_BALANCED", "1") == "1")
-        net = P.plan_network(geo, ntw=self.ntw, ntw0=ntw0, balanced=bal)
+        self.batch_hint = batch_hint      # typical clips per launch: small batches get latency-oriented programs
+        net = P.plan_network(geo, ntw=self.ntw, ntw0=ntw0, balanced=bal, batch_hint=batch_hint)
         self.dims = net["dims"]
         self.fwd = [_DevPlan(pl, self.device, self.prec) for pl in net["fwd"]]
         # operand precision of the input-gradient passes (default: same as the forward)

@@ -50,6 +50,18 @@ def set_precision(real: str = None, syn: str = None, bwd: str = None, train: str
             _PRECISION[k] = v
 
 
+def _batch_hint(b: int):
+    """Clips-per-launch bucket an engine's programs are planned for (plan.latency_variant): the next power of two
+    up to 512, None (throughput-oriented programs) beyond."""
+    b = int(b)
+    if b > 512:
+        return None
+    h = 1
+    while h < b:
+        h *= 2
+    return h
+
+
 def get_precision() -> Dict[str, str]:
     return dict(_PRECISION)
 
@@ -258,24 +270,26 @@ class ConvNet3D(nn.Module):
 
     def _train_engine(self, x):
         from . import train
-        key = ("train", x.shape[1], x.shape[3], x.shape[4], self.logit.weight.shape[0], _PRECISION["train"], _PRECISION["train_bwd"],
+        hint = _batch_hint(x.shape[0])
+        key = ("train", x.shape[1], x.shape[3], x.shape[4], self.logit.weight.shape[0], hint, _PRECISION["train"], _PRECISION["train_bwd"],
                x.device.index if x.device.index is not None else torch.cuda.current_device())
         te = _ENGINES.get(key)
         if te is None:
             te = train.TrainEngine(P.NetGeometry(x.shape[1], x.shape[3], x.shape[4]), self.logit.weight.shape[0],
                                    self.avg_pool.kernel_size, x.device, prec=_PRECISION["train"],
-                                   prec_bwd=_PRECISION["train_bwd"])
+                                   prec_bwd=_PRECISION["train_bwd"], batch_hint=hint)
             _ENGINES[key] = te
         return te
 
     def _gm_engine(self, x):
         from . import train
-        key = ("gm", x.shape[1], x.shape[3], x.shape[4], self.logit.weight.shape[0], _PRECISION["match"],
+        hint = _batch_hint(x.shape[0])
+        key = ("gm", x.shape[1], x.shape[3], x.shape[4], self.logit.weight.shape[0], hint, _PRECISION["match"],
                x.device.index if x.device.index is not None else torch.cuda.current_device())
         te = _ENGINES.get(key)
         if te is None:
             te = train.GradMatchEngine(P.NetGeometry(x.shape[1], x.shape[3], x.shape[4]), self.logit.weight.shape[0],
-                                       self.avg_pool.kernel_size, x.device, prec=_PRECISION["match"])
+                                       self.avg_pool.kernel_size, x.device, prec=_PRECISION["match"], batch_hint=hint)
             _ENGINES[key] = te
         return te
 

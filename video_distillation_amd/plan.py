@@ -796,11 +796,26 @@ class NetGeometry:
 _PLAN_CACHE: Dict[Tuple, Dict[str, object]] = {}
 
 
-def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: int = 1, balanced: bool = False) -> Dict[str, object]:
+SMALL_TILES_FIRST = (2, 4, 7, 8)
+
+
+def latency_variant(pl: ConvPlan, batch_hint: Optional[int], make) -> ConvPlan:
+    """For a launch of ``batch_hint`` clips that would start fewer workgroups than the chip has slots (2 per CU), the
+    time is one workgroup's latency -- K steps x MFMAs per step: prefer the decomposition with the smallest M tile
+    count per wave (same padded work, more and shorter workgroups).  ``make(mtw_options)`` rebuilds the program."""
+    if not batch_hint or pl.grid(batch_hint) >= 512:
+        return pl
+    alt = make(SMALL_TILES_FIRST)
+    return alt if alt.grid(batch_hint) > pl.grid(batch_hint) and alt.rows_total <= pl.rows_total else pl
+
+
+def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: int = 1, balanced: bool = False,
+                 batch_hint: Optional[int] = None) -> Dict[str, object]:
     """All tile programs of one ConvNet3D geometry: forward L0..L2 and the input-gradient
     passes (one per parity class per layer).  ``ntw`` / ``ntw0`` = N tiles per wave of the layer-1/2
-    and of the first-layer forward programs."""
-    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw, ntw0, balanced)
+    and of the first-layer forward programs; ``batch_hint`` = clips per launch the programs will typically see
+    (small batches get latency-oriented decompositions, see ``latency_variant``)."""
+    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw, ntw0, balanced, batch_hint)
     if key in _PLAN_CACHE:
         return _PLAN_CACHE[key]
     dims = geo.layer_dims()
@@ -821,6 +836,8 @@ def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: i
                 # 7-tile boxes: same tables, but executed by 2 x 2 waves of 3 M tiles x 2 N tiles + one N tile of the
                 # seventh M tile each (kernel template BAL): 7 MFMAs per K step for 4 A reads instead of 7
                 pl = dataclasses.replace(pl, MW=2, MTW=3, NTW=2, meta=dict(pl.meta, balanced=1))
+        pl = latency_variant(pl, batch_hint, lambda opts, li=li, cin=cin, cout=cout, t=t, h=h, w=w: plan_forward_cl(
+            "fwd%d" % li, cin, cout, t, h, w, dims[li][11], feat_out=(li == 2), lds_budget=lds_budget, mtw_options=opts))
         fwd.append(pl)
     bwd = []
     for li in range(3):
@@ -828,8 +845,13 @@ def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: i
         if li == 0 and h % 2 == 0 and w % 2 == 0:
             bwd.append([plan_dgrad_pix("bwd0_merged", cin, cout, t, h, w, lds_budget=lds_budget)])
             continue
-        bwd.append([plan_dgrad("bwd%d_%d%d" % (li, ph, pw), cin, cout, t, h, w, ph, pw, pixel_out=(li == 0),
-                               lds_budget=lds_budget) for ph, pw in dgrad_classes(h, w)])
+        layer = []
+        for ph, pw in dgrad_classes(h, w):
+            def make(opts, li=li, cin=cin, cout=cout, t=t, h=h, w=w, ph=ph, pw=pw):
+                return plan_dgrad("bwd%d_%d%d" % (li, ph, pw), cin, cout, t, h, w, ph, pw, pixel_out=(li == 0),
+                                  lds_budget=lds_budget, mtw_options=opts)
+            layer.append(latency_variant(make((7, 8, 4, 2)), batch_hint, make))
+        bwd.append(layer)
     out = {"geo": geo, "dims": dims, "fwd": fwd, "bwd": bwd}
     _PLAN_CACHE[key] = out
     return out

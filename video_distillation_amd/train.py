@@ -37,12 +37,13 @@ def standardize(x: torch.Tensor) -> torch.Tensor:
 
 class TrainEngine:
     def __init__(self, geo: P.NetGeometry, num_classes: int, pool_kernel: Tuple[int, int, int], device,
-                 prec: str = "f16x3", prec_bwd: str = "f16x3"):
+                 prec: str = "f16x3", prec_bwd: str = "f16x3", batch_hint: Optional[int] = None):
         self.geo = geo
         self.device = torch.device(device)
         self.K = int(num_classes)
         self.pool_kernel = tuple(int(k) for k in pool_kernel)
-        self.eng = EmbedEngine(geo, prec=prec, device=device, chunk=1 << 30, prec_bwd=prec_bwd)
+        self.batch_hint = batch_hint
+        self.eng = EmbedEngine(geo, prec=prec, device=device, chunk=1 << 30, prec_bwd=prec_bwd, batch_hint=batch_hint)
         if self.eng.planes_bwd > self.eng.planes or (prec[:2] != prec_bwd[:2]):
             raise ValueError("backward operands are read from the forward's activations: %s / %s do not combine"
                              % (prec, prec_bwd))
@@ -190,15 +191,18 @@ class GradMatchEngine(TrainEngine):
     ``select`` epilogue; the second convT of the downward sweep accumulates with fp32 atomics.
     Operands are bf16 hi+lo pairs (bf16x3): adjoints span many orders of magnitude."""
 
-    def __init__(self, geo: P.NetGeometry, num_classes: int, pool_kernel, device, prec: str = "bf16x3"):
+    def __init__(self, geo: P.NetGeometry, num_classes: int, pool_kernel, device, prec: str = "bf16x3",
+                 batch_hint: Optional[int] = None):
         if prec != "bf16x3":
             raise ValueError("GradMatchEngine: bf16x3 operands only (adjoints span fp32's exponent range and are not scaled)")
-        super().__init__(geo, num_classes, pool_kernel, device, prec=prec, prec_bwd=prec)
+        super().__init__(geo, num_classes, pool_kernel, device, prec=prec, prec_bwd=prec, batch_hint=batch_hint)
         eng = self.eng
         self.sel = [_DevPlan(eng.fwd[0].plan, self.device, eng.prec)]
         for li in (1, 2):
             cin, cout, t, h, w = eng.dims[li][:5]
             pl = P.plan_forward_cl("sel%d" % li, 2 * cin, cout, t, h, w, eng.dims[li][11], feat_out=(li == 2))
+            pl = P.latency_variant(pl, batch_hint, lambda opts, li=li, cin=cin, cout=cout, t=t, h=h, w=w: P.plan_forward_cl(
+                "sel%d" % li, 2 * cin, cout, t, h, w, eng.dims[li][11], feat_out=(li == 2), mtw_options=opts))
             dp = _DevPlan(pl, self.device, eng.prec)
             dp.params.src_split_cc = cin // 8
             dp.params.src_clip_stride4 = pl.clip_stride4 // 2      # each of the two source tensors holds cin channels per clip
@@ -207,7 +211,7 @@ class GradMatchEngine(TrainEngine):
             dp.params.select = 1
         # the pooling decisions come from an f16x3 forward (operand error ~4e-7, like fp32's own rounding;
         # bf16 pairs are exact to ~1e-5 only and flip near-tied windows far more often than the reference)
-        self.eng_fwd = EmbedEngine(geo, prec="f16x3", device=device, chunk=1 << 30)
+        self.eng_fwd = EmbedEngine(geo, prec="f16x3", device=device, chunk=1 << 30, batch_hint=batch_hint)
         self.bwdV = [[_DevPlan(dp.plan, self.device, eng.prec_bwd) for dp in layer] for layer in eng.bwd]
         for layer in self.bwdV:
             for dp in layer:
