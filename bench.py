@@ -141,9 +141,11 @@ def main():
 
     from video_distillation_amd import distill, plan
     geo = plan.NetGeometry(args.frames, args.size, args.size)
-    backend = distill.HipBackend(geo, device, prec_real=args.prec_real, prec_syn=args.prec_syn, chunk=args.chunk,
-                                 prec_bwd=args.prec_bwd)
     c_lo, c_hi = distill.class_range(args.classes, rank, world)
+    from video_distillation_amd.networks import _batch_hint
+    backend = distill.HipBackend(geo, device, prec_real=args.prec_real, prec_syn=args.prec_syn, chunk=args.chunk,
+                                 prec_bwd=args.prec_bwd,
+                                 syn_batch_hint=_batch_hint((c_hi - c_lo) * args.ipc) if os.environ.get("VD_SYN_HINT", "1") == "1" else None)
     shard = args.shard
     if shard == "auto":
         shard = "batch" if (world > 1 and args.batch_real % world == 0 and args.method == "dm") else "class"

@@ -287,3 +287,24 @@ def test_other_geometries_forward_and_input_gradient(geom):
     per = [_rel(dx[i], _grad_fp64(x[i:i + 1], gf[i:i + 1], params)[0])[0] for i in range(3)]
     print("   input gradient per-clip rel-l2 vs fp64:", ["%.1e" % v for v in per])
     assert sum(v < 1e-4 for v in per) >= 2 and max(per) < 3e-2       # arg-max flips confined to single clips
+
+
+def test_latency_oriented_programs_equal_throughput_programs():
+    """batch_hint only changes the decomposition into workgroups (plan.latency_variant): forward features and
+    the input gradient must be bitwise those of the default programs (same K order per output)."""
+    from video_distillation_amd import distill, engine, plan
+    for geom in ((16, 112, 112), (8, 64, 64)):
+        geo = plan.NetGeometry(*geom)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        x = torch.randn(5, geom[0], 3, geom[1], geom[2], device="cuda", generator=g)
+        gf = torch.randn(5, geo.num_feat, device="cuda", generator=g)
+        w = distill.fresh_network_weights(3, "cuda:0")
+        outs = []
+        for hint in (None, 8):
+            eng = engine.EmbedEngine(geo, prec="f16x3", chunk=8, prec_bwd="f16", batch_hint=hint)
+            eng.set_weights(w)
+            f, sv = eng.forward(x, keep=True)
+            outs.append((f, eng.backward(sv, gf), [(p.plan.MTW, p.plan.ncl) for p in eng.fwd] + [(p.plan.MTW, p.plan.ncl) for l in eng.bwd for p in l]))
+        torch.cuda.synchronize()
+        assert outs[0][2] != outs[1][2], "the hint did not change any program"
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -88,14 +88,14 @@ class HipBackend:
     """Production backend: EmbedEngine (MFMA kernels) + the small HIP kernels."""
 
     def __init__(self, geo: P.NetGeometry, device, prec_real: str = "f16", prec_syn: str = "f16x3", chunk: int = 512,
-                 prec_bwd: Optional[str] = "f16"):
+                 prec_bwd: Optional[str] = "f16", syn_batch_hint: Optional[int] = None):
         from . import engine, hip
         self.hip = hip
         self.device = torch.device(device)
         self.geo = geo
         self.eng_real = engine.EmbedEngine(geo, prec=prec_real, device=device, chunk=chunk)
         self.eng_syn = self.eng_real if (prec_syn == prec_real and not prec_bwd) else \
-            engine.EmbedEngine(geo, prec=prec_syn, device=device, chunk=chunk, prec_bwd=prec_bwd)
+            engine.EmbedEngine(geo, prec=prec_syn, device=device, chunk=chunk, prec_bwd=prec_bwd, batch_hint=syn_batch_hint)
         self.num_feat = geo.num_feat
         # Two HIP streams: the real-clip forward (98.5 % of the FLOPs, large launches) runs on one,
         # the synthetic-clip forward + backward + optimiser (small launches that cannot fill 256
