@@ -313,7 +313,7 @@ def _build_type(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, out_fn
 
 def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps, widx_fn,
                n_out, NT, MW, mtw_options, epi, pool_t, relu, out_index, out_valid, n_stride,
-               out_clip_stride, out_chunk_stride, out_shape, lds_budget, ncl_options=(1,), force_box=None):
+               out_clip_stride, out_chunk_stride, out_shape, lds_budget, ncl_options=(1,), force_box=None, ntw=1):
     """Generic planner.  Row (a,b,c) has its tap-(0,0,0) origin at source slot coords
     (row_stride[0]*a+row_origin[0], ...).  ``taps`` is a list of non-negative (df,dh,dw)."""
     F, H, W = src_grid
@@ -335,7 +335,10 @@ def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps
                 continue
             # programs with <= 4 accumulator tiles per wave run the box-walking instantiation, whose DMA register
             # budget is 14 groups of 64 slots per wave
-            budget = lds_budget if MTW > 4 else min(lds_budget, (NT * MW * 14 * 64 * 100) // 112 - 64)
+            # (waves x 14 x 64 slots; the planned patch incl. pitch padding must stay below it)
+            waves = (NT // ntw) * MW
+            dma_cap = waves * (14 if MTW * ntw <= 4 else 17) * 64
+            budget = min(lds_budget, dma_cap - 64)
 
             def slot_fn(na, nb, nc, ncl=ncl):
                 e = ext(na, nb, nc)
@@ -354,6 +357,7 @@ def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps
     _, MTW, ncl, box = best
     na, nb, nc = box
     mt_pad = MW * MTW
+    dma_cap_final = (NT // ntw) * MW * (14 if MTW * ntw <= 4 else 17) * 64
 
     def row_lin(a, b, c):
         return (sa * a, sb * b, sc * c)
@@ -378,7 +382,7 @@ def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps
                         return out_index(ci, a, b, c)  # relative to the box's out_rel
 
                     bt = _build_type(box, group, row_lin, taps_p, ext(na, nb, nc), mt_pad, pooled,
-                                     out_fn, valid_fn, ncl, slot_cap=int(lds_budget * 1.12))
+                                     out_fn, valid_fn, ncl, slot_cap=min(int(lds_budget * 1.12), dma_cap_final))
                     type_key[key] = len(types)
                     types.append(bt)
                 boxes.append([type_key[key], f0, h0, w0, out_index(0, a0, b0, c0) - out_index(0, 0, 0, 0), 0])
@@ -465,7 +469,7 @@ def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: 
     ncl_options = sorted({1, max_ncl} | {n for n in (2, 4, 8) if n <= max_ncl})
     plan = _make_plan(name, (t_in, h_in, w_in), CC, rows, (2, 2, 2), (-1, -3, -3), (1, 2, 2), taps,
                       widx_fn, cout, NT, MW, mtw_options, epi, pool_t, True, out_index, None, n_stride,
-                      clip_stride, chunk_stride, out_shape, lds_budget, ncl_options)
+                      clip_stride, chunk_stride, out_shape, lds_budget, ncl_options, ntw=ntw)
     plan.NTW = ntw
     return plan
 
@@ -520,7 +524,7 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
         return ci * clip_stride + (a * Ho + b // 2) * Wo + c // 2
     plan = _make_plan(name, (t_in * cin, h_in, OW), 1, rows, (2, 2, 2), (-cin, -3, 0), (cin, 2, 1), taps,
                       widx_fn, cout, NT, MW, mtw_options, EPI_POOL_CL, 1, True, out_index, None, 0,
-                      clip_stride, chunk_stride, (cout // 8, T, Ho, Wo, 8), lds_budget, (1,))
+                      clip_stride, chunk_stride, (cout // 8, T, Ho, Wo, 8), lds_budget, (1,), ntw=ntw)
     plan.out_t_stride = Ho * Wo
     plan.NTW = ntw
     rowp = pix_row_pitch(w_in)
