@@ -84,6 +84,9 @@ int vd_conv_mfma(const VdConvParams* params, void* stream);
  * one box type, NT=2 MW=2 MTW=4 S=32, pooled channels-last output, no arg-max): a persistent
  * kernel, one workgroup per CU, B fragments resident in registers, next patch DMA'd into a second
  * LDS buffer under the current box's MFMAs.  Same results as vd_conv_mfma. */
+/* First-layer forward (x1 formats, 2x2-wave layout, no arg-max) with the layer's B fragments resident in registers
+ * across the workgroup's box walk; same results as vd_conv_mfma on the same program, bitwise. */
+int vd_conv0_breg(const VdConvParams* p, void* stream);
 int vd_conv0_persistent(const VdConvParams* params, void* stream);
 
 /* fp32 weights -> MFMA-fragment-ordered 16-bit operands (hi plane, and lo plane for the x3

@@ -731,6 +731,186 @@ __global__ __launch_bounds__(256, 1) void conv0_persistent_kernel(const VdConvPa
     }
 }
 
+// First-layer kernel with register-resident weights (single-pass formats, 2 x 2 waves, 4 M tiles per wave, one
+// box type, 32 K steps): the layer's B fragments -- 64 KB in all, identical for every box -- are loaded into 128
+// VGPRs once per workgroup and reused for every box it walks.  The generic program re-fetches them per box with
+// 8 vector loads per K step and workgroup, which saturates the CU's texture-address unit (PMC: 63 % busy over the
+// whole kernel); here a box costs 14 gather loads + 14 LDS-DMAs + 2 slot stores per wave and nothing inside the K
+// loop.  Single patch buffer, two workgroups per CU; pooled outputs staged through LDS exactly like the generic
+// kernel (bitwise the same results).
+template <int PREC>
+__global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p, const int boxes_per_wg) {
+    constexpr int MTW = 4, S = 32, LU = 14, NCH = 64, Q = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int half = lane >> 5;
+    const int32_t* a_tab = p.tables + p.tab_ofs[0];
+    const int32_t* o_tab = p.tables + p.tab_ofs[1];
+    const int32_t* t_tab = p.tables + p.tab_ofs[2];
+    const int plane_bytes = p.lds_plane_bytes;
+    const int ngroups = (int)(p.gather_stride >> 6);
+    const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);
+    int* lds_tap = reinterpret_cast<int*>(smem + plane_bytes);
+    int* lds_otab = lds_tap + 2 * S;
+    for (int k = tid; k < 2 * S; k += 256) lds_tap[k] = t_tab[k];
+    for (int k = tid; k < 32; k += 256) lds_otab[k] = o_tab[k];
+    int a_off[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
+    uint4 breg[S];
+    {
+        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)wn * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) breg[s] = wp[(int64_t)s * 128];
+    }
+    const int n = wn * 32 + (lane & 31);
+    const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
+    const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
+    const int total = p.nclips * p.nbox;            // ncl == 1
+    // XCD-contiguous ranges of boxes, as in the generic kernel
+    int wgid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int b_lo = wgid * boxes_per_wg;
+    const int b_hi = (b_lo + boxes_per_wg < total) ? b_lo + boxes_per_wg : total;
+    uint16_t* stg = reinterpret_cast<uint16_t*>(smem);
+    asm volatile("" ::: "memory");
+    for (int b = b_lo; b < b_hi; ++b) {
+        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
+        // ---- gather entries, then the patch DMA (all entries consumed before the first DMA) ----
+        {
+            const int32_t* gtab = p.gather + (int64_t)bi * p.gather_stride;
+            const uint32_t* csrc = src + (p.clip_index != nullptr ? p.clip_index[clip0] : (int64_t)clip0) * p.src_clip_stride4;
+            uint32_t off[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int gi = wave + u * 4;
+                const int e = gtab[((gi < ngroups) ? gi : ngroups - 1) * 64 + lane];
+                off[u] = (e >= 0) ? (uint32_t)(e & 0xFFFFFF) : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) asm volatile("" : "+v"(off[u]));
+            int gi = wave;
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                asm volatile("" : "+s"(gi));
+                if (gi < ngroups) {
+                    const uint32_t* gp = (off[u] != 0xFFFFFFFFu) ? csrc + off[u] : zslot;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                     (__attribute__((address_space(3))) void*)(smem + gi * 1024), 16, 0, 0);
+                }
+                gi += 4;
+            }
+        }
+        const int out_rel = p.boxes[bi * 8 + 3];
+        __syncthreads();                 // patch landed (vmcnt(0) + barrier); also publishes the LDS tables
+        // ---- K loop: A one step ahead, B from registers ----
+        f32x16 acc[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+        uint4 A[2][MTW];
+        {
+            const int tp0 = lds_tap[half];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) A[0][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp0);
+        }
+        int tp = lds_tap[2 + half];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int tp_next = lds_tap[2 * ((s + 2 < S) ? s + 2 : S - 1) + half];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) A[(s + 1) & 1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) acc[i] = mfma16<PREC>(A[s & 1][i], breg[s], acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            tp = tp_next;
+        }
+        __syncthreads();                 // every wave is done reading the patch: the staging tile aliases it
+        // ---- epilogue: bias + ReLU + (1,2,2) max-pool, staged through LDS, 16-byte slot stores ----
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int gi = wm * MTW + i;
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                const int r0 = 8 * qh;
+                float m0 = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 2], acc[i][r0 + 3]));
+                float m1 = fmaxf(fmaxf(acc[i][r0 + 4], acc[i][r0 + 5]), fmaxf(acc[i][r0 + 6], acc[i][r0 + 7]));
+                m0 = fmaxf(m0 + bias, 0.f); m1 = fmaxf(m1 + bias, 0.f);
+                const int q = (gi * 4 + half + 2 * qh) * 2;
+                uint16_t hi, lo;
+                split16<PREC>(m0, hi, lo);
+                stg[q * NCH + n] = hi;
+                split16<PREC>(m1, hi, lo);
+                stg[(q + 1) * NCH + n] = hi;
+            }
+        }
+        __syncthreads();
+        {
+            const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
+            const int64_t lim64 = out_total - out_base;
+            const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
+            uint4* dslots = reinterpret_cast<uint4*>(p.dst) + out_base;
+            for (int item = tid; item < (Q << 3); item += 256) {
+                const int q = item >> 3, cc = item & 7;
+                const int o = lds_otab[q >> 1];
+                const int base = o + (q & 1) * p.out_t_stride;
+                if (o < 0 || base >= lim) continue;
+                dslots[(uint32_t)base + (uint32_t)cc * (uint32_t)p.out_chunk_stride] = *reinterpret_cast<const uint4*>(stg + q * NCH + cc * 8);
+            }
+        }
+        __syncthreads();                 // the staging tile has been read: the next box's DMA may overwrite it
+    }
+}
+
+template <int PREC>
+static int launch_conv0_breg(const VdConvParams& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.nclips * p.nbox;
+    if (total <= 0) return 0;
+    static int ncu = 0;
+    auto kern = conv0_breg_kernel<PREC>;
+    if (ncu == 0) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || ncu <= 0) return e != hipSuccess ? (int)e : -4;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+    }
+    const size_t lds = (size_t)p.lds_plane_bytes + (2 * 32 + 32) * sizeof(int) + 16;
+    if (lds > 80 * 1024) return -3;
+    const int64_t slots = (int64_t)ncu * 2;
+    const int gens = p.persist > 0 ? p.persist : 4;
+    int per = (int)((total + slots * gens - 1) / (slots * gens));
+    if (per < 1) per = 1;
+    const int64_t grid = (total + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p, per);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vd_conv0_breg(const VdConvParams* pp, void* stream) {
+    if (pp == nullptr) return -1;
+    const VdConvParams& p = *pp;
+    if (p.NT != 2 || p.MW != 2 || p.MTW != 4 || (p.NTW != 0 && p.NTW != 1) || p.S != 32 || p.CC != 1 || p.ncl != 1 ||
+        p.ntypes != 1 || p.epi != VD_EPI_POOL_CL || p.pool_t != 1 || p.argmax != nullptr || !p.relu ||
+        (p.gather_stride >> 6) > 4 * 14 || 8 * 1024 > p.lds_plane_bytes)
+        return -2;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p.prec == VD_PREC_F16) return launch_conv0_breg<VD_PREC_F16>(p, st);
+    if (p.prec == VD_PREC_BF16) return launch_conv0_breg<VD_PREC_BF16>(p, st);
+    return -2;
+}
+
 template <int PREC>
 static int launch_conv0_persistent(const VdConvParams& p, hipStream_t st) {
     const int total = ((p.nclips + p.ncl - 1) / p.ncl) * p.nbox;

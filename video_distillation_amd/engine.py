@@ -67,6 +67,12 @@ class _DevPlan:
                               and (plan.NT, plan.MW, plan.MTW, plan.S) == (2, 2, 4, 32) and len(plan.types) == 1
                               and 2 * p.lds_plane_bytes + 8 * plan.S + 16 <= 160 * 1024)
 
+        # first layer, x1 formats, 2x2-wave layout: kernel with the layer's B fragments resident in registers
+        self.breg_ok = (os.environ.get("VD_L0_BREG", "1") == "1" and not hip.is_x3(prec)
+                        and plan.epi == P.EPI_POOL_CL and plan.pool_t == 1 and plan.CC == 1 and plan.ncl == 1 and plan.NTW == 1
+                        and (plan.NT, plan.MW, plan.MTW, plan.S) == (2, 2, 4, 32) and len(plan.types) == 1
+                        and int(gt.shape[1]) // 64 <= 56 and plan.relu)
+
     def pack(self, w: torch.Tensor) -> None:
         assert w.dtype == torch.float32 and w.is_contiguous()
         lo = self.wpk[1] if self.wpk.shape[0] == 2 else None
@@ -87,6 +93,9 @@ class _DevPlan:
         p.dst = dst_ptr; p.dst_plane_stride = dst_plane_stride
         p.argmax = 0 if argmax is None else argmax.data_ptr()
         p.nclips = nclips
+        if self.breg_ok and argmax is None and not p.dbg:
+            hip.check(hip.lib().vd_conv0_breg(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv0_breg(%s)" % self.plan.name)
+            return
         if self.persistent_ok and argmax is None and not p.dbg:
             hip.check(hip.lib().vd_conv0_persistent(ctypes.byref(p), hip.stream_ptr(src.device)),
                       "vd_conv0_persistent(%s)" % self.plan.name)
@@ -110,7 +119,9 @@ class EmbedEngine:
         # tiles, and the first layer in the single-pass formats (measured: x1 +7 %, x3 -6 % -> x3 keeps one)
         self.ntw = int(os.environ.get("VD_NTW", "2"))
         if ntw0 is None:
-            ntw0 = int(os.environ.get("VD_NTW0", "1" if (hip.is_x3(self.prec) or self.ntw != 2) else "2"))
+            # (x1 formats: the register-resident-B kernel runs the 2x2-wave one-N-tile layout)
+            breg = os.environ.get("VD_L0_BREG", "1") == "1"
+            ntw0 = int(os.environ.get("VD_NTW0", "1" if (hip.is_x3(self.prec) or self.ntw != 2 or breg) else "2"))
         bal = (self.ntw == 2 and not hip.is_x3(self.prec) and os.environ.get("VD_BALANCED", "1") == "1")
         self.batch_hint = batch_hint      # typical clips per launch: small batches get latency-oriented programs
         net = P.plan_network(geo, ntw=self.ntw, ntw0=ntw0, balanced=bal, batch_hint=batch_hint)
