@@ -24,7 +24,7 @@ def per_kernel(path, counter):
 (f, order), (w, _) = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
 res = {}
 # run_l1.py launches, in dispatch order: pix2rows, then the forward programs of layers 0, 1, 2
-keys = [k for k in order if k[0].startswith("pix2rows_kernel")][:1] + [k for k in order if k[0].startswith("void conv_mfma_kernel")][:3]
+keys = [k for k in order if k[0].startswith("pix2rows_kernel")][:1] + [k for k in order if k[0].startswith("void conv")][:3]
 labels = ["pix2rows_f16", "conv0_fwd_f16", "conv1_fwd_f16", "conv2_fwd_f16"]
 for key, label in zip(keys, labels):
     fv = sum(f[key]) / len(f[key])
