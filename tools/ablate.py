@@ -1,5 +1,6 @@
 """In-process ablation of the forward kernels (dbg: 1 = no epilogue, 2 = no K loop, 4 = no patch DMA)."""
 import sys, os
+os.environ.setdefault("VD_LIB_VARIANT", "dbg")   # needs the build with the dbg hooks (hip.build(debug_hooks=True))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from video_distillation_amd import engine, plan

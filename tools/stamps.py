@@ -1,5 +1,6 @@
 """Diagnostic: per-workgroup phase timeline (s_memtime) of a forward layer."""
 import sys, os
+os.environ.setdefault("VD_LIB_VARIANT", "dbg")   # needs the build with the dbg hooks (hip.build(debug_hooks=True))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from video_distillation_amd import engine, plan

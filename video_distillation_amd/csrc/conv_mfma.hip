@@ -74,6 +74,16 @@ __device__ __forceinline__ void split16(float v, uint16_t& hi, uint16_t& lo) {
 // instantiation so that the extra parameters cost the hot forward / dgrad programs no scalar registers.
 // minimum waves per SIMD the register allocation must allow: the short first-layer programs (<= 4 accumulator
 // tiles, single-pass formats) hide their per-box latencies with more resident workgroups
+// Ablation / timing hooks (VdConvParams.dbg) are compiled in only with -DVD_DBG_HOOKS=1 (tools/ablate.py, stamps.py
+// load that build): in the production library the conditions are the constant 0 and cost the hot loops nothing.
+#ifndef VD_DBG_HOOKS
+#define VD_DBG_HOOKS 0
+#endif
+#if VD_DBG_HOOKS
+#define VD_DBG(p) ((p).dbg)
+#else
+#define VD_DBG(p) 0
+#endif
 #ifndef VD_OCC_SMALL
 #define VD_OCC_SMALL 2
 #endif
@@ -123,9 +133,9 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
     // Each workgroup walks `boxes_per_wg` consecutive boxes (launching one workgroup per box is
     // dispatch-rate bound for the first layer: ~100 000 boxes of ~10 us each per launch).
     unsigned long long t_stamp[8];
-    auto stamp = [&](int k) { if (p.dbg & 8) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); t_stamp[k] = t; } };
+    auto stamp = [&](int k) { if (VD_DBG(p) & 8) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); t_stamp[k] = t; } };
     auto finish = [&]() {
-        if ((p.dbg & 8) && tid == 0 && p.stamps != nullptr) {
+        if ((VD_DBG(p) & 8) && tid == 0 && p.stamps != nullptr) {
             stamp(7);
             unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)blockIdx.x * 8;
             for (int k = 0; k < 8; ++k) o[k] = t_stamp[k];
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
         //  second-order instantiations: two scalar registers the hot programs do not pay for)
         const uint4* wp = wbase + (EXT ? (((int64_t)bi * p.w_box_stride) >> 3) : (int64_t)0) + ((int64_t)cc * S * p.NT + wn * NTW) * 64 + lane;
         auto load_b = [&](int s, uint4* bh, uint4* bl) {
-            const int sc = (p.dbg & 16) ? 0 : ((s < S) ? s : S - 1);   // dbg 16: always the same (cached) B fragment
+            const int sc = (VD_DBG(p) & 16) ? 0 : ((s < S) ? s : S - 1);   // dbg 16: always the same (cached) B fragment
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 bh[j] = wp[(int64_t)sc * wstep + j * 64];
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
         // (conv padding, pitch padding, clips beyond the batch) reads a 16-byte zero slot.
         // (all table entries are consumed BEFORE the first DMA is issued: with an LDS-DMA in flight
         //  hipcc waits vmcnt(0) at the next use of an ordinary load, which would serialise the DMAs)
-        if (HOIST && !(p.dbg & 4)) {
+        if (HOIST && !(VD_DBG(p) & 4)) {
             int gi = wave;
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
                 gi += nwaves;
             }
         }
-        if (!HOIST && !(p.dbg & 4)) {
+        if (!HOIST && !(VD_DBG(p) & 4)) {
             constexpr int LB = 8;
             for (int g0 = wave; g0 < ngroups; g0 += nwaves * LB) {
                 uint32_t off[LB];
@@ -314,13 +324,13 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
         __syncthreads();
         if (cc == 0) stamp(3);
         // ---- K loop over tap pairs ---------------------------------------------------------
-        if (p.dbg & 2) continue;
+        if (VD_DBG(p) & 2) continue;
         // B fragments are fetched DB steps ahead (counted vmcnt), A fragments one full step ahead
         // (x1: two register sets) or half a step ahead (x3: registers are short).
         if constexpr (!X3) {
             // tap offsets live in LDS and are read one step before the A reads that need them
             auto tap_of = [&](int st) {
-                const int sc = (p.dbg & 32) ? 0 : ((st < S) ? st : S - 1);   // dbg 32: every step reads the same LDS rows
+                const int sc = (VD_DBG(p) & 32) ? 0 : ((st < S) ? st : S - 1);   // dbg 32: every step reads the same LDS rows
                 return lds_tap[2 * sc + half];
             };
             uint4 A[AD + 1][MA];
@@ -331,7 +341,38 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
                 for (int i = 0; i < MA; ++i) A[d][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
             }
             int tp = tap_of(AD);
-            for (int s = 0; s < S; s += DB + 1) {
+            int s = 0;
+            for (; s + DB < S; s += DB + 1) {   // full groups of DB+1 steps: no bound checks in the hot loop
+#pragma unroll
+                for (int u = 0; u <= DB; ++u) {
+                    load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
+                    const int tp_next = tap_of(s + u + AD + 1);
+#pragma unroll
+                    for (int i = 0; i < MA; ++i) {
+                        if (i > 0 && (VD_DBG(p) & 64)) { A[(u + AD) % (AD + 1)][i] = A[(u + AD) % (AD + 1)][0]; continue; }   // dbg 64: one LDS read per step
+                        if (NTW == 2 && BAL == 0 && i == MTW - 1 && short_row) continue;
+                        A[(u + AD) % (AD + 1)][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
+                    }
+                    VD_SCHED_BARRIER();
+                    VD_PRIO(1);
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) {
+                        if (NTW == 2 && BAL == 0 && i == MTW - 1 && short_row) continue;
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+                            acc[j * MTW + i] = mfma16<PREC>(A[u % (AD + 1)][i], bqh[u][j], acc[j * MTW + i]);
+                    }
+                    if constexpr (BAL) {   // seventh M tile: this wave's single N tile of it (wave row picks which)
+                        uint4 bx = bqh[u][0];
+                        if (wm) bx = bqh[u][1];
+                        acc[MTW * NTW] = mfma16<PREC>(A[u % (AD + 1)][MTW], bx, acc[MTW * NTW]);
+                    }
+                    VD_PRIO(0);
+                    VD_SCHED_BARRIER();
+                    tp = tp_next;
+                }
+            }
+            if (s < S) {                      // remaining 1..DB steps
 #pragma unroll
                 for (int u = 0; u <= DB; ++u) {
                     if (s + u >= S) break;
@@ -339,15 +380,15 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
                     const int tp_next = tap_of(s + u + AD + 1);
 #pragma unroll
                     for (int i = 0; i < MA; ++i) {
-                        if (i > 0 && (p.dbg & 64)) { A[(u + AD) % (AD + 1)][i] = A[(u + AD) % (AD + 1)][0]; continue; }   // dbg 64: one LDS read per step
-                        if (NTW == 2 && i == MTW - 1 && short_row) continue;
+                        if (i > 0 && (VD_DBG(p) & 64)) { A[(u + AD) % (AD + 1)][i] = A[(u + AD) % (AD + 1)][0]; continue; }   // dbg 64: one LDS read per step
+                        if (NTW == 2 && BAL == 0 && i == MTW - 1 && short_row) continue;
                         A[(u + AD) % (AD + 1)][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
                     }
                     VD_SCHED_BARRIER();
                     VD_PRIO(1);
 #pragma unroll
                     for (int i = 0; i < MTW; ++i) {
-                        if (NTW == 2 && i == MTW - 1 && short_row) continue;
+                        if (NTW == 2 && BAL == 0 && i == MTW - 1 && short_row) continue;
 #pragma unroll
                         for (int j = 0; j < NTW; ++j)
                             acc[j * MTW + i] = mfma16<PREC>(A[u % (AD + 1)][i], bqh[u][j], acc[j * MTW + i]);
@@ -403,7 +444,7 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < H1; ++i) {
-                        if (NTW == 2 && i == H1 - 1 && short_row) continue;
+                        if (NTW == 2 && BAL == 0 && i == H1 - 1 && short_row) continue;
 #pragma unroll
                         for (int j = 0; j < NTW; ++j) {
                             acc[j * MTW + H0 + i] = mfma16<PREC>(A1l[i], bh[j], acc[j * MTW + H0 + i]);
@@ -420,7 +461,7 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
 
     // ---- epilogue ---------------------------------------------------------------------
     stamp(4);
-    if (p.dbg & 1) { if (acc[0][0] == 123.456f) reinterpret_cast<float*>(p.dst)[0] = 1.f; continue; }
+    if (VD_DBG(p) & 1) { if (acc[0][0] == 123.456f) reinterpret_cast<float*>(p.dst)[0] = 1.f; continue; }
     const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
     const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
 

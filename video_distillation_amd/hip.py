@@ -44,18 +44,21 @@ class VdConvParams(ctypes.Structure):
     ]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into libvd_hip.so (in-tree)."""
-    if not force and os.path.exists(LIB_PATH):
+def build(force: bool = False, verbose: bool = False, debug_hooks: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into libvd_hip.so (in-tree).  ``debug_hooks`` builds the
+    variant libvd_hip_dbg.so with the ablation / timing hooks of VdConvParams.dbg compiled in
+    (-DVD_DBG_HOOKS=1; used by tools/ablate.py and tools/stamps.py via VD_LIB_VARIANT=dbg)."""
+    out = LIB_PATH.replace(".so", "_dbg.so") if debug_hooks else LIB_PATH
+    if not force and os.path.exists(out):
         newest = max(os.path.getmtime(s) for s in SOURCES + [os.path.join(_HERE, "..", "include", "vd_hip.h")])
-        if os.path.getmtime(LIB_PATH) >= newest:
-            return LIB_PATH
+        if os.path.getmtime(out) >= newest:
+            return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + SOURCES
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + (["-DVD_DBG_HOOKS=1"] if debug_hooks else []) + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return out
 
 
 _lib: Optional[ctypes.CDLL] = None
@@ -64,11 +67,14 @@ _lib: Optional[ctypes.CDLL] = None
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_PATH
+        if os.environ.get("VD_LIB_VARIANT") == "dbg":      # profiling tools: the build with the dbg hooks compiled in
+            path = build(debug_hooks=True)
+        if not os.path.exists(path):
             raise RuntimeError(
                 "libvd_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(there is no CPU or eager fallback for the HIP path)" % LIB_PATH)
-        L = ctypes.CDLL(LIB_PATH)
+                "(there is no CPU or eager fallback for the HIP path)" % path)
+        L = ctypes.CDLL(path)
         for name in EXPORTS:
             if not hasattr(L, name):
                 raise RuntimeError("libvd_hip.so does not export %s" % name)
