@@ -524,7 +524,8 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
         return ci * clip_stride + (a * Ho + b // 2) * Wo + c // 2
     plan = _make_plan(name, (t_in * cin, h_in, OW), 1, rows, (2, 2, 2), (-cin, -3, 0), (cin, 2, 1), taps,
                       widx_fn, cout, NT, MW, mtw_options, EPI_POOL_CL, 1, True, out_index, None, 0,
-                      clip_stride, chunk_stride, (cout // 8, T, Ho, Wo, 8), lds_budget, (1,), ntw=ntw)
+                      clip_stride, chunk_stride, (cout // 8, T, Ho, Wo, 8), lds_budget, (1,), ntw=ntw,
+                      force_box=tuple(int(v) for v in os.environ["VD_L0_BOX"].split(",")) if os.environ.get("VD_L0_BOX") else None)
     plan.out_t_stride = Ho * Wo
     plan.NTW = ntw
     rowp = pix_row_pitch(w_in)
