@@ -232,6 +232,25 @@ _PERMS4 = list(itertools.permutations(range(4)))
 
 def _build_type(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, out_fn, valid_fn, ncl, pad_search=True,
                 slot_cap=1 << 30):
+    """Pooled boxes: which four row groups (pool windows) share an MFMA tile is free -- the kernel is table-driven --
+    so the enumeration order of the groups (which axis runs fastest) is searched too, next to the LDS pitches."""
+    if not pooled:
+        return _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, out_fn, valid_fn, ncl, pad_search,
+                                 slot_cap, (0, 1, 2))
+    best = None
+    for order in ((0, 1, 2), (0, 2, 1), (1, 0, 2), (2, 0, 1), (1, 2, 0), (2, 1, 0)):
+        bt = _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, out_fn, valid_fn, ncl, pad_search,
+                               slot_cap, order)
+        key = (round(bt.conflict_cycles, 3), bt.pitch_c)
+        if best is None or key < best[0]:
+            best = (key, bt)
+        if bt.conflict_cycles <= 4.0 + 1e-9 and bt.pitch_c * ncl <= slot_cap:
+            break
+    return best[1]
+
+
+def _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, out_fn, valid_fn, ncl, pad_search,
+                      slot_cap, order):
     """Build one BoxType.  ``row_lin(a,b,c)`` -> (f,h,w) patch-relative slot coords of the row
     origin; ``tap_list`` -> (df,dh,dw); ``out_fn`` gives the output index of a group / row.
     Searches LDS pitches (and, for pooled tiles, which of a tile's four row groups sits in
@@ -240,8 +259,15 @@ def _build_type(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, out_fn
     pf, ph, pw = patch_ext
     ga, gb, gc = group
     if pooled:
-        groups = [(ci, a, b, c) for ci in range(ncl) for a in range(0, na, ga) for b in range(0, nb, gb)
-                  for c in range(0, nc, gc)]
+        axes = (range(0, na, ga), range(0, nb, gb), range(0, nc, gc))
+        groups = []
+        for ci in range(ncl):           # `order` lists the axes from slowest to fastest
+            for x in axes[order[0]]:
+                for y in axes[order[1]]:
+                    for z in axes[order[2]]:
+                        abc = [0, 0, 0]
+                        abc[order[0]], abc[order[1]], abc[order[2]] = x, y, z
+                        groups.append((ci, abc[0], abc[1], abc[2]))
         ngr = len(groups)
         # coordinates of the 8 rows of every group: [ngr, 8, 4] = (ci, f, h, w)
         gcoord = np.zeros((ngr, 8, 4), dtype=np.int64)
