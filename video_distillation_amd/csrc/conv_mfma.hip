@@ -772,6 +772,8 @@ __global__ __launch_bounds__(256, 1) void conv0_persistent_kernel(const VdConvPa
     }
 }
 
+#define VD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 // First-layer kernel with register-resident weights (single-pass formats, 2 x 2 waves, 4 M tiles per wave, one
 // box type, 32 K steps): the layer's B fragments -- 64 KB in all, identical for every box -- are loaded into 128
 // VGPRs once per workgroup and reused for every box it walks.  The generic program re-fetches them per box with
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
             __builtin_amdgcn_sched_barrier(0);
             tp = tp_next;
         }
-        __syncthreads();                 // every wave is done reading the patch: the staging tile aliases it
+        VD_LDS_BARRIER();                // every wave is done reading the patch: the staging tile aliases it
         // ---- epilogue: bias + ReLU + (1,2,2) max-pool, staged through LDS, 16-byte slot stores ----
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
@@ -895,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
                 stg[(q + 1) * NCH + n] = hi;
             }
         }
-        __syncthreads();
+        VD_LDS_BARRIER();
         {
             const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
             const int64_t lim64 = out_total - out_base;
@@ -909,7 +911,9 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
                 dslots[(uint32_t)base + (uint32_t)cc * (uint32_t)p.out_chunk_stride] = *reinterpret_cast<const uint4*>(stg + q * NCH + cc * 8);
             }
         }
-        __syncthreads();                 // the staging tile has been read: the next box's DMA may overwrite it
+        // the staging tile has been read: the next box's DMA may overwrite it.  LDS-only barrier: a full
+        // __syncthreads() would also wait (vmcnt) for this box's slot stores to complete
+        VD_LDS_BARRIER();
     }
 }
 
