@@ -446,7 +446,7 @@ def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: 
     assert cin % 8 == 0 and cout % 32 == 0
     if ntw == 2:
         assert cout == 128
-        mtw_options = (4,)
+        mtw_options = tuple(int(v) for v in os.environ.get("VD_NTW2_MTW", "4").split(","))
     CC = cin // 8
     T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
     To, Ho, Wo = T // pool_t, OH // 2, OW // 2
