@@ -164,6 +164,10 @@ int vd_clip_minor_pix(const float* x, int64_t nclips, int T, int H, int W, void*
 int vd_pack_dy(const void* dy, int64_t dy_plane_slots, int planes, int64_t nclips, int N, int T, int OH, int OW,
                int nt, int noh, int now, void* dst, int64_t dst_plane_elems, void* stream);
 
+/* Conv3d bias gradient from the POOLED gradient and the arg-max bytes of the layer (layouts as in vd_unpool_relu_bwd):
+ * db[n] += sum of g over clips and pooled positions whose window was alive (bit 7 clear); accumulates (fp32 atomics). */
+int vd_bias_grad_pooled(const float* g, const uint8_t* argmax, int64_t nclips, int C, int64_t npos, int g_layout, float* db,
+                        void* stream);
 /* db[n] += sum over clips and positions of dy (hi + lo planes) -- Conv3d bias gradient. */
 int vd_bias_grad(const void* dy, int64_t dy_plane_slots, int planes, int64_t nclips, int N, int64_t npos, int prec,
                  const float* scale_inv, float* db, void* stream);

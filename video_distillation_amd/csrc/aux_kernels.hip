@@ -855,6 +855,44 @@ extern "C" int vd_bias_grad(const void* dy, int64_t dy_plane_slots, int planes, 
     return (int)hipGetLastError();
 }
 
+// Bias gradient straight from the POOLED gradient: the dense dy has one non-zero per pool window -- the pooled
+// value, if the window was alive -- so db[n] = sum over clips and pooled positions of g where bit 7 of the arg-max
+// byte is clear.  Reads 4-8x fewer bytes than summing the dense dy slots (vd_bias_grad).
+__global__ __launch_bounds__(256) void bias_grad_pooled_kernel(const float* __restrict__ g, const uint8_t* __restrict__ amax,
+                                                                int C, int64_t npos, int g_layout, int pos_per_block,
+                                                                float* __restrict__ db) {
+    __shared__ float red[256];
+    const int64_t clip = blockIdx.x;
+    const int n = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C;
+    const int64_t p0 = (int64_t)blockIdx.y * pos_per_block;
+    const int64_t p1 = (p0 + pos_per_block < npos) ? p0 + pos_per_block : npos;
+    const int CC = C >> 3;
+    float acc = 0.f;
+    for (int64_t pos = p0 + pl; pos < p1; pos += npl) {
+        int64_t gi, ai;
+        if (g_layout == 0) { gi = (clip * C + n) * npos + pos; ai = gi; }
+        else { gi = (clip * npos + pos) * C + n; ai = ((clip * CC + (n >> 3)) * npos + pos) * 8 + (n & 7); }
+        if (!(amax[ai] & 0x80)) acc += g[gi];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (pl == 0) {
+        for (int k = 1; k < npl; ++k) acc += red[k * C + n];
+        atomicAdd(&db[n], acc);
+    }
+}
+
+extern "C" int vd_bias_grad_pooled(const float* g, const uint8_t* argmax, int64_t nclips, int C, int64_t npos, int g_layout,
+                                   float* db, void* stream) {
+    if (C <= 0 || C > 256 || 256 % C != 0 || C % 8 != 0 || nclips > 0x7fffffff) return -2;
+    if (nclips <= 0 || npos <= 0) return 0;
+    const int ppb = 256;
+    const unsigned gy = (unsigned)((npos + ppb - 1) / ppb);
+    hipLaunchKernelGGL(bias_grad_pooled_kernel, dim3((unsigned)nclips, gy), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g,
+                       argmax, C, npos, g_layout, ppb, db);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // Training half of the classifier head + loss + optimiser (evaluate_synset / epoch('train'),
 // reference utils.py:765-792, 852): one workgroup per clip, everything per clip fits LDS.

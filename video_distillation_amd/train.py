@@ -138,9 +138,9 @@ class TrainEngine:
             hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am), ctypes.c_int64(nb), cout, To, Ho, Wo, pt, T, OH, OW,
                                            layout, hip.ptr(dy[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(sc), st),
                       "vd_unpool_relu_bwd")
-            hip.check(L.vd_bias_grad(hip.ptr(dy), ctypes.c_int64(nslots), eng.planes_bwd, ctypes.c_int64(nb), cout,
-                                     ctypes.c_int64(T * OH * OW), eng.prec_bwd, hip.ptr(inv), hip.ptr(g[2 * li + 1]), st),
-                      "vd_bias_grad")
+            # bias gradient from the pooled gradient (the dense dy has one non-zero per live pool window)
+            hip.check(L.vd_bias_grad_pooled(hip.ptr(grad), hip.ptr(am), ctypes.c_int64(nb), cout, ctypes.c_int64(To * Ho * Wo),
+                                            layout, hip.ptr(g[2 * li + 1]), st), "vd_bias_grad_pooled")
             op = self._wgrad(li, nb)
             if li == 0:
                 op.run(x, True, 0, dy, nslots, g[0], out_scale=inv)
@@ -330,9 +330,9 @@ class GradMatchEngine(TrainEngine):
                 if hv:
                     # parameter side: z_l = conv(a_l, W_l) + b_l carries zbar_l, and g_{a_l} = convT(dz_l, W_l) carries gbar_l
                     op = self._wgrad(li, nb)
-                    hip.check(L.vd_bias_grad(hip.ptr(zb), ctypes.c_int64(nslots), eng.planes_bwd, ctypes.c_int64(nb), cout,
-                                             ctypes.c_int64(T * OH * OW), eng.prec_bwd, hip.ptr(None), hip.ptr(hv[2 * li + 1]), st),
-                              "vd_bias_grad")
+                    hip.check(L.vd_bias_grad_pooled(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout,
+                                                    ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(hv[2 * li + 1]), st),
+                              "vd_bias_grad_pooled")
                     if li == 0:
                         op.run(state["x"], True, 0, zb, nslots, hv[0])
                     else:
