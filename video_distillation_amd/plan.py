@@ -437,6 +437,21 @@ def _lane_cols():
     return lane & 31, lane >> 5
 
 
+def _memo(fn):
+    """Per-process cache of a layer planner: engines with different precisions / batch hints ask for the same
+    programs again and again, and the pitch / tile-assignment search is the expensive part."""
+    cache = {}
+
+    def wrapped(*args, **kwargs):
+        key = (args, tuple(sorted(kwargs.items())), os.environ.get("VD_L0_BOX"), os.environ.get("VD_NTW2_MTW"))
+        if key not in cache:
+            cache[key] = fn(*args, **kwargs)
+        return cache[key]
+    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+    return wrapped
+
+
+@_memo
 def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, pool_t: int,
                     feat_out: bool, lds_budget: int = 3700, mtw_options=(7, 8, 4, 2), ntw: int = 1) -> ConvPlan:
     """Forward Conv3d(cin->cout) + ReLU + MaxPool(pool_t,2,2) over a channels-last chunked
@@ -506,6 +521,7 @@ def pix_row_pitch(w: int) -> int:
     return -(-(w + 8) // 8) * 8
 
 
+@_memo
 def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_budget: int = 3700,
                      mtw_options=(4,), ntw: int = 1) -> ConvPlan:
     """First layer: Conv3d(3->cout) + ReLU + MaxPool(1,2,2).  Source = 16-bit pixel rows made by
@@ -565,6 +581,7 @@ def dgrad_classes(h: int, w: int):
     return [(ph, pw) for ph in range(min(2, h)) for pw in range(min(2, w))]
 
 
+@_memo
 def plan_dgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, ph: int, pw: int,
                pixel_out: bool, lds_budget: int = 3700, mtw_options=(7, 8, 4, 2)) -> ConvPlan:
     """Input gradient of Conv3d(cin->cout, k(3,7,7), s(1,2,2), p(1,3,3)) for the input positions
@@ -627,6 +644,7 @@ def plan_dgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, 
     return plan
 
 
+@_memo
 def plan_dgrad_pix(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, lds_budget: int = 3700,
                    mtw_options=(7, 8)) -> ConvPlan:
     """Input gradient of the FIRST layer (cin = 3 pixel channels) with the four stride-2 parity
@@ -699,6 +717,7 @@ def plan_wgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, 
     return _plan_wgrad(name, cin, cout, t_in, h_in, w_in, nclips, lds_budget, block)
 
 
+@_memo
 def _plan_wgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, nclips: int,
                 lds_budget: int, block) -> ConvPlan:
     """Weight gradient of Conv3d(cin->cout, k(3,7,7), s(1,2,2), p(1,3,3)) as a tile program of the SAME
