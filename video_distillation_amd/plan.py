@@ -855,8 +855,16 @@ def latency_variant(pl: ConvPlan, batch_hint: Optional[int], make) -> ConvPlan:
     count per wave (same padded work, more and shorter workgroups).  ``make(mtw_options)`` rebuilds the program."""
     if not batch_hint or pl.grid(batch_hint) >= 512:
         return pl
-    alt = make(SMALL_TILES_FIRST)
-    return alt if alt.grid(batch_hint) > pl.grid(batch_hint) and alt.rows_total <= pl.rows_total else pl
+    slack = float(os.environ.get("VD_LAT_SLACK", "1.05"))     # a few per cent of padding rows are cheaper than a long workgroup
+    best = pl
+    for opts in (SMALL_TILES_FIRST, (4,), (2,)):
+        try:
+            alt = make(opts)
+        except ValueError:
+            continue
+        if alt.grid(batch_hint) > best.grid(batch_hint) and alt.rows_total <= pl.rows_total * slack:
+            best = alt
+    return best
 
 
 def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: int = 1, balanced: bool = False,
