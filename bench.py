@@ -243,7 +243,7 @@ def main():
                 cc = [n for (name, n, a, b) in prof if name == lname]
                 if tt:
                     out["roofline"][lname + "_tflops"] = 2.0 * macs[li] * float(np.mean(cc)) / float(np.mean(tt)) / 1e12
-        if args.eval_epochs > 0 and args.method == "dm":
+        if args.eval_epochs > 0 and args.method == "dm" and world == 1:    # (single process: gather_syn is a collective)
             out["eval"] = run_eval(args, trainer, pool, device)
         if world == 1 and not args.no_cpu_baseline and args.method == "dm":
             out["cpu_baseline"] = cpu_baseline(args, trainer, backend, args.warmup + args.steps, geo)
