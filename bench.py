@@ -171,9 +171,6 @@ def main():
                                      hal_w, hal_b, lr_dynamic=1.0, lr_hal=0.01, rank=rank, world=world)
         trainer.image_syn = trainer.dynamic
         trainer.global_loss = lambda l: l
-        trainer.sync = lambda: torch.cuda.synchronize()
-        _step = trainer.step
-        trainer.step = lambda it, overlap=False: _step(it)
 
     def barrier():
         if world > 1:

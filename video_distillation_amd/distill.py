@@ -407,34 +407,65 @@ class S2DTrainer:
         static_idx = self.spc * label + 2 * idx + ds
         return static_idx.astype(np.int64), dynamic_idx.astype(np.int64)
 
-    def step(self, it: int, draws=None) -> torch.Tensor:
+    def step(self, it: int, draws=None, overlap: bool = False) -> torch.Tensor:
+        """One s2d iteration over this rank's classes.  With a two-stream backend the real-clip forward runs on
+        one stream and hallucinator + synthetic forward / backward + optimiser on the other (as in DMTrainer);
+        ``overlap`` leaves the work in flight so that consecutive iterations overlap (``sync()`` before reading)."""
         be, ncls = self.be, len(self.classes)
         dev = self.dynamic.device
-        be.set_weights(be.new_network(seed=it))
+        weights = be.new_network(seed=it)
         sidx_np, didx_np = self.indices(it, draws)
         sidx, didx = torch.as_tensor(sidx_np, device=dev), torch.as_tensor(didx_np, device=dev)
-        image_syn = be.hallucinate(self.static, self.dynamic, sidx, didx, self.hal_w, self.hal_b)
         idx = sample_real_indices(it, self.pool.counts, self.pool.offsets, self.batch_real, self.classes)
-        f_real = be.embed_pool(self.pool.clips, torch.as_tensor(idx, device=dev))
-        f_syn, handle = be.embed_keep(image_syn)
-        loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
-        g_img = be.embed_backward(handle, g_syn)
-        g_dyn, g_stat, g_w, g_b = be.hallucinate_backward(g_img, self.static, self.dynamic, sidx, didx, self.hal_w,
-                                                          self.train_static)
-        if self.world > 1:   # the hallucinator is shared by all classes: one 1.3 KB all-reduce
-            import torch.distributed as dist
-            flat = torch.cat([g_w.reshape(-1), g_b.reshape(-1)])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            g_w, g_b = flat[:324].view_as(g_w), flat[324:]
-        first = self.steps_done == 0
-        be.sgd(self.dynamic, self.buf_d, g_dyn, self.lr_dynamic, self.momentum, first)
-        be.sgd(self.hal_w, self.buf_w, g_w.contiguous(), self.lr_hal, self.momentum, first)
-        be.sgd(self.hal_b, self.buf_b, g_b.contiguous(), self.lr_hal, self.momentum, first)
-        if self.train_static:
-            be.sgd(self.static, self.buf_s, g_stat, self.lr_static, self.momentum, first)
+        idx_t = torch.as_tensor(idx, device=dev)
+        two = getattr(be, "two_streams", False)
+        on_real, on_syn = (be.on_real, be.on_syn) if two else (_NullCtx, _NullCtx)
+        if two:
+            be.fork()
+            idx_t.record_stream(be.s_real)
+            for t in (sidx, didx):
+                t.record_stream(be.s_syn)
+            for w in weights:
+                w.record_stream(be.s_real)
+                w.record_stream(be.s_syn)
+            with on_real():
+                be.eng_real.set_weights(weights)
+                f_real = be.embed_pool(self.pool.clips, idx_t)
+        else:
+            be.set_weights(weights)
+            f_real = be.embed_pool(self.pool.clips, idx_t)
+        with on_syn():
+            if two:
+                be.eng_syn.set_weights(weights)
+            image_syn = be.hallucinate(self.static, self.dynamic, sidx, didx, self.hal_w, self.hal_b)
+            f_syn, handle = be.embed_keep(image_syn)
+            if two:
+                be.real_to_syn(f_real)
+            loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
+            g_img = be.embed_backward(handle, g_syn)
+            g_dyn, g_stat, g_w, g_b = be.hallucinate_backward(g_img, self.static, self.dynamic, sidx, didx, self.hal_w,
+                                                              self.train_static)
+            if self.world > 1:   # the hallucinator is shared by all classes: one 1.3 KB all-reduce
+                import torch.distributed as dist
+                flat = torch.cat([g_w.reshape(-1), g_b.reshape(-1)])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                g_w, g_b = flat[:324].view_as(g_w), flat[324:]
+            first = self.steps_done == 0
+            be.sgd(self.dynamic, self.buf_d, g_dyn, self.lr_dynamic, self.momentum, first)
+            be.sgd(self.hal_w, self.buf_w, g_w.contiguous(), self.lr_hal, self.momentum, first)
+            be.sgd(self.hal_b, self.buf_b, g_b.contiguous(), self.lr_hal, self.momentum, first)
+            if self.train_static:
+                be.sgd(self.static, self.buf_s, g_stat, self.lr_static, self.momentum, first)
+            loss = loss_c.sum()
+        if two and not overlap:
+            be.join(loss, g_dyn, g_w, g_b)
         self.steps_done += 1
         self.last_grads = (g_dyn, g_w, g_b)
-        return loss_c.sum()
+        return loss
+
+    def sync(self) -> None:
+        if getattr(self.be, "two_streams", False):
+            self.be.join()
 
 
 # ------------------------------------------------------------------------------------------------
