@@ -94,6 +94,12 @@ int vd_conv0_persistent(const VdConvParams* params, void* stream);
 int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, void* out_hi, void* out_lo,
                     int prec, void* stream);
 
+/* out[i] = (float) rn16(w[i]) in the 16-bit format of `prec` (f16 / bf16): the weights of the fresh
+ * network of a DM iteration (get_network, distill_baseline.py:334) rounded once, so that the real-clip
+ * forward (single-pass operands), the synthetic-clip forward (hi+lo operands) and the input gradient all
+ * use identical weights.  out may alias w. */
+int vd_round_operand(const float* w, int64_t n, int prec, float* out, void* stream);
+
 /* (B,T,3,H,W) fp32 clips (the reference's input layout, networks.py:748) -> first-layer
  * source: 16-bit pixel rows [B][T*3][H][pitch], pitch = roundup8(W+8), row = 3 zeros, the W
  * pixels, zeros.  clip_index (optional, [nclips]) gathers batch clip b from x[clip_index[b]]:

@@ -268,3 +268,159 @@ def test_g11_evaluate_synset_multi_static_on_hip(golden_dir):
     assert abs(acc_train - float(z["acc_train"])) < 1e-6
     l1 = np.array([float(p.double().abs().sum()) for p in net_out.parameters()])
     np.testing.assert_allclose(l1, z["params_after_l1"], rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# The SHIPPED precision mode (real f16 / syn f16x3 / input gradient f16): what bench.py times.
+# Measured errors are appended to gpurun_out/r02_parity.json (copied to profiles/ by hand).
+# ------------------------------------------------------------------------------------------------
+MODES = {"mixed": dict(prec_real="f16", prec_syn="f16x3", prec_bwd="f16"),
+         "x3": dict(prec_real="f16x3", prec_syn="f16x3", prec_bwd="f16x3")}
+
+
+def _record(key, value):
+    import json
+    path = os.environ.get("VD_PARITY_LOG", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                        "gpurun_out", "r02_parity.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = value
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm())
+
+
+def test_g3_two_dm_steps_shipped_mixed_mode(golden_dir):
+    """G3 (two reference DM iterations incl. momentum) in the mode bench.py times.  Bars: loss 1e-3 (north_star);
+    pixel gradient / update rel-L2 2e-3 (single-pass f16 input gradient: 5e-4 operand rounding + the arg-max
+    flips the fp32 reference itself shows against fp64, 3.9e-4)."""
+    from video_distillation_amd import distill, plan
+    import video_distillation_amd.distill as D
+    z = np.load(os.path.join(golden_dir, "g3_dm_steps.npz"))
+    geo = plan.NetGeometry(8, 64, 64)
+    be = _FixedNetBackend(distill.HipBackend(geo, "cuda:0", **MODES["mixed"]), z["net_seeds"])
+    (syn,) = randn(z["syn_seed"], (3, 8, 3, 64, 64))
+    reals = [randn(z["real_seeds"][it], *[(4, 8, 3, 64, 64)] * 3) for it in range(2)]
+    pool = types.SimpleNamespace(clips=torch.cat([torch.cat(r) for r in reals]).cuda(), counts=[4, 4, 4], offsets=[0, 4, 8])
+    tr = distill.DMTrainer(be, pool, 3, 1, 4, lr_img=float(z["lr"]), momentum=float(z["momentum"]), image_syn=syn.cuda())
+    orig, losses, upd = D.sample_real_indices, [], []
+    prev = syn.clone()
+    try:
+        for it in range(2):
+            D.sample_real_indices = lambda it_, counts, offsets, b, classes, it=it: np.concatenate(
+                [it * 12 + offsets[c] + np.arange(4) for c in classes]).astype(np.int64)
+            losses.append(float(tr.step(it)))
+            cur = tr.image_syn.cpu().clone()
+            ref_prev = syn[:, ::2, :, ::4, ::4] if it == 0 else torch.tensor(z["syn1"])
+            upd.append(_rel((cur - prev)[:, ::2, :, ::4, ::4], torch.tensor(z["syn%d" % (it + 1)]) - ref_prev))
+            prev = cur
+    finally:
+        D.sample_real_indices = orig
+    lerr = [abs(a / b - 1) for a, b in zip(losses, z["losses"])]
+    _record("g3_mixed", {"loss_rel": lerr, "update_rel_l2": upd})
+    print("G3 mixed: loss rel", lerr, "update rel-l2", upd)
+    assert max(lerr) < 1e-3
+    assert max(upd) < 2e-3
+
+
+def test_g5_s2d_step_shipped_mixed_mode(golden_dir):
+    from video_distillation_amd import distill, plan
+    import video_distillation_amd.distill as D
+    z = np.load(os.path.join(golden_dir, "g5_s2d_step.npz"))
+    C, vpc, spc, dpc = 3, 1, 2, 2
+    geo = plan.NetGeometry(8, 64, 64)
+    be = _FixedNetBackend(distill.HipBackend(geo, "cuda:0", **MODES["mixed"]), {0: int(z["net_seed"])})
+    static_syn, dynamic_syn = randn(z["data_seed"], (C * spc, 3, 64, 64), (C, dpc, 8, 1, 64, 64))
+    reals = randn(z["real_seed"], *[(4, 8, 3, 64, 64)] * C)
+    pool = types.SimpleNamespace(clips=torch.cat(reals).cuda(), counts=[4] * C, offsets=[0, 4, 8])
+    tr = distill.S2DTrainer(be, pool, C, vpc, spc, dpc, 4, static_syn.cuda(), dynamic_syn.cuda(),
+                            torch.tensor(z["hal_w"]).cuda(), torch.tensor(z["hal_b"]).cuda(), lr_dynamic=10.0, lr_hal=0.01)
+    orig = D.sample_real_indices
+    try:
+        D.sample_real_indices = lambda it_, counts, offsets, b, classes: np.concatenate(
+            [offsets[c] + np.arange(4) for c in classes]).astype(np.int64)
+        loss = float(tr.step(0, draws=(z["draws_dyn"], z["draws_sta"])))
+    finally:
+        D.sample_real_indices = orig
+    g_dyn, g_w, g_b = tr.last_grads
+    g_dyn = g_dyn.view(C, dpc, 8, 1, 64, 64).cpu()
+    rec = {"loss_rel": abs(loss / float(z["loss"]) - 1), "g_dynamic_rel_l2": _rel(g_dyn[:, :, :, :, ::4, ::4], z["g_dynamic"]),
+           "g_hal_w_rel_l2": _rel(g_w.cpu(), z["g_hal_w"]), "g_hal_b_rel_l2": _rel(g_b.cpu(), z["g_hal_b"])}
+    _record("g5_mixed", rec)
+    print("G5 mixed:", rec)
+    assert rec["loss_rel"] < 1e-3
+    assert rec["g_dynamic_rel_l2"] < 2e-3 and rec["g_hal_w_rel_l2"] < 2e-3 and rec["g_hal_b_rel_l2"] < 2e-3
+    assert int((g_dyn.abs().sum(dim=(2, 3, 4, 5)) == 0).sum()) == C * (dpc - 1)
+
+
+def test_g12_late_regime_dm_run(golden_dir):
+    """G12: 24 reference DM iterations (batch_real 64) whose feature difference is only ~4 % of the feature norm
+    (class-patterned real clips, synthetic clips initialised from a real one): the regime in which an absolute error on
+    mean f_real weighs most on the gradient.
+
+    (a) the all-f16x3 trainer, free-running, against the reference's trajectory: every loss within 1e-3; the pixel
+        gradient of the first six steps within 1e-3 (measured 4e-5).  Later steps are recorded, not asserted: a single
+        pooling near-tie resolved the other way in the last layer moves 1/2048 of the gradient (3e-2 rel-L2) and, at
+        lr 50, the trajectories part from there on -- the fp32 reference is as arbitrary at such a tie as we are.
+    (b) the SHIPPED mixed mode, teacher-forced onto the f16x3 trainer's states (same synthetic clips and momentum before
+        every step; the routing of the gradient comes from the same exact-weight forward in both, so no tie can differ):
+        loss within 1e-3, gradient within 3e-3 rel-L2 of the f16x3 gradient at every step (measured 1.7e-3 .. 2.3e-3:
+        what is left of the real side's weight-rounding perturbation, ~8e-5 |f| on the class mean, over a feature
+        difference of 4e-2 |f|; it scales as 1/difference, so 3e-4 at a 25 % difference, 1e-4 at a random start).
+    (c) the same without the value pass (synthetic features from the exact-weight forward): recorded as the ablation."""
+    from video_distillation_amd import distill, plan
+    import video_distillation_amd.distill as D
+    z = np.load(os.path.join(golden_dir, "g12_dm_late.npz"))
+    C, B, steps, NP, mu = int(z["C"]), int(z["batch_real"]), int(z["steps"]), int(z["pool_per_class"]), float(z["momentum"])
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    base = torch.randn(C, 8, 3, 64, 64, generator=g)
+    pool_t = torch.stack([base[c] + 0.1 * torch.randn(NP, 8, 3, 64, 64, generator=g) for c in range(C)])
+    geo = plan.NetGeometry(8, 64, 64)
+    seeds = {it: int(z["net_seed0"]) + it for it in range(steps)}
+    pool = types.SimpleNamespace(clips=pool_t.reshape(C * NP, 8, 3, 64, 64).cuda(), counts=[NP] * C, offsets=[0, NP])
+
+    def trainer(mode, value_pass=True):
+        inner = distill.HipBackend(geo, "cuda:0", **MODES[mode])
+        if not value_pass:
+            inner.weight_format = None
+        return distill.DMTrainer(_FixedNetBackend(inner, seeds), pool, C, 1, B, lr_img=float(z["lr"]), momentum=mu,
+                                 image_syn=pool_t[:, 0].clone().cuda())
+    ta, tb, tc = trainer("x3"), trainer("mixed"), trainer("mixed", value_pass=False)
+    assert tb.be.weight_format == "f16" and tc.be.weight_format is None and ta.be.weight_format is None
+    sub = lambda t: t.cpu()[:, ::2, :, ::4, ::4]       # noqa: E731
+    orig = D.sample_real_indices
+    rec = {"x3_vs_reference": {"loss": [], "grad": []}, "mixed_vs_x3": {"loss": [], "grad": []},
+           "mixed_novaluepass_vs_x3": {"loss": [], "grad": []}}
+    try:
+        for it in range(steps):
+            D.sample_real_indices = lambda it_, counts, offsets, b, classes, it=it: np.concatenate(
+                [offsets[c] + z["picks"][it][c] for c in classes]).astype(np.int64)
+            state = (ta.image_syn.clone(), ta.buf.clone(), ta.steps_done)
+            la = float(ta.step(it))
+            ga = ta.buf - mu * state[1] if it > 0 else ta.buf.clone()       # buf = mu*buf + g
+            rec["x3_vs_reference"]["loss"].append(abs(la / float(z["losses"][it]) - 1))
+            rec["x3_vs_reference"]["grad"].append(_rel(sub(ga), z["grads"][it]))
+            for tr, key in ((tb, "mixed_vs_x3"), (tc, "mixed_novaluepass_vs_x3")):
+                tr.image_syn.copy_(state[0]); tr.buf.copy_(state[1]); tr.steps_done = state[2]
+                lt = float(tr.step(it))
+                gt = tr.buf - mu * state[1] if it > 0 else tr.buf.clone()
+                rec[key]["loss"].append(abs(lt / la - 1))
+                rec[key]["grad"].append(_rel(gt, ga))
+    finally:
+        D.sample_real_indices = orig
+    rec["feature_diff_over_norm"] = [float(v) for v in z["rel_diff"].mean(1)]
+    _record("g12", rec)
+    for k in ("x3_vs_reference", "mixed_vs_x3", "mixed_novaluepass_vs_x3"):
+        print("G12 %s: max loss rel %.2e, grad rel-l2 max %.2e median %.2e" % (k, max(rec[k]["loss"]), max(rec[k]["grad"]),
+                                                                              float(np.median(rec[k]["grad"]))))
+    assert max(rec["x3_vs_reference"]["loss"]) < 1e-3
+    assert max(rec["x3_vs_reference"]["grad"][:6]) < 1e-3
+    assert max(rec["mixed_vs_x3"]["loss"]) < 1e-3
+    assert max(rec["mixed_vs_x3"]["grad"]) < 3e-3
+    assert np.median(rec["mixed_novaluepass_vs_x3"]["grad"]) > 1.5 * np.median(rec["mixed_vs_x3"]["grad"])   # the value pass earns its cost

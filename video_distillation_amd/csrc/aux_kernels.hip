@@ -65,6 +65,24 @@ extern "C" int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, v
     return (int)hipGetLastError();
 }
 
+// out = (float) rn16(w): the network's weights rounded ONCE to the single-pass operand format, so that
+// every pass of a step (single-pass real-clip forward, split-precision synthetic-clip forward, input
+// gradient) multiplies by the SAME weights -- the step is then the exact step of the network rn16(W),
+// and weight rounding cannot show up as a bias between mean f_real and mean f_syn.
+__global__ void round_operand_kernel(const float* __restrict__ w, int64_t n, int prec, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = w[i];
+    out[i] = (prec == VD_PREC_BF16 || prec == VD_PREC_BF16X3) ? (float)(__bf16)v : (float)(_Float16)v;
+}
+
+extern "C" int vd_round_operand(const float* w, int64_t n, int prec, float* out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(round_operand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), w, n, prec, out);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // one thread per 8 output elements (16 bytes) of a padded 16-bit pixel row:
 // out[row][8j .. 8j+7] = x[row][8j-3 .. 8j+4] (zero outside [0,W))

@@ -107,11 +107,32 @@ class HipBackend:
             self.s_real = torch.cuda.Stream(device=self.device, priority=pr)
             self.s_syn = torch.cuda.Stream(device=self.device, priority=ps)
         self._ev_real = None
+        # Mixed mode (single-pass real side + hi/lo synthetic side of the same 16-bit format).  The real side
+        # multiplies by rn16(W): a SYSTEMATIC perturbation of mean f_real (~2e-4 |f|, it does not average out over
+        # the 64 clips of a batch) that the exact-weight synthetic side does not share, so it lands undiminished in
+        # mean f_real - mean f_syn (measured on fixture G12, where that difference is 4 % of |f|: 0.5 % of the
+        # gradient).  Rounding the weights for ALL passes is no cure: the pooling decisions of rn16(W) differ from the
+        # reference's (gradient off by 3e-2).  So the synthetic clips get TWO forwards: one with the exact weights,
+        # whose ReLU / arg-max decisions route the gradient exactly as the reference does, and a "value pass" with
+        # rn16(W), whose features enter the loss -- both sides of the difference then carry the same perturbation.
+        self.weight_format = prec_real if (prec_real in ("f16", "bf16") and prec_syn == prec_real + "x3"
+                                           and os.environ.get("VD_VALUE_PASS", "1") == "1") else None
         self.resident_rows = os.environ.get("VD_RESIDENT_ROWS", "1") == "1"
         self._pool_rows = None
 
     def new_network(self, seed: int):
         return fresh_network_weights(seed, self.device)
+
+    def embed_syn(self, x: torch.Tensor, weights):
+        """(features that enter the loss, handle for ``embed_backward``) of the synthetic clips; sets the synthetic
+        engine's weights itself.  See ``weight_format`` above for the two forwards of the mixed mode."""
+        eng = self.eng_syn
+        eng.set_weights(weights)
+        feats, handle = eng.forward(x, keep=True)
+        if self.weight_format is not None:
+            eng.set_weights(weights, quantize=self.weight_format)
+            feats = eng.forward(x)
+        return feats, handle
 
     def set_weights(self, weights) -> None:
         self.eng_real.set_weights(weights)
@@ -300,8 +321,7 @@ class DMTrainer:
                 be.eng_real.set_weights(weights)
                 f_real = self._real_features(idx_t)
             with on_syn():
-                be.eng_syn.set_weights(weights)
-                f_syn, handle = be.embed_keep(self.image_syn)
+                f_syn, handle = be.embed_syn(self.image_syn, weights)
                 be.real_to_syn(f_real)
                 loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
                 grad = be.embed_backward(handle, g_syn)
@@ -435,10 +455,11 @@ class S2DTrainer:
             be.set_weights(weights)
             f_real = be.embed_pool(self.pool.clips, idx_t)
         with on_syn():
-            if two:
-                be.eng_syn.set_weights(weights)
             image_syn = be.hallucinate(self.static, self.dynamic, sidx, didx, self.hal_w, self.hal_b)
-            f_syn, handle = be.embed_keep(image_syn)
+            if two:
+                f_syn, handle = be.embed_syn(image_syn, weights)
+            else:
+                f_syn, handle = be.embed_keep(image_syn)
             if two:
                 be.real_to_syn(f_real)
             loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)

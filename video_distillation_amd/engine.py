@@ -103,6 +103,26 @@ class _DevPlan:
         hip.check(hip.lib().vd_conv_mfma(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv_mfma(%s)" % self.plan.name)
 
 
+def round_weights(params: Sequence[torch.Tensor], prec: str) -> List[torch.Tensor]:
+    """[w0, b0, w1, b1, w2, b2, ...] with every conv WEIGHT replaced by (float) rn16(w) in the operand format
+    ``prec`` (biases are added in fp32 and stay as they are).  A mixed-precision step -- real clips single-pass
+    f16, synthetic clips hi+lo f16 pairs, f16 input gradient -- that is fed these weights multiplies by the SAME
+    weights in every pass: it is the exact step of the network rn16(W), so weight rounding cannot appear as a
+    bias between mean f_real and mean f_syn (that bias is what grows, relative to the gradient, as the
+    distillation converges and the difference of the means shrinks)."""
+    out, L = [], hip.lib()
+    for i, p in enumerate(params):
+        if i % 2 == 0 and p.dim() == 5 and i < 6:
+            p = p.detach().to(torch.float32).contiguous()
+            q = torch.empty_like(p)
+            hip.check(L.vd_round_operand(hip.ptr(p), ctypes.c_int64(p.numel()), hip.PREC[prec], hip.ptr(q),
+                                         hip.stream_ptr(p.device)), "vd_round_operand")
+            out.append(q)
+        else:
+            out.append(p)
+    return out
+
+
 class EmbedEngine:
     def __init__(self, geo: P.NetGeometry, prec: str = "bf16x3", device="cuda:0", chunk: int = 256,
                  prec_bwd: Optional[str] = None, ntw0: Optional[int] = None, batch_hint: Optional[int] = None):
@@ -146,9 +166,12 @@ class EmbedEngine:
             self._ws[name] = t
         return t[:n].view(*shape)
 
-    def set_weights(self, params: Sequence[torch.Tensor]) -> None:
-        """params = [w0, b0, w1, b1, w2, b2] fp32 on the device (ConvNet3D.features order)."""
+    def set_weights(self, params: Sequence[torch.Tensor], quantize: Optional[str] = None) -> None:
+        """params = [w0, b0, w1, b1, w2, b2] fp32 on the device (ConvNet3D.features order).  ``quantize`` ('f16' /
+        'bf16'): round the three weight tensors to that operand format first (``round_weights``)."""
         ws = [p.detach().to(self.device, torch.float32).contiguous() for p in params[:6]]
+        if quantize is not None:
+            ws = round_weights(ws, quantize)
         self._weights = ws
         for li in range(3):
             self.fwd[li].pack(ws[2 * li])

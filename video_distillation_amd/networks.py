@@ -62,6 +62,17 @@ def _batch_hint(b: int):
     return h
 
 
+def _weight_format():
+    """Mixed mode (real single-pass f16/bf16, synthetic clips the hi+lo pairs of the same format): clips that carry a
+    gradient get a second forward with the weights rounded to the real side's operand format, and THOSE features are
+    returned (the pooling decisions that route the gradient stay those of the exact weights): both sides of a DM class
+    term then carry the same weight-rounding perturbation.  See distill.HipBackend.weight_format."""
+    r, s = _PRECISION["real"], _PRECISION["syn"]
+    if r in ("f16", "bf16") and s == r + "x3" and os.environ.get("VD_VALUE_PASS", "1") == "1":
+        return r
+    return None
+
+
 def get_precision() -> Dict[str, str]:
     return dict(_PRECISION)
 
@@ -90,6 +101,10 @@ class _EmbedFunction(torch.autograd.Function):
         net._sync_engine(eng)
         if need_grad:
             feats, saved = eng.forward(x, keep=True)
+            q = _weight_format()
+            if q is not None:       # value pass of the mixed mode (see distill.HipBackend.weight_format)
+                net._sync_engine(eng, quantize=q)
+                feats = eng.forward(x)
             ctx.saved = saved
             ctx.eng = eng
             ctx.wkey = net._weights_key()
@@ -207,10 +222,10 @@ class ConvNet3D(nn.Module):
     def _weights_key(self):
         return tuple((p.data_ptr(), p._version) for p in self._feature_params())
 
-    def _sync_engine(self, eng) -> None:
-        key = self._weights_key()
+    def _sync_engine(self, eng, quantize=None) -> None:
+        key = (self._weights_key(), quantize)
         if getattr(eng, "_owner_key", None) != (id(self), key):
-            eng.set_weights(self._feature_params())
+            eng.set_weights(self._feature_params(), quantize=quantize)
             eng._owner_key = (id(self), key)
 
     def _use_hip(self, x) -> bool:
