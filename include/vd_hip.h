@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 1
+#define VD_ABI_VERSION 2
 
 /* operand precision of the MFMA contraction (accumulation is always fp32) */
 #define VD_PREC_BF16   0   /* bf16 operands, one MFMA per product                       */
@@ -207,11 +207,14 @@ int vd_resplit_slots(const void* src_hi, const void* src_lo, int64_t n_elems, in
  * adjoints of the head's parameter gradients (v_w, v_b) and of the feature gradient (gbar_feats) -> adjoint of
  * the features (abar_feats), through the CE Hessian and the saved arg-max frames / dropout mask.  wbar [K][C] /
  * bbar [K] (optional, accumulated with fp32 atomics): adjoint of the head's own parameters -- the head rows of
- * the Hessian-vector product MTT's unrolled inner loop needs (distill_baseline.py:250-252). */
+ * the Hessian-vector product MTT's unrolled inner loop needs (distill_baseline.py:250-252).
+ * logits == NULL: no loss Hessian (logitbar = 0) -- for a caller that differentiates its own loss on top of
+ * net(x) (the autograd path of ConvNet3D.forward); dlogbar_out (optional, [nclips][K]) receives the adjoint of
+ * dlogits, which that caller chains through its loss. */
 int vd_head_second_order(const float* logits, const float* dlogits, const int32_t* amax_t, const float* dropped,
                          const float* mask, const float* w, const float* v_w, const float* v_b, const float* gbar_feats,
                          int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K, float* abar_feats,
-                         float* wbar, float* bbar, void* stream);
+                         float* wbar, float* bbar, float* dlogbar_out, void* stream);
 int vd_sgd_momentum_wd(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, float wd, int first,
                        void* stream);
 

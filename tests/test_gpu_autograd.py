@@ -1,0 +1,217 @@
+"""The reference-shaped autograd calls on the HIP path: ``torch.autograd.grad(criterion(net(x), y), params,
+create_graph=True)`` (distill_baseline.py:250), ``ReparamModule.forward(x, flat_param=)`` (reparam_module.py:148-159)
+and ``loss.backward()`` of a plain training step -- no ``param_grads``, no trainer -- against fixtures G9 / G10
+(generated from the reference) and fp64 autograd of the oracle."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def _net(seed, C, im=64, frames=8):
+    from video_distillation_amd import networks
+    torch.manual_seed(seed)
+    net = networks.ConvNet3D(3, C, 128, 3, 'relu', 'none', 'maxpooling', frames=frames, im_size=(im, im))
+    net.dropout.p = 0.0
+    return net.cuda().train()
+
+
+def test_first_order_backward_matches_fp64():
+    """loss.backward() through net(x): all 8 parameter gradients and d/dx vs fp64 autograd of the oracle."""
+    C = 5
+    net = _net(7, C)
+    g = torch.Generator().manual_seed(70)
+    x = torch.randn(3, 8, 3, 64, 64, generator=g)
+    y = torch.tensor([1, 4, 2])
+    xs = x.cuda().requires_grad_(True)
+    loss = torch.nn.CrossEntropyLoss()(net(xs), y.cuda())
+    loss.backward()
+    p64 = [p.detach().cpu().double().requires_grad_(True) for p in net.parameters()]
+    x64 = x.double().requires_grad_(True)
+    l64 = torch.nn.functional.cross_entropy(R.convnet3d_logits(x64, p64), y)
+    g64 = torch.autograd.grad(l64, p64 + [x64])
+    assert abs(float(loss) - float(l64)) / float(l64) < 1e-4
+    errs = [_rel(p.grad, gr) for p, gr in zip(net.parameters(), g64[:8])] + [_rel(xs.grad, g64[8])]
+    print("first-order errs", ["%.1e" % e for e in errs])
+    assert max(errs) < 2e-3 and sorted(errs)[4] < 1e-4      # a pooling near-tie may route one window differently than fp64
+
+
+def test_embed_with_parameter_gradients():
+    """embed(x) with parameters that require a gradient (not the frozen DM fast path)."""
+    net = _net(8, 4)
+    g = torch.Generator().manual_seed(80)
+    x = torch.randn(2, 8, 3, 64, 64, generator=g)
+    up = torch.randn(2, 256, generator=g)          # 128 channels x 2 frames at 64x64x8
+    f = net.embed(x.cuda())
+    assert f.requires_grad
+    (f * up.cuda()).sum().backward()
+    p64 = [p.detach().cpu().double().requires_grad_(True) for p in net._feature_params()]
+    f64 = R.convnet3d_embed(x.double(), p64)
+    g64 = torch.autograd.grad((f64 * up.double()).sum(), p64)
+    assert _rel(f, f64) < 1e-5
+    errs = [_rel(p.grad, gr) for p, gr in zip(net._feature_params(), g64)]
+    assert max(errs) < 2e-3, errs
+    assert net.logit.weight.grad is None
+
+
+def test_g9_reference_shaped_gradient_matching(golden_dir):
+    """Fixture G9 exactly as the upstream DC loop writes it against the reference API: net(x), criterion,
+    torch.autograd.grad(..., create_graph=True), match_loss, backward to the synthetic clips."""
+    from video_distillation_amd import utils
+    z = np.load(os.path.join(golden_dir, "g9_grad_match.npz"))
+    C, lab = int(z["C"]), int(z["label"])
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    real = torch.randn(3, 8, 3, 64, 64, generator=g)
+    syn = torch.randn(2, 8, 3, 64, 64, generator=g)
+    net = _net(int(z["net_seed"]), C)
+    net_parameters = list(net.parameters())
+    criterion = torch.nn.CrossEntropyLoss().cuda()
+    lab_r, lab_s = torch.full((3,), lab).cuda(), torch.full((2,), lab).cuda()
+    gw_real = torch.autograd.grad(criterion(net(real.cuda()), lab_r), net_parameters)
+    gw_real = list((_.detach().clone() for _ in gw_real))
+    np.testing.assert_allclose([float(t.double().abs().sum()) for t in gw_real], z["gw_real_l1"], rtol=2e-3)
+    for metric in ("ours", "mse", "cos"):
+        args = types.SimpleNamespace(device="cuda", dis_metric=metric)
+        xs = syn.cuda().requires_grad_(True)
+        gw_syn = torch.autograd.grad(criterion(net(xs), lab_s), net_parameters, create_graph=True)
+        if metric == "ours":
+            np.testing.assert_allclose([float(t.detach().double().abs().sum()) for t in gw_syn], z["gw_syn_l1"], rtol=2e-3)
+        loss = utils.match_loss(gw_syn, gw_real, args)
+        for p in net_parameters:
+            p.grad = None
+        loss.backward()                                   # the reference's callers backward into everything
+        rel = abs(float(loss) - float(z["loss_" + metric])) / abs(float(z["loss_" + metric]))
+        got = xs.grad[0] if metric == "ours" else xs.grad[:, 3]
+        gerr = _rel(got, z["grad_" + metric])
+        l1 = [float(xs.grad[b].double().abs().sum()) for b in range(2)]
+        print("G9 (net(x) + autograd.grad) %s: loss rel %.1e, grad rel-l2 %.1e" % (metric, rel, gerr))
+        assert rel < 1e-3
+        assert gerr < 2e-2                               # arg-max flips allowed (see test_gpu_train G9)
+        np.testing.assert_allclose(l1, z["grad_l1_" + metric], rtol=2e-2)
+        assert all(p.grad is not None for p in net_parameters)       # H v landed in the parameters, as with torch ops
+
+
+def test_second_order_matches_fused_engine_and_fp64():
+    """d <v, dCE/dparams> / d(x, params) through the autograd Functions == the trainers' fused GradMatchEngine.vjp,
+    and both == fp64 double backward of the oracle."""
+    C = 4
+    net = _net(9, C)
+    g = torch.Generator().manual_seed(90)
+    x = torch.randn(2, 8, 3, 64, 64, generator=g)
+    y = torch.tensor([3, 0])
+    params = list(net.parameters())
+    v = [torch.randn(p.shape, generator=g) * 0.1 for p in params]
+    xs = x.cuda().requires_grad_(True)
+    gw = torch.autograd.grad(torch.nn.CrossEntropyLoss()(net(xs), y.cuda()), params, create_graph=True)
+    phi = sum((a * b.cuda()).sum() for a, b in zip(gw, v))
+    got = torch.autograd.grad(phi, [xs] + params)
+    # fp64 oracle
+    p64 = [p.detach().cpu().double().requires_grad_(True) for p in params]
+    x64 = x.double().requires_grad_(True)
+    gw64 = torch.autograd.grad(torch.nn.functional.cross_entropy(R.convnet3d_logits(x64, p64), y), p64, create_graph=True)
+    want = torch.autograd.grad(sum((a * b.double()).sum() for a, b in zip(gw64, v)), [x64] + p64)
+    errs = [_rel(a, b) for a, b in zip(got, want)]
+    print("second-order errs (x, 8 params)", ["%.1e" % e for e in errs])
+    assert max(errs) < 5e-3 and sorted(errs)[4] < 2e-4
+    # fused engine
+    te = net._gm_engine(x.cuda())
+    _, _, _, state = te.param_grads(x.cuda(), y.cuda(), [p.detach() for p in params], None)
+    dx, hv = te.vjp(state, [t.cuda() for t in v], [p.detach() for p in params], param_adjoint=True)
+    assert _rel(got[0], dx) < 1e-4
+    assert max(_rel(a, b) for a, b in zip(got[1:], hv)) < 1e-4
+
+
+def test_g10_reference_shaped_mtt_through_reparam_module(golden_dir):
+    """Fixture G10 (one MTT iteration of the reference, distill_baseline.py:213-262) re-run line by line against
+    ReparamModule(ConvNet3D).forward(x, flat_param=...) on the HIP path."""
+    from video_distillation_amd.reparam_module import ReparamModule
+    z = np.load(os.path.join(golden_dir, "g10_mtt_step.npz"))
+    C, n_syn, syn_steps = int(z["C"]), int(z["n_syn"]), int(z["syn_steps"])
+    net = _net(int(z["net_seed"]), C)
+    starting = [p.detach().clone() for p in net.parameters()]
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    target = [p.cpu() + 0.02 * p.cpu().abs().mean() * torch.randn(p.shape, generator=g) for p in starting]
+    image_syn = torch.randn(n_syn, 8, 3, 64, 64, generator=g).cuda().requires_grad_(True)
+    label_syn = torch.tensor(z["labels"]).cuda()
+    syn_lr = torch.tensor(float(z["syn_lr"])).cuda().requires_grad_(True)
+    student_net = ReparamModule(net)
+    student_net.train()
+    num_params = sum([np.prod(p.size()) for p in (student_net.parameters())])
+    assert num_params == sum(int(np.prod(s)) for s in R.param_shapes(3, C))
+    target_params = torch.cat([p.reshape(-1) for p in target], 0).cuda()
+    student_params = [torch.cat([p.reshape(-1) for p in starting], 0).requires_grad_(True)]
+    starting_params = torch.cat([p.reshape(-1) for p in starting], 0)
+    criterion = torch.nn.CrossEntropyLoss().cuda()
+    for step in range(syn_steps):
+        these = torch.tensor(z["indices"][step]).cuda()
+        forward_params = student_params[-1].unsqueeze(0).expand(1, -1)        # the DataParallel form, one device
+        out = student_net(image_syn[these], flat_param=forward_params)
+        ce = criterion(out, label_syn[these])
+        grad = torch.autograd.grad(ce, student_params[-1], create_graph=True)[0]
+        student_params.append(student_params[-1] - syn_lr * grad)
+    param_loss = torch.nn.functional.mse_loss(student_params[-1], target_params, reduction="sum") / num_params
+    param_dist = torch.nn.functional.mse_loss(starting_params, target_params, reduction="sum") / num_params
+    grand_loss = param_loss / param_dist
+    grand_loss.backward()
+    want = torch.tensor(z["grad_img"]).double()
+    per = [_rel(image_syn.grad[b, ::2, :, ::2, ::2], want[b]) for b in range(n_syn)]
+    print("G10 (ReparamModule) grand %.6f vs %.6f, d/dlr %.5e vs %.5e, per-clip %s"
+          % (float(grand_loss), float(z["grand_loss"]), float(syn_lr.grad), float(z["grad_lr"]), ["%.1e" % e for e in per]))
+    assert abs(float(grand_loss) - float(z["grand_loss"])) / float(z["grand_loss"]) < 1e-3
+    assert abs(float(syn_lr.grad) - float(z["grad_lr"])) / abs(float(z["grad_lr"])) < 1e-2
+    assert max(per) < 5e-2 and sorted(per)[len(per) // 2] < 2e-3
+    assert abs(float(student_params[-1].detach().double().abs().sum()) / float(z["final_l1"]) - 1) < 1e-5
+
+
+def test_no_torch_conv_kernels_on_the_autograd_path():
+    """The reference-shaped double-backward call must not touch MIOpen / ATen convolution or pooling kernels: profile it
+    with torch.profiler and look at the device kernel names."""
+    from torch.profiler import ProfilerActivity, profile
+    from video_distillation_amd import utils
+    net = _net(11, 4)
+    params = list(net.parameters())
+    g = torch.Generator().manual_seed(110)
+    xs = torch.randn(2, 8, 3, 64, 64, generator=g).cuda().requires_grad_(True)
+    y = torch.tensor([1, 2]).cuda()
+    gw_real = [torch.randn_like(p) for p in params]
+    crit = torch.nn.CrossEntropyLoss()
+    args = types.SimpleNamespace(device="cuda", dis_metric="ours")
+
+    def run():
+        gw = torch.autograd.grad(crit(net(xs), y), params, create_graph=True)
+        utils.match_loss(gw, gw_real, args).backward()
+    run()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        run()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    bad = [n for n in names if any(t in n.lower() for t in ("miopen", "convolution", "conv3d", "conv_depthwise", "max_pool",
+                                                             "avg_pool", "im2col", "col2im", "cudnn", "naive_conv", "gemm", "cijk_"))]
+    ours = [n for n in names if "conv_mfma_kernel" in n]
+    print("device kernels seen:", len(names), "ours:", len(ours), "suspicious:", bad)
+    assert ours, "the MFMA kernels did not show up in the trace"
+    assert not bad, bad
+
+
+def test_cpu_and_foreign_architectures_raise():
+    from video_distillation_amd import networks
+    net = networks.ConvNet3D(3, 5, 128, 3, 'relu', 'none', 'maxpooling', 8, (64, 64))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 8, 3, 64, 64))
+    other = networks.ConvNet3D(3, 5, 128, 3, 'relu', 'instancenorm', 'avgpooling', 8, (64, 64)).cuda()
+    with pytest.raises(NotImplementedError):
+        other(torch.zeros(1, 8, 3, 64, 64).cuda())
+    with pytest.raises(NotImplementedError):
+        other.embed(torch.zeros(1, 8, 3, 64, 64).cuda())

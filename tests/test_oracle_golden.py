@@ -97,6 +97,26 @@ def test_g3_two_dm_steps(golden_dir):
     assert abs(float(syns[1].double().abs().sum()) / float(z["syn2_abs"]) - 1) < 1e-6
 
 
+def test_g12_late_regime_first_steps(golden_dir):
+    """Fixture G12 (24 reference DM iterations in the small-difference regime): the oracle reproduces the first two
+    iterations (loss, pixel gradient, updated clips); the GPU test runs all 24."""
+    z = load(golden_dir, "g12_dm_late.npz")
+    C, B, NP = int(z["C"]), int(z["batch_real"]), int(z["pool_per_class"])
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    base = torch.randn(C, 8, 3, 64, 64, generator=g)
+    pool = torch.stack([base[c] + 0.1 * torch.randn(NP, 8, 3, 64, 64, generator=g) for c in range(C)])
+    syn, buf = pool[:, 0].clone(), None
+    for it in range(2):
+        params = R.init_params(int(z["net_seed0"]) + it)
+        reals = [pool[c, torch.as_tensor(z["picks"][it][c])] for c in range(C)]
+        loss, grad = R.dm_loss_and_grad(params, reals, syn, ipc=1)
+        np.testing.assert_allclose(float(loss), z["losses"][it], rtol=1e-5)
+        close(grad[:, ::2, :, ::4, ::4], z["grads"][it], rtol=1e-4, atol=1e-9)
+        syn, buf = R.sgd_momentum_step(syn, grad, buf, float(z["lr"]), float(z["momentum"]))
+        close(syn[:, ::2, :, ::4, ::4], z["syns"][it])
+    assert 0.03 < float(z["rel_diff"].mean()) < 0.05      # the regime the fixture is about
+
+
 @pytest.mark.parametrize("shards", [[[0, 1], [2]], [[0], [1], [2]]])
 def test_g8_class_sharding_identity(golden_dir, shards):
     z = load(golden_dir, "g3_dm_steps.npz")

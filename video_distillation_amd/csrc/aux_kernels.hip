@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(256) void head_second_order_kernel(
     const float* __restrict__ dropped, const float* __restrict__ mask, const float* __restrict__ w,
     const float* __restrict__ v_w, const float* __restrict__ v_b, const float* __restrict__ gbar_feats, int B, int C, int To,
     int Ho, int Wo, int kt, int kh, int kw, int K, float* __restrict__ abar_feats, float* __restrict__ wbar,
-    float* __restrict__ bbar) {
+    float* __restrict__ bbar, float* __restrict__ dlogbar_out) {
     extern __shared__ float sm[];
     const int Tp = To - kt + 1;
     float* u = sm;                   // [Tp][C]  m * avgpool(gbar_feats), later m * dropbar
@@ -1098,11 +1098,16 @@ __global__ __launch_bounds__(256) void head_second_order_kernel(
         if (mask != nullptr) a *= mask[((int64_t)clip * C + c) * Tp + t];
         u[i] = a;
     }
-    const float* z = logits + (int64_t)clip * K;
-    float m = -3.402823466e38f;
-    for (int k = 0; k < K; ++k) m = fmaxf(m, z[k]);
-    float ssum = 0.f;
-    for (int k = 0; k < K; ++k) ssum += __expf(z[k] - m);
+    // logits == nullptr: no loss Hessian (the caller differentiates its own loss; autograd path of ConvNet3D.forward):
+    // dlogbar is handed out through dlogbar_out and logitbar = 0.
+    const bool hess = (logits != nullptr);
+    const float* z = hess ? logits + (int64_t)clip * K : nullptr;
+    float m = -3.402823466e38f, ssum = 1.f;
+    if (hess) {
+        for (int k = 0; k < K; ++k) m = fmaxf(m, z[k]);
+        ssum = 0.f;
+        for (int k = 0; k < K; ++k) ssum += __expf(z[k] - m);
+    }
     __syncthreads();
     const int32_t* am = amax_t + (int64_t)clip * K;
     const float* dl = dlogits + (int64_t)clip * K;
@@ -1112,17 +1117,18 @@ __global__ __launch_bounds__(256) void head_second_order_kernel(
         const float* dr = dropped + ((int64_t)clip * Tp + t) * C;
         float a = v_b[k];
         for (int c = 0; c < C; ++c) a += w[k * C + c] * u[t * C + c] + v_w[k * C + c] * dr[c];
-        const float p = __expf(z[k] - m) / ssum;
+        const float p = hess ? __expf(z[k] - m) / ssum : 0.f;
         dlb[k] = a;
         pk[k] = p;
         part += p * a;
+        if (dlogbar_out != nullptr) dlogbar_out[(int64_t)clip * K + k] = a;
     }
     __shared__ float dot_s;
     const float dot0 = block_sum(part, red);       // valid in thread 0 only
     if (threadIdx.x == 0) dot_s = dot0;
     __syncthreads();
     const float dot = dot_s;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) dlb[k] = pk[k] * (dlb[k] - dot) / (float)B;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) dlb[k] = hess ? pk[k] * (dlb[k] - dot) / (float)B : 0.f;
     __syncthreads();
     if (wbar != nullptr) {
         // adjoint of the logit conv's own parameters (Hessian-vector product for MTT):
@@ -1156,13 +1162,13 @@ __global__ __launch_bounds__(256) void head_second_order_kernel(
 extern "C" int vd_head_second_order(const float* logits, const float* dlogits, const int32_t* amax_t, const float* dropped,
                                     const float* mask, const float* w, const float* v_w, const float* v_b,
                                     const float* gbar_feats, int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw,
-                                    int K, float* abar_feats, float* wbar, float* bbar, void* stream) {
+                                    int K, float* abar_feats, float* wbar, float* bbar, float* dlogbar_out, void* stream) {
     if (nclips <= 0) return 0;
     if (Ho - kh + 1 != 1 || Wo - kw + 1 != 1 || To - kt + 1 < 1) return -2;
     const size_t lds = ((size_t)(To - kt + 1) * C + 2 * (size_t)K) * sizeof(float);
     hipLaunchKernelGGL(head_second_order_kernel, dim3((unsigned)nclips), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
                        logits, dlogits, amax_t, dropped, mask, w, v_w, v_b, gbar_feats, (int)nclips, C, To, Ho, Wo, kt, kh, kw, K,
-                       abar_feats, wbar, bbar);
+                       abar_feats, wbar, bbar, dlogbar_out);
     return (int)hipGetLastError();
 }
 

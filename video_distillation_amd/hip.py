@@ -79,7 +79,7 @@ def lib() -> ctypes.CDLL:
             if not hasattr(L, name):
                 raise RuntimeError("libvd_hip.so does not export %s" % name)
             getattr(L, name).restype = {"vd_program_info": ctypes.c_int64, "vd_program_free": None}.get(name, ctypes.c_int)
-        if L.vd_abi_version() != 1:
+        if L.vd_abi_version() != 2:
             raise RuntimeError("libvd_hip.so ABI version mismatch")
         _lib = L
     return _lib

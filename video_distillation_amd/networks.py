@@ -14,9 +14,12 @@ Execution
   * ``hip_train_step`` -- one ``epoch('train')`` iteration of ``evaluate_synset`` (forward, CE
     loss, all parameter gradients, SGD with momentum / weight decay) on the HIP path
     (train.TrainEngine: weight gradients are tile programs of the same MFMA kernel).
-  * callers that need double backward (DC / MTT with ``create_graph=True``) or a custom loss on
-    parameter gradients run the same graph through torch-ROCm ops.
-There is no CPU compute path: ``embed`` on a CPU tensor raises.
+  * ``net(x)`` / ``embed(x)`` with parameters that require a gradient are autograd Functions over the same HIP
+    passes, differentiable TWICE: ``torch.autograd.grad(criterion(net(x), y), params, create_graph=True)`` -- the
+    reference's DC / MTT call (distill_baseline.py:250) -- and a ``backward()`` through a loss on those gradients run
+    train.GradMatchEngine's first- and second-order passes (``_FeatFunction`` / ``_HeadFunction``).
+  * ``ReparamModule`` -- the flat-parameter wrapper of reparam_module.py (``forward(x, flat_param=...)``).
+There is no CPU and no torch-op (eager) compute path: CPU tensors and non-default architectures raise.
 """
 from __future__ import annotations
 
@@ -144,6 +147,102 @@ class _ParamGradFunction(torch.autograd.Function):
         return ctx.te.vjp(ctx.state, v, list(net.parameters())), None, None, None
 
 
+def _zeros_like_or(t, ref):
+    return torch.zeros_like(ref) if t is None else t
+
+
+class _FeatFunction(torch.autograd.Function):
+    """features = embed(x; w0,b0,w1,b1,w2,b2), differentiable w.r.t. the clips AND the parameters, twice."""
+
+    @staticmethod
+    def forward(ctx, x, net, *params6):
+        te = net._gm_engine(x)
+        feats, fs = te.ag_feat_forward(x, params6)
+        ctx.te, ctx.fs = te, fs
+        ctx.save_for_backward(x, *params6)
+        return feats
+
+    @staticmethod
+    def backward(ctx, g):
+        x, *params6 = ctx.saved_tensors
+        need_dx, need_p = ctx.needs_input_grad[0], any(ctx.needs_input_grad[2:])
+        outs = _FeatBackward.apply(g, x, ctx.te, ctx.fs, need_dx, need_p, torch.is_grad_enabled(), *params6)
+        return (outs[0], None) + tuple(outs[1:])
+
+
+class _FeatBackward(torch.autograd.Function):
+    """(dx, dw0, db0, dw1, db1, dw2, db2) = backward of the conv levels for g_feat; its own backward is the second-order
+    pass (train.GradMatchEngine.ag_feat_second_order): adjoints of g_feat, x and the parameters for adjoints of the six
+    parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, g_feat, x, te, fs, need_dx, need_p, keep, *params6):
+        dx, g, bs = te.ag_feat_backward(fs, g_feat, params6, need_dx, need_p, keep)
+        ctx.te, ctx.fs, ctx.bs = te, fs, bs
+        ctx.save_for_backward(x, *params6)
+        ctx.set_materialize_grads(False)
+        return (dx,) + (tuple(g) if g is not None else (None,) * 6)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, vx, *v6):
+        if vx is not None:
+            raise NotImplementedError("ConvNet3D: second derivative through the INPUT gradient is not built "
+                                      "(only through the parameter gradients, which is what DC / MTT need)")
+        if ctx.bs is None:
+            raise RuntimeError("ConvNet3D: double backward needs the first backward to run with create_graph=True")
+        x, *params6 = ctx.saved_tensors
+        if all(t is None for t in v6):
+            return (None,) * (7 + 6)
+        gbar3, xbar, hv = ctx.te.ag_feat_second_order(ctx.fs, ctx.bs, v6, params6, any(ctx.needs_input_grad[7:]))
+        return (gbar3, xbar, None, None, None, None, None) + (tuple(hv) if hv is not None else (None,) * 6)
+
+
+class _HeadFunction(torch.autograd.Function):
+    """logits = max_t conv1x1x1(dropout(avgpool(features)))  (networks.py:741-745), twice differentiable."""
+
+    @staticmethod
+    def forward(ctx, feats, mask, te, w, b):
+        hs = te.head_forward(feats.detach().to(torch.float32).contiguous(), mask, w, b)
+        ctx.te, ctx.hs = te, hs
+        ctx.save_for_backward(feats, w)
+        return hs["logits"]
+
+    @staticmethod
+    def backward(ctx, dlog):
+        feats, w = ctx.saved_tensors
+        g_feat, g_w, g_b = _HeadBackward.apply(dlog, feats, w, ctx.te, ctx.hs)
+        return g_feat, None, None, g_w, g_b
+
+
+class _HeadBackward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dlog, feats, w, te, hs):
+        dlog = dlog.detach().to(torch.float32).contiguous()
+        g_w = torch.zeros((te.K, te.C), dtype=torch.float32, device=dlog.device)
+        g_b = torch.zeros(te.K, dtype=torch.float32, device=dlog.device)
+        g_feat = te.head_backward(hs, dlog, g_w, g_b)
+        ctx.te, ctx.hs = te, hs
+        ctx.save_for_backward(dlog, feats, w)
+        ctx.set_materialize_grads(False)
+        return g_feat, g_w.view(w.shape), g_b
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gbar_feat, v_w, v_b):
+        dlog, feats, w = ctx.saved_tensors
+        te = ctx.te
+        if gbar_feat is None and v_w is None and v_b is None:
+            return None, None, None, None, None
+        gbar_feat = torch.zeros_like(feats) if gbar_feat is None else gbar_feat.detach().to(torch.float32).contiguous()
+        v_w = (torch.zeros((te.K, te.C), dtype=torch.float32, device=dlog.device) if v_w is None
+               else v_w.detach().to(torch.float32).reshape(te.K, te.C).contiguous())
+        v_b = torch.zeros(te.K, dtype=torch.float32, device=dlog.device) if v_b is None else v_b.detach().to(torch.float32).contiguous()
+        abar, wbar, _, dlogbar = te.head_second_order(ctx.hs, dlog, gbar_feat, v_w, v_b, want_params=True, hessian=False)
+        return dlogbar, abar, wbar.view(w.shape), None, None
+
+
+
 class ConvNet3D(nn.Module):
     def __init__(self, channel, num_classes, net_width, net_depth, net_act, net_norm, net_pooling, frames,
                  im_size=(32, 32), dropout_keep_prob=0.5):
@@ -228,21 +327,28 @@ class ConvNet3D(nn.Module):
             eng.set_weights(self._feature_params(), quantize=quantize)
             eng._owner_key = (id(self), key)
 
-    def _use_hip(self, x) -> bool:
-        if not self._hip_ok or not x.is_cuda:
-            return False
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self._feature_params()):
-            return False   # parameter gradients / double backward: torch-ROCm ops (section 8(f)-1)
-        return True
+    def _all_params(self):
+        """The 8 tensors in parameters() order, read by ATTRIBUTE: under ReparamModule they are views of the flat
+        parameter set as plain attributes (reparam_module.py:110-115), not registered nn.Parameters."""
+        return self._feature_params() + [self.logit.weight, self.logit.bias]
+
+    def _check_hip(self, x, what: str) -> None:
+        if not x.is_cuda:
+            raise RuntimeError("video_distillation_amd.ConvNet3D.%s has no CPU path: move the clips to a HIP "
+                               "device (the CPU restatement lives in oracle/, for tests only)" % what)
+        if not self._hip_ok:
+            raise NotImplementedError("ConvNet3D.%s: only get_network('ConvNet3D')'s architecture (3 input channels, width "
+                                      "128, depth 3, ReLU, no norm, max pooling; utils.py:608) has a HIP path, and there "
+                                      "is no torch-op fallback" % what)
 
     def embed(self, x):
-        if not x.is_cuda:
-            raise RuntimeError("video_distillation_amd.ConvNet3D.embed has no CPU path: move the clips to a HIP "
-                               "device (the CPU restatement lives in oracle/, for tests only)")
-        if self._use_hip(x):
-            return _EmbedFunction.apply(x, self)
-        out = self.features(x.permute(0, 2, 1, 3, 4))
-        return out.view(out.size(0), -1)
+        """networks.py:747-751.  Frozen parameters (the DM loop, distill_baseline.py:336-349): mixed-precision fast path,
+        gradient to the clips only.  Parameters that require a gradient: the twice-differentiable path."""
+        self._check_hip(x, "embed")
+        params = self._feature_params()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _FeatFunction.apply(x, self, *params)
+        return _EmbedFunction.apply(x, self)
 
     def _infer_hip(self, x):
         """Inference logits on the HIP path: MFMA features + fused head kernel (avg-pool, 1x1x1
@@ -352,9 +458,14 @@ class ConvNet3D(nn.Module):
         return logits, loss
 
     def forward(self, x):
-        if (self._hip_ok and x.is_cuda and not self.training and not torch.is_grad_enabled()):
+        """networks.py:738-745 on the HIP path.  Evaluation without gradient: MFMA features + fused head kernel.
+        Otherwise (training mode, or anything requires a gradient): ``_FeatFunction`` + ``_HeadFunction`` -- logits that
+        are differentiable w.r.t. clips and parameters, twice (``create_graph=True``, distill_baseline.py:250)."""
+        self._check_hip(x, "forward")
+        params = self._all_params()
+        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        if not need and not self.training:
             return self._infer_hip(x)
-        out = self.features(x.permute(0, 2, 1, 3, 4))
-        out = self.logit(self.dropout(self.avg_pool(out)))
-        logits = out.squeeze(3).squeeze(3)
-        return torch.max(logits, 2)[0]
+        te = self._gm_engine(x)
+        feats = _FeatFunction.apply(x, self, *params[:6])
+        return _HeadFunction.apply(feats, self._dropout_mask(x, te), te, params[6], params[7])

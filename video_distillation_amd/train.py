@@ -79,6 +79,85 @@ class TrainEngine:
         return feats, nb, (am0, am1, am2)
 
     # ------------------------------------------------------------------------------------
+    def _acts(self, nb: int):
+        eng = self.eng
+        per1 = int(np.prod(eng.fwd[0].plan.out_shape[:-1]))
+        per2 = int(np.prod(eng.fwd[1].plan.out_shape[:-1]))
+        acts = [None, eng._buf("act1", (eng.planes, nb * per1, 8), torch.int16),
+                eng._buf("act2", (eng.planes, nb * per2, 8), torch.int16)]
+        return acts, [0, nb * per1, nb * per2]
+
+    def head_forward(self, feats: torch.Tensor, mask: Optional[torch.Tensor], w: torch.Tensor, b: torch.Tensor) -> dict:
+        """AvgPool3d -> dropout mask -> 1x1x1 conv -> max over frames (networks.py:741-745) of (B, num_feat) features.
+        Returns the head state {logits, dropped, amt, mask, wl, bl}."""
+        L, st = hip.lib(), hip.stream_ptr(self.device)
+        B = int(feats.shape[0])
+        wl = w.detach().reshape(self.K, self.C).to(torch.float32).contiguous()
+        bl = b.detach().to(torch.float32).contiguous()
+        kt, kh, kw = self.pool_kernel
+        dropped = torch.empty((B, self.Tp, self.C), dtype=torch.float32, device=self.device)
+        logits = torch.empty((B, self.K), dtype=torch.float32, device=self.device)
+        amt = torch.empty((B, self.K), dtype=torch.int32, device=self.device)
+        if mask is not None:
+            mask = mask.to(self.device, torch.float32).contiguous()
+            assert tuple(mask.shape) == (B, self.C, self.Tp), mask.shape
+        hip.check(L.vd_head_train_fwd(hip.ptr(feats), hip.ptr(mask), hip.ptr(wl), hip.ptr(bl), ctypes.c_int64(B), self.C,
+                                      self.To, self.Ho, self.Wo, kt, kh, kw, self.K, hip.ptr(dropped), hip.ptr(logits),
+                                      hip.ptr(amt), st), "vd_head_train_fwd")
+        return dict(logits=logits, dropped=dropped, amt=amt, mask=mask, wl=wl, bl=bl)
+
+    def head_backward(self, hs: dict, dlog: torch.Tensor, g_w: torch.Tensor, g_b: torch.Tensor) -> torch.Tensor:
+        """Backward of ``head_forward`` for the logit gradient ``dlog`` (B,K): accumulates into g_w / g_b (zeroed by the
+        caller), returns the feature gradient (B, num_feat)."""
+        L, st = hip.lib(), hip.stream_ptr(self.device)
+        B = int(dlog.shape[0])
+        kt, kh, kw = self.pool_kernel
+        g_feat = torch.empty((B, self.eng.num_feat), dtype=torch.float32, device=self.device)
+        hip.check(L.vd_head_train_bwd(hip.ptr(dlog), hip.ptr(hs["amt"]), hip.ptr(hs["dropped"]), hip.ptr(hs["mask"]),
+                                      hip.ptr(hs["wl"]), ctypes.c_int64(B), self.C, self.To, self.Ho, self.Wo, kt, kh, kw,
+                                      self.K, hip.ptr(g_w), hip.ptr(g_b), hip.ptr(g_feat), st), "vd_head_train_bwd")
+        return g_feat
+
+    def feat_backward(self, x: torch.Tensor, nb: int, am, g_feat: torch.Tensor, g: Optional[Sequence[torch.Tensor]],
+                      dx: Optional[torch.Tensor] = None) -> None:
+        """Backward of the three conv levels for the feature gradient ``g_feat`` (nb, num_feat): per layer, last to
+        first, un-pool + ReLU backward, bias gradient, weight gradient (accumulated into g[0..5], zeroed by the caller;
+        skipped when ``g`` is None) and the input-gradient passes (down to the pixels, into ``dx``, when given).  The
+        engine's weights / packed dgrad operands must be current; activations are read from the engine workspace."""
+        eng, L, st = self.eng, hip.lib(), hip.stream_ptr(self.device)
+        acts, act_plane = self._acts(nb)
+        grad, layout = g_feat, 0
+        scaled = eng.prec_bwd in (hip.PREC["f16"], hip.PREC["f16x3"])
+        for li in (2, 1, 0):
+            cin, cout, t, h, w, T, OH, OW, To, Ho, Wo, pt = eng.dims[li]
+            nslots = nb * (cout // 8) * T * OH * OW
+            dy = eng._buf("dy%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)
+            lo = dy[1] if eng.planes_bwd == 2 else None
+            sc = inv = None
+            if scaled:
+                scb = eng._buf("gscale%d" % li, (4,), torch.float32)
+                hip.check(L.vd_absmax_scale(hip.ptr(grad), ctypes.c_int64(grad.numel()), ctypes.c_float(1024.0),
+                                            hip.ptr(scb), st), "vd_absmax_scale")
+                sc, inv = scb, scb[1:]
+            hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout, To, Ho, Wo, pt, T, OH, OW,
+                                           layout, hip.ptr(dy[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(sc), st),
+                      "vd_unpool_relu_bwd")
+            if g is not None:
+                # bias gradient from the pooled gradient (the dense dy has one non-zero per live pool window)
+                hip.check(L.vd_bias_grad_pooled(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout,
+                                                ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(g[2 * li + 1]), st),
+                          "vd_bias_grad_pooled")
+                op = self._wgrad(li, nb)
+                if li == 0:
+                    op.run(x, True, 0, dy, nslots, g[0], out_scale=inv)
+                else:
+                    op.run(acts[li], False, act_plane[li], dy, nslots, g[2 * li], out_scale=inv)
+            if li > 0 or dx is not None:
+                out = dx if li == 0 else eng._buf("dx%d" % li, (nb, t, h, w, cin), torch.float32)
+                for dp in eng.bwd[li]:
+                    dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb, out_scale=inv)
+                grad, layout = out, 1
+
     def loss_and_grads(self, x: torch.Tensor, labels: torch.Tensor, params: Sequence[torch.Tensor],
                        mask: Optional[torch.Tensor] = None, state: Optional[dict] = None):
         """x (B,T,3,H,W) fp32 (already standardised), labels (B,) int64, params = the 8 network
@@ -93,67 +172,20 @@ class TrainEngine:
         for li in (1, 2):
             for dp in eng.bwd[li]:
                 dp.pack(eng._weights[2 * li])
-        feats, nb, (am0, am1, am2) = self._forward(x, params)
-        per1 = int(np.prod(eng.fwd[0].plan.out_shape[:-1]))
-        per2 = int(np.prod(eng.fwd[1].plan.out_shape[:-1]))
-        acts = [None, eng._buf("act1", (eng.planes, nb * per1, 8), torch.int16),
-                eng._buf("act2", (eng.planes, nb * per2, 8), torch.int16)]
-        act_plane = [0, nb * per1, nb * per2]
-
-        wl = params[6].detach().reshape(self.K, self.C).to(torch.float32).contiguous()
-        bl = params[7].detach().to(torch.float32).contiguous()
-        kt, kh, kw = self.pool_kernel
-        dropped = torch.empty((B, self.Tp, self.C), dtype=torch.float32, device=self.device)
-        logits = torch.empty((B, self.K), dtype=torch.float32, device=self.device)
-        amt = torch.empty((B, self.K), dtype=torch.int32, device=self.device)
-        if mask is not None:
-            mask = mask.to(self.device, torch.float32).contiguous()
-            assert tuple(mask.shape) == (B, self.C, self.Tp), mask.shape
-        hip.check(L.vd_head_train_fwd(hip.ptr(feats), hip.ptr(mask), hip.ptr(wl), hip.ptr(bl), ctypes.c_int64(B), self.C,
-                                      self.To, self.Ho, self.Wo, kt, kh, kw, self.K, hip.ptr(dropped), hip.ptr(logits),
-                                      hip.ptr(amt), st), "vd_head_train_fwd")
+        feats, nb, am = self._forward(x, params)
+        hs = self.head_forward(feats, mask, params[6], params[7])
+        logits = hs["logits"]
         loss_c = torch.empty(B, dtype=torch.float32, device=self.device)
         dlog = torch.empty((B, self.K), dtype=torch.float32, device=self.device)
         hip.check(L.vd_ce_loss(hip.ptr(logits), hip.ptr(labels), B, self.K, hip.ptr(loss_c), hip.ptr(dlog), st), "vd_ce_loss")
         self.gflat.zero_()
         g = self.grads()
-        g_feat = torch.empty((B, eng.num_feat), dtype=torch.float32, device=self.device)
-        hip.check(L.vd_head_train_bwd(hip.ptr(dlog), hip.ptr(amt), hip.ptr(dropped), hip.ptr(mask), hip.ptr(wl),
-                                      ctypes.c_int64(B), self.C, self.To, self.Ho, self.Wo, kt, kh, kw, self.K,
-                                      hip.ptr(g[6]), hip.ptr(g[7]), hip.ptr(g_feat), st), "vd_head_train_bwd")
-
-        grad, layout = g_feat, 0
-        scaled = eng.prec_bwd in (hip.PREC["f16"], hip.PREC["f16x3"])
-        for li, am in ((2, am2), (1, am1), (0, am0)):
-            cin, cout, t, h, w, T, OH, OW, To, Ho, Wo, pt = eng.dims[li]
-            nslots = nb * (cout // 8) * T * OH * OW
-            dy = eng._buf("dy%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)
-            lo = dy[1] if eng.planes_bwd == 2 else None
-            sc = inv = None
-            if scaled:
-                scb = eng._buf("gscale%d" % li, (4,), torch.float32)
-                hip.check(L.vd_absmax_scale(hip.ptr(grad), ctypes.c_int64(grad.numel()), ctypes.c_float(1024.0),
-                                            hip.ptr(scb), st), "vd_absmax_scale")
-                sc, inv = scb, scb[1:]
-            hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am), ctypes.c_int64(nb), cout, To, Ho, Wo, pt, T, OH, OW,
-                                           layout, hip.ptr(dy[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(sc), st),
-                      "vd_unpool_relu_bwd")
-            # bias gradient from the pooled gradient (the dense dy has one non-zero per live pool window)
-            hip.check(L.vd_bias_grad_pooled(hip.ptr(grad), hip.ptr(am), ctypes.c_int64(nb), cout, ctypes.c_int64(To * Ho * Wo),
-                                            layout, hip.ptr(g[2 * li + 1]), st), "vd_bias_grad_pooled")
-            op = self._wgrad(li, nb)
-            if li == 0:
-                op.run(x, True, 0, dy, nslots, g[0], out_scale=inv)
-            else:
-                op.run(acts[li], False, act_plane[li], dy, nslots, g[2 * li], out_scale=inv)
-            if li > 0:
-                out = eng._buf("dx%d" % li, (nb, t, h, w, cin), torch.float32)
-                for dp in eng.bwd[li]:
-                    dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb, out_scale=inv)
-                grad, layout = out, 1
+        g_feat = self.head_backward(hs, dlog, g[6], g[7])
+        self.feat_backward(x, nb, am, g_feat, g)
         if state is not None:
-            state.update(nb=nb, am=(am0, am1, am2), dropped=dropped, logits=logits, dlog=dlog, amt=amt, mask=mask,
-                         wl=wl, act_plane=act_plane, x=x)
+            _, act_plane = self._acts(nb)
+            state.update(nb=nb, am=am, dropped=hs["dropped"], logits=logits, dlog=dlog, amt=hs["amt"], mask=hs["mask"],
+                         wl=hs["wl"], act_plane=act_plane, x=x)
         return loss_c.mean(), logits, g
 
     # ------------------------------------------------------------------------------------
@@ -253,93 +285,192 @@ class GradMatchEngine(TrainEngine):
             state["ws"], eng._ws = eng._ws, keep_ws
         return loss, logits, g, state
 
+    # -- pieces of the adjoint sweep (shared by the fused ``vjp`` and the autograd path of ConvNet3D.forward) ----------
+    def _pack_adjoint(self, W: Sequence[torch.Tensor], V: Sequence[torch.Tensor]) -> None:
+        eng = self.eng
+        for li in range(3):
+            for dp in eng.bwd[li]:
+                dp.pack(W[2 * li])
+            for dp in self.bwdV[li]:
+                dp.pack(V[2 * li])
+        self.sel[0].pack(V[0])
+        for li in (1, 2):
+            self.sel[li].pack(torch.cat([V[2 * li], W[2 * li]], dim=1).contiguous())
+
+    def _sweep_bufs(self, nb: int):
+        eng, geo = self.eng, self.geo
+        rowp = P.pix_row_pitch(geo.width)
+        n_slots0 = nb * geo.frames * 3 * geo.height * (rowp // 8)
+        per1 = int(np.prod(eng.fwd[0].plan.out_shape[:-1]))
+        per2 = int(np.prod(eng.fwd[1].plan.out_shape[:-1]))
+        n1, n2 = nb * per1, nb * per2
+        slots0 = eng._buf("slots0", (eng.planes, n_slots0, 8), torch.int16)
+        act1 = eng._buf("act1", (eng.planes, n1, 8), torch.int16)
+        act2 = eng._buf("act2", (eng.planes, n2, 8), torch.int16)
+        gbar1 = eng._buf("gbar1", (eng.planes, n1, 8), torch.int16)
+        gbar2 = eng._buf("gbar2", (eng.planes, n2, 8), torch.int16)
+        return n_slots0, n1, n2, slots0, act1, act2, gbar1, gbar2
+
+    def _up_sweep(self, nb: int, am, V: Sequence[torch.Tensor]) -> torch.Tensor:
+        """gbar_{l+1} = P_l (conv(a_l, V_l) + vb_l + conv(gbar_l, W_l)), gbar_0 = 0  ->  gbar_3 (nb, num_feat): the tangent
+        of the features in the parameter direction V, equally the adjoint of the feature gradient."""
+        eng = self.eng
+        n_slots0, n1, n2, slots0, act1, act2, gbar1, gbar2 = self._sweep_bufs(nb)
+        gbar3 = torch.empty((nb, eng.num_feat), dtype=torch.float32, device=self.device)
+        self.sel[0].run(slots0, n_slots0, V[1], gbar1.data_ptr(), n1, am[0], nb)
+        for dp, a, gb in ((self.sel[1], act1, gbar1), (self.sel[2], act2, gbar2)):
+            off = gb.data_ptr() - a.data_ptr()
+            assert off % 4 == 0
+            dp.params.src_split_off4 = off // 4
+        self.sel[1].run(act1, n1, V[3], gbar2.data_ptr(), n2, am[1], nb)
+        self.sel[2].run(act2, n2, V[5], gbar3.data_ptr(), 0, am[2], nb)
+        return gbar3
+
+    def _down_sweep(self, nb: int, am, abar: torch.Tensor, x: torch.Tensor, hv: Optional[Sequence[torch.Tensor]]) -> torch.Tensor:
+        """abar_l = convT(P_l^T abar_{l+1}, W_l) + convT(dz_l, V_l) from abar_3 = ``abar`` down to the pixels; with ``hv`` the
+        parameter side (weight / bias adjoints of the three conv levels) is accumulated into hv[0..5]."""
+        eng, geo, L, st = self.eng, self.geo, hip.lib(), hip.stream_ptr(self.device)
+        _, n1, n2, _, act1, act2, gbar1, gbar2 = self._sweep_bufs(nb)
+        dx = torch.empty((nb, geo.frames, geo.channel, geo.height, geo.width), dtype=torch.float32, device=self.device)
+        grad, layout = abar, 0
+        for li in (2, 1, 0):
+            cin, cout, t, h, w, T, OH, OW, To, Ho, Wo, pt = eng.dims[li]
+            nslots = nb * (cout // 8) * T * OH * OW
+            dy = eng._buf("dy%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)       # dz_l of the first-order pass
+            zb = eng._buf("zb%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)
+            lo = zb[1] if eng.planes_bwd == 2 else None
+            hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout, To, Ho, Wo, pt, T, OH,
+                                           OW, layout, hip.ptr(zb[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(None), st),
+                      "vd_unpool_relu_bwd")
+            out = dx if li == 0 else eng._buf("ax%d" % li, (nb, t, h, w, cin), torch.float32)
+            for dp in eng.bwd[li]:
+                dp.run(zb, nslots, None, out.data_ptr(), 0, None, nb)
+            for dp in self.bwdV[li]:
+                dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb)
+            if hv:
+                # parameter side: z_l = conv(a_l, W_l) + b_l carries zbar_l, and g_{a_l} = convT(dz_l, W_l) carries gbar_l
+                op = self._wgrad(li, nb)
+                hip.check(L.vd_bias_grad_pooled(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout,
+                                                ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(hv[2 * li + 1]), st),
+                          "vd_bias_grad_pooled")
+                if li == 0:
+                    op.run(x, True, 0, zb, nslots, hv[0])
+                else:
+                    a_l, g_l, n_l = (act1, gbar1, n1) if li == 1 else (act2, gbar2, n2)
+                    op.run(a_l, False, n_l, zb, nslots, hv[2 * li])
+                    op.run(g_l, False, n_l, dy, nslots, hv[2 * li])
+            grad, layout = out, 1
+        return dx
+
+    def _views(self, n_tensors: int):
+        flat = torch.zeros(sum(self.sizes[:n_tensors]), dtype=torch.float32, device=self.device)
+        out, o = [], 0
+        for shp, n in zip(self.shapes[:n_tensors], self.sizes[:n_tensors]):
+            out.append(flat[o:o + n].view(*shp))
+            o += n
+        return out
+
+    def head_second_order(self, hs: dict, dlog: torch.Tensor, gbar_feat: torch.Tensor, v_w: torch.Tensor, v_b: torch.Tensor,
+                          want_params: bool, hessian: bool):
+        """Second-order pass through the head.  ``hessian``: fused with the Hessian of the mean cross-entropy (dlog must
+        then be that loss's own logit gradient) -- the trainers' path; otherwise the adjoint of ``dlog`` is returned
+        for the caller's loss to chain through.  -> (abar_feats, wbar, bbar, dlogbar)."""
+        L, st = hip.lib(), hip.stream_ptr(self.device)
+        nb = int(dlog.shape[0])
+        kt, kh, kw = self.pool_kernel
+        abar = torch.empty((nb, self.eng.num_feat), dtype=torch.float32, device=self.device)
+        wbar = torch.zeros((self.K, self.C), dtype=torch.float32, device=self.device) if want_params else None
+        bbar = torch.zeros(self.K, dtype=torch.float32, device=self.device) if want_params else None
+        dlogbar = None if hessian else torch.empty((nb, self.K), dtype=torch.float32, device=self.device)
+        hip.check(L.vd_head_second_order(hip.ptr(hs["logits"] if hessian else None), hip.ptr(dlog), hip.ptr(hs["amt"]),
+                                         hip.ptr(hs["dropped"]), hip.ptr(hs["mask"]), hip.ptr(hs["wl"]), hip.ptr(v_w),
+                                         hip.ptr(v_b), hip.ptr(gbar_feat), ctypes.c_int64(nb), self.C, self.To, self.Ho, self.Wo,
+                                         kt, kh, kw, self.K, hip.ptr(abar), hip.ptr(wbar), hip.ptr(bbar), hip.ptr(dlogbar), st),
+                  "vd_head_second_order")
+        return abar, wbar, bbar, dlogbar
+
     def vjp(self, state: dict, v: Sequence[Optional[torch.Tensor]], params: Sequence[torch.Tensor],
             param_adjoint: bool = False):
         """d (sum_i <v_i, g_i(x)>) / dx for the ``param_grads`` call that produced ``state``.  With
         ``param_adjoint`` also d (sum_i <v_i, g_i>) / d params -- the Hessian-vector product H v of the
         CE loss w.r.t. the parameters (MTT's unrolled inner loop) -- returned as (dx, [8 tensors])."""
-        eng, L, st = self.eng, hip.lib(), hip.stream_ptr(self.device)
-        geo = self.geo
-        nb = state["nb"]
-        am = state["am"]
+        eng = self.eng
+        nb, am = state["nb"], state["am"]
         W = [p.detach().to(self.device, torch.float32).contiguous() for p in params]
         V = [torch.zeros_like(w) if t is None else t.detach().to(self.device, torch.float32).contiguous().view_as(w)
              for t, w in zip(v, W)]
         keep_ws, eng._ws = eng._ws, state["ws"]
         try:
-            for li in range(3):
-                for dp in eng.bwd[li]:
-                    dp.pack(W[2 * li])
-                for dp in self.bwdV[li]:
-                    dp.pack(V[2 * li])
-            self.sel[0].pack(V[0])
-            for li in (1, 2):
-                self.sel[li].pack(torch.cat([V[2 * li], W[2 * li]], dim=1).contiguous())
-            rowp = P.pix_row_pitch(geo.width)
-            n_slots0 = nb * geo.frames * 3 * geo.height * (rowp // 8)
-            per1 = int(np.prod(eng.fwd[0].plan.out_shape[:-1]))
-            per2 = int(np.prod(eng.fwd[1].plan.out_shape[:-1]))
-            n1, n2 = nb * per1, nb * per2
-            slots0 = eng._buf("slots0", (eng.planes, n_slots0, 8), torch.int16)
-            act1 = eng._buf("act1", (eng.planes, n1, 8), torch.int16)
-            act2 = eng._buf("act2", (eng.planes, n2, 8), torch.int16)
-            gbar1 = eng._buf("gbar1", (eng.planes, n1, 8), torch.int16)
-            gbar2 = eng._buf("gbar2", (eng.planes, n2, 8), torch.int16)
-            gbar3 = torch.empty((nb, eng.num_feat), dtype=torch.float32, device=self.device)
-            hv = None
-            if param_adjoint:
-                hflat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=self.device)
-                hv, o = [], 0
-                for shp, n in zip(self.shapes, self.sizes):
-                    hv.append(hflat[o:o + n].view(*shp))
-                    o += n
-            # ---- upward sweep -------------------------------------------------------------
-            self.sel[0].run(slots0, n_slots0, V[1], gbar1.data_ptr(), n1, am[0], nb)
-            for dp, a, gb in ((self.sel[1], act1, gbar1), (self.sel[2], act2, gbar2)):
-                off = gb.data_ptr() - a.data_ptr()
-                assert off % 4 == 0
-                dp.params.src_split_off4 = off // 4
-            self.sel[1].run(act1, n1, V[3], gbar2.data_ptr(), n2, am[1], nb)
-            self.sel[2].run(act2, n2, V[5], gbar3.data_ptr(), 0, am[2], nb)
-            # ---- head -----------------------------------------------------------------------
-            kt, kh, kw = self.pool_kernel
-            abar = torch.empty((nb, eng.num_feat), dtype=torch.float32, device=self.device)
-            vw = V[6].reshape(self.K, self.C).contiguous()
-            hip.check(L.vd_head_second_order(hip.ptr(state["logits"]), hip.ptr(state["dlog"]), hip.ptr(state["amt"]),
-                                             hip.ptr(state["dropped"]), hip.ptr(state["mask"]), hip.ptr(state["wl"]), hip.ptr(vw),
-                                             hip.ptr(V[7]), hip.ptr(gbar3), ctypes.c_int64(nb), self.C, self.To, self.Ho, self.Wo,
-                                             kt, kh, kw, self.K, hip.ptr(abar), hip.ptr(hv[6] if hv else None),
-                                             hip.ptr(hv[7] if hv else None), st), "vd_head_second_order")
-            # ---- downward sweep -------------------------------------------------------------
-            dx = torch.empty((nb, geo.frames, geo.channel, geo.height, geo.width), dtype=torch.float32, device=self.device)
-            grad, layout = abar, 0
-            for li in (2, 1, 0):
-                cin, cout, t, h, w, T, OH, OW, To, Ho, Wo, pt = eng.dims[li]
-                nslots = nb * (cout // 8) * T * OH * OW
-                dy = eng._buf("dy%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)       # dz_l of the first-order pass
-                zb = eng._buf("zb%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)
-                lo = zb[1] if eng.planes_bwd == 2 else None
-                hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout, To, Ho, Wo, pt, T, OH,
-                                               OW, layout, hip.ptr(zb[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(None), st),
-                          "vd_unpool_relu_bwd")
-                out = dx if li == 0 else eng._buf("ax%d" % li, (nb, t, h, w, cin), torch.float32)
-                for dp in eng.bwd[li]:
-                    dp.run(zb, nslots, None, out.data_ptr(), 0, None, nb)
-                for dp in self.bwdV[li]:
-                    dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb)
-                if hv:
-                    # parameter side: z_l = conv(a_l, W_l) + b_l carries zbar_l, and g_{a_l} = convT(dz_l, W_l) carries gbar_l
-                    op = self._wgrad(li, nb)
-                    hip.check(L.vd_bias_grad_pooled(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout,
-                                                    ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(hv[2 * li + 1]), st),
-                              "vd_bias_grad_pooled")
-                    if li == 0:
-                        op.run(state["x"], True, 0, zb, nslots, hv[0])
-                    else:
-                        a_l, g_l, n_l = (act1, gbar1, n1) if li == 1 else (act2, gbar2, n2)
-                        op.run(a_l, False, n_l, zb, nslots, hv[2 * li])
-                        op.run(g_l, False, n_l, dy, nslots, hv[2 * li])
-                grad, layout = out, 1
+            self._pack_adjoint(W, V)
+            hv = self._views(8) if param_adjoint else None
+            gbar3 = self._up_sweep(nb, am, V)
+            abar, wbar, bbar, _ = self.head_second_order(state, state["dlog"], gbar3, V[6].reshape(self.K, self.C).contiguous(),
+                                                         V[7], param_adjoint, hessian=True)
+            if hv:
+                hv[6].view(self.K, self.C).copy_(wbar)
+                hv[7].copy_(bbar)
+            dx = self._down_sweep(nb, am, abar, state["x"], hv)
         finally:
             eng._ws = keep_ws
         return (dx, hv) if param_adjoint else dx
+
+    # -- autograd path: every piece as its own call with caller-held state (networks._FeatFunction / _HeadFunction) --------
+    _KEEP = ("act1", "act2", "slots0")
+
+    def ag_feat_forward(self, x: torch.Tensor, params6: Sequence[torch.Tensor]):
+        """features (B, num_feat) of the clips with the activations / arg-max of all levels kept -> (feats, fstate)."""
+        eng = self.eng
+        x = x.detach().to(self.device, torch.float32).contiguous()
+        keep_ws, eng._ws = eng._ws, {}
+        try:
+            feats, nb, am = self._forward(x, [p.detach() for p in params6])
+            ws = eng._ws
+        finally:
+            eng._ws = keep_ws
+        return feats, dict(ws=ws, nb=nb, am=am, x=x)
+
+    def ag_feat_backward(self, fs: dict, g_feat: torch.Tensor, params6: Sequence[torch.Tensor], need_dx: bool,
+                         need_params: bool, keep: bool):
+        """First-order backward of the conv levels: -> (dx or None, [6 parameter gradients] or None, bstate).  ``keep``:
+        the first-order gradients at the conv outputs stay in bstate for ``ag_feat_second_order`` (create_graph)."""
+        eng = self.eng
+        ws = {k: v for k, v in fs["ws"].items() if k in self._KEEP}
+        if not keep:
+            ws.update(getattr(self, "_scratch", {}))
+        W = [p.detach().to(self.device, torch.float32).contiguous() for p in params6]
+        keep_ws, eng._ws = eng._ws, ws
+        try:
+            for li in ((0, 1, 2) if need_dx else (1, 2)):
+                for dp in eng.bwd[li]:
+                    dp.pack(W[2 * li])
+            g = self._views(6) if need_params else None
+            geo = self.geo
+            dx = torch.empty((fs["nb"], geo.frames, geo.channel, geo.height, geo.width), dtype=torch.float32,
+                             device=self.device) if need_dx else None
+            self.feat_backward(fs["x"], fs["nb"], fs["am"], g_feat.detach().to(torch.float32).contiguous(), g, dx)
+        finally:
+            eng._ws = keep_ws
+        if not keep:
+            self._scratch = {k: v for k, v in ws.items() if k not in self._KEEP}
+            return dx, g, None
+        return dx, g, dict(ws=ws)
+
+    def ag_feat_second_order(self, fs: dict, bs: dict, v6: Sequence[Optional[torch.Tensor]], params6: Sequence[torch.Tensor],
+                             need_params: bool):
+        """Adjoints of an ``ag_feat_backward`` call for the adjoints ``v6`` of its six parameter gradients:
+        -> (adjoint of g_feat (nb, num_feat), adjoint of x, [6 parameter adjoints] or None)."""
+        eng = self.eng
+        nb, am = fs["nb"], fs["am"]
+        W = [p.detach().to(self.device, torch.float32).contiguous() for p in params6]
+        V = [torch.zeros_like(w) if t is None else t.detach().to(self.device, torch.float32).contiguous().view_as(w)
+             for t, w in zip(v6, W)]
+        keep_ws, eng._ws = eng._ws, bs["ws"]
+        try:
+            self._pack_adjoint(W, V)
+            hv = self._views(6) if need_params else None
+            gbar3 = self._up_sweep(nb, am, V)
+            abar = torch.zeros((nb, eng.num_feat), dtype=torch.float32, device=self.device)
+            xbar = self._down_sweep(nb, am, abar, fs["x"], hv)
+        finally:
+            eng._ws = keep_ws
+        return gbar3, xbar, hv

@@ -5,6 +5,9 @@ Same names, argument meaning and error behaviour as the reference functions cite
 docstring, so that its driver scripts can ``from video_distillation_amd.utils import ...``
 unchanged.  ``args`` is the reference's duck-typed namespace (``device``, ``dis_metric``,
 ``lr_net``, ``epoch_eval_train``, ``batch_train``, ``model``, ``eval_mode``).
+
+Everything here runs on the HIP kernels, with one stated exception: ``Conv3DNet(mode='add')`` -- a constructor option no
+script of the reference selects (utils.py:1179 default 'concat') -- composes torch ops.
 """
 from __future__ import annotations
 
@@ -55,12 +58,28 @@ def get_network(model, channel, num_classes, im_size=(32, 32), frames=16, dist=T
         gpu_num = torch.cuda.device_count()
         if gpu_num > 0:
             device = 'cuda'
+            net = net.to(device)
             if gpu_num > 1:
-                net = nn.DataParallel(net)
+                net = SingleDeviceParallel(net)
         else:
             device = 'cpu'
-        net = net.to(device)
+            net = net.to(device)
     return net
+
+
+class SingleDeviceParallel(nn.Module):
+    """What ``get_network(dist=True)`` returns when several GPUs are visible.  The reference wraps the net in
+    ``nn.DataParallel`` there (utils.py:615-623) and its drivers reach through ``.module`` (distill_baseline.py:339-347).
+    This build scales as ONE PROCESS PER GPU (torch.distributed over RCCL) -- threads replicating a
+    module over devices inside one process are exactly what it avoids -- so the wrapper keeps the ``.module`` surface and
+    runs the net on its own device."""
+
+    def __init__(self, module: nn.Module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *inputs, **kwargs):
+        return self.module(*inputs, **kwargs)
 
 
 class TensorDataset(Dataset):
@@ -304,10 +323,11 @@ def epoch(mode, dataloader, net, optimizer, criterion, args):
             img = _standardize(img)
             lab = datum[1].long().to(args.device)
             n_b = lab.shape[0]
-            hip_step = (mode == 'train' and hasattr(net, 'hip_trainable') and net.hip_trainable(img, optimizer, criterion))
-            if hip_step:    # forward + loss + backward + optimizer.step() on the HIP path
-                output, loss = net.hip_train_step(img, lab, optimizer)
-            else:
+            core = net.module if isinstance(net, SingleDeviceParallel) else net
+            hip_step = (mode == 'train' and hasattr(core, 'hip_trainable') and core.hip_trainable(img, optimizer, criterion))
+            if hip_step:    # forward + loss + backward + optimizer.step() fused on the HIP path
+                output, loss = core.hip_train_step(img, lab, optimizer)
+            else:           # any other optimiser / loss: the autograd Functions of ConvNet3D.forward (HIP as well)
                 output = net(img)
                 loss = criterion(output, lab)
             # statistics stay on the device; one host transfer per epoch instead of one per batch
