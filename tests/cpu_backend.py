@@ -125,3 +125,5 @@ class OracleMTTOps:
         return out[0], list(out[1:])
 
     sgd = OracleBackend.sgd
+    hallucinate = OracleBackend.hallucinate
+    hallucinate_backward = OracleBackend.hallucinate_backward

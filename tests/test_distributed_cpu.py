@@ -261,7 +261,7 @@ def test_mtt_trainer_reverse_sweep_matches_reference_golden():
     want = torch.tensor(z["grad_img"])
     assert float((g_img[:, ::2, :, ::2, ::2] - want).norm() / want.norm()) < 2e-3
     np.testing.assert_allclose(tr.image_syn.numpy(), (image_syn - 100.0 * g_img).numpy(), rtol=1e-5, atol=1e-6)   # first step: buf = g
-    assert abs(tr.syn_lr - max(float(z["syn_lr"]) - 1e-5 * g_lr, 0.001)) < 1e-9
+    assert abs(float(tr.syn_lr) - max(float(z["syn_lr"]) - 1e-5 * float(g_lr), 0.001)) < 1e-9
 
 
 def _worker_mtt(rank, world, port, q):
@@ -272,7 +272,7 @@ def _worker_mtt(rank, world, port, q):
         z, tr, traj, chunks, _ = _mtt_setup(rank, world)
         grand = tr.step(0, traj, start_epoch=0, index_chunks=chunks)
         if rank == 0:
-            q.put((grand, tr.last_grads[0].numpy(), tr.last_grads[1]))
+            q.put((float(grand), tr.last_grads[0].numpy(), float(tr.last_grads[1])))
     finally:
         dist.destroy_process_group()
 
@@ -287,3 +287,80 @@ def test_mtt_trainer_batch_sharded_two_ranks_gloo():
     assert abs(g_lr - tr.last_grads[1]) / abs(g_lr) < 1e-3
     ref = tr.last_grads[0].numpy()
     assert np.linalg.norm(g_img - ref) / np.linalg.norm(ref) < 1e-3
+
+
+# ---- s2d under MTT ("MTT+Ours", BASELINE config 5): fixture G13 from the reference's loop; batch sharding ----
+
+def _s2d_mtt_setup(rank=0, world=1, ops=None, dev="cpu"):
+    from tests.cpu_backend import OracleMTTOps
+    z = np.load(os.path.join(GOLDEN, "g13_s2d_mtt_step.npz"))
+    C = int(z["C"])
+    start = R.init_params(int(z["net_seed"]), 3, C)
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    target = [p + 0.02 * p.abs().mean() * torch.randn(p.shape, generator=g) for p in start]
+    static = torch.randn(C * int(z["spc"]), 3, 64, 64, generator=g)
+    dynamic = torch.randn(C, int(z["dpc"]), 8, 1, 64, 64, generator=g)
+    tr = distill.S2DMTTTrainer(ops or OracleMTTOps(), C, int(z["vpc"]), int(z["spc"]), int(z["dpc"]), static.clone().to(dev),
+                               dynamic.clone().to(dev), torch.tensor(z["hal_w"]).to(dev), torch.tensor(z["hal_b"]).to(dev),
+                               float(z["syn_lr"]), lr_dynamic=float(z["lr_dynamic"]), lr_hal=float(z["lr_hal"]),
+                               lr_lr=float(z["lr_lr"]), syn_steps=int(z["syn_steps"]), batch_syn=int(z["batch_syn"]),
+                               expert_epochs=1, max_start_epoch=1, lr_static=float(z["lr_static"]), train_static=True,
+                               rank=rank, world=world)
+    chunks = [torch.tensor(row[row >= 0]) for row in z["indices"]]
+    tr.draws = [(d[d >= 0], s[s >= 0]) for d, s in zip(z["draws_dyn"], z["draws_sta"])]
+    return z, tr, [start, target], chunks
+
+
+def check_s2d_mtt_against_g13(z, tr, grand, tol=2e-3):
+    C, dpc = int(z["C"]), int(z["dpc"])
+    g_dyn, g_w, g_b, g_stat, g_lr = tr.last_grads
+    rel = lambda a, b: float((torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double()).norm() / torch.as_tensor(b).double().norm())   # noqa: E731
+    assert abs(float(grand) - float(z["grand_loss"])) / float(z["grand_loss"]) < 1e-4
+    assert abs(float(g_lr) - float(z["grad_lr"])) / abs(float(z["grad_lr"])) < tol
+    gd = g_dyn.view(C, dpc, 8, 1, 64, 64).cpu()
+    assert rel(gd[:, :, :, :, ::4, ::4], z["g_dynamic"]) < tol
+    assert rel(g_stat.cpu()[:, :, ::4, ::4], z["g_static"]) < tol
+    assert rel(g_w, z["g_hal_w"]) < tol and rel(g_b, z["g_hal_b"]) < tol
+    # memories no student step drew stay untouched: exactly zero gradient rows
+    assert ((gd.abs().sum(dim=(2, 3, 4, 5)) == 0) == torch.tensor(z["g_dynamic_rowabs"] == 0)).all()
+    assert ((g_stat.cpu().abs().sum(dim=(1, 2, 3)) == 0) == torch.tensor(z["g_static_rowabs"] == 0)).all()
+    # the four optimiser steps (first step: buf = g) and the clipped syn_lr
+    np.testing.assert_allclose(tr.hal_w.cpu().numpy(), z["hal_w_after"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(tr.hal_b.cpu().numpy(), z["hal_b_after"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(tr.dynamic.view(C, dpc, 8, 1, 64, 64).cpu()[:, :, :, :, ::4, ::4].numpy(), z["dynamic_after"],
+                               rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(tr.static.cpu()[:, :, ::4, ::4].numpy(), z["static_after"], rtol=1e-3, atol=1e-4)
+    assert abs(float(tr.syn_lr) - float(z["syn_lr_after"])) < 1e-7
+
+
+def test_s2d_mtt_trainer_matches_reference_golden():
+    z, tr, traj, chunks = _s2d_mtt_setup()
+    grand = tr.step(0, traj, start_epoch=0, index_chunks=chunks)
+    check_s2d_mtt_against_g13(z, tr, grand)
+
+
+def _worker_s2d_mtt(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z, tr, traj, chunks = _s2d_mtt_setup(rank, world)
+        grand = tr.step(0, traj, start_epoch=0, index_chunks=chunks)
+        if rank == 1:       # any rank holds the full result after the all-reduces
+            q.put((float(grand), [t.numpy() for t in tr.last_grads[:4]], float(tr.last_grads[4]), tr.hal_w.numpy(), float(tr.syn_lr)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_s2d_mtt_trainer_batch_sharded_two_ranks_gloo():
+    """Student batches of 1 and 2 composed clips split over 2 ranks (one rank idles in the single-item steps): the
+    all-reduced memories / hallucinator gradients and the updates equal the single-rank iteration."""
+    z, tr, traj, chunks = _s2d_mtt_setup()
+    want = float(tr.step(0, traj, start_epoch=0, index_chunks=chunks))
+    grand, grads, g_lr, hal_w, syn_lr = _spawn(_worker_s2d_mtt, 2)
+    assert abs(grand - want) / want < 1e-5
+    for got, ref in zip(grads, tr.last_grads[:4]):
+        assert np.linalg.norm(got - ref.numpy()) / np.linalg.norm(ref.numpy()) < 1e-3
+    assert abs(g_lr - float(tr.last_grads[4])) / abs(g_lr) < 1e-3
+    np.testing.assert_allclose(hal_w, tr.hal_w.numpy(), rtol=1e-4, atol=1e-7)
+    assert abs(syn_lr - float(tr.syn_lr)) < 1e-8

@@ -215,3 +215,54 @@ def test_cpu_and_foreign_architectures_raise():
         other(torch.zeros(1, 8, 3, 64, 64).cuda())
     with pytest.raises(NotImplementedError):
         other.embed(torch.zeros(1, 8, 3, 64, 64).cuda())
+
+
+def test_g13_reference_shaped_s2d_mtt(golden_dir):
+    """Fixture G13 ("MTT+Ours", distill_s2d_ms.py:236-300) re-run line by line against this package's Conv3DNet,
+    ReparamModule and ConvNet3D: hallucinator-composed student batches, create_graph through flat_param, backward of the
+    grand loss into dynamic / static memories, hallucinator and syn_lr."""
+    from video_distillation_amd import utils
+    from video_distillation_amd.reparam_module import ReparamModule
+    z = np.load(os.path.join(golden_dir, "g13_s2d_mtt_step.npz"))
+    C, vpc, spc, dpc = int(z["C"]), int(z["vpc"]), int(z["spc"]), int(z["dpc"])
+    net = _net(int(z["net_seed"]), C)
+    starting = [p.detach().clone() for p in net.parameters()]
+    g = torch.Generator().manual_seed(int(z["data_seed"]))
+    target = [p.cpu() + 0.02 * p.cpu().abs().mean() * torch.randn(p.shape, generator=g) for p in starting]
+    static_syn = torch.randn(C * spc, 3, 64, 64, generator=g).cuda().requires_grad_(True)
+    dynamic_syn = torch.randn(C, dpc, 8, 1, 64, 64, generator=g).cuda().requires_grad_(True)
+    hal = utils.Conv3DNet(img_size=64)
+    hal.load_state_dict({"encoder.weight": torch.tensor(z["hal_w"]), "encoder.bias": torch.tensor(z["hal_b"])})
+    hal = hal.cuda()
+    syn_lr = torch.tensor(float(z["syn_lr"])).cuda().requires_grad_(True)
+    student_net = ReparamModule(net)
+    student_net.train()
+    num_params = sum([np.prod(p.size()) for p in (student_net.parameters())])
+    target_params = torch.cat([p.reshape(-1) for p in target], 0).cuda()
+    student_params = [torch.cat([p.reshape(-1) for p in starting], 0).requires_grad_(True)]
+    starting_params = torch.cat([p.reshape(-1) for p in starting], 0)
+    criterion = torch.nn.CrossEntropyLoss().cuda()
+    for step in range(int(z["syn_steps"])):
+        keep = z["indices"][step] >= 0
+        these_indices = torch.tensor(z["indices"][step][keep]).cuda()
+        label = these_indices // vpc
+        idx = these_indices % vpc
+        dynamic_idx = 2 * idx + torch.tensor(z["draws_dyn"][step][keep]).cuda()
+        static_idx = spc * label + 2 * idx + torch.tensor(z["draws_sta"][step][keep]).cuda()
+        x = hal(static_syn[static_idx, :, :, :], dynamic_syn[label, dynamic_idx, :, :, :, :])
+        out = student_net(x, flat_param=student_params[-1])
+        loss = criterion(out, label.long())
+        grad = torch.autograd.grad(loss, student_params[-1], create_graph=True)[0]
+        student_params.append(student_params[-1] - syn_lr * grad)
+    param_loss = torch.nn.functional.mse_loss(student_params[-1], target_params, reduction="sum") / num_params
+    param_dist = torch.nn.functional.mse_loss(starting_params, target_params, reduction="sum") / num_params
+    grand_loss = param_loss / param_dist
+    grand_loss.backward()
+    errs = {"dynamic": _rel(dynamic_syn.grad[:, :, :, :, ::4, ::4], z["g_dynamic"]), "static": _rel(static_syn.grad[:, :, ::4, ::4], z["g_static"]),
+            "hal_w": _rel(hal.encoder.weight.grad, z["g_hal_w"]), "hal_b": _rel(hal.encoder.bias.grad, z["g_hal_b"]),
+            "lr": abs(float(syn_lr.grad) - float(z["grad_lr"])) / abs(float(z["grad_lr"]))}
+    print("G13 (reference-shaped) grand %.6f vs %.6f" % (float(grand_loss), float(z["grand_loss"])), {k: "%.1e" % v for k, v in errs.items()})
+    assert abs(float(grand_loss) - float(z["grand_loss"])) / float(z["grand_loss"]) < 1e-3
+    assert max(errs.values()) < 5e-3
+    rowabs = dynamic_syn.grad.abs().sum(dim=(2, 3, 4, 5)).cpu().numpy()
+    assert ((rowabs == 0) == (z["g_dynamic_rowabs"] == 0)).all()

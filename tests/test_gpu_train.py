@@ -367,3 +367,16 @@ def test_g10_mtt_step_on_hip_vs_reference_golden(golden_dir):
     np.testing.assert_allclose(got_l1, z["grad_l1"], rtol=2e-2)
     # optimiser bookkeeping on the device
     np.testing.assert_allclose(tr.image_syn.cpu().numpy(), (image_syn - 100.0 * g_img.cpu()).numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_g13_s2d_mtt_trainer_on_hip_vs_reference_golden():
+    """distill.S2DMTTTrainer on the HIP ops vs fixture G13 (one "MTT+Ours" iteration of the reference,
+    distill_s2d_ms.py:189-300): grand loss, gradients of dynamic / static memories, hallucinator and syn_lr, and the
+    four optimiser updates."""
+    from tests.test_distributed_cpu import _s2d_mtt_setup, check_s2d_mtt_against_g13
+    from video_distillation_amd import distill, plan
+    ops = distill.HipMTTOps(plan.NetGeometry(8, 64, 64), 3, "cuda:0", dropout_p=0.0)
+    z, tr, traj, chunks = _s2d_mtt_setup(ops=ops, dev="cuda")
+    grand = tr.step(0, traj, start_epoch=0, index_chunks=chunks)
+    print("G13 grand %.6f vs %.6f, d/dlr %.5e vs %.5e" % (float(grand), float(z["grand_loss"]), float(tr.last_grads[4]), float(z["grad_lr"])))
+    check_s2d_mtt_against_g13(z, tr, grand, tol=5e-3)

@@ -439,6 +439,78 @@ def g12(networks):
         grad_l1=np.array([float(gk.double().abs().sum()) for gk in grads]))
 
 
+def g13(networks, utils):
+    # G13: one "MTT+Ours" iteration (distill_s2d_ms.py:189-300) around the reference's ReparamModule, ConvNet3D and
+    # Conv3DNet: per student step the batch is composed by the hallucinator from randomly drawn static / dynamic memories,
+    # the grand loss is back-propagated to dynamic memories, static memories, hallucinator and syn_lr, and the four
+    # SGD optimisers (momentum .95 / .9 for syn_lr, :107-110) take one step.  C=3, vpc=1, spc=2, dpc=2.
+    sys.path.insert(0, REF)
+    from reparam_module import ReparamModule
+    C, vpc, spc, dpc, syn_steps, batch_syn = 3, 1, 2, 2, 3, 2
+    net = make_net(networks, 131, C, 64, 8)
+    net.dropout.p = 0.0
+    starting = [p.detach().clone() for p in net.parameters()]
+    g = torch.Generator().manual_seed(1301)
+    target = [p + 0.02 * p.abs().mean() * torch.randn(p.shape, generator=g) for p in starting]
+    static_syn = torch.randn(C * spc, 3, 64, 64, generator=g).requires_grad_(True)
+    dynamic_syn = torch.randn(C, dpc, 8, 1, 64, 64, generator=g).requires_grad_(True)
+    torch.manual_seed(1302)
+    hals = torch.nn.ModuleList([utils.Conv3DNet(img_size=64)])
+    w0, b0 = hals[0].encoder.weight.detach().clone(), hals[0].encoder.bias.detach().clone()
+    syn_lr = torch.tensor(0.01).requires_grad_(True)
+    lr_static, lr_dynamic, lr_hal, lr_lr = 10.0, 100.0, 0.01, 1e-5
+    optimizer_static = torch.optim.SGD([static_syn], lr=lr_static, momentum=0.95)
+    optimizer_dynamic = torch.optim.SGD([dynamic_syn], lr=lr_dynamic, momentum=0.95)
+    optimizer_hals = torch.optim.SGD(hals.parameters(), lr=lr_hal, momentum=0.95)
+    optimizer_lr = torch.optim.SGD([syn_lr], lr=lr_lr, momentum=0.9)
+    student_net = ReparamModule(net)
+    student_net.train()
+    num_params = sum([np.prod(p.size()) for p in (student_net.parameters())])
+    target_params = torch.cat([p.reshape(-1) for p in target], 0)
+    student_params = [torch.cat([p.reshape(-1) for p in starting], 0).requires_grad_(True)]
+    starting_params = torch.cat([p.reshape(-1) for p in starting], 0)
+    criterion = torch.nn.CrossEntropyLoss()
+    torch.manual_seed(1311)
+    indices_chunks, used, draws_d, draws_s = [], [], [], []
+    for step in range(syn_steps):
+        if not indices_chunks:
+            indices = torch.randperm(C * vpc)
+            indices_chunks = list(torch.split(indices, batch_syn))
+        these_indices = indices_chunks.pop()
+        label = these_indices // vpc
+        idx = these_indices % vpc
+        rd = torch.randint(2, (these_indices.shape[0],))
+        dynamic_idx = 2 * idx + rd
+        rs = torch.randint(2, (these_indices.shape[0],))
+        static_idx = spc * label + 2 * idx + rs
+        used.append(these_indices.clone()); draws_d.append(rd.clone()); draws_s.append(rs.clone())
+        x = hals[0](static_syn[static_idx, :, :, :], dynamic_syn[label, dynamic_idx, :, :, :, :])
+        out = student_net(x, flat_param=student_params[-1])
+        loss = criterion(out, label.long())
+        grad = torch.autograd.grad(loss, student_params[-1], create_graph=True)[0]
+        student_params.append(student_params[-1] - syn_lr * grad)
+    param_loss = torch.nn.functional.mse_loss(student_params[-1], target_params, reduction="sum") / num_params
+    param_dist = torch.nn.functional.mse_loss(starting_params, target_params, reduction="sum") / num_params
+    grand_loss = param_loss / param_dist
+    for o in (optimizer_static, optimizer_dynamic, optimizer_hals, optimizer_lr):
+        o.zero_grad()
+    grand_loss.backward()
+    gd, gs = dynamic_syn.grad.clone(), static_syn.grad.clone()
+    gw, gb, glr = hals[0].encoder.weight.grad.clone(), hals[0].encoder.bias.grad.clone(), syn_lr.grad.clone()
+    for o in (optimizer_static, optimizer_dynamic, optimizer_hals, optimizer_lr):
+        o.step()
+    syn_lr.data = syn_lr.data.clip(min=0.001)
+    pad = lambda lst: np.stack([np.pad(t.numpy(), (0, batch_syn - len(t)), constant_values=-1) for t in lst])   # noqa: E731
+    npz("g13_s2d_mtt_step.npz", net_seed=131, data_seed=1301, hal_seed=1302, C=C, vpc=vpc, spc=spc, dpc=dpc, syn_steps=syn_steps,
+        batch_syn=batch_syn, indices=pad(used), draws_dyn=pad(draws_d), draws_sta=pad(draws_s), hal_w=w0, hal_b=b0,
+        syn_lr=0.01, lr_static=lr_static, lr_dynamic=lr_dynamic, lr_hal=lr_hal, lr_lr=lr_lr,
+        grand_loss=grand_loss.detach(), grad_lr=glr, g_hal_w=gw, g_hal_b=gb,
+        g_dynamic=gd[:, :, :, :, ::4, ::4], g_dynamic_rowabs=gd.abs().sum(dim=(2, 3, 4, 5)),
+        g_static=gs[:, :, ::4, ::4], g_static_rowabs=gs.abs().sum(dim=(1, 2, 3)),
+        hal_w_after=hals[0].encoder.weight.detach(), hal_b_after=hals[0].encoder.bias.detach(), syn_lr_after=syn_lr.detach(),
+        dynamic_after=dynamic_syn.detach()[:, :, :, :, ::4, ::4], static_after=static_syn.detach()[:, :, ::4, ::4])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -447,7 +519,7 @@ def main():
     for name, fn in (("g1", lambda: g1(networks)), ("g2", lambda: g2_g3(networks)), ("g4", lambda: g4_g5(networks, utils)),
                      ("g6", lambda: g6(networks, utils)), ("g7", lambda: g7(networks, utils)),
                      ("g9", lambda: g9(networks, utils)), ("g10", lambda: g10(networks, utils)),
-                     ("g11", lambda: g11(networks, utils)), ("g12", lambda: g12(networks))):
+                     ("g11", lambda: g11(networks, utils)), ("g12", lambda: g12(networks)), ("g13", lambda: g13(networks, utils))):
         if not only or name in only:
             fn()
 

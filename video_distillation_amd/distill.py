@@ -705,6 +705,8 @@ class HipMTTOps:
         return self.te.vjp(state, v, params, param_adjoint=True)
 
     sgd = HipGMOps.sgd
+    hallucinate = HipBackend.hallucinate
+    hallucinate_backward = HipBackend.hallucinate_backward
 
 
 class MTTTrainer:
@@ -719,10 +721,13 @@ class MTTTrainer:
                             thetabar_s = thetabar_{s+1} + Hv
 
     All per-step state (activations, arg-max, first-order gradients at the conv outputs) of the
-    unrolled loop stays resident in HBM between the forward and the reverse sweep.
+    unrolled loop stays resident in HBM between the forward and the reverse sweep, and so do the scalars
+    (syn_lr, its momentum, the two distances, d/d syn_lr): an iteration enqueues without a host sync.
     Multi-GPU: the synthetic batch of every student step is split over ranks (what the reference's
     DataParallel does, :238-241); the flat parameter gradient and the Hessian-vector product are
     all-reduced per inner step (2 x 14.6 MB), pixel gradients are rank-disjoint and summed once."""
+
+    LR_MOMENTUM = 0.5           # optimizer_lr = SGD([syn_lr], lr_lr, momentum=0.5), distill_baseline.py:108
 
     def __init__(self, ops, num_classes: int, image_syn: torch.Tensor, label_syn: torch.Tensor, syn_lr: float,
                  lr_img: float, lr_lr: float, syn_steps: int, batch_syn: int, expert_epochs: int, max_start_epoch: int,
@@ -730,7 +735,9 @@ class MTTTrainer:
         self.ops, self.num_classes = ops, num_classes
         self.image_syn, self.label_syn = image_syn.contiguous(), label_syn
         self.buf = torch.zeros_like(self.image_syn)
-        self.syn_lr, self.lr_buf = float(syn_lr), 0.0
+        dev = self.image_syn.device
+        self.syn_lr = torch.tensor(float(syn_lr), dtype=torch.float32, device=dev)
+        self.lr_buf = torch.zeros((), dtype=torch.float32, device=dev)
         self.lr_img, self.lr_lr, self.momentum = float(lr_img), float(lr_lr), float(momentum)
         self.syn_steps, self.batch_syn = int(syn_steps), int(batch_syn)
         self.expert_epochs, self.max_start_epoch = int(expert_epochs), int(max_start_epoch)
@@ -738,17 +745,40 @@ class MTTTrainer:
         self.steps_done = 0
         self.last_grads = None
 
-    def _allreduce(self, tensors):
+    # -- what differs between raw synthetic clips and the s2d composition ---------------------------------------------
+    def _num_items(self) -> int:
+        return int(self.image_syn.shape[0])
+
+    def _begin(self, dev) -> None:
+        self._g_img = torch.zeros_like(self.image_syn)
+
+    def _clips(self, batch: torch.Tensor, sel: slice, step: int, it: int):
+        """-> (clips of this rank's share ``batch[sel]`` of the student batch, their labels, context for ``_push``)."""
+        mine = batch[sel]
+        return self.image_syn[mine], self.label_syn.to(mine.device)[mine], mine
+
+    def _push(self, ctx, dx: torch.Tensor) -> None:
+        self._g_img.index_add_(0, ctx, dx)
+
+    def _finish(self, update: bool):
+        g_img = self._g_img
         if self.world > 1:
             import torch.distributed as dist
-            flat = flatten_params(tensors)
+            dist.all_reduce(g_img, op=dist.ReduceOp.SUM)
+        if update:
+            self.ops.sgd(self.image_syn, self.buf, g_img, self.lr_img, self.momentum, first=(self.steps_done == 0))
+        return (g_img,)
+
+    # -------------------------------------------------------------------------------------------------------------------
+    def _allreduce(self, flat: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            import torch.distributed as dist
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            return unflatten_params(flat, self.num_classes)
-        return tensors
+        return flat
 
     def step(self, it: int, trajectory, start_epoch: Optional[int] = None, index_chunks=None, update: bool = True):
         """``trajectory``: one expert (list over epochs of the 8 parameter tensors, as stored in
-        ``replay_buffer_N.pt``, buffer.py:75-104).  Returns the grand loss (python float)."""
+        ``replay_buffer_N.pt``, buffer.py:75-104).  Returns the grand loss as a 0-dim device tensor."""
         dev = self.image_syn.device
         rng = np.random.default_rng([it, 17])
         if start_epoch is None:
@@ -759,47 +789,137 @@ class MTTTrainer:
             index_chunks, pending = [], []
             for _ in range(self.syn_steps):
                 if not pending:
-                    perm = torch.as_tensor(rng.permutation(self.image_syn.shape[0]))
+                    perm = torch.as_tensor(rng.permutation(self._num_items()))
                     pending = list(torch.split(perm, self.batch_syn))
                 index_chunks.append(pending.pop())
+        self._begin(dev)
         theta0 = flatten_params(start)
         theta = theta0.clone()
         tape = []
-        for idx in index_chunks:
+        for step, idx in enumerate(index_chunks):
             idx = idx.to(dev)
-            mine = idx[self.rank::self.world] if self.world > 1 else idx       # this rank's share of the batch
-            share = float(mine.numel()) / float(idx.numel())
+            sel = slice(self.rank, None, self.world) if self.world > 1 else slice(None)    # this rank's share of the batch
+            n_mine = len(range(*sel.indices(int(idx.numel()))))
+            share = float(n_mine) / float(idx.numel())
             params = unflatten_params(theta, self.num_classes)
-            if mine.numel():
-                g, handle = self.ops.grads(params, self.image_syn[mine], self.label_syn.to(dev)[mine])
-                g = [t * share for t in g]
+            if n_mine:
+                x, labels, ctx = self._clips(idx, sel, step, it)
+                g, handle = self.ops.grads(params, x, labels)
+                g = flatten_params(g)
+                if share != 1.0:
+                    g = g * share
             else:
-                g, handle = [torch.zeros_like(p) for p in params], None
-            g = flatten_params(self._allreduce(g))
-            tape.append((mine, share, handle, g))
+                g, handle, ctx = torch.zeros_like(theta), None, None
+            g = self._allreduce(g)
+            tape.append((ctx, share, handle, g))
             theta = theta - self.syn_lr * g
-        dist0 = float(((theta0 - target) ** 2).sum())
-        grand = float(((theta - target) ** 2).sum()) / dist0
+        dist0 = ((theta0 - target) ** 2).sum()
+        grand = ((theta - target) ** 2).sum() / dist0
         # ---- reverse sweep ---------------------------------------------------------------------
         tbar = 2.0 * (theta - target) / dist0
-        g_img = torch.zeros_like(self.image_syn)
-        g_lr = 0.0
-        for mine, share, handle, g in reversed(tape):
-            g_lr -= float((tbar * g).sum())
+        g_lr = torch.zeros((), dtype=torch.float32, device=dev)
+        for ctx, share, handle, g in reversed(tape):
+            g_lr = g_lr - (tbar * g).sum()
             if handle is not None:
                 v = unflatten_params(tbar * (-self.syn_lr * share), self.num_classes)
                 dx, hv = self.ops.hvp(handle, v)
-                g_img.index_add_(0, mine, dx)
+                self._push(ctx, dx)
+                hv = flatten_params(hv)
             else:
-                hv = [torch.zeros_like(p) for p in unflatten_params(tbar, self.num_classes)]
-            tbar = tbar + flatten_params(self._allreduce(hv))
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(g_img, op=dist.ReduceOp.SUM)
-        self.last_grads = (g_img, g_lr)
+                hv = torch.zeros_like(tbar)
+            tbar = tbar + self._allreduce(hv)
+        self.last_grads = self._finish(update) + (g_lr,)
         if update:
-            self.ops.sgd(self.image_syn, self.buf, g_img, self.lr_img, self.momentum, first=(self.steps_done == 0))
-            self.lr_buf = g_lr if self.steps_done == 0 else self.momentum * self.lr_buf + g_lr     # optimizer_lr: SGD(lr_lr, .5)
-            self.syn_lr = max(self.syn_lr - self.lr_lr * self.lr_buf, 0.001)                       # .clip(min=0.001), :269
+            mu = self.LR_MOMENTUM
+            self.lr_buf = g_lr.clone() if self.steps_done == 0 else mu * self.lr_buf + g_lr
+            self.syn_lr = torch.clamp(self.syn_lr - self.lr_lr * self.lr_buf, min=0.001)         # .clip(min=0.001), :269
             self.steps_done += 1
         return grand
+
+
+class S2DMTTTrainer(MTTTrainer):
+    """MTT over static + dynamic memories ("MTT+Ours", distill_s2d_ms.py:189-300; BASELINE config 5): the clip of item
+    i = (class, v) of a student batch is hallucinator(static[spc*class + 2v + r_s], dynamic[class, 2v + r_d]) with two
+    fresh randint(2) draws per item and step (:248-256); the grand loss is back-propagated through the unrolled
+    student steps AND the hallucinator to the dynamic memories, the hallucinator's 327 parameters and (unless
+    ``--no_train_static``) the static memories, each under SGD(momentum .95) (:107-110); syn_lr under SGD(lr_lr, momentum
+    .9) (:110) with the .clip(min=0.001) of :291.  The student batch of a step is split over ranks like MTTTrainer's;
+    memory / hallucinator gradients are summed over ranks once per iteration."""
+
+    LR_MOMENTUM = 0.9
+
+    def __init__(self, ops, num_classes: int, vpc: int, spc: int, dpc: int, static_syn: torch.Tensor, dynamic_syn: torch.Tensor,
+                 hal_w: torch.Tensor, hal_b: torch.Tensor, syn_lr: float, lr_dynamic: float, lr_hal: float, lr_lr: float,
+                 syn_steps: int, batch_syn: int, expert_epochs: int, max_start_epoch: int, lr_static: float = 0.0,
+                 train_static: bool = False, momentum: float = 0.95, rank: int = 0, world: int = 1):
+        self.vpc, self.spc, self.dpc = int(vpc), int(spc), int(dpc)
+        self.static = static_syn.contiguous()
+        self.dynamic = dynamic_syn.reshape((-1,) + tuple(dynamic_syn.shape[2:])).contiguous()      # rows (class, dpc) flattened
+        super().__init__(ops, num_classes, self.dynamic, None, syn_lr, lr_dynamic, lr_lr, syn_steps, batch_syn, expert_epochs,
+                         max_start_epoch, momentum=momentum, rank=rank, world=world)
+        self.image_syn = self.dynamic                  # device / bookkeeping handle of the base class
+        self.hal_w, self.hal_b = hal_w.clone().contiguous(), hal_b.clone().contiguous()
+        self.lr_dynamic, self.lr_hal, self.lr_static = float(lr_dynamic), float(lr_hal), float(lr_static)
+        self.train_static = bool(train_static)
+        self.buf_d = self.buf
+        self.buf_w, self.buf_b = torch.zeros_like(self.hal_w), torch.zeros_like(self.hal_b)
+        self.buf_s = torch.zeros_like(self.static) if train_static else None
+        self.draws = None        # optional fixed randint draws: [step] -> (dynamic (batch,), static (batch,)) for the WHOLE batch
+
+    def _num_items(self) -> int:
+        return self.num_classes * self.vpc
+
+    def _begin(self, dev) -> None:
+        self._g_dyn = torch.zeros_like(self.dynamic)
+        self._g_stat = torch.zeros_like(self.static) if self.train_static else None
+        self._g_w = torch.zeros_like(self.hal_w)
+        self._g_b = torch.zeros_like(self.hal_b)
+        self._pos = {}
+
+    def indices(self, these: torch.Tensor, step: int, it: int):
+        """distill_s2d_ms.py:248-252 for the items ``these`` of the student batch of ``step`` (the draws are made for the
+        whole batch from a per-(iteration, step) seed, so every sharding composes the same clips)."""
+        n = int(these.numel())
+        if self.draws is not None:
+            dd, ds = (torch.as_tensor(np.asarray(t), dtype=torch.int64) for t in self.draws[step])
+        else:
+            r = np.random.default_rng([it, step, 23])
+            dd, ds = torch.as_tensor(r.integers(0, 2, n)), torch.as_tensor(r.integers(0, 2, n))
+        label = these // self.vpc
+        idx = these % self.vpc
+        dynamic_idx = label * self.dpc + 2 * idx + dd.to(these.device)       # row of the flattened (class, dpc) memory
+        static_idx = self.spc * label + 2 * idx + ds.to(these.device)
+        return label, static_idx, dynamic_idx
+
+    def _clips(self, batch: torch.Tensor, sel: slice, step: int, it: int):
+        label, sidx, didx = (t[sel].contiguous() for t in self.indices(batch, step, it))
+        x = self.ops.hallucinate(self.static, self.dynamic, sidx, didx, self.hal_w, self.hal_b)
+        return x, label, (sidx, didx)
+
+    def _push(self, ctx, dx: torch.Tensor) -> None:
+        sidx, didx = ctx
+        g_dyn, g_stat, g_w, g_b = self.ops.hallucinate_backward(dx.contiguous(), self.static, self.dynamic, sidx, didx, self.hal_w,
+                                                                self.train_static)
+        self._g_dyn += g_dyn
+        self._g_w += g_w.reshape(self._g_w.shape)
+        self._g_b += g_b
+        if self.train_static:
+            self._g_stat += g_stat
+
+    def _finish(self, update: bool):
+        if self.world > 1:
+            import torch.distributed as dist
+            flat = torch.cat([self._g_w.reshape(-1), self._g_b.reshape(-1)])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            self._g_w, self._g_b = flat[:self._g_w.numel()].view_as(self._g_w).contiguous(), flat[self._g_w.numel():].contiguous()
+            dist.all_reduce(self._g_dyn, op=dist.ReduceOp.SUM)
+            if self.train_static:
+                dist.all_reduce(self._g_stat, op=dist.ReduceOp.SUM)
+        if update:
+            first = self.steps_done == 0
+            self.ops.sgd(self.dynamic, self.buf_d, self._g_dyn, self.lr_dynamic, self.momentum, first)
+            self.ops.sgd(self.hal_w, self.buf_w, self._g_w, self.lr_hal, self.momentum, first)
+            self.ops.sgd(self.hal_b, self.buf_b, self._g_b, self.lr_hal, self.momentum, first)
+            if self.train_static:
+                self.ops.sgd(self.static, self.buf_s, self._g_stat, self.lr_static, self.momentum, first)
+        return (self._g_dyn, self._g_w, self._g_b, self._g_stat)
