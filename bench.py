@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: DM distillation steps/s (miniUCF101 shape, IPC=1) on N MI355X.
+"""Headline benchmark: distillation steps/s on N MI355X, for the five BASELINE.json configurations.
 
-One step = one iteration of the reference's DM loop body (distill_baseline.py:334-355):
-fresh random ConvNet3D, C=50 class terms (64 real + ipc synthetic 112x112x16 clips each),
-backward to the synthetic pixels, SGD-momentum step.  Synthetic data (no dataset ships):
-randn clips standardised per channel, 93 clips per class, generated on the device.
-
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py                                   # config 2: DM, miniUCF101 shape, IPC=1, 112x112x16 (the headline)
+    python bench.py --method s2d                      # config 3: DM + static/dynamic memories
+    python bench.py --method dc  --classes 51 --ipc 5                       # config 4: gradient matching
+    python bench.py --method mtt --classes 400 --frames 8 --size 64         # config 5: MTT + static/dynamic memories
+    python bench.py --frames 8 --size 64              # config 1's shape (the reference's CPU-runnable case) on the GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 3
 
-Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
-  roofline      -- the dominant kernel (conv_mfma, second conv layer, real-clip forward):
-                   algorithmic FLOP per launch / mean launch time (HIP events on the launch
-                   stream) against the 2.5 PFLOP/s dense 16-bit MFMA peak;
-  cpu_baseline  -- the CPU oracle (torch fp32 ops == what the reference runs on a CPU) timed on
-                   this host on a bounded sample (whole class terms), extrapolated to steps/s.
+One step = one iteration of the reference's loop body (DM: distill_baseline.py:334-355; s2d: distill_s2d_ms.py:393-438;
+MTT+Ours: distill_s2d_ms.py:189-300; DC: the upstream loop around match_loss, utils.py:655).  Synthetic data (no dataset
+ships): randn clips standardised per channel, generated on the device; inputs resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line (contract in the task description).  `value` = steps / wall time of the timed region
+(barrier + synchronize on both sides, max over ranks); `ms_per_step_median` is the median of the per-step intervals
+between HIP events recorded behind each step's last kernel.  Extra objects:
+  roofline      -- the conv tile program with the largest share of the timed region's GPU time: algorithmic FLOP per launch
+                   / mean launch time (HIP events on the launch stream, inside the timed region) against the 2.5 PFLOP/s
+                   dense 16-bit MFMA peak; `peak_measured` = this box's MFMA-saturating microbenchmark (vd_mfma_peak);
+                   `traffic` = HBM bytes per launch from the committed PMC passes (static, see traffic_source);
+  cpu_baseline  -- the CPU oracle (torch fp32 ops == what the reference runs on a CPU) timed on this host's cores on a
+                   bounded sample of the same workload, extrapolated to steps/s; rank 0, N=1 only;
+  eval          -- evaluate_synset on the synthetic clips (HIP train step + HIP inference): top-1 beside the metric;
+  sustained     -- the same step loop run for --sustain-seconds: steps/s once clocks have settled.
 """
 import argparse
 import json
@@ -29,6 +37,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
+PEAK_TFLOPS = 2500.0        # dense 16-bit MFMA, MI355X_MICROARCH.md
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -38,7 +48,7 @@ def parse():
     ap.add_argument("--classes", type=int, default=50)
     ap.add_argument("--ipc", type=int, default=1)
     ap.add_argument("--batch-real", type=int, default=64)
-    ap.add_argument("--pool-per-class", type=int, default=93)
+    ap.add_argument("--pool-per-class", type=int, default=None, help="real clips per class (default 93; 1 for --method mtt)")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=112)
     ap.add_argument("--prec-real", default=os.environ.get("VD_PREC_REAL", "f16"))
@@ -47,42 +57,186 @@ def parse():
                     help="operand precision of the input-gradient passes (single-pass fp16 with power-of-two scaling)")
     ap.add_argument("--chunk", type=int, default=3200, help="real clips per launch (all of a single-GPU step by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-classes", type=int, default=10, help="class terms timed for the CPU baseline")
+    ap.add_argument("--cpu-classes", type=int, default=10, help="dm/s2d: class terms timed for the CPU baseline")
     ap.add_argument("--shard", default="auto", choices=["auto", "class", "batch"],
                     help="multi-GPU decomposition: whole classes per rank, or 1/N of every class's real batch per rank "
                          "(+ one all-reduce of the per-class feature sums); auto = batch when batch_real %% N == 0")
-    ap.add_argument("--syn-steps", type=int, default=10, help="--method mtt: unrolled student steps (sh/baseline/MTT.sh)")
-    ap.add_argument("--batch-syn", type=int, default=256, help="--method mtt: synthetic clips per student step")
-    ap.add_argument("--method", default="dm", choices=["dm", "s2d", "dc", "mtt"],
-                    help="dm = distill_baseline.py DM (headline); s2d = DM + static/dynamic memories (config 3); "
-                         "dc = gradient matching with match_loss (config 4: use --classes 51 --ipc 5); "
-                         "mtt = trajectory matching (config 5: use --classes 400 --frames 8 --size 64)")
-    ap.add_argument("--eval-epochs", type=int, default=0,
-                    help="after the timed steps, run evaluate_synset on the synthetic clips for this many epochs (HIP train "
-                         "step + HIP inference, SURVEY 8(d): eval top-1 beside the metric) and report it under 'eval'")
+    ap.add_argument("--syn-steps", type=int, default=10, help="--method mtt: unrolled student steps (sh/s2d/s2d_MTT_ms_K400.sh)")
+    ap.add_argument("--batch-syn", type=int, default=256, help="--method mtt: composed clips per student step")
+    ap.add_argument("--mtt-raw", action="store_true", help="--method mtt: raw synthetic clips (distill_baseline.py MTT) instead of "
+                                                           "the static/dynamic composition of config 5")
+    ap.add_argument("--method", default="dm", choices=["dm", "s2d", "dc", "mtt"])
+    ap.add_argument("--eval-epochs", type=int, default=10,
+                    help="dm: after the timed steps run evaluate_synset on the synthetic clips for this many epochs (0 = skip)")
+    ap.add_argument("--sustain-seconds", type=float, default=5.0, help="length of the sustained leg (0 = skip)")
     ap.add_argument("--dis-metric", default="ours", choices=["ours", "mse", "cos"], help="match_loss metric of --method dc")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------------------------------
 def conv_layer_macs(geo):
     return [d[1] * d[5] * d[6] * d[7] * d[0] * 147 for d in geo.layer_dims()]
 
 
-def pmc_traffic(clips_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per
-    MI355X_MICROARCH.md), scaled to this run's clips per launch; None if no PMC pass is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+def pmc_traffic(name, clips_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE passes, corrected as
+    MI355X_MICROARCH.md prescribes), rescaled to this run's clips per launch.  A STATIC figure from profiles/, not a
+    measurement of this run -> (bytes or None, source label)."""
+    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", fn)
+        if os.path.exists(path):
+            rec = json.load(open(path)).get(name)
+            if rec:
+                return rec["hbm_bytes_per_launch"] * clips_per_launch / rec["clips_per_launch"], "profiles/%s (static, rescaled)" % fn
+    return None, None
+
+
+def mfma_peak(device):
+    """This box's measured dense f16 MFMA rate (TFLOP/s): vd_mfma_peak, best of 3 launches of ~10 ms."""
+    from video_distillation_amd import hip
+    blocks, iters = 256 * 8, 4000
+    out = torch.empty(blocks * 256, dtype=torch.float32, device=device)
+    best = 0.0
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        hip.check(hip.lib().vd_mfma_peak(blocks, iters, hip.ptr(out), hip.stream_ptr(device)), "vd_mfma_peak")
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, blocks * 4 * iters * 8 * 32768.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return best
+
+
+def best_threads(fn):
+    """Thread count for the CPU baseline: the fastest of a short calibration (all logical CPUs is NOT the fastest on the
+    GPU box's 2 x 64-core host: 256 threads ran 10x slower than 32)."""
+    ncpu = os.cpu_count() or 1
+    best = (None, 1)
+    for th in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
+        torch.set_num_threads(th)
+        fn()
+        tc = time.perf_counter()
+        fn()
+        tc = time.perf_counter() - tc
+        if best[0] is None or tc < best[0]:
+            best = (tc, th)
+    torch.set_num_threads(best[1])
+    return best[1], ncpu
+
+
+class Harness:
+    def __init__(self, args, device, rank, world):
+        self.args, self.device, self.rank, self.world = args, device, rank, world
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, step, sync, mark, profile_sink=None):
+        """W untimed + K timed steps; -> (wall seconds [max over ranks], per-step ms list, launch profile)."""
+        from video_distillation_amd import engine
+        a = self.args
+        for it in range(a.warmup):
+            step(it)
+        sync()
+        self.barrier()
+        engine.LAUNCH_PROFILE = []
+        marks = [mark()]
+        t0 = time.perf_counter()
+        losses = []
+        for it in range(a.warmup, a.warmup + a.steps):
+            losses.append(step(it))
+            marks.append(mark())
+        sync()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        prof, engine.LAUNCH_PROFILE = engine.LAUNCH_PROFILE, None
+        if self.world > 1:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt], device=self.device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax)
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
+        return dt, per_step, prof, losses
+
+    def sustained(self, step, sync, first_it):
+        a = self.args
+        if a.sustain_seconds <= 0:
+            return None
+        self.barrier()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            for _ in range(max(1, a.steps // 4)):
+                step(first_it + n)
+                n += 1
+            sync()
+            torch.cuda.synchronize()
+            stop = torch.tensor([1.0 if time.perf_counter() - t0 >= a.sustain_seconds else 0.0], device=self.device)
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(stop, op=dist.ReduceOp.MAX)
+            if float(stop) > 0:
+                break
+        self.barrier()
+        dt = time.perf_counter() - t0
+        return {"seconds": dt, "steps": n, "value": n / dt, "unit": "steps/s"}
+
+
+def roofline_from_profile(prof, device, kernel_labels):
+    """Aggregate the launch profile by tile program; the program with the largest total time is the dominant kernel."""
+    from video_distillation_amd import hip
+    agg = {}
+    for name, prec, flop, e0, e1 in prof:
+        rec = agg.setdefault((name, prec), [0.0, 0, 0.0])
+        rec[0] += e0.elapsed_time(e1) * 1e-3
+        rec[1] += 1
+        rec[2] += flop
+    if not agg:
         return None
-    rec = json.load(open(path))["conv1_fwd_f16"]
-    return rec["hbm_bytes_per_launch"] * clips_per_launch / rec["clips_per_launch"]
+    inv = {v: k for k, v in hip.PREC.items()}
+    total = sum(v[0] for v in agg.values())
+    ranked = sorted(agg.items(), key=lambda kv: -kv[1][0])
+    (name, prec), (secs, n, flop) = ranked[0]
+    achieved = flop / secs / 1e12
+    x3 = hip.is_x3(prec)
+    return {"bound": "mfma", "kernel": "%s, tile program '%s', operands %s" % (kernel_labels.get(name, "conv_mfma_kernel"), name, inv[prec]),
+            "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
+            "launches": n, "mean_launch_ms": secs / n * 1e3, "flop_per_launch": flop / n,
+            "share_of_conv_time": secs / total,
+            "note": ("hi+lo operand pairs: 3 MFMAs per algorithmic product, so 1/3 of peak is this program's ceiling" if x3 else None),
+            "programs": [{"program": k[0], "operands": inv[k[1]], "launches": v[1], "ms_total": v[0] * 1e3,
+                          "tflops": v[2] / v[0] / 1e12 if v[0] > 0 else None} for k, v in ranked[:8]]}
 
 
-def cpu_baseline(args, trainer, backend, it, geo):
-    """Time the oracle on `cpu_classes` whole class terms (fwd 64 real + ipc syn, bwd to pixels)
-    with the SAME weights and clips the GPU used for iteration `it`; also returns the loss
-    parity of those class terms."""
+def finish(h, out, extra_rank0=None):
+    if h.rank == 0:
+        print(json.dumps(out))
+    if h.world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def base_record(args, h, metric, dt, per_step, dtype, workload, parallelism, precision):
+    med = float(np.median(per_step))
+    return {"metric": metric, "value": args.steps / dt, "unit": "steps/s", "n_gpus": h.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": med,
+            "value_median": 1e3 / med, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic", "config": {"workload": workload, "precision": precision, "parallelism": parallelism}}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# DM / s2d (configs 1-3)
+# ------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_dm(args, trainer, backend, it, s2d=None):
+    """The oracle on `cpu_classes` whole class terms (fwd 64 real + ipc syn, bwd to pixels -- for s2d through the
+    hallucinator to the memories) with the SAME weights and clips the GPU uses for iteration `it`; also the loss parity of
+    those class terms in the shipped precision mode."""
     from oracle import ref_cpu as R
     from video_distillation_amd import distill
     ncls = min(args.cpu_classes, len(trainer.classes))
@@ -90,40 +244,333 @@ def cpu_baseline(args, trainer, backend, it, geo):
     weights = backend.new_network(seed=it)
     params = [w.cpu() for w in weights]
     idx = distill.sample_real_indices(it, trainer.pool.counts, trainer.pool.offsets, args.batch_real, classes)
-    real = trainer.pool.clips[torch.as_tensor(idx, device=trainer.pool.clips.device)].cpu()
-    syn = trainer.image_syn[:ncls * args.ipc].detach().clone()
-    # GPU loss of exactly these class terms
-    backend.set_weights(weights)
-    f_real = backend.embed_pool(trainer.pool.clips, torch.as_tensor(idx, device=syn.device))
-    f_syn, _ = backend.embed_keep(syn)
+    dev = trainer.pool.clips.device
+    real = trainer.pool.clips[torch.as_tensor(idx, device=dev)].cpu()
+    if s2d is None:
+        syn = trainer.image_syn[:ncls * args.ipc].detach().clone()
+    else:
+        sidx, didx = (torch.as_tensor(t, device=dev) for t in trainer.indices(it))
+        n = ncls * trainer.vpc
+        syn = backend.hallucinate(trainer.static, trainer.dynamic, sidx[:n], didx[:n], trainer.hal_w, trainer.hal_b)
+    backend.eng_real.set_weights(weights)
+    f_real = backend.embed_pool(trainer.pool.clips, torch.as_tensor(idx, device=dev))
+    f_syn, _ = backend.embed_syn(syn, weights)
     loss_gpu = float(backend.dm_loss(f_real, f_syn, ncls)[0].sum())
     reals = [real[c * args.batch_real:(c + 1) * args.batch_real] for c in range(ncls)]
-    # thread count: the best of a short calibration (all logical CPUs is NOT the fastest on this
-    # host: 256 threads ran 10x slower than 32 on the 2 x 64-core EPYC of the GPU box)
-    ncpu = os.cpu_count() or 1
-    best = (None, 1)
-    for th in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
-        torch.set_num_threads(th)
+
+    def probe():
         with torch.no_grad():
-            R.convnet3d_embed(reals[0][:4], params)
-            tc = time.perf_counter()
             R.convnet3d_embed(reals[0][:8], params)
-            tc = time.perf_counter() - tc
-        if best[0] is None or tc < best[0]:
-            best = (tc, th)
-    torch.set_num_threads(best[1])
+    threads, ncpu = best_threads(probe)
+    per_cls = syn.shape[0] // ncls
     t0 = time.perf_counter()
-    loss_cpu, _ = R.dm_loss_and_grad(params, reals, syn.cpu(), args.ipc)
+    if s2d is None:
+        loss_cpu, _ = R.dm_loss_and_grad(params, reals, syn.cpu(), per_cls)
+    else:
+        st = trainer.static.cpu().requires_grad_(False)
+        dy = trainer.dynamic.cpu().requires_grad_(True)
+        w, b = trainer.hal_w.cpu().requires_grad_(True), trainer.hal_b.cpu().requires_grad_(True)
+        img = R.hallucinator(st[sidx[:n].cpu()], dy[didx[:n].cpu()], w, b)
+        loss_cpu = torch.zeros(())
+        for c in range(ncls):
+            loss_cpu = loss_cpu + R.dm_class_term(R.convnet3d_embed(reals[c], params).detach(),
+                                                  R.convnet3d_embed(img[c * per_cls:(c + 1) * per_cls], params))
+        torch.autograd.grad(loss_cpu, [dy, w, b])
+        loss_cpu = loss_cpu.detach()
     dt = time.perf_counter() - t0
     per_step = dt / ncls * args.classes
-    return {"value": 1.0 / per_step, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d of %d class terms (%d real + %d syn clips %dx%dx%d each, fwd + bwd to pixels), %.1f s, "
-                      "extrapolated x%d; threads = fastest of a calibration over 8..%d (host has %d logical CPUs)" % (
-                          ncls, args.classes, args.batch_real, args.ipc, args.size, args.size,
-                          args.frames, dt, args.classes // ncls, ncpu, ncpu),
+    return {"value": 1.0 / per_step, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "%d of %d class terms (%d real + %d syn clips %dx%dx%d each, fwd + bwd to %s), %.1f s, extrapolated x%.1f; "
+                      "threads = fastest of a calibration over 8..%d (host has %d logical CPUs)" % (
+                          ncls, args.classes, args.batch_real, per_cls, args.size, args.size, args.frames,
+                          "pixels" if s2d is None else "dynamic memories + hallucinator", dt, args.classes / ncls, ncpu, ncpu),
             "loss_rel_err_vs_gpu": abs(loss_gpu - float(loss_cpu)) / abs(float(loss_cpu))}
 
 
+def run_eval(args, trainer, pool, device, rank):
+    """evaluate_synset (utils.py:848-886) on the current synthetic clips: a fresh ConvNet3D trained for --eval-epochs
+    epochs with the HIP train step, tested (3 passes, HIP inference) on 4 held-out pool clips per class.  The pool is
+    synthetic noise, so the accuracy is chance level by construction; it is reported because the metric names it."""
+    import types
+    from video_distillation_amd import utils
+    C = args.classes
+    syn = trainer.gather_syn().detach().clone()            # (collective: every rank calls)
+    if rank != 0:
+        return None
+    labels = torch.arange(C, device=device).repeat_interleave(args.ipc)
+    have = [c for c in range(C) if pool.counts[c] > 4 and (c in trainer.classes or trainer.__dict__.get("shard") == "batch")]
+    idx = torch.as_tensor([pool.offsets[c] + pool.counts[c] - 1 - k for c in have for k in range(4)], device=device)
+    test = utils.TensorDataset(pool.clips[idx], torch.as_tensor(have, device=device).repeat_interleave(4))
+    loader = torch.utils.data.DataLoader(test, batch_size=64, shuffle=False)
+    eargs = types.SimpleNamespace(device=device, lr_net=0.01, epoch_eval_train=args.eval_epochs, batch_train=256,
+                                  model="ConvNet3D", eval_mode="SS")
+    net = utils.get_network("ConvNet3D", 3, C, (args.size, args.size), frames=args.frames, dist=False).to(device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, acc_train, acc_test, _ = utils.evaluate_synset(0, net, syn, labels, loader, eargs, mode="none")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"top1": float(acc_test), "acc_train": float(acc_train), "epochs": args.eval_epochs + 1, "seconds": dt,
+            "ms_per_epoch": dt / (args.eval_epochs + 1) * 1e3, "test_clips": int(idx.numel()),
+            "note": "synthetic noise pool: top-1 is chance (%.3f) by construction" % (1.0 / C)}
+
+
+def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
+    device, rank, world = h.device, h.rank, h.world
+    s2d = args.method == "s2d"
+    if not s2d:
+        trainer = distill.DMTrainer(backend, pool, args.classes, args.ipc, args.batch_real, lr_img=1.0, momentum=0.5,
+                                    rank=rank, world=world, shard=shard)
+    else:   # sh/s2d/s2d_DM_ms.sh: vpc 1, spc 2, dpc 2, static frozen, SGD(.95) on dynamic memory + hallucinator
+        gen = torch.Generator(device=device); gen.manual_seed(77)
+        static_syn = torch.randn(args.classes * 2, 3, args.size, args.size, device=device, generator=gen)
+        dynamic_syn = torch.randn(args.classes, 2, args.frames, 1, args.size, args.size, device=device, generator=gen)
+        hal_w = torch.empty(3, 4, 3, 3, 3, device=device).uniform_(-0.096, 0.096, generator=gen)
+        hal_b = torch.empty(3, device=device).uniform_(-0.096, 0.096, generator=gen)
+        trainer = distill.S2DTrainer(backend, pool, args.classes, 1, 2, 2, args.batch_real, static_syn, dynamic_syn,
+                                     hal_w, hal_b, lr_dynamic=1.0, lr_hal=0.01, rank=rank, world=world)
+    gl = trainer.global_loss if hasattr(trainer, "global_loss") else (lambda l: l)
+
+    def step(it):
+        return gl(trainer.step(it, overlap=True))
+    dt, per_step, prof, losses = h.run(step, trainer.sync, trainer.mark)
+    sustained = h.sustained(step, trainer.sync, args.warmup + args.steps)
+    ev = None
+    if args.eval_epochs > 0 and not s2d:
+        ev = run_eval(args, trainer, pool, device, rank)
+    out = None
+    if rank == 0:
+        macs = conv_layer_macs(geo)
+        nsyn = args.ipc if not s2d else 1
+        step_flop = 2.0 * sum(macs) * (args.classes * (args.batch_real + nsyn) + args.classes * nsyn)
+        name = "DM" if not s2d else "DM+Ours s2d"
+        out = base_record(
+            args, h, "distillation steps/sec (%s, miniUCF101 IPC=%d)" % (name, args.ipc), dt, per_step,
+            args.prec_real, "miniUCF101-shaped %s IPC=%d: C=%d classes x (%d real + %d syn) clips %dx%dx%d, ConvNet3D depth 3, "
+            "fresh net per step%s" % (name, args.ipc, args.classes, args.batch_real, nsyn, args.size, args.size, args.frames,
+                                      "; vpc 1 / spc 2 / dpc 2, static memories frozen" if s2d else ""),
+            ("real batch sharded x%d + all-reduce of per-class feature sums (410 KB); synthetic clips class-owned, no gradient "
+             "exchange" % world) if trainer.__dict__.get("shard") == "batch" else
+            "class-sharded x%d (owner-computes, no gradient exchange%s)" % (world, "; 1.3 KB all-reduce of the hallucinator gradient" if s2d else ""),
+            {"real_clips": args.prec_real, "syn_clips_fwd": args.prec_syn, "input_gradient": args.prec_bwd, "accumulate": "f32",
+             "syn_value_pass": backend.weight_format})
+        out["config"]["pool_per_class"] = args.pool_per_class
+        out["config"]["real_pool"] = ("resident in HBM: fp32 clips + the same clips converted once to the first layer's 16-bit pixel "
+                                      "rows; a real batch is an index list, no per-step conversion") if backend.resident_rows else \
+            "resident in HBM as fp32, converted per step"
+        out["loss_last"] = float(losses[-1]) / args.classes
+        out["step_tflops"] = step_flop / (dt / args.steps) / 1e12
+        out["step_frac_of_mfma_peak"] = out["step_tflops"] / PEAK_TFLOPS
+        labels = {"fwd1": "conv_mfma_kernel<PREC, 3, false, 2, 1> (balanced 7-tile layout; conv layer 1 forward, real clips)",
+                  "fwd0": "conv0_breg_kernel<PREC> (conv layer 0 forward)"}
+        roof = roofline_from_profile(prof, device, labels)
+        if roof:
+            clips = roof["flop_per_launch"] / (2.0 * macs[1]) if "fwd1" in roof["kernel"] else None
+            roof["traffic"], roof["traffic_source"] = pmc_traffic("conv1_fwd_f16", clips) if clips else (None, None)
+            roof["peak_measured"] = mfma_peak(device)
+            roof["frac_of_measured"] = roof["achieved"] / roof["peak_measured"]
+            for p in roof["programs"]:
+                if p["program"] in ("fwd0", "fwd2") and p["operands"] == args.prec_real:
+                    roof[p["program"] + "_tflops"] = p["tflops"]
+            out["roofline"] = roof
+        if sustained:
+            out["sustained"] = sustained
+        if ev:
+            out["eval"] = ev
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_dm(args, trainer, backend, args.warmup + args.steps, s2d if s2d else None)
+    finish(h, out)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# gradient matching (config 4)
+# ------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_dc(args, trainer, geo, it):
+    """The oracle on 2 class terms of the same step: dCE/dparams on the real batch (detached), on the synthetic clips with
+    create_graph, match_loss, backward to the pixels."""
+    from oracle import ref_cpu as R
+    from video_distillation_amd import distill
+    import torch.nn.functional as F
+    ncls = min(2, len(trainer.classes))
+    dev = trainer.image_syn.device
+    params = [p.cpu().requires_grad_(True) for p in distill.fresh_full_network(it, args.classes, dev)]
+    idx = distill.sample_real_indices(it, trainer.pool.counts, trainer.pool.offsets, args.batch_real, trainer.classes[:ncls])
+    real = trainer.pool.clips[torch.as_tensor(idx, device=dev)].cpu()
+
+    def probe():
+        with torch.no_grad():
+            R.convnet3d_embed(real[:8], params)
+    threads, ncpu = best_threads(probe)
+    t0 = time.perf_counter()
+    total = 0.0
+    for k in range(ncls):
+        c = trainer.classes[k]
+        xr = real[k * args.batch_real:(k + 1) * args.batch_real]
+        gw_real = [g.detach() for g in torch.autograd.grad(
+            F.cross_entropy(R.convnet3d_logits(xr, params), torch.full((xr.shape[0],), c)), params)]
+        xs = trainer.image_syn[k * args.ipc:(k + 1) * args.ipc].detach().cpu().requires_grad_(True)
+        gw_syn = torch.autograd.grad(F.cross_entropy(R.convnet3d_logits(xs, params), torch.full((args.ipc,), c)), params,
+                                     create_graph=True)
+        loss = R.match_loss(gw_syn, gw_real, args.dis_metric)
+        torch.autograd.grad(loss, xs)
+        total += float(loss)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / (dt / ncls * args.classes), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "%d of %d class terms (%d real clips first-order + %d syn clips double backward, %dx%dx%d, dropout off), "
+                      "%.1f s, extrapolated x%.1f; threads = fastest of a calibration over 8..%d" % (
+                          ncls, args.classes, args.batch_real, args.ipc, args.size, args.size, args.frames, dt,
+                          args.classes / ncls, ncpu)}
+
+
+def bench_dc(args, h, distill, geo, pool):
+    """Config 4: one step = one `for it` iteration of distill.GMTrainer with get_loops(ipc) (ipc 1 / 5 -> outer 1, inner 1)."""
+    from video_distillation_amd import networks, utils
+    device, rank, world = h.device, h.rank, h.world
+    outer, inner = utils.get_loops(args.ipc)
+    ops = distill.HipGMOps(device, args.dis_metric)
+    trainer = distill.GMTrainer(ops, pool, geo, args.classes, args.ipc, args.batch_real, lr_img=0.1, rank=rank, world=world,
+                                outer_loop=outer, inner_loop=inner)
+
+    def mark():
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def step(it):
+        return trainer.global_loss(trainer.step(it))
+    dt, per_step, prof, losses = h.run(step, lambda: None, mark)
+    sustained = h.sustained(step, lambda: None, args.warmup + args.steps)
+    out = None
+    if rank == 0:
+        macs = sum(conv_layer_macs(geo))
+        # per class term: real batch fwd + bwd (dgrad + wgrad = 2 x fwd), synthetic clips fwd + bwd + second-order sweep
+        # (up: 2 x fwd, down: 2 x dgrad) -- algorithmic products, every pass counted once
+        step_flop = 2.0 * macs * len(range(args.classes)) * (args.batch_real * 3 + args.ipc * (3 + 4)) * outer
+        out = base_record(args, h, "distillation steps/sec (DC gradient matching '%s', IPC=%d)" % (args.dis_metric, args.ipc),
+                          dt, per_step, networks.get_precision()["match"],
+                          "HMDB51-shaped gradient matching: C=%d classes x (%d real + %d syn) clips %dx%dx%d, fresh net per step, "
+                          "outer_loop %d inner_loop %d" % (args.classes, args.batch_real, args.ipc, args.size, args.size,
+                                                           args.frames, outer, inner),
+                          "class-sharded x%d (owner-computes, no gradient exchange)" % world, networks.get_precision())
+        out["loss_last"] = float(losses[-1]) / args.classes
+        out["step_tflops"] = step_flop / (dt / args.steps) / 1e12
+        out["step_frac_of_mfma_peak"] = out["step_tflops"] / PEAK_TFLOPS
+        roof = roofline_from_profile(prof, device, {})
+        if roof:
+            roof["traffic"], roof["traffic_source"] = None, None
+            roof["peak_measured"] = mfma_peak(device)
+            out["roofline"] = roof
+        if sustained:
+            out["sustained"] = sustained
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_dc(args, trainer, geo, args.warmup + args.steps)
+    finish(h, out)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# trajectory matching (config 5)
+# ------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_mtt(args, tr, traj, C, s2d):
+    """The oracle on a reduced iteration: 2 unrolled student steps of 32 clips each (create_graph), grand loss, backward to
+    the clips / syn_lr -- extrapolated by (syn_steps / 2) x (batch_syn / 32)."""
+    from oracle import ref_cpu as R
+    steps, nb = 2, min(32, tr.batch_syn)
+    dev = tr.image_syn.device
+    if s2d:
+        these = torch.arange(nb, device=dev)
+        label, sidx, didx = tr.indices(these, 0, 0)
+        x = tr.ops.hallucinate(tr.static, tr.dynamic, sidx, didx, tr.hal_w, tr.hal_b).cpu()
+        labels = label.cpu()
+    else:
+        x, labels = tr.image_syn[:nb].cpu(), tr.label_syn[:nb].cpu()
+    start = [p.cpu() for p in traj[0]]
+    target = [p.cpu() for p in traj[1]]
+
+    def probe():
+        with torch.no_grad():
+            R.convnet3d_embed(x[:8], start)
+    threads, ncpu = best_threads(probe)
+    t0 = time.perf_counter()
+    R.mtt_step(start, target, x, labels, 0.01, [torch.arange(nb)] * steps)
+    dt = time.perf_counter() - t0
+    scale = (tr.syn_steps / steps) * (tr.batch_syn / nb)
+    return {"value": 1.0 / (dt * scale), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "%d unrolled student steps x %d clips %dx%dx%d (create_graph) + backward of the grand loss, %.1f s, "
+                      "extrapolated x%.0f to %d steps x %d clips (hallucinator excluded); threads = fastest of a calibration "
+                      "over 8..%d" % (steps, nb, args.size, args.size, args.frames, dt, scale, tr.syn_steps, tr.batch_syn, ncpu)}
+
+
+def bench_mtt(args, h, distill, geo):
+    """Config 5 ("Kinetics-400 MTT+Ours"): one iteration = syn_steps unrolled student steps on batch_syn hallucinator-composed
+    clips + the reverse sweep to dynamic memories, hallucinator and syn_lr (static frozen, sh/s2d/s2d_MTT_ms_K400.sh); expert
+    buffer = random-walk parameter lists shared by all ranks; every step's batch is split over the ranks."""
+    from video_distillation_amd import networks
+    device, rank, world = h.device, h.rank, h.world
+    C = args.classes
+    gen = torch.Generator(device=device); gen.manual_seed(99)
+    traj = [distill.fresh_full_network(5, C, device)]
+    for e in range(11):
+        traj.append([p + 0.01 * p.abs().mean() * torch.randn(p.shape, device=device, generator=gen) for p in traj[-1]])
+    s2d = not args.mtt_raw
+    if s2d:
+        vpc, spc, dpc = 1, 2, 2
+        batch = min(args.batch_syn, C * vpc)
+        ops = distill.HipMTTOps(geo, C, device, dropout_p=0.5, batch_hint=batch // max(world, 1))
+        static = torch.randn(C * spc, 3, args.size, args.size, device=device, generator=gen)
+        dynamic = torch.randn(C, dpc, args.frames, 1, args.size, args.size, device=device, generator=gen)
+        hal_w = torch.empty(3, 4, 3, 3, 3, device=device).uniform_(-0.096, 0.096, generator=gen)
+        hal_b = torch.empty(3, device=device).uniform_(-0.096, 0.096, generator=gen)
+        tr = distill.S2DMTTTrainer(ops, C, vpc, spc, dpc, static, dynamic, hal_w, hal_b, syn_lr=0.01, lr_dynamic=1.0, lr_hal=1e-3,
+                                   lr_lr=1e-6, syn_steps=args.syn_steps, batch_syn=batch, expert_epochs=1, max_start_epoch=10,
+                                   rank=rank, world=world)
+    else:
+        batch = min(args.batch_syn, C * args.ipc)
+        ops = distill.HipMTTOps(geo, C, device, dropout_p=0.5, batch_hint=batch // max(world, 1))
+        image_syn = torch.randn(C * args.ipc, args.frames, 3, args.size, args.size, device=device, generator=gen)
+        label_syn = torch.arange(C, device=device).repeat_interleave(args.ipc)
+        tr = distill.MTTTrainer(ops, C, image_syn, label_syn, syn_lr=0.01, lr_img=1.0, lr_lr=1e-6, syn_steps=args.syn_steps,
+                                batch_syn=batch, expert_epochs=1, max_start_epoch=10, rank=rank, world=world)
+
+    def mark():
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def step(it):
+        return tr.step(it, traj)
+    dt, per_step, prof, losses = h.run(step, lambda: None, mark)
+    sustained = h.sustained(step, lambda: None, args.warmup + args.steps)
+    out = None
+    if rank == 0:
+        macs = sum(conv_layer_macs(geo))
+        # per student step and clip: fwd + first-order bwd (2 x fwd) + second-order sweep with parameter adjoints
+        # (up 2 x fwd, down 2 x dgrad + 2 x wgrad)
+        step_flop = 2.0 * macs * tr.syn_steps * tr.batch_syn * (3 + 6)
+        out = base_record(args, h, "distillation steps/sec (MTT%s, syn_steps=%d)" % ("+Ours s2d" if s2d else "", args.syn_steps), dt,
+                          per_step, networks.get_precision()["match"],
+                          "Kinetics-400-shaped trajectory matching%s: C=%d classes, %d clips %dx%dx%d per student step x %d steps, "
+                          "expert_epochs 1, synthetic random-walk expert buffer" % (
+                              " over static+dynamic memories (vpc 1 / spc 2 / dpc 2, static frozen)" if s2d else "", C, tr.batch_syn,
+                              args.size, args.size, args.frames, args.syn_steps),
+                          "student batch split x%d, all-reduce of flat gradient + Hessian-vector product per inner step" % world,
+                          networks.get_precision())
+        out["grand_loss_last"] = float(losses[-1])
+        out["syn_lr"] = float(tr.syn_lr)
+        out["step_tflops"] = step_flop / (dt / args.steps) / 1e12
+        out["step_frac_of_mfma_peak"] = out["step_tflops"] / PEAK_TFLOPS
+        roof = roofline_from_profile(prof, device, {})
+        if roof:
+            roof["traffic"], roof["traffic_source"] = None, None
+            roof["peak_measured"] = mfma_peak(device)
+            out["roofline"] = roof
+        if sustained:
+            out["sustained"] = sustained
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_mtt(args, tr, traj, C, s2d)
+    finish(h, out)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -138,14 +585,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=device)
+    if args.pool_per_class is None:
+        args.pool_per_class = 1 if args.method == "mtt" else 93
 
     from video_distillation_amd import distill, plan
-    geo = plan.NetGeometry(args.frames, args.size, args.size)
-    c_lo, c_hi = distill.class_range(args.classes, rank, world)
     from video_distillation_amd.networks import _batch_hint
-    backend = distill.HipBackend(geo, device, prec_real=args.prec_real, prec_syn=args.prec_syn, chunk=args.chunk,
-                                 prec_bwd=args.prec_bwd,
-                                 syn_batch_hint=_batch_hint((c_hi - c_lo) * args.ipc) if os.environ.get("VD_SYN_HINT", "1") == "1" else None)
+    geo = plan.NetGeometry(args.frames, args.size, args.size)
+    h = Harness(args, device, rank, world)
+    if args.method == "mtt":
+        return bench_mtt(args, h, distill, geo)
+    c_lo, c_hi = distill.class_range(args.classes, rank, world)
     shard = args.shard
     if shard == "auto":
         shard = "batch" if (world > 1 and args.batch_real % world == 0 and args.method == "dm") else "class"
@@ -155,221 +604,12 @@ def main():
         pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device,
                                           seed=1234 + rank)
     if args.method == "dc":
-        return bench_dc(args, distill, geo, pool, device, rank, world)
-    if args.method == "mtt":
-        return bench_mtt(args, distill, geo, pool, device, rank, world)
-    if args.method == "dm":
-        trainer = distill.DMTrainer(backend, pool, args.classes, args.ipc, args.batch_real, lr_img=1.0, momentum=0.5,
-                                    rank=rank, world=world, shard=shard)
-    else:   # sh/s2d/s2d_DM_ms.sh: vpc 1, spc 2, dpc 2, static frozen, SGD(.95) on dynamic memory + hallucinator
-        gen = torch.Generator(device=device); gen.manual_seed(77)
-        static_syn = torch.randn(args.classes * 2, 3, args.size, args.size, device=device, generator=gen)
-        dynamic_syn = torch.randn(args.classes, 2, args.frames, 1, args.size, args.size, device=device, generator=gen)
-        hal_w = torch.empty(3, 4, 3, 3, 3, device=device).uniform_(-0.096, 0.096, generator=gen)
-        hal_b = torch.empty(3, device=device).uniform_(-0.096, 0.096, generator=gen)
-        trainer = distill.S2DTrainer(backend, pool, args.classes, 1, 2, 2, args.batch_real, static_syn, dynamic_syn,
-                                     hal_w, hal_b, lr_dynamic=1.0, lr_hal=0.01, rank=rank, world=world)
-        trainer.image_syn = trainer.dynamic
-        trainer.global_loss = lambda l: l
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for it in range(args.warmup):
-        trainer.step(it, overlap=True)
-    trainer.sync()
-    backend.eng_real.profile = []           # HIP-event pairs around the dominant kernel's launches
-    barrier()
-    t0 = time.perf_counter()
-    losses = []
-    for it in range(args.warmup, args.warmup + args.steps):
-        losses.append(trainer.global_loss(trainer.step(it, overlap=True)))
-    trainer.sync()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
-    prof = backend.eng_real.profile
-    backend.eng_real.profile = None
-
-    if rank == 0:
-        macs = conv_layer_macs(geo)
-        step_flop = 2.0 * sum(macs) * (args.classes * (args.batch_real + args.ipc) + args.classes * args.ipc)
-        ms_per_step = dt / args.steps * 1e3
-        out = {
-            "metric": "distillation steps/sec (%s, miniUCF101 IPC=%d)" % ("DM" if args.method == "dm" else "DM+Ours s2d", args.ipc),
-            "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f16" if args.prec_real == "f16" else args.prec_real, "data": "synthetic",
-            "config": {"workload": "miniUCF101-shaped DM IPC=%d: C=%d classes x (%d real + %d syn) clips %dx%dx%d, "
-                                   "ConvNet3D depth 3, fresh net per step" % (args.ipc, args.classes, args.batch_real,
-                                                                               args.ipc, args.size, args.size, args.frames),
-                       "precision": {"real_clips": args.prec_real, "syn_clips_fwd": args.prec_syn, "input_gradient": args.prec_bwd,
-                                     "accumulate": "f32"},
-                       "parallelism": ("real batch sharded x%d + all-reduce of per-class feature sums (410 KB); synthetic clips "
-                                       "class-owned, no gradient exchange" % world) if trainer.__dict__.get("shard") == "batch" else
-                                      "class-sharded x%d (owner-computes, no gradient exchange)" % world,
-                       "pool_per_class": args.pool_per_class,
-                       "real_pool": "resident in HBM: fp32 clips + the same clips converted once to the first layer's 16-bit pixel "
-                                    "rows; a real batch is an index list (get_images + cast of the reference), no per-step "
-                                    "conversion" if backend.resident_rows else "resident in HBM as fp32, converted per step"},
-            "loss_last": float(losses[-1]) / args.classes,
-            "step_tflops": step_flop / (dt / args.steps) / 1e12,
-            "step_frac_of_mfma_peak": step_flop / (dt / args.steps) / 2.5e15,
-        }
-        # roofline of the dominant kernel: fwd conv layer 1 over the real clips
-        if prof:
-            times = [a.elapsed_time(b) * 1e-3 for (name, n, a, b) in prof if name == "fwd1"]
-            clips = [n for (name, n, a, b) in prof if name == "fwd1"]
-            flop_per_launch = 2.0 * macs[1] * float(np.mean(clips))
-            achieved = flop_per_launch / float(np.mean(times)) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<%s, 3, false, 2, 1> = PREC %s, balanced 7-tile layout (conv layer 1 fwd, real clips)" % (
-                                   {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}[args.prec_real], args.prec_real)
-                               if not args.prec_real.endswith("x3") else "conv_mfma_kernel<%s, 7> (conv layer 1 fwd, real clips)" % args.prec_real,
-                               "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
-                               "traffic": pmc_traffic(float(np.mean(clips))), "launches": len(times), "mean_launch_ms": float(np.mean(times)) * 1e3,
-                               "flop_per_launch": flop_per_launch}
-            for lname, li in (("fwd0", 0), ("fwd2", 2)):
-                tt = [a.elapsed_time(b) * 1e-3 for (name, n, a, b) in prof if name == lname]
-                cc = [n for (name, n, a, b) in prof if name == lname]
-                if tt:
-                    out["roofline"][lname + "_tflops"] = 2.0 * macs[li] * float(np.mean(cc)) / float(np.mean(tt)) / 1e12
-        if args.eval_epochs > 0 and args.method == "dm" and world == 1:    # (single process: gather_syn is a collective)
-            out["eval"] = run_eval(args, trainer, pool, device)
-        if world == 1 and not args.no_cpu_baseline and args.method == "dm":
-            out["cpu_baseline"] = cpu_baseline(args, trainer, backend, args.warmup + args.steps, geo)
-        print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def run_eval(args, trainer, pool, device):
-    """evaluate_synset (utils.py:848-886) on the current synthetic clips: a fresh ConvNet3D trained for
-    --eval-epochs epochs with the HIP train step, tested (3 passes, HIP inference) on 4 held-out pool clips per
-    class.  The pool is synthetic noise, so the accuracy is chance level by construction; the timing is the point."""
-    import types
-    from video_distillation_amd import utils
-    C = args.classes
-    syn = trainer.gather_syn().detach().clone()
-    labels = torch.arange(C, device=device).repeat_interleave(args.ipc)
-    idx = torch.as_tensor([pool.offsets[c] + pool.counts[c] - 1 - k for c in range(C) for k in range(4)], device=device)
-    test = utils.TensorDataset(pool.clips[idx], torch.arange(C, device=device).repeat_interleave(4))
-    loader = torch.utils.data.DataLoader(test, batch_size=64, shuffle=False)
-    eargs = types.SimpleNamespace(device=device, lr_net=0.01, epoch_eval_train=args.eval_epochs, batch_train=256,
-                                  model="ConvNet3D", eval_mode="SS")
-    net = utils.get_network("ConvNet3D", 3, C, (args.size, args.size), frames=args.frames, dist=False).to(device)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    _, acc_train, acc_test, _ = utils.evaluate_synset(0, net, syn, labels, loader, eargs, mode="none")
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"epochs": args.eval_epochs + 1, "seconds": dt, "ms_per_epoch": dt / (args.eval_epochs + 1) * 1e3,
-            "acc_train": float(acc_train), "acc_test": float(acc_test), "test_clips": int(idx.numel()),
-            "note": "synthetic noise pool: test accuracy is chance by construction"}
-
-
-def bench_dc(args, distill, geo, pool, device, rank, world):
-    """Secondary line: gradient matching, one step = one `for it` iteration of
-    distill.GMTrainer with get_loops(ipc) (ipc 1 / 5 -> outer 1, inner 1: no network update inside)."""
-    from video_distillation_amd import utils
-    outer, inner = utils.get_loops(args.ipc)
-    ops = distill.HipGMOps(device, args.dis_metric)
-    trainer = distill.GMTrainer(ops, pool, geo, args.classes, args.ipc, args.batch_real, lr_img=0.1, rank=rank, world=world,
-                                outer_loop=outer, inner_loop=inner)
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-    for it in range(args.warmup):
-        trainer.step(it)
-    barrier()
-    t0 = time.perf_counter()
-    losses = [trainer.global_loss(trainer.step(it)) for it in range(args.warmup, args.warmup + args.steps)]
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
-    if rank == 0:
-        from video_distillation_amd import networks
-        print(json.dumps({
-            "metric": "distillation steps/sec (DC gradient matching '%s', IPC=%d)" % (args.dis_metric, args.ipc),
-            "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": networks.get_precision()["match"], "data": "synthetic",
-            "config": {"workload": "gradient matching: C=%d classes x (%d real + %d syn) clips %dx%dx%d, fresh net per step, "
-                                   "outer_loop %d inner_loop %d" % (args.classes, args.batch_real, args.ipc, args.size, args.size,
-                                                                    args.frames, outer, inner),
-                       "precision": networks.get_precision(),
-                       "parallelism": "class-sharded x%d (owner-computes, no gradient exchange)" % world},
-            "loss_last": float(losses[-1]) / args.classes}))
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def bench_mtt(args, distill, geo, pool, device, rank, world):
-    """Secondary line: one MTT iteration = syn_steps unrolled student steps on
-    batch_syn synthetic clips + the reverse sweep to the pixels and syn_lr; expert buffer = random-walk
-    parameter lists (11 epochs) shared by all ranks; every step's batch is split over the ranks."""
-    from video_distillation_amd import networks
-    C = args.classes
-    gen = torch.Generator(device=device); gen.manual_seed(99)
-    image_syn = torch.randn(C * args.ipc, args.frames, 3, args.size, args.size, device=device, generator=gen)
-    label_syn = torch.arange(C, device=device).repeat_interleave(args.ipc)
-    traj = [distill.fresh_full_network(5, C, device)]
-    for e in range(11):
-        traj.append([p + 0.01 * p.abs().mean() * torch.randn(p.shape, device=device, generator=gen) for p in traj[-1]])
-    ops = distill.HipMTTOps(geo, C, device, dropout_p=0.5, batch_hint=min(args.batch_syn, C * args.ipc) // max(world, 1))
-    tr = distill.MTTTrainer(ops, C, image_syn, label_syn, syn_lr=0.01, lr_img=1.0, lr_lr=1e-6, syn_steps=args.syn_steps,
-                            batch_syn=min(args.batch_syn, C * args.ipc), expert_epochs=1, max_start_epoch=10, rank=rank, world=world)
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-    for it in range(args.warmup):
-        tr.step(it, traj)
-    barrier()
-    t0 = time.perf_counter()
-    losses = [tr.step(it, traj) for it in range(args.warmup, args.warmup + args.steps)]
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
-    if rank == 0:
-        print(json.dumps({
-            "metric": "distillation steps/sec (MTT, syn_steps=%d)" % args.syn_steps,
-            "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": networks.get_precision()["match"], "data": "synthetic",
-            "config": {"workload": "trajectory matching: C=%d classes, %d synthetic clips %dx%dx%d, syn_steps %d x batch_syn %d, "
-                                   "expert_epochs 1, synthetic random-walk expert buffer" % (
-                                       C, C * args.ipc, args.size, args.size, args.frames, args.syn_steps, tr.batch_syn),
-                       "precision": networks.get_precision(),
-                       "parallelism": "student batch split x%d, all-reduce of flat gradient + Hessian-vector product per inner step" % world},
-            "grand_loss_last": float(losses[-1]), "syn_lr": tr.syn_lr}))
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+        return bench_dc(args, h, distill, geo, pool)
+    nsyn = (c_hi - c_lo) * (args.ipc if args.method == "dm" else 1)
+    backend = distill.HipBackend(geo, device, prec_real=args.prec_real, prec_syn=args.prec_syn, chunk=args.chunk,
+                                 prec_bwd=args.prec_bwd,
+                                 syn_batch_hint=_batch_hint(nsyn) if os.environ.get("VD_SYN_HINT", "1") == "1" else None)
+    return bench_dm(args, h, distill, plan, geo, pool, backend, shard)
 
 
 if __name__ == "__main__":

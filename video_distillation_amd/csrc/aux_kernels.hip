@@ -974,8 +974,16 @@ __global__ __launch_bounds__(64) void ce_loss_kernel(const float* __restrict__ l
     float sum = 0.f;
     for (int k = lane; k < K; k += 64) sum += __expf(z[k] - m);
     sum = wave_sum(sum);
-    const int y = (int)labels[clip];
+    const int64_t yl = labels[clip];
     const float lse = m + __logf(sum);
+    if (yl < 0 || yl >= K) {
+        // a label outside [0, K): torch raises; without a host sync the loud failure is a NaN loss and gradient
+        const float nan = __uint_as_float(0x7fc00000u);
+        if (lane == 0) loss_per_clip[clip] = nan;
+        for (int k = lane; k < K; k += 64) dlogits[(int64_t)clip * K + k] = nan;
+        return;
+    }
+    const int y = (int)yl;
     if (lane == 0) loss_per_clip[clip] = lse - z[y];
     const float invB = 1.f / (float)B;
     for (int k = lane; k < K; k += 64) dlogits[(int64_t)clip * K + k] = (__expf(z[k] - lse) - (k == y ? 1.f : 0.f)) * invB;
@@ -1225,6 +1233,36 @@ extern "C" int vd_standardize(const float* x, int64_t n, double* scratch2, float
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sum_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, scratch2);
     hipLaunchKernelGGL(standardize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, scratch2, out);
+    return (int)hipGetLastError();
+}
+
+// MFMA-saturating microbenchmark ("a measured MFMA-saturating microbenchmark beside the spec
+// figure"): every wave issues `iters` x 8 independent v_mfma_f32_32x32x16_f16 from registers, no memory traffic in the
+// loop.  FLOP = grid * 4 waves * iters * 8 * 32768.
+typedef _Float16 vd_f16x8 __attribute__((ext_vector_type(8)));
+typedef float vd_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* __restrict__ out) {
+    vd_f16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (float)((threadIdx.x + i) & 15)); b[i] = (_Float16)(0.002f * (float)((threadIdx.x * 3 + i) & 7)); }
+    vd_f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {}, c4 = {}, c5 = {}, c6 = {}, c7 = {};
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c4, 0, 0, 0);
+        c5 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c5, 0, 0, 0);
+        c6 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c6, 0, 0, 0);
+        c7 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c7, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i] + c4[i] + c5[i] + c6[i] + c7[i];
+    out[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+extern "C" int vd_mfma_peak(int blocks, int iters, float* out, void* stream) {
+    if (blocks <= 0 || iters <= 0 || out == nullptr) return -1;
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), iters, out);
     return (int)hipGetLastError();
 }
 

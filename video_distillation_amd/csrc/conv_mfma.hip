@@ -23,6 +23,7 @@
 // Replaces nn.Conv3d / nn.ReLU / nn.MaxPool3d of ConvNet3D.features (reference
 // networks.py:757, 768-770, 799) and the input-gradient half of their autograd backward.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 #include "../../include/vd_hip.h"
@@ -45,6 +46,30 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Per-kernel, per-DEVICE launch preparation (160 KB dynamic LDS attribute, CU count): hipFuncSetAttribute applies to the
+// current device only, and several host threads / devices may launch the same instantiation.
+struct VdDevCache {
+    std::mutex mu;
+    bool done[64] = {};
+    int ncu[64] = {};
+};
+static int vd_dev_prepare(const void* kern, VdDevCache& c, int& ncu) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return -4;
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.done[dev]) {
+        e = hipDeviceGetAttribute(&c.ncu[dev], hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || c.ncu[dev] <= 0) return e != hipSuccess ? (int)e : -4;
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        c.done[dev] = true;
+    }
+    ncu = c.ncu[dev];
+    return 0;
+}
 
 template <int PREC>
 __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, f32x16 c) {
@@ -921,17 +946,10 @@ template <int PREC>
 static int launch_conv0_breg(const VdConvParams& p, hipStream_t st) {
     const int64_t total = (int64_t)p.nclips * p.nbox;
     if (total <= 0) return 0;
-    static int ncu = 0;
     auto kern = conv0_breg_kernel<PREC>;
-    if (ncu == 0) {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return (int)e;
-        e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess || ncu <= 0) return e != hipSuccess ? (int)e : -4;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-    }
+    static VdDevCache cache;
+    int ncu = 0;
+    if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
     const size_t lds = (size_t)p.lds_plane_bytes + (2 * 32 + 32) * sizeof(int) + 16;
     if (lds > 80 * 1024) return -3;
     const int64_t slots = (int64_t)ncu * 2;
@@ -960,25 +978,14 @@ template <int PREC>
 static int launch_conv0_persistent(const VdConvParams& p, hipStream_t st) {
     const int total = ((p.nclips + p.ncl - 1) / p.ncl) * p.nbox;
     if (total <= 0) return 0;
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return (int)e;
-        e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess || ncu <= 0) return e != hipSuccess ? (int)e : -4;
-    }
+    auto kern = conv0_persistent_kernel<PREC>;
+    static VdDevCache cache;
+    int ncu = 0;
+    if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
     const int per = (total + ncu - 1) / ncu;
     const int grid = (total + per - 1) / per;
     const size_t lds = (size_t)2 * p.lds_plane_bytes + (size_t)2 * p.S * sizeof(int) + 16;
     if (lds > 160 * 1024) return -3;
-    auto kern = conv0_persistent_kernel<PREC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p, per);
     return (int)hipGetLastError();
 }
@@ -1006,18 +1013,9 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     auto kern = conv_mfma_kernel<PREC, MTW, SO, NTW, BAL>;
     if (p.NT % NTW != 0) return -2;
     const int ncols = p.NT / NTW;
-    static bool attr_set = false;
-    static int ncu = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        int dev = 0;
-        e = hipGetDevice(&dev);
-        if (e != hipSuccess) return (int)e;
-        e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess || ncu <= 0) return e != hipSuccess ? (int)e : -4;
-        attr_set = true;
-    }
+    static VdDevCache cache;
+    int ncu = 0;
+    if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
     // resident workgroups per CU: LDS and the register budget of this instantiation (MTW 4: 3 waves
     // per SIMD, otherwise 2; x3 variants of MTW 4 use more registers -> 2)
     int occ = (int)((160 * 1024) / lds);

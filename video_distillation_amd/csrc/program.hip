@@ -15,6 +15,7 @@
 struct VdProgram {
     VdConvParams p;
     int32_t* d_tables;     // one allocation: type_desc | tables | boxes | gather | widx | col_off
+    const int32_t* d_widx; // the weight gather index inside d_tables
     void* d_zero;
     void* d_wpk;
     int64_t n_widx;
@@ -32,8 +33,10 @@ extern "C" int vd_program_load(const void* blob, int64_t nbytes, int prec, VdPro
     if (memcmp(h, VD_PROG_MAGIC, 8) != 0) return -2;
     const int64_t n_desc = h[H_N_DESC], n_tab = h[H_N_TABLES], n_box = h[H_N_BOXES], n_gat = h[H_N_GATHER], n_w = h[H_N_WIDX],
                   n_col = h[H_N_COLOFF];
+    if (n_desc < 0 || n_tab < 0 || n_box < 0 || n_gat < 0 || n_w < 0 || n_col < 0) return -3;      // every section count
     const int64_t n_int = n_desc + n_tab + n_box + n_gat + n_w + n_col;
-    if (n_int < 0 || nbytes != (int64_t)(H_WORDS * sizeof(int64_t)) + n_int * (int64_t)sizeof(int32_t)) return -3;
+    if (nbytes != (int64_t)(H_WORDS * sizeof(int64_t)) + n_int * (int64_t)sizeof(int32_t)) return -3;
+    if (h[H_NBOX] < 0 || h[H_GSTRIDE] < 0 || n_gat != h[H_NBOX] * h[H_GSTRIDE] || n_box != 8 * h[H_NBOX]) return -3;
     if (prec < 0 || prec > 3) return -4;
     VdProgram* g = static_cast<VdProgram*>(calloc(1, sizeof(VdProgram)));
     if (g == nullptr) return -5;
@@ -57,7 +60,7 @@ extern "C" int vd_program_load(const void* blob, int64_t nbytes, int prec, VdPro
     p.tables = d;               d += n_tab;
     p.boxes = d;                d += n_box;
     p.gather = d;               d += n_gat;
-    /* widx */                  d += n_w;
+    g->d_widx = d;              d += n_w;
     p.col_off = n_col > 0 ? d : nullptr;
     p.gather_stride = h[H_GSTRIDE];
     p.zero_slot = g->d_zero;
@@ -79,7 +82,7 @@ extern "C" int vd_program_load(const void* blob, int64_t nbytes, int prec, VdPro
 
 extern "C" int vd_program_pack_weights(VdProgram* g, const float* w, void* stream) {
     if (g == nullptr || w == nullptr || g->n_widx <= 0) return -1;
-    const int32_t* widx = g->p.gather + (int64_t)g->p.nbox * g->p.gather_stride;      // the array after the gather table
+    const int32_t* widx = g->d_widx;
     uint16_t* hi = static_cast<uint16_t*>(g->d_wpk);
     return vd_pack_weights(w, widx, g->n_widx, hi, g->planes == 2 ? hi + g->n_widx : nullptr, g->p.prec, stream);
 }

@@ -370,8 +370,18 @@ class DMTrainer:
         if getattr(self.be, "two_streams", False):
             self.be.join()
 
+    def mark(self):
+        """A timing event behind the last kernel of the latest step (bench.py: per-step times under overlap)."""
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(self.be.s_syn if getattr(self.be, "two_streams", False) else torch.cuda.current_stream(self.image_syn.device))
+        return ev
+
     def gather_syn(self) -> torch.Tensor:
-        """All synthetic clips in class order on every rank (evaluation / ``images_*.pt``)."""
+        """All synthetic clips in class order on every rank (evaluation / ``images_*.pt``).  Waits for the steps still
+        in flight on the trainer's own streams first: with ``overlap=True`` the SGD write of the latest step may not have
+        landed when the caller's stream starts copying."""
+        if hasattr(self, "sync"):
+            self.sync()
         if self.world == 1:
             return self.image_syn
         import torch.distributed as dist
@@ -487,6 +497,11 @@ class S2DTrainer:
     def sync(self) -> None:
         if getattr(self.be, "two_streams", False):
             self.be.join()
+
+    def mark(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(self.be.s_syn if getattr(self.be, "two_streams", False) else torch.cuda.current_stream(self.dynamic.device))
+        return ev
 
 
 # ------------------------------------------------------------------------------------------------

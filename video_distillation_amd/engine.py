@@ -19,6 +19,11 @@ from . import hip
 from . import plan as P
 
 
+# Measurement hook (bench.py): a list here makes every tile-program launch append
+# (program name, precision id, algorithmic FLOP of the launch, start event, end event) -- HIP events on the launch stream.
+LAUNCH_PROFILE: Optional[list] = None
+
+
 class _DevPlan:
     """A ConvPlan with its tables resident on the device and a reusable parameter block."""
 
@@ -93,14 +98,20 @@ class _DevPlan:
         p.dst = dst_ptr; p.dst_plane_stride = dst_plane_stride
         p.argmax = 0 if argmax is None else argmax.data_ptr()
         p.nclips = nclips
+        prof = LAUNCH_PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self.breg_ok and argmax is None and not p.dbg:
             hip.check(hip.lib().vd_conv0_breg(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv0_breg(%s)" % self.plan.name)
-            return
-        if self.persistent_ok and argmax is None and not p.dbg:
+        elif self.persistent_ok and argmax is None and not p.dbg:
             hip.check(hip.lib().vd_conv0_persistent(ctypes.byref(p), hip.stream_ptr(src.device)),
                       "vd_conv0_persistent(%s)" % self.plan.name)
-            return
-        hip.check(hip.lib().vd_conv_mfma(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv_mfma(%s)" % self.plan.name)
+        else:
+            hip.check(hip.lib().vd_conv_mfma(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv_mfma(%s)" % self.plan.name)
+        if prof is not None:
+            e1.record()
+            prof.append((self.plan.name, self.prec, 2.0 * self.plan.meta.get("macs_per_unit", 0) * nclips, e0, e1))
 
 
 def round_weights(params: Sequence[torch.Tensor], prec: str) -> List[torch.Tensor]:
@@ -313,7 +324,7 @@ class WgradOp:
         self.planes = 2 if hip.is_x3(self.prec) else 1
         self.device = torch.device(device)
         blk = os.environ.get("VD_WG_BLOCK")
-        self.plan = P.plan_wgrad("wgrad", cin, cout, t, h, w, nclips, block=tuple(int(v) for v in blk.split(",")) if blk else None)
+        self.plan = P.plan_wgrad("wgrad%dx%d" % (cin, cout), cin, cout, t, h, w, nclips, block=tuple(int(v) for v in blk.split(",")) if blk else None)
         self.dp = _DevPlan(self.plan, self.device, self.prec)
         self.T, self.OH, self.OW = self.plan.meta["grid"]
         self.CCb = self.plan.CC

@@ -422,7 +422,9 @@ def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps
                     pool_t=pool_t, relu=relu, n_out=n_out, n_stride=n_stride,
                     out_clip_stride=out_clip_stride, out_chunk_stride=out_chunk_stride,
                     out_shape=tuple(out_shape), rows_total=len(boxes) * mt_pad * 32 // ncl,
-                    rows_useful=rows_useful, meta={"box": box})
+                    rows_useful=rows_useful,
+                    # algorithmic multiply-accumulates per clip: output rows x taps x input channels x output columns
+                    meta={"box": box, "macs_per_unit": int(rows_useful) * ntaps * CC * 8 * int(n_out)})
 
 
 # ----------------------------------------------------------------------------------------
@@ -573,6 +575,7 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
     rowp = pix_row_pitch(w_in)
     plan.w_step4, plan.row_pitch4 = 1, rowp // 2
     plan.chunk_stride4 = plan.clip_stride4 = t_in * cin * h_in * (rowp // 2)
+    plan.meta["macs_per_unit"] = T * OH * OW * cin * 3 * 7 * 7 * cout        # (the kw-slot carries an eighth, zero-weight tap)
     return plan
 
 
@@ -691,6 +694,7 @@ def plan_dgrad_pix(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: i
                       clip_stride, 0, (t_in, cin, h_in, w_in), lds_budget, (max_ncl,))
     n = np.arange(32)
     plan.col_off = np.where(n < cin * 4, (n // 4) * h_in * w_in + ((n // 2) % 2) * w_in + (n % 2), 0).astype(np.int32)
+    plan.meta["macs_per_unit"] = T * OH * OW * cin * 3 * 7 * 7 * cout        # all four parity classes = the layer's forward count
     return plan
 
 
@@ -785,7 +789,8 @@ def _plan_wgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int,
                     rows_total=len(boxes) * MTW * 32, rows_useful=len(boxes) * len(rows_tap), meta={"box": (nt, noh, now)})
     plan.atomic = True
     plan.w_box_stride = CCb * S * NT * 64 * 8
-    plan.meta.update({"blocks": blocks, "positions": positions, "grid": (T, OH, OW), "nclips": nclips, "cout": cout})
+    plan.meta.update({"blocks": blocks, "positions": positions, "grid": (T, OH, OW), "nclips": nclips, "cout": cout,
+                      "macs_per_unit": T * OH * OW * KT * KH * KW * cout * nclips})       # unit = one input channel
     return plan
 
 
