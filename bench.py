@@ -271,6 +271,10 @@ def cpu_baseline_dm(args, trainer, backend, it, s2d=None):
         dy = trainer.dynamic.cpu().requires_grad_(True)
         w, b = trainer.hal_w.cpu().requires_grad_(True), trainer.hal_b.cpu().requires_grad_(True)
         img = R.hallucinator(st[sidx[:n].cpu()], dy[didx[:n].cpu()], w, b)
+        if os.environ.get("VD_BENCH_DEBUG"):
+            print("debug s2d: |img cpu| %g |syn gpu| %g |st| %g |dy| %g |w| %g diff %g" % (
+                float(img.norm()), float(syn.norm()), float(st.norm()), float(dy.norm()), float(w.norm()),
+                float((img.detach() - syn.cpu()).norm())), file=sys.stderr)
         loss_cpu = torch.zeros(())
         for c in range(ncls):
             loss_cpu = loss_cpu + R.dm_class_term(R.convnet3d_embed(reals[c], params).detach(),
@@ -284,6 +288,7 @@ def cpu_baseline_dm(args, trainer, backend, it, s2d=None):
                       "threads = fastest of a calibration over 8..%d (host has %d logical CPUs)" % (
                           ncls, args.classes, args.batch_real, per_cls, args.size, args.size, args.frames,
                           "pixels" if s2d is None else "dynamic memories + hallucinator", dt, args.classes / ncls, ncpu, ncpu),
+            "loss_cpu_sample": float(loss_cpu), "loss_gpu_sample": loss_gpu,
             "loss_rel_err_vs_gpu": abs(loss_gpu - float(loss_cpu)) / abs(float(loss_cpu))}
 
 
@@ -307,7 +312,9 @@ def run_eval(args, trainer, pool, device, rank):
     net = utils.get_network("ConvNet3D", 3, C, (args.size, args.size), frames=args.frames, dist=False).to(device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    _, acc_train, acc_test, _ = utils.evaluate_synset(0, net, syn, labels, loader, eargs, mode="none")
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):        # evaluate_synset prints its own progress line, like the reference
+        _, acc_train, acc_test, _ = utils.evaluate_synset(0, net, syn, labels, loader, eargs, mode="none")
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"top1": float(acc_test), "acc_train": float(acc_train), "epochs": args.eval_epochs + 1, "seconds": dt,
@@ -328,7 +335,9 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
         hal_w = torch.empty(3, 4, 3, 3, 3, device=device).uniform_(-0.096, 0.096, generator=gen)
         hal_b = torch.empty(3, device=device).uniform_(-0.096, 0.096, generator=gen)
         trainer = distill.S2DTrainer(backend, pool, args.classes, 1, 2, 2, args.batch_real, static_syn, dynamic_syn,
-                                     hal_w, hal_b, lr_dynamic=1.0, lr_hal=0.01, rank=rank, world=world)
+                                     hal_w, hal_b, lr_dynamic=0.01, lr_hal=1e-9, rank=rank, world=world)
+        # (lr_dynamic = the reference's default, distill_s2d_ms.py:477; lr_hal scaled down from its 0.01: on the synthetic noise
+        #  pool the hallucinator gradient is ~1e7 and the default diverges within three steps)
     gl = trainer.global_loss if hasattr(trainer, "global_loss") else (lambda l: l)
 
     def step(it):
@@ -520,8 +529,8 @@ def bench_mtt(args, h, distill, geo):
         dynamic = torch.randn(C, dpc, args.frames, 1, args.size, args.size, device=device, generator=gen)
         hal_w = torch.empty(3, 4, 3, 3, 3, device=device).uniform_(-0.096, 0.096, generator=gen)
         hal_b = torch.empty(3, device=device).uniform_(-0.096, 0.096, generator=gen)
-        tr = distill.S2DMTTTrainer(ops, C, vpc, spc, dpc, static, dynamic, hal_w, hal_b, syn_lr=0.01, lr_dynamic=1.0, lr_hal=1e-3,
-                                   lr_lr=1e-6, syn_steps=args.syn_steps, batch_syn=batch, expert_epochs=1, max_start_epoch=10,
+        tr = distill.S2DMTTTrainer(ops, C, vpc, spc, dpc, static, dynamic, hal_w, hal_b, syn_lr=0.01, lr_dynamic=0.01, lr_hal=0.01,
+                                   lr_lr=1e-5, syn_steps=args.syn_steps, batch_syn=batch, expert_epochs=1, max_start_epoch=10,
                                    rank=rank, world=world)
     else:
         batch = min(args.batch_syn, C * args.ipc)
