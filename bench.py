@@ -102,7 +102,7 @@ def mfma_peak(device):
     for _ in range(4):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        hip.check(hip.lib().vd_mfma_peak(blocks, iters, hip.ptr(out), hip.stream_ptr(device)), "vd_mfma_peak")
+        hip.check(hip.lib().vd_mfma_peak(blocks, iters, 0, hip.ptr(out), hip.stream_ptr(device)), "vd_mfma_peak")
         e1.record()
         torch.cuda.synchronize()
         best = max(best, blocks * 4 * iters * 8 * 32768.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12)

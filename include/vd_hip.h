@@ -215,10 +215,11 @@ int vd_head_second_order(const float* logits, const float* dlogits, const int32_
                          const float* mask, const float* w, const float* v_w, const float* v_b, const float* gbar_feats,
                          int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K, float* abar_feats,
                          float* wbar, float* bbar, float* dlogbar_out, void* stream);
-/* MFMA-saturating microbenchmark: blocks x 4 waves each issue iters x 8 independent v_mfma_f32_32x32x16_f16 (32768 FLOP
- * each) from registers; out receives blocks*256 floats.  The measured dense 16-bit peak that bench.py prints beside the
- * 2.5 PFLOP/s spec figure. */
-int vd_mfma_peak(int blocks, int iters, float* out, void* stream);
+/* MFMA-saturating microbenchmark: blocks x 4 waves each issue iters x 8 groups of 32768 FLOP from registers on
+ * pseudo-random operands (shape 0: v_mfma_f32_32x32x16_f16; 1: pairs of v_mfma_f32_16x16x32_f16); out receives
+ * blocks*256 floats.  The measured dense 16-bit peak that bench.py prints beside the 2.5 PFLOP/s spec figure
+ * (BASELINE.md section 3). */
+int vd_mfma_peak(int blocks, int iters, int shape, float* out, void* stream);
 int vd_sgd_momentum_wd(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, float wd, int first,
                        void* stream);
 

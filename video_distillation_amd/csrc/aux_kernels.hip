@@ -1237,32 +1237,61 @@ extern "C" int vd_standardize(const float* x, int64_t n, double* scratch2, float
 }
 
 // MFMA-saturating microbenchmark ("a measured MFMA-saturating microbenchmark beside the spec
-// figure"): every wave issues `iters` x 8 independent v_mfma_f32_32x32x16_f16 from registers, no memory traffic in the
-// loop.  FLOP = grid * 4 waves * iters * 8 * 32768.
+// figure").  Every wave issues `iters` x 8 MFMA groups from registers, no memory traffic in the loop.  The operands
+// are pseudo-random and a different register pair feeds each group (the chip sheds clock with the energy per MFMA, so
+// constant or trivial operands over-state what a real kernel can reach; MI355X_MICROARCH.md, DVFS give-back).
+//   shape 0: v_mfma_f32_32x32x16_f16, 8 independent accumulators;  shape 1: v_mfma_f32_16x16x32_f16, the same
+//   output tiles as 4 x (16x16) each, two instructions per 32x32x16 equivalent (same FLOP per group).
+// FLOP = blocks * 4 waves * iters * 8 * 32768 either way.
 typedef _Float16 vd_f16x8 __attribute__((ext_vector_type(8)));
 typedef float vd_f32x16 __attribute__((ext_vector_type(16)));
+typedef float vd_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ vd_f16x8 peak_operand(uint32_t seed) {
+    vd_f16x8 v;
+    for (int i = 0; i < 8; ++i) {
+        seed = seed * 1664525u + 1013904223u;
+        v[i] = (_Float16)(((float)(seed >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.25f);
+    }
+    return v;
+}
+
+template <int SHAPE>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* __restrict__ out) {
-    vd_f16x8 a, b;
-    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (float)((threadIdx.x + i) & 15)); b[i] = (_Float16)(0.002f * (float)((threadIdx.x * 3 + i) & 7)); }
-    vd_f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {}, c4 = {}, c5 = {}, c6 = {}, c7 = {};
-    for (int i = 0; i < iters; ++i) {
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
-        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
-        c4 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c4, 0, 0, 0);
-        c5 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c5, 0, 0, 0);
-        c6 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c6, 0, 0, 0);
-        c7 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c7, 0, 0, 0);
+    vd_f16x8 a[8], b[8];
+    for (int t = 0; t < 8; ++t) {
+        a[t] = peak_operand((uint32_t)(threadIdx.x * 131 + t * 7 + blockIdx.x));
+        b[t] = peak_operand((uint32_t)(threadIdx.x * 17 + t * 29 + 5));
     }
     float s = 0.f;
-    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i] + c4[i] + c5[i] + c6[i] + c7[i];
+    if constexpr (SHAPE == 0) {
+        vd_f32x16 c[8] = {};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) c[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], b[t], c[t], 0, 0, 0);
+        }
+        for (int t = 0; t < 8; ++t)
+            for (int i = 0; i < 16; ++i) s += c[t][i];
+    } else {
+        vd_f32x4 c[16] = {};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                c[2 * t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b[t], c[2 * t], 0, 0, 0);
+                c[2 * t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(t + 1) & 7], b[t], c[2 * t + 1], 0, 0, 0);
+            }
+        }
+        for (int t = 0; t < 16; ++t)
+            for (int i = 0; i < 4; ++i) s += c[t][i];
+    }
     out[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-extern "C" int vd_mfma_peak(int blocks, int iters, float* out, void* stream) {
-    if (blocks <= 0 || iters <= 0 || out == nullptr) return -1;
-    hipLaunchKernelGGL(mfma_peak_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), iters, out);
+extern "C" int vd_mfma_peak(int blocks, int iters, int shape, float* out, void* stream) {
+    if (blocks <= 0 || iters <= 0 || out == nullptr || shape < 0 || shape > 1) return -1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (shape == 0) hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, iters, out);
+    else hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, iters, out);
     return (int)hipGetLastError();
 }
 
