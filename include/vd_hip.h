@@ -70,6 +70,9 @@ typedef struct VdConvParams {
     int32_t mt_valid;             /* NTW = 2: M tiles per box that carry rows (< MW*MTW: the last wave row skips its padding tile); 0 = all */
     int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
+    int32_t b_hi_only;            /* x3 precisions: the lo plane of the packed B operand is all zero (weights already rounded to the
+                                   * 16-bit format: the value pass of the mixed mode) -> the A_hi x B_lo MFMA is skipped (2 of 3) */
+    int32_t reserved0;
 } VdConvParams;
 
 int vd_abi_version(void);

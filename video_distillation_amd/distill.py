@@ -333,7 +333,7 @@ class DMTrainer:
             return loss
         be.set_weights(weights)
         f_real = self._real_features(idx_t)
-        f_syn, handle = be.embed_keep(self.image_syn)
+        f_syn, handle = be.embed_syn(self.image_syn, weights) if hasattr(be, "embed_syn") else be.embed_keep(self.image_syn)
         loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
         grad = be.embed_backward(handle, g_syn)
         be.sgd(self.image_syn, self.buf, grad, self.lr_img, self.momentum, first=(self.steps_done == 0))
@@ -466,10 +466,7 @@ class S2DTrainer:
             f_real = be.embed_pool(self.pool.clips, idx_t)
         with on_syn():
             image_syn = be.hallucinate(self.static, self.dynamic, sidx, didx, self.hal_w, self.hal_b)
-            if two:
-                f_syn, handle = be.embed_syn(image_syn, weights)
-            else:
-                f_syn, handle = be.embed_keep(image_syn)
+            f_syn, handle = be.embed_syn(image_syn, weights) if hasattr(be, "embed_syn") else be.embed_keep(image_syn)
             if two:
                 be.real_to_syn(f_real)
             loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
