@@ -610,8 +610,7 @@ def main():
     if shard == "batch":   # every rank holds the whole pool (11 GB) and embeds its slice of each class batch
         pool = distill.RealPool.synthetic(args.classes, list(range(args.classes)), args.pool_per_class, geo, device, seed=1234)
     else:
-        pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device,
-                                          seed=1234 + rank)
+        pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device, seed=1234)
     if args.method == "dc":
         return bench_dc(args, h, distill, geo, pool)
     nsyn = (c_hi - c_lo) * (args.ipc if args.method == "dm" else 1)

@@ -111,7 +111,7 @@ def test_real_batch_sampling_is_sharding_invariant():
     np.testing.assert_array_equal(full, parts)
     assert len(set(full[:64])) == 64 and full[:64].max() < 93          # a permutation prefix of class 0
     assert distill.sample_real_indices(8, counts, offsets, 64, range(6)).tolist() != full.tolist()
-    few = distill.sample_real_indices(1, [3], [0], 8, [0])             # fewer clips than batch_real
+    few = distill.sample_real_indices(1, [3], [0], 8, [0], allow_repeat=True)     # fewer clips than batch_real: opt-in only
     assert few.shape == (8,) and few.max() < 3
     assert distill.sample_real_indices(1, counts, offsets, 64, []).shape == (0,)
 
@@ -364,3 +364,66 @@ def test_s2d_mtt_trainer_batch_sharded_two_ranks_gloo():
     assert abs(g_lr - float(tr.last_grads[4])) / abs(g_lr) < 1e-3
     np.testing.assert_allclose(hal_w, tr.hal_w.numpy(), rtol=1e-4, atol=1e-7)
     assert abs(syn_lr - float(tr.syn_lr)) < 1e-8
+
+
+# ---- the bench's own partition at full width: C = 50 classes over 8 ranks (blocks 7,7,6,6,6,6,6,6; batch mode 8 x 8) ----
+
+def _c50_run(rank, world, shard):
+    """One DM iteration, C=50, ipc=1, batch_real=8, 64x64x8 clips generated from a seed (identical on every rank)."""
+    C, B = 50, 8
+    g = torch.Generator().manual_seed(5050)
+    clips = torch.randn(C * B, 8, 3, 64, 64, generator=g)
+    syn = torch.randn(C, 8, 3, 64, 64, generator=g)
+    pool = _Pool(); pool.clips = clips; pool.counts = [B] * C; pool.offsets = [c * B for c in range(C)]
+    lo, hi = distill.class_range(C, rank, world)
+    tr = distill.DMTrainer(OracleBackend(), pool, C, 1, B, lr_img=0.5, momentum=0.5, rank=rank, world=world,
+                           image_syn=syn[lo:hi].clone(), shard=shard)
+    losses = [float(tr.global_loss(tr.step(it))) for it in range(1)]
+    return losses, tr.gather_syn(), (lo, hi)
+
+
+def _worker_c50(rank, world, port, q, shard):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        losses, syn, span = _c50_run(rank, world, shard)
+        spans = [None] * world
+        dist.all_gather_object(spans, span)
+        if rank == 0:
+            q.put((losses, syn.numpy(), spans))
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_c50_class(rank, world, port, q):
+    _worker_c50(rank, world, port, q, "class")
+
+
+def _worker_c50_batch(rank, world, port, q):
+    _worker_c50(rank, world, port, q, "batch")
+
+
+_C50_CACHE = {}
+
+
+@pytest.mark.parametrize("worker", [_worker_c50_class, _worker_c50_batch])
+def test_dm_trainer_eight_ranks_fifty_classes(worker):
+    """world 8, C = 50: uneven class blocks (7,7,6,...) with ragged all-gather of the synthetic clips, and the batch
+    mode with one real clip of every class per rank; both equal the single-rank run."""
+    if "ref" not in _C50_CACHE:
+        torch.set_num_threads(8)
+        _C50_CACHE["ref"] = _c50_run(0, 1, "class")
+    want_l, want_syn, _ = _C50_CACHE["ref"]
+    losses, syn, spans = _spawn(worker, 8)
+    assert [b - a for a, b in spans] == [7, 7, 6, 6, 6, 6, 6, 6] and spans[0][0] == 0 and spans[-1][1] == 50
+    np.testing.assert_allclose(losses, want_l, rtol=2e-5)
+    np.testing.assert_allclose(syn, want_syn.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_class_with_fewer_clips_than_batch_real_is_rejected():
+    """The reference takes the n available clips and averages over n (distill_baseline.py:85); the batched kernels need
+    equal batches, so a short class is an error (never a silently re-weighted mean)."""
+    with pytest.raises(ValueError):
+        distill.sample_real_indices(1, [3], [0], 8, [0])
+    assert distill.sample_real_indices(1, [3], [0], 8, [0], allow_repeat=True).shape == (8,)

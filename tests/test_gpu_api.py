@@ -424,3 +424,29 @@ def test_g12_late_regime_dm_run(golden_dir):
     assert max(rec["mixed_vs_x3"]["loss"]) < 1e-3
     assert max(rec["mixed_vs_x3"]["grad"]) < 3e-3
     assert np.median(rec["mixed_novaluepass_vs_x3"]["grad"]) > 1.5 * np.median(rec["mixed_vs_x3"]["grad"])   # the value pass earns its cost
+
+
+def test_two_gpu_bench_matches_single_gpu_loss():
+    """Multi-GPU readiness (skipped on a one-GPU box): `bench.py --gpus 2` launched exactly as the driver does
+    (torch.distributed.run, one process per GPU, RCCL) in fresh child processes, next to a one-GPU run of the same
+    steps; the all-reduced DM loss of rank 0 must equal the single-GPU loss, for both decompositions."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:          # (device_count does not initialise the GPU)
+        pytest.skip("needs two visible GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--eval-epochs", "0", "--sustain-seconds", "0",
+              "--classes", "10", "--pool-per-class", "70"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(cmd):
+        out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + common)
+    for shard in ("class", "batch"):
+        two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                   "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--shard", shard] + common)
+        assert two["n_gpus"] == 2
+        assert abs(two["loss_last"] / one["loss_last"] - 1) < 1e-4, (shard, two["loss_last"], one["loss_last"])

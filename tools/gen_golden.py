@@ -511,6 +511,64 @@ def g13(networks, utils):
         dynamic_after=dynamic_syn.detach()[:, :, :, :, ::4, ::4], static_after=static_syn.detach()[:, :, ::4, ::4])
 
 
+def g14(networks, utils):
+    # F4 interchange: the on-disk artefacts exactly as the reference's drivers write them -- hal_{it}.pt =
+    # ModuleList[Conv3DNet].state_dict() (distill_s2d_ms.py:373), dynamic_{it}.pt = dynamic_syn.flatten(0, 1).cpu() (:364, 374),
+    # images_{it}.pt = static / synthetic clips .cpu() (:372, distill_baseline.py:329), the static-memory file a dict with
+    # key "image" (:97), replay_buffer_0.pt = list[expert] of list[epoch] of [p.detach().cpu() for p in net.parameters()]
+    # (buffer.py:75-104; a narrow ConvNet3D keeps the file small) -- plus an npz with the same values for the tests.
+    # The reverse direction is checked right here: files written by video_distillation_amd.checkpoint load into the
+    # reference's own modules.
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from video_distillation_amd import checkpoint
+    d = os.path.join(OUT, "f4")
+    os.makedirs(d, exist_ok=True)
+    torch.manual_seed(1401)
+    hals = torch.nn.ModuleList([utils.Conv3DNet(img_size=16) for _ in range(2)])
+    g = torch.Generator().manual_seed(1402)
+    C, spc, dpc, T, S = 3, 2, 2, 4, 16
+    static_syn = torch.randn(C * spc, 3, S, S, generator=g)
+    dynamic_syn = torch.randn(C, dpc, T, 1, S, S, generator=g)
+    image_syn = torch.randn(C, T, 3, S, S, generator=g)
+    torch.save(hals.state_dict(), os.path.join(d, "hal_7.pt"))
+    torch.save(dynamic_syn.flatten(0, 1).detach().cpu(), os.path.join(d, "dynamic_7.pt"))
+    torch.save(static_syn.detach().cpu(), os.path.join(d, "images_7.pt"))
+    torch.save({"image": static_syn.detach().cpu()}, os.path.join(d, "static_memory.pt"))
+    torch.save(image_syn.detach().cpu(), os.path.join(d, "images_baseline_7.pt"))
+    trajectories = []
+    for e in range(1):
+        torch.manual_seed(1410 + e)
+        net = networks.ConvNet3D(channel=3, num_classes=3, net_width=8, net_depth=3, net_act='relu', net_norm='none',
+                                 net_pooling='maxpooling', im_size=(64, 64), frames=8)
+        stamps = [[p.detach().cpu() for p in net.parameters()]]
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(0.99)
+        stamps.append([p.detach().cpu() for p in net.parameters()])
+        trajectories.append(stamps)
+    torch.save(trajectories, os.path.join(d, "replay_buffer_0.pt"))
+    npz(os.path.join("f4", "values.npz"), hal_w=torch.stack([h.encoder.weight.detach() for h in hals]),
+        hal_b=torch.stack([h.encoder.bias.detach() for h in hals]), static=static_syn, dynamic=dynamic_syn, image_syn=image_syn,
+        traj_l1=np.array([[float(p.double().abs().sum()) for p in st] for st in trajectories[0]]),
+        traj_shapes=np.array([list(p.shape) + [0] * (5 - p.dim()) for p in trajectories[0][0]]))
+    # reverse direction: our writers -> the reference's loaders
+    with tempfile.TemporaryDirectory() as tmp:
+        checkpoint.save_s2d(tmp, 3, dynamic_syn, [h.encoder.weight for h in hals], [h.encoder.bias for h in hals], best=True)
+        checkpoint.save_images(tmp, 3, image_syn, best=True)
+        checkpoint.save_expert_buffer(tmp, trajectories)
+        again = torch.nn.ModuleList([utils.Conv3DNet(img_size=16) for _ in range(2)])
+        again.load_state_dict(torch.load(os.path.join(tmp, "hal_3.pt")))                  # strict: same keys
+        assert all(torch.equal(a.encoder.weight, b.encoder.weight) for a, b in zip(again, hals))
+        again.load_state_dict(torch.load(os.path.join(tmp, "weights_best.pt")))
+        assert torch.equal(torch.load(os.path.join(tmp, "dynamic_3.pt")), dynamic_syn.flatten(0, 1))
+        assert torch.equal(torch.load(os.path.join(tmp, "images_best.pt")), image_syn)
+        buf = torch.load(os.path.join(tmp, "replay_buffer_0.pt"))                          # distill_baseline.py:128
+        start = torch.cat([p.data.reshape(-1) for p in buf[0][0]], 0)                        # :216
+        assert start.numel() == sum(p.numel() for p in trajectories[0][0])
+    print("f4: reference-written files in %s; checkpoint.py's files load into the reference's modules" % d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -519,7 +577,7 @@ def main():
     for name, fn in (("g1", lambda: g1(networks)), ("g2", lambda: g2_g3(networks)), ("g4", lambda: g4_g5(networks, utils)),
                      ("g6", lambda: g6(networks, utils)), ("g7", lambda: g7(networks, utils)),
                      ("g9", lambda: g9(networks, utils)), ("g10", lambda: g10(networks, utils)),
-                     ("g11", lambda: g11(networks, utils)), ("g12", lambda: g12(networks)), ("g13", lambda: g13(networks, utils))):
+                     ("g11", lambda: g11(networks, utils)), ("g12", lambda: g12(networks)), ("g13", lambda: g13(networks, utils)), ("g14", lambda: g14(networks, utils))):
         if not only or name in only:
             fn()
 

@@ -45,16 +45,21 @@ def class_range(num_classes: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def sample_real_indices(it: int, counts: Sequence[int], offsets: Sequence[int], batch_real: int,
-                        classes: Sequence[int]) -> np.ndarray:
+                        classes: Sequence[int], allow_repeat: bool = False) -> np.ndarray:
     """Pool indices of the real batch of every class in ``classes`` for iteration ``it``: the
     on-device counterpart of ``np.random.permutation(indices_class[c])[:n]``
     (distill_baseline.py:85).  Seeded per (iteration, class) so that every sharding draws the
-    same batches."""
+    same batches.  A class with fewer than ``batch_real`` clips: the reference takes the n it has and averages over
+    n; the batched kernels need equal batches, so this raises unless ``allow_repeat`` (clips then repeat cyclically,
+    which RE-WEIGHTS that class's mean -- an explicit opt-in, not a default)."""
     out = []
     for c in classes:
         rng = np.random.default_rng([it, c])
         perm = rng.permutation(counts[c])[:batch_real]
-        if perm.size < batch_real:   # fewer clips than batch_real: the reference would just take them all
+        if perm.size < batch_real:
+            if not allow_repeat or perm.size == 0:
+                raise ValueError("class %d has %d real clips, fewer than batch_real=%d (pass a smaller batch_real, or "
+                                 "allow_repeat=True to repeat clips cyclically)" % (c, counts[c], batch_real))
             perm = np.resize(perm, batch_real)
         out.append(offsets[c] + perm)
     return np.concatenate(out).astype(np.int64) if out else np.zeros(0, dtype=np.int64)
@@ -242,20 +247,21 @@ class RealPool:
 
     @staticmethod
     def synthetic(num_classes: int, classes: Sequence[int], per_class: int, geo: P.NetGeometry, device, seed: int = 1234):
-        """randn clips standardised per channel, generated on the device."""
-        gen = torch.Generator(device=device)
-        gen.manual_seed(seed)
+        """randn clips standardised per channel, generated on the device.  Every class is drawn from its
+        own generator (seeded by ``seed`` and the class id) and standardised on its own, so a class's clips do not
+        depend on which rank holds it: every sharding of a benchmark run works on the same data."""
         n = len(classes) * per_class
         clips = torch.empty((n, geo.frames, 3, geo.height, geo.width), dtype=torch.float32, device=device)
-        step = 64
-        for i in range(0, n, step):
-            clips[i:i + step].normal_(generator=gen)
-        mean = clips.mean(dim=(0, 1, 3, 4), keepdim=True)
-        std = clips.std(dim=(0, 1, 3, 4), keepdim=True)
-        clips.sub_(mean).div_(std)
         counts = [per_class] * num_classes
         offsets = [0] * num_classes
         for k, c in enumerate(classes):
+            gen = torch.Generator(device=device)
+            gen.manual_seed(int(seed) * 1000003 + int(c))
+            blk = clips[k * per_class:(k + 1) * per_class]
+            blk.normal_(generator=gen)
+            mean = blk.mean(dim=(0, 1, 3, 4), keepdim=True)
+            std = blk.std(dim=(0, 1, 3, 4), keepdim=True)
+            blk.sub_(mean).div_(std)
             offsets[c] = k * per_class
         return RealPool(clips, counts, offsets)
 
