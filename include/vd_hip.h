@@ -218,6 +218,34 @@ int vd_head_second_order(const float* logits, const float* dlogits, const int32_
                          const float* mask, const float* w, const float* v_w, const float* v_b, const float* gbar_feats,
                          int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K, float* abar_feats,
                          float* wbar, float* bbar, float* dlogbar_out, void* stream);
+/* ---- planner in C++ (csrc/planner.cpp): no Python / offline step on the way to a launch ------------------------------
+ * vd_program_build plans the FORWARD tile program of ConvNet3D level `layer` (0: Conv3d(3->64)+ReLU+MaxPool(1,2,2) over
+ * pixel rows; 1, 2: Conv3d(->128)+ReLU+MaxPool(2,2,2) over channels-last slots; networks.py:792-814) for clips of
+ * frames x height x width and operand precision `prec`, choosing box shape, LDS pitches, wave layout and -- for
+ * batch_hint > 0 clips per launch -- the latency-oriented decomposition exactly as the Python planner does, and
+ * returns the serialised program (malloc'd; vd_blob_free) that vd_program_load consumes. */
+int vd_program_build(int layer, int frames, int height, int width, int prec, int batch_hint, void** blob, int64_t* nbytes);
+void vd_blob_free(void* blob);
+
+/* ---- ConvNet3D.embed (networks.py:747-751) as one handle: nothing but this header, the library and device pointers.
+ * The handle owns the three planned programs and their packed weights; clips / features / workspace are caller-owned.
+ *   vd_embed_create          plans + loads the three forward programs of the geometry (batch_hint: typical clips per call, 0 = large)
+ *   vd_embed_workspace_bytes bytes of scratch vd_embed_forward needs for nclips clips (pixel rows + two activation tensors)
+ *   vd_embed_set_weights     packs w0, w1, w2 (fp32 device tensors, the reference's Conv3d layouts) into MFMA operands; b0..b2
+ *                            (fp32 device vectors) are read by the launches and must stay alive
+ *   vd_embed_forward         features[nclips][vd_embed_num_features] = embed(clips[(clip_index ? clip_index[b] : b)]),
+ *                            clips (.,T,3,H,W) fp32 -- the reference's input layout; asynchronous on `stream`
+ * Errors: -1 bad argument, -6 no weights set, -7 workspace too small, otherwise the failing call's code. */
+typedef struct VdEmbed VdEmbed;
+int vd_embed_create(int frames, int height, int width, int prec, int batch_hint, VdEmbed** out);
+int64_t vd_embed_num_features(const VdEmbed* e);
+int64_t vd_embed_workspace_bytes(const VdEmbed* e, int64_t nclips);
+int vd_embed_set_weights(VdEmbed* e, const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                         const float* b2, void* stream);
+int vd_embed_forward(VdEmbed* e, const float* clips, const int64_t* clip_index, int64_t nclips, void* workspace,
+                     int64_t workspace_bytes, float* features, void* stream);
+void vd_embed_free(VdEmbed* e);
+
 /* MFMA-saturating microbenchmark: blocks x 4 waves each issue iters x 8 groups of 32768 FLOP from registers on
  * pseudo-random operands (shape 0: v_mfma_f32_32x32x16_f16; 1: pairs of v_mfma_f32_16x16x32_f16); out receives
  * blocks*256 floats.  The measured dense 16-bit peak that bench.py prints beside the 2.5 PFLOP/s spec figure

@@ -1,0 +1,48 @@
+"""The C++ planner (csrc/planner.cpp, vd_program_build) against the Python planner: byte-identical serialised forward
+programs for the benchmark geometries, an odd one, both operand-precision families and small-batch hints.  No GPU needed:
+planning is host code."""
+import ctypes
+import os
+
+import pytest
+
+from video_distillation_amd import hip, plan
+
+LIB = hip.LIB_PATH
+
+
+def _cpp_blob(lib, layer, geo, prec, hint):
+    blob, n = ctypes.c_void_p(), ctypes.c_int64()
+    rc = lib.vd_program_build(layer, geo.frames, geo.height, geo.width, hip.PREC[prec], hint or 0, ctypes.byref(blob), ctypes.byref(n))
+    assert rc == 0, rc
+    try:
+        return ctypes.string_at(blob, n.value)
+    finally:
+        lib.vd_blob_free(blob)
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libvd_hip.so not built")
+@pytest.mark.parametrize("dims,prec,hint", [((16, 112, 112), "f16", None), ((16, 112, 112), "f16x3", 64), ((8, 64, 64), "f16", None),
+                                            ((8, 64, 64), "bf16x3", 8), ((8, 64, 64), "f16x3", 256), ((8, 80, 96), "f16", 4),
+                                            ((4, 64, 64), "f16x3", None)])
+def test_cpp_planner_emits_the_python_planner_s_programs(dims, prec, hint):
+    lib = ctypes.CDLL(LIB)
+    lib.vd_blob_free.restype = None
+    geo = plan.NetGeometry(*dims)
+    x3 = prec.endswith("x3")
+    net = plan.plan_network(geo, ntw=2, ntw0=1, balanced=not x3, batch_hint=hint)
+    for layer in range(3):
+        want = plan.export_program(net["fwd"][layer])
+        got = _cpp_blob(lib, layer, geo, prec, hint)
+        assert len(got) == len(want), (layer, len(got), len(want))
+        assert got == want, "layer %d differs" % layer
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libvd_hip.so not built")
+def test_cpp_planner_argument_errors():
+    lib = ctypes.CDLL(LIB)
+    blob, n = ctypes.c_void_p(), ctypes.c_int64()
+    assert lib.vd_program_build(3, 16, 112, 112, 1, 0, ctypes.byref(blob), ctypes.byref(n)) == -1
+    assert lib.vd_program_build(0, 16, 112, 112, 7, 0, ctypes.byref(blob), ctypes.byref(n)) == -1
+    assert lib.vd_program_build(0, 16, 8, 8, 1, 0, ctypes.byref(blob), ctypes.byref(n)) == -2
+    assert lib.vd_program_build(0, 16, 112, 112, 1, 0, None, ctypes.byref(n)) == -1

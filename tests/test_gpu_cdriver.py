@@ -42,3 +42,31 @@ def test_c_driver_runs_embed_through_the_c_abi(tmp_path, prec, x3, tol):
     eng = engine.EmbedEngine(plan.NetGeometry(T, H, W), prec=prec, chunk=B)
     eng.set_weights([p.cuda() for p in params])
     assert torch.equal(eng.forward(x.cuda()).cpu(), feats)        # same programs, same kernels: bitwise
+
+
+@pytest.mark.parametrize("prec,tol", [("f16", 2e-3), ("f16x3", 3e-5)])
+def test_c_driver_with_the_library_s_own_planner(tmp_path, prec, tol):
+    """examples/embed_standalone.cpp: vd_embed_create plans the programs in C++ (no Python-made blob), workspace size from
+    vd_embed_workspace_bytes; features bitwise equal to the Python engine's (whose programs come from plan.py)."""
+    from video_distillation_amd import engine, hip, plan
+    T, H, W, B = 8, 64, 64, 5
+    d = str(tmp_path)
+    params = R.init_params(23)[:6]
+    g = torch.Generator().manual_seed(24)
+    x = torch.randn(B, T, 3, H, W, generator=g)
+    np.concatenate([p.numpy().reshape(-1) for p in params]).astype(np.float32).tofile(os.path.join(d, "weights.bin"))
+    x.numpy().astype(np.float32).tofile(os.path.join(d, "clips.bin"))
+    exe = os.path.join(d, "embed_standalone")
+    libdir = os.path.dirname(hip.LIB_PATH)
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-o", exe, os.path.join(ROOT, "examples", "embed_standalone.cpp"),
+                    "-L" + libdir, "-lvd_hip", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([exe, d, str(B), str(T), str(H), str(W), str(hip.PREC[prec])], check=True, capture_output=True, text=True)
+    print(out.stdout.strip())
+    feats = torch.from_numpy(np.fromfile(os.path.join(d, "feats_standalone.bin"), dtype=np.float32).reshape(B, -1))
+    want = R.convnet3d_embed(x, params)
+    rel = float((feats - want).norm() / want.norm())
+    print("standalone C driver vs oracle rel-l2 %.2e (%s)" % (rel, prec))
+    assert feats.shape == want.shape and rel < tol
+    eng = engine.EmbedEngine(plan.NetGeometry(T, H, W), prec=prec, chunk=B, batch_hint=B)
+    eng.set_weights([p.cuda() for p in params])
+    assert torch.equal(eng.forward(x.cuda()).cpu(), feats)

@@ -49,8 +49,8 @@ extern "C" int vd_program_load(const void* blob, int64_t nbytes, int prec, VdPro
     g->n_widx = n_w;
     if (e == hipSuccess && n_w > 0) e = hipMalloc(&g->d_wpk, (size_t)g->planes * n_w * sizeof(uint16_t));
     if (e != hipSuccess) {
-        if (g->d_tables) hipFree(g->d_tables);
-        if (g->d_zero) hipFree(g->d_zero);
+        if (g->d_tables) (void)hipFree(g->d_tables);
+        if (g->d_zero) (void)hipFree(g->d_zero);
         free(g);
         return (int)e;
     }
@@ -94,7 +94,12 @@ extern "C" int vd_program_run(VdProgram* g, const void* src, int64_t src_plane_s
     p.src = src; p.src_plane_stride4 = src_plane_slots * 4;
     p.bias = bias; p.dst = dst; p.dst_plane_stride = dst_plane_stride;
     p.argmax = argmax; p.clip_index = clip_index; p.nclips = nclips;
-    return vd_conv_mfma(&p, stream);
+    // first-layer programs in the single-pass formats and the 2 x 2-wave layout run the kernel that keeps the layer's B
+    // fragments in registers across its box walk (bitwise the same results; same rule as engine._DevPlan)
+    const bool breg = p.prec < 2 && p.epi == VD_EPI_POOL_CL && p.pool_t == 1 && p.CC == 1 && p.ncl == 1 && p.NTW <= 1 &&
+                      p.NT == 2 && p.MW == 2 && p.MTW == 4 && p.S == 32 && p.ntypes == 1 && (p.gather_stride >> 6) <= 56 &&
+                      p.relu && argmax == nullptr;
+    return breg ? vd_conv0_breg(&p, stream) : vd_conv_mfma(&p, stream);
 }
 
 extern "C" int64_t vd_program_info(const VdProgram* g, int what) {
@@ -111,8 +116,85 @@ extern "C" int64_t vd_program_info(const VdProgram* g, int what) {
 
 extern "C" void vd_program_free(VdProgram* g) {
     if (g == nullptr) return;
-    if (g->d_tables) hipFree(g->d_tables);
-    if (g->d_zero) hipFree(g->d_zero);
-    if (g->d_wpk) hipFree(g->d_wpk);
+    if (g->d_tables) (void)hipFree(g->d_tables);
+    if (g->d_zero) (void)hipFree(g->d_zero);
+    if (g->d_wpk) (void)hipFree(g->d_wpk);
     free(g);
+}
+
+
+// ---- ConvNet3D.embed as ONE handle: planner (csrc/planner.cpp) + programs + launches -----------------------------------
+struct VdEmbed {
+    VdProgram* prog[3];
+    int frames, height, width, prec, planes;
+    int64_t slots0_per_clip, slots1_per_clip, slots2_per_clip, nfeat;
+    const float* bias[3];
+    bool has_weights;
+};
+
+extern "C" int vd_embed_create(int frames, int height, int width, int prec, int batch_hint, VdEmbed** out) {
+    if (out == nullptr) return -1;
+    VdEmbed* e = static_cast<VdEmbed*>(calloc(1, sizeof(VdEmbed)));
+    if (e == nullptr) return -5;
+    for (int l = 0; l < 3; ++l) {
+        void* blob = nullptr;
+        int64_t n = 0;
+        int rc = vd_program_build(l, frames, height, width, prec, batch_hint, &blob, &n);
+        if (rc == 0) { rc = vd_program_load(blob, n, prec, &e->prog[l]); vd_blob_free(blob); }
+        if (rc != 0) { vd_embed_free(e); return rc; }
+    }
+    e->frames = frames; e->height = height; e->width = width; e->prec = prec;
+    e->planes = (prec == VD_PREC_BF16X3 || prec == VD_PREC_F16X3) ? 2 : 1;
+    const int rowp = ((width + 8 + 7) / 8) * 8;
+    e->slots0_per_clip = (int64_t)frames * 3 * height * (rowp / 8);
+    e->slots1_per_clip = e->prog[0]->p.out_clip_stride;
+    e->slots2_per_clip = e->prog[1]->p.out_clip_stride;
+    e->nfeat = e->prog[2]->p.out_clip_stride;
+    *out = e;
+    return 0;
+}
+
+extern "C" int64_t vd_embed_num_features(const VdEmbed* e) { return e ? e->nfeat : -1; }
+
+extern "C" int64_t vd_embed_workspace_bytes(const VdEmbed* e, int64_t nclips) {
+    if (e == nullptr || nclips < 0) return -1;
+    return (int64_t)e->planes * nclips * (e->slots0_per_clip + e->slots1_per_clip + e->slots2_per_clip) * 16 + 3 * 256;
+}
+
+extern "C" int vd_embed_set_weights(VdEmbed* e, const float* w0, const float* b0, const float* w1, const float* b1,
+                                    const float* w2, const float* b2, void* stream) {
+    if (e == nullptr || !w0 || !b0 || !w1 || !b1 || !w2 || !b2) return -1;
+    const float* w[3] = {w0, w1, w2};
+    for (int l = 0; l < 3; ++l) {
+        const int rc = vd_program_pack_weights(e->prog[l], w[l], stream);
+        if (rc != 0) return rc;
+    }
+    e->bias[0] = b0; e->bias[1] = b1; e->bias[2] = b2;       // read by the launches: the caller keeps them alive
+    e->has_weights = true;
+    return 0;
+}
+
+extern "C" int vd_embed_forward(VdEmbed* e, const float* clips, const int64_t* clip_index, int64_t nclips, void* workspace,
+                                int64_t workspace_bytes, float* features, void* stream) {
+    if (e == nullptr || clips == nullptr || features == nullptr || nclips < 0 || nclips > 0x7fffffff) return -1;
+    if (!e->has_weights) return -6;
+    if (nclips == 0) return 0;
+    if (workspace == nullptr || workspace_bytes < vd_embed_workspace_bytes(e, nclips)) return -7;
+    auto align = [](char* p) { return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~(uintptr_t)255); };
+    const int64_t n0 = nclips * e->slots0_per_clip, n1 = nclips * e->slots1_per_clip, n2 = nclips * e->slots2_per_clip;
+    char* rows = align(static_cast<char*>(workspace));
+    char* act1 = align(rows + (int64_t)e->planes * n0 * 16);
+    char* act2 = align(act1 + (int64_t)e->planes * n1 * 16);
+    int rc = vd_pix2rows(clips, clip_index, nclips, e->frames, e->height, e->width, rows, e->planes == 2 ? rows + n0 * 16 : nullptr,
+                         e->prec, stream);
+    if (rc == 0) rc = vd_program_run(e->prog[0], rows, n0, e->bias[0], act1, n1, nullptr, nullptr, (int)nclips, stream);
+    if (rc == 0) rc = vd_program_run(e->prog[1], act1, n1, e->bias[1], act2, n2, nullptr, nullptr, (int)nclips, stream);
+    if (rc == 0) rc = vd_program_run(e->prog[2], act2, n2, e->bias[2], features, 0, nullptr, nullptr, (int)nclips, stream);
+    return rc;
+}
+
+extern "C" void vd_embed_free(VdEmbed* e) {
+    if (e == nullptr) return;
+    for (int l = 0; l < 3; ++l) vd_program_free(e->prog[l]);
+    free(e);
 }
