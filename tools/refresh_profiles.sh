@@ -1,33 +1,35 @@
 #!/bin/bash
 # Regenerate the evidence under profiles/ on a GPU box (run from the repo root through gpurun);
-# results land in gpurun_out/prof/ and are copied to profiles/ by hand afterwards.
+# results land in gpurun_out/prof/ and are copied to profiles/r02_* by hand afterwards.
+# Every rocprofv3 run is bounded by `timeout` and writes csv (the rocpd default has hung a box for its whole limit).
 set -u
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-python3 bench.py --steps 8 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_1gpu.json
+python3 bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_1gpu.json
+python3 bench.py --method s2d --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_s2d.json
+python3 bench.py --frames 8 --size 64 --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_config1_shape.json
+python3 bench.py --method dc --classes 51 --ipc 5 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_dc.json
+python3 bench.py --method mtt --classes 400 --frames 8 --size 64 --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_mtt.json
+python3 tools/mfma_peak.py > $OUT/mfma_peak.txt 2>/dev/null
+python3 tools/bench_aux.py > $OUT/aux_kernels_gbps.json 2>/dev/null
 cd /tmp
 prof() {  # name, then the program and its arguments
   local name=$1; shift
   timeout -k 5 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- "$@" > $OUT/$name.log 2>&1
   cp $(ls $OUT/$name/*/*kernel_stats.csv | head -1) $OUT/${name}_kernel_stats.csv
 }
-prof bench python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline
+prof bench python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --eval-epochs 0 --sustain-seconds 0
 grep '"metric"' $OUT/bench.log | tail -1 > $OUT/bench_1gpu_under_rocprof.json
-VD_SKIP_TORCH=1 prof train_step python3 $ROOT/tools/bench_train.py 50
-prof dc python3 $ROOT/bench.py --method dc --classes 8 --ipc 5 --steps 2 --warmup 1
-prof mtt python3 $ROOT/bench.py --method mtt --classes 400 --frames 8 --size 64 --pool-per-class 1 --steps 2 --warmup 1
+prof s2d python3 $ROOT/bench.py --method s2d --steps 8 --warmup 2 --no-cpu-baseline --sustain-seconds 0
+prof dc python3 $ROOT/bench.py --method dc --classes 8 --ipc 5 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0
+prof mtt python3 $ROOT/bench.py --method mtt --classes 400 --frames 8 --size 64 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 5 280 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/tools/run_l1.py 512 f16 > $OUT/pmc_$c.log 2>&1
   cp $(ls $OUT/pmc_$c/*/*counter_collection.csv | head -1) $OUT/pmc_${c}_counter_collection.csv
 done
 cd $ROOT
 python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE_counter_collection.csv $OUT/pmc_WRITE_SIZE_counter_collection.csv 512 $OUT/pmc_traffic.json > /dev/null
-python3 tools/bench_aux.py > $OUT/aux_kernels_gbps.json 2>/dev/null
-python3 bench.py --method dc --classes 51 --ipc 5 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_dc.json
-python3 bench.py --method mtt --classes 400 --frames 8 --size 64 --pool-per-class 1 --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_mtt.json
-python3 bench.py --method s2d --steps 8 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_s2d.json
-VD_SKIP_TORCH=0 python3 tools/bench_train.py 50 2>/dev/null | grep -v amdgpu > $OUT/train_step_vs_torch.txt
-rm -rf $OUT/bench $OUT/train_step $OUT/dc $OUT/mtt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+rm -rf $OUT/bench $OUT/s2d $OUT/dc $OUT/mtt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 ls -la $OUT
