@@ -70,8 +70,7 @@ typedef struct VdConvParams {
     int32_t mt_valid;             /* NTW = 2: M tiles per box that carry rows (< MW*MTW: the last wave row skips its padding tile); 0 = all */
     int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
-    int32_t b_hi_only;            /* x3 precisions: the lo plane of the packed B operand is all zero (weights already rounded to the
-                                   * 16-bit format: the value pass of the mixed mode) -> the A_hi x B_lo MFMA is skipped (2 of 3) */
+    int32_t reserved1;
     int32_t reserved0;
 } VdConvParams;
 
@@ -158,6 +157,28 @@ int vd_match_rows_fwd(const float* gr, const float* gs, int64_t rows, int len, f
  * sums in acc as produced by the forward).  gout = upstream scalar gradient. */
 int vd_match_rows_bwd(const float* gr, const float* gs, int64_t rows, int len, int mode, const float* acc,
                       const float* gout, float* g_gs, void* stream);
+
+/* The same for a whole list of gradient tensors (match_loss iterates the 8 parameter tensors of the network,
+ * utils.py:660-664) in ONE launch: segment i = tensor pair i viewed as [rows][len]; `reserved` != 0 marks a FLAT segment
+ * (rows = element count, len = 1: only the global sums of 'mse' / 'cos' are wanted; a row view of 'ours' with len == 1 --
+ * a trailing unit axis, e.g. the (K,128,1,1,1) logit weights -- is NOT flat: each element is its own cosine row);
+ * the backward writes d/d gs of segment i to seg[i].g. */
+#define VD_MATCH_MAX_SEG 16
+typedef struct VdMatchSeg {
+    const float* gr;
+    const float* gs;
+    float* g;                     /* backward only */
+    int64_t rows;
+    int32_t len;
+    int32_t reserved;
+} VdMatchSeg;
+typedef struct VdMatchBatch {
+    int32_t nseg;
+    int32_t reserved;
+    VdMatchSeg seg[VD_MATCH_MAX_SEG];
+} VdMatchBatch;
+int vd_match_rows_fwd_multi(const VdMatchBatch* batch, float* acc, void* stream);
+int vd_match_rows_bwd_multi(const VdMatchBatch* batch, int mode, const float* acc, const float* gout, void* stream);
 
 /* Operand preparation for the weight-gradient tile program (plan.plan_wgrad):
  *  vd_clip_minor_cl : channels-last slots [plane][clip][C/8][npos][8 ch] -> clip-minor slots

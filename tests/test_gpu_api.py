@@ -450,3 +450,29 @@ def test_two_gpu_bench_matches_single_gpu_loss():
                    "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--shard", shard] + common)
         assert two["n_gpus"] == 2
         assert abs(two["loss_last"] / one["loss_last"] - 1) < 1e-4, (shard, two["loss_last"], one["loss_last"])
+
+
+def test_match_loss_trailing_unit_axis_rows_and_many_tensors():
+    """'ours' on a 5-D tensor whose last axis is 1 (the (K,128,1,1,1) logit-conv gradient): every element is its own
+    cosine row, 0 or 2 by sign (utils.py:649-651 fall-through) -- not a flat sum; and a list longer than one launch's 16
+    segments."""
+    from video_distillation_amd import utils
+    g = torch.Generator().manual_seed(77)
+    shapes = [(4, 3, 1, 1, 1), (5, 2, 3, 7, 7), (6,), (3, 4)] + [(2, 3, 1, 2, 2)] * 17
+    gr = [torch.randn(s, generator=g) for s in shapes]
+    gs = [torch.randn(s, generator=g) for s in shapes]
+    for metric in ("ours", "mse", "cos"):
+        args = types.SimpleNamespace(device="cuda", dis_metric=metric)
+        xs = [t.cuda().requires_grad_(True) for t in gs]
+        val = utils.match_loss(xs, [t.cuda() for t in gr], args)
+        val.backward()
+        ref_in = [t.clone().requires_grad_(True) for t in gs]
+        want = R.match_loss(ref_in, gr, metric)
+        want.backward()
+        assert abs(float(val) - float(want)) <= 1e-4 * abs(float(want)), (metric, float(val), float(want))
+        for a, b in zip(xs, ref_in):
+            got = a.grad.cpu() if a.grad is not None else torch.zeros_like(b)
+            ref = b.grad if b.grad is not None else torch.zeros_like(b)
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-3, atol=1e-5)
+    per = float(utils.distance_wb(gr[0].cuda(), gs[0].cuda()))
+    assert abs(per - float(R.distance_wb(gr[0], gs[0]))) < 1e-4 and per > 1.0        # some of the 12 sign pairs disagree

@@ -653,17 +653,32 @@ extern "C" int vd_hallucinator_bwd(const float* g_out, const float* stat, const 
 // ------------------------------------------------------------------------------------------
 // match_loss row reductions.  Short rows (len <= 64, e.g. the 7-wide rows of the 5-D Conv3d
 // gradients): one lane-group per row, 64/grp rows per wave.  Long rows: a wave per row.
-__global__ __launch_bounds__(256) void match_rows_fwd_kernel(const float* __restrict__ gr, const float* __restrict__ gs,
-                                                              int64_t rows, int len, float* __restrict__ acc) {
+__host__ __device__ inline int64_t vd_match_blocks(int64_t rows, int len) {
+    int64_t blocks = (len == 1) ? (rows + 1023) / 1024 : (len <= 8) ? (rows + 255) / 256 : (rows + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+
+// forward: every block ends with 5 atomics onto the SAME 5 accumulators, which the L2 serialises (~8 ns each): with
+// up to 1024 blocks per tensor the closing atomics were 120 of the kernel's 130 us; 96 long-running blocks per tensor
+// keep the loads in flight (grid-stride) and cut them to a few us.
+__host__ __device__ inline int64_t vd_match_blocks_fwd(int64_t rows, int len) {
+    const int64_t b = vd_match_blocks(rows, len);
+    return b > 96 ? 96 : b;
+}
+
+__device__ __forceinline__ void match_rows_fwd_body(const float* __restrict__ gr, const float* __restrict__ gs,
+                                                    int64_t rows, int len, float* __restrict__ acc, const int64_t nblk, const bool flat) {
     __shared__ float red[16];
     float s_cos = 0.f, s_mse = 0.f, s_dot = 0.f, s_rr = 0.f, s_ss = 0.f;
-    if (len == 1) {
+    if (flat) {
         // flat sums ('mse' / 'cos' metrics): 16-byte loads, grid-stride
         const int64_t n4 = rows >> 2;
         const float4* r4 = reinterpret_cast<const float4*>(gr);
         const float4* s4 = reinterpret_cast<const float4*>(gs);
         const bool aligned = ((reinterpret_cast<uintptr_t>(gr) | reinterpret_cast<uintptr_t>(gs)) & 15) == 0;
-        const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+        const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)nblk * blockDim.x;
         int64_t done = 0;
         if (aligned) {
             for (int64_t i = tid0; i < n4; i += nt) {
@@ -681,7 +696,7 @@ __global__ __launch_bounds__(256) void match_rows_fwd_kernel(const float* __rest
         }
     } else if (len <= 8) {
         // one thread per row
-        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)nblk * blockDim.x) {
             float d = 0.f, a = 0.f, b = 0.f, m = 0.f;
             for (int k = 0; k < len; ++k) {
                 const float x = gr[r * len + k], y = gs[r * len + k];
@@ -694,7 +709,7 @@ __global__ __launch_bounds__(256) void match_rows_fwd_kernel(const float* __rest
         // one wave per row
         const int lane = threadIdx.x & 63;
         const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-        const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+        const int64_t nw = ((int64_t)nblk * blockDim.x) >> 6;
         for (int64_t r = wid; r < rows; r += nw) {
             float d = 0.f, a = 0.f, b = 0.f, m = 0.f;
             for (int k = lane; k < len; k += 64) {
@@ -716,11 +731,37 @@ __global__ __launch_bounds__(256) void match_rows_fwd_kernel(const float* __rest
     }
 }
 
+__global__ __launch_bounds__(256) void match_rows_fwd_kernel(const float* __restrict__ gr, const float* __restrict__ gs,
+                                                              int64_t rows, int len, float* __restrict__ acc) {
+    match_rows_fwd_body(gr, gs, rows, len, acc, gridDim.x, len == 1);
+}
+
+// all tensors of a gradient list in ONE launch: blockIdx.y = segment (a match_loss call used to be 8 launches of
+// 5-35 us each, i.e. launch-bound at 2-3 % of HBM bandwidth)
+__global__ __launch_bounds__(256) void match_rows_fwd_multi_kernel(const VdMatchBatch b, float* __restrict__ acc) {
+    const VdMatchSeg& sg = b.seg[blockIdx.y];
+    const int64_t nblk = vd_match_blocks_fwd(sg.rows, sg.reserved ? 1 : (sg.len == 1 ? 2 : sg.len));
+    if ((int64_t)blockIdx.x >= nblk) return;
+    match_rows_fwd_body(sg.gr, sg.gs, sg.rows, sg.len, acc, nblk, sg.reserved != 0);
+}
+
+extern "C" int vd_match_rows_fwd_multi(const VdMatchBatch* b, float* acc, void* stream) {
+    if (b == nullptr || acc == nullptr || b->nseg < 0 || b->nseg > VD_MATCH_MAX_SEG) return -1;
+    int64_t gx = 0;
+    for (int i = 0; i < b->nseg; ++i) {
+        if (b->seg[i].rows <= 0 || b->seg[i].len <= 0 || !b->seg[i].gr || !b->seg[i].gs) return -1;
+        const int64_t nb = vd_match_blocks_fwd(b->seg[i].rows, b->seg[i].reserved ? 1 : (b->seg[i].len == 1 ? 2 : b->seg[i].len));
+        gx = gx > nb ? gx : nb;
+    }
+    if (b->nseg == 0) return 0;
+    hipLaunchKernelGGL(match_rows_fwd_multi_kernel, dim3((unsigned)gx, (unsigned)b->nseg), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), *b, acc);
+    return (int)hipGetLastError();
+}
+
 extern "C" int vd_match_rows_fwd(const float* gr, const float* gs, int64_t rows, int len, float* acc, void* stream) {
     if (rows <= 0 || len <= 0) return 0;
-    int64_t blocks = (len == 1) ? (rows + 1023) / 1024 : (len <= 8) ? (rows + 255) / 256 : (rows + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
+    const int64_t blocks = vd_match_blocks(rows, len);
     hipLaunchKernelGGL(match_rows_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        gr, gs, rows, len, acc);
     return (int)hipGetLastError();
@@ -729,13 +770,13 @@ extern "C" int vd_match_rows_fwd(const float* gr, const float* gs, int64_t rows,
 // d/d gs.  mode 0: per-row cosine distance; with n=|r|, m=|s|, den=n*m+eps:
 //   d(1 - <r,s>/den)/ds = -r/den + <r,s> * n * s / (m * den^2)
 // mode 1: 2*(s-r).  mode 2: the same cosine formula with the GLOBAL sums acc[2..4].
-__global__ __launch_bounds__(256) void match_rows_bwd_kernel(const float* __restrict__ gr, const float* __restrict__ gs,
-                                                              int64_t rows, int len, int mode, const float* __restrict__ acc,
-                                                              const float* __restrict__ gout, float* __restrict__ g) {
+__device__ __forceinline__ void match_rows_bwd_body(const float* __restrict__ gr, const float* __restrict__ gs,
+                                                    int64_t rows, int len, int mode, const float* __restrict__ acc,
+                                                    const float* __restrict__ gout, float* __restrict__ g, const int64_t nblk) {
     const float go = gout[0];
     if (mode == 1) {
         const int64_t n = rows * len;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)nblk * blockDim.x)
             g[i] = go * 2.f * (gs[i] - gr[i]);
         return;
     }
@@ -744,12 +785,12 @@ __global__ __launch_bounds__(256) void match_rows_bwd_kernel(const float* __rest
         const float den = nr * ns + 0.000001f;
         const float c1 = -1.f / den, c2 = (ns > 0.f) ? d * nr / (ns * den * den) : 0.f;
         const int64_t n = rows * len;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)nblk * blockDim.x)
             g[i] = go * (c1 * gr[i] + c2 * gs[i]);
         return;
     }
     if (len <= 8) {
-        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)nblk * blockDim.x) {
             float d = 0.f, a = 0.f, b = 0.f;
             for (int k = 0; k < len; ++k) {
                 const float x = gr[r * len + k], y = gs[r * len + k];
@@ -762,7 +803,7 @@ __global__ __launch_bounds__(256) void match_rows_bwd_kernel(const float* __rest
     } else {
         const int lane = threadIdx.x & 63;
         const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-        const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+        const int64_t nw = ((int64_t)nblk * blockDim.x) >> 6;
         for (int64_t r = wid; r < rows; r += nw) {
             float d = 0.f, a = 0.f, b = 0.f;
             for (int k = lane; k < len; k += 64) {
@@ -775,6 +816,34 @@ __global__ __launch_bounds__(256) void match_rows_bwd_kernel(const float* __rest
             for (int k = lane; k < len; k += 64) g[r * len + k] = go * (c1 * gr[r * len + k] + c2 * gs[r * len + k]);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void match_rows_bwd_kernel(const float* __restrict__ gr, const float* __restrict__ gs,
+                                                              int64_t rows, int len, int mode, const float* __restrict__ acc,
+                                                              const float* __restrict__ gout, float* __restrict__ g) {
+    match_rows_bwd_body(gr, gs, rows, len, mode, acc, gout, g, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void match_rows_bwd_multi_kernel(const VdMatchBatch b, int mode, const float* __restrict__ acc,
+                                                                    const float* __restrict__ gout) {
+    const VdMatchSeg& sg = b.seg[blockIdx.y];
+    const int64_t nblk = vd_match_blocks(sg.rows * (mode == 0 ? 1 : sg.len), mode == 0 ? (sg.len == 1 ? 2 : sg.len) : 1);
+    if ((int64_t)blockIdx.x >= nblk) return;
+    match_rows_bwd_body(sg.gr, sg.gs, sg.rows, sg.len, mode, acc, gout, sg.g, nblk);
+}
+
+extern "C" int vd_match_rows_bwd_multi(const VdMatchBatch* b, int mode, const float* acc, const float* gout, void* stream) {
+    if (b == nullptr || acc == nullptr || gout == nullptr || b->nseg < 0 || b->nseg > VD_MATCH_MAX_SEG || mode < 0 || mode > 2) return -1;
+    int64_t gx = 0;
+    for (int i = 0; i < b->nseg; ++i) {
+        if (b->seg[i].rows <= 0 || b->seg[i].len <= 0 || !b->seg[i].gr || !b->seg[i].gs || !b->seg[i].g) return -1;
+        const int64_t nb = vd_match_blocks(b->seg[i].rows * (mode == 0 ? 1 : b->seg[i].len), mode == 0 ? (b->seg[i].len == 1 ? 2 : b->seg[i].len) : 1);
+        gx = gx > nb ? gx : nb;
+    }
+    if (b->nseg == 0) return 0;
+    hipLaunchKernelGGL(match_rows_bwd_multi_kernel, dim3((unsigned)gx, (unsigned)b->nseg), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), *b, mode, acc, gout);
+    return (int)hipGetLastError();
 }
 
 extern "C" int vd_match_rows_bwd(const float* gr, const float* gs, int64_t rows, int len, int mode, const float* acc,

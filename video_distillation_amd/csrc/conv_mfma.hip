@@ -24,7 +24,6 @@
 // networks.py:757, 768-770, 799) and the input-gradient half of their autograd backward.
 #include <hip/hip_runtime.h>
 #include <mutex>
-#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/vd_hip.h"
@@ -430,64 +429,58 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
                 }
             }
         } else {
-            // b_hi_only (value pass of the mixed mode: weights pre-rounded, lo plane zero): the A_hi x B_lo product is
-            // dropped -- two loop bodies, chosen once per chunk, so the hot loop carries no run-time condition
-            auto x3_loop = [&](auto hi_only) {
-                constexpr bool HI_ONLY = decltype(hi_only)::value;
-                int tap_cur = lds_tap[half];
-                uint4 A0h[H0], A0l[H0], A1h[H1], A1l[H1];
-    #pragma unroll
-                for (int i = 0; i < H0; ++i) {
-                    A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_cur);
-                    A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_cur);
-                }
-                for (int s = 0; s < S; s += DB + 1) {
-    #pragma unroll
-                    for (int u = 0; u <= DB; ++u) {
-                        if (s + u >= S) break;
-                        load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
-                        uint4 bh[NTW], bl[NTW];
-    #pragma unroll
-                        for (int j = 0; j < NTW; ++j) { bh[j] = bqh[u][j]; bl[j] = bql[u][j]; }
-                        const int sn = (s + u + 1 < S) ? s + u + 1 : s + u;
-                        const int tap_next = lds_tap[2 * sn + half];
-    #pragma unroll
-                        for (int i = 0; i < H1; ++i) {
-                            A1h[i] = *reinterpret_cast<const uint4*>(smem + a_off[H0 + i] + tap_cur);
-                            A1l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[H0 + i] + tap_cur);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-                        for (int i = 0; i < H0; ++i)
-    #pragma unroll
-                            for (int j = 0; j < NTW; ++j) {
-                                acc[j * MTW + i] = mfma16<PREC>(A0l[i], bh[j], acc[j * MTW + i]);
-                                if constexpr (!HI_ONLY) acc[j * MTW + i] = mfma16<PREC>(A0h[i], bl[j], acc[j * MTW + i]);
-                                acc[j * MTW + i] = mfma16<PREC>(A0h[i], bh[j], acc[j * MTW + i]);
-                            }
-                        __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-                        for (int i = 0; i < H0; ++i) {
-                            A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
-                            A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_next);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-                        for (int i = 0; i < H1; ++i) {
-                            if (NTW == 2 && BAL == 0 && i == H1 - 1 && short_row) continue;
-    #pragma unroll
-                            for (int j = 0; j < NTW; ++j) {
-                                acc[j * MTW + H0 + i] = mfma16<PREC>(A1l[i], bh[j], acc[j * MTW + H0 + i]);
-                                if constexpr (!HI_ONLY) acc[j * MTW + H0 + i] = mfma16<PREC>(A1h[i], bl[j], acc[j * MTW + H0 + i]);
-                                acc[j * MTW + H0 + i] = mfma16<PREC>(A1h[i], bh[j], acc[j * MTW + H0 + i]);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        tap_cur = tap_next;
+            int tap_cur = lds_tap[half];
+            uint4 A0h[H0], A0l[H0], A1h[H1], A1l[H1];
+#pragma unroll
+            for (int i = 0; i < H0; ++i) {
+                A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_cur);
+                A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_cur);
+            }
+            for (int s = 0; s < S; s += DB + 1) {
+#pragma unroll
+                for (int u = 0; u <= DB; ++u) {
+                    if (s + u >= S) break;
+                    load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
+                    uint4 bh[NTW], bl[NTW];
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) { bh[j] = bqh[u][j]; bl[j] = bql[u][j]; }
+                    const int sn = (s + u + 1 < S) ? s + u + 1 : s + u;
+                    const int tap_next = lds_tap[2 * sn + half];
+#pragma unroll
+                    for (int i = 0; i < H1; ++i) {
+                        A1h[i] = *reinterpret_cast<const uint4*>(smem + a_off[H0 + i] + tap_cur);
+                        A1l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[H0 + i] + tap_cur);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < H0; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j) {
+                            acc[j * MTW + i] = mfma16<PREC>(A0l[i], bh[j], acc[j * MTW + i]);
+                            acc[j * MTW + i] = mfma16<PREC>(A0h[i], bl[j], acc[j * MTW + i]);
+                            acc[j * MTW + i] = mfma16<PREC>(A0h[i], bh[j], acc[j * MTW + i]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < H0; ++i) {
+                        A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
+                        A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_next);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < H1; ++i) {
+                        if (NTW == 2 && BAL == 0 && i == H1 - 1 && short_row) continue;
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j) {
+                            acc[j * MTW + H0 + i] = mfma16<PREC>(A1l[i], bh[j], acc[j * MTW + H0 + i]);
+                            acc[j * MTW + H0 + i] = mfma16<PREC>(A1h[i], bl[j], acc[j * MTW + H0 + i]);
+                            acc[j * MTW + H0 + i] = mfma16<PREC>(A1h[i], bh[j], acc[j * MTW + H0 + i]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    tap_cur = tap_next;
                 }
-            };
-            if (p.b_hi_only) x3_loop(std::true_type{}); else x3_loop(std::false_type{});
+            }
         }
     }
 

@@ -183,10 +183,6 @@ class EmbedEngine:
         ws = [p.detach().to(self.device, torch.float32).contiguous() for p in params[:6]]
         if quantize is not None:
             ws = round_weights(ws, quantize)
-        # weights already in the operand format of an x3 engine: the packed lo plane is all zero, the kernel skips it
-        hi_only = int(quantize is not None and hip.is_x3(self.prec) and hip.PREC[quantize] == self.prec - 2)
-        for dp in self.fwd:
-            dp.params.b_hi_only = hi_only
         self._weights = ws
         for li in range(3):
             self.fwd[li].pack(ws[2 * li])

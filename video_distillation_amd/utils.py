@@ -207,7 +207,8 @@ def _rows_view(t):
 
 
 class _MatchLossFunction(torch.autograd.Function):
-    """All three metrics over a list of gradient tensors; differentiable w.r.t. gw_syn."""
+    """All three metrics over a list of gradient tensors; differentiable w.r.t. gw_syn.  One launch per direction for
+    the whole list (vd_match_rows_*_multi)."""
 
     @staticmethod
     def forward(ctx, mode, n, *tensors):
@@ -215,16 +216,25 @@ class _MatchLossFunction(torch.autograd.Function):
         dev = gw_syn[0].device
         L, st = hip.lib(), hip.stream_ptr(dev)
         acc = torch.zeros(5, dtype=torch.float32, device=dev)
-        keep = []
+        keep, batches = [], [hip.VdMatchBatch()]
         for gs, gr in zip(gw_syn, gw_real):
             if mode == 0 and gs.dim() == 1:
                 keep.append(None)
                 continue
             gs_c, gr_c = gs.detach().float().contiguous(), gr.detach().float().contiguous()
             rows, ln = _rows_view(gs_c) if mode == 0 else (gs_c.numel(), 1)   # mse / cos: flat sums
-            hip.check(L.vd_match_rows_fwd(hip.ptr(gr_c), hip.ptr(gs_c), ctypes.c_int64(rows), ln, hip.ptr(acc), st),
-                      "vd_match_rows_fwd")
+            if rows <= 0 or ln <= 0:
+                keep.append(None)
+                continue
+            if batches[-1].nseg == 16:
+                batches.append(hip.VdMatchBatch())
+            b = batches[-1]
+            sg = b.seg[b.nseg]
+            sg.gr, sg.gs, sg.g, sg.rows, sg.len, sg.reserved = gr_c.data_ptr(), gs_c.data_ptr(), 0, rows, ln, int(mode != 0)
+            b.nseg += 1
             keep.append((gs_c, gr_c, rows, ln))
+        for b in batches:
+            hip.check(L.vd_match_rows_fwd_multi(ctypes.byref(b), hip.ptr(acc), st), "vd_match_rows_fwd_multi")
         ctx.keep, ctx.mode, ctx.n = keep, mode, n
         ctx.acc = acc
         if mode == 0:
@@ -238,16 +248,23 @@ class _MatchLossFunction(torch.autograd.Function):
         L = hip.lib()
         gout = gout.detach().float().contiguous().view(1)
         st = hip.stream_ptr(gout.device)
-        grads = []
+        grads, batches = [], [hip.VdMatchBatch()]
         for item in ctx.keep:
             if item is None:
                 grads.append(None)
                 continue
             gs_c, gr_c, rows, ln = item
             g = torch.empty_like(gs_c)
-            hip.check(L.vd_match_rows_bwd(hip.ptr(gr_c), hip.ptr(gs_c), ctypes.c_int64(rows), ln, ctx.mode,
-                                          hip.ptr(ctx.acc), hip.ptr(gout), hip.ptr(g), st), "vd_match_rows_bwd")
+            if batches[-1].nseg == 16:
+                batches.append(hip.VdMatchBatch())
+            b = batches[-1]
+            sg = b.seg[b.nseg]
+            sg.gr, sg.gs, sg.g, sg.rows, sg.len, sg.reserved = gr_c.data_ptr(), gs_c.data_ptr(), g.data_ptr(), rows, ln, int(ctx.mode != 0)
+            b.nseg += 1
             grads.append(g)
+        for b in batches:
+            hip.check(L.vd_match_rows_bwd_multi(ctypes.byref(b), ctx.mode, hip.ptr(ctx.acc), hip.ptr(gout), st),
+                      "vd_match_rows_bwd_multi")
         return (None, None) + tuple(grads) + (None,) * ctx.n
 
 
