@@ -319,13 +319,24 @@ class ConvNet3D(nn.Module):
                 self.features[6].weight, self.features[6].bias]
 
     def _weights_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self._feature_params())
+        return tuple((p.data_ptr(), p._version) for p in self._feature_params()) + (getattr(self, "_pack_epoch", 0),)
+
+    def invalidate(self) -> None:
+        """Force a re-pack of the MFMA operands at the next ``embed`` / ``forward``.  The packed copy is keyed on every
+        parameter's storage address and autograd version counter, which optimisers and ``copy_`` / ``load_state_dict``
+        bump; an in-place edit through ``.data`` (``p.data.mul_(2)``) does NOT bump it -- call this after such an edit."""
+        self._pack_epoch = getattr(self, "_pack_epoch", 0) + 1
 
     def _sync_engine(self, eng, quantize=None) -> None:
+        # the cached engines outlive nets: remember the owner by a weak reference, not by id() (a new net may be built
+        # at a freed net's address, on storage the caching allocator hands out again)
+        import weakref
         key = (self._weights_key(), quantize)
-        if getattr(eng, "_owner_key", None) != (id(self), key):
+        owner = getattr(eng, "_owner_ref", None)
+        if owner is None or owner() is not self or getattr(eng, "_owner_key", None) != key:
             eng.set_weights(self._feature_params(), quantize=quantize)
-            eng._owner_key = (id(self), key)
+            eng._owner_key = key
+            eng._owner_ref = weakref.ref(self)
 
     def _all_params(self):
         """The 8 tensors in parameters() order, read by ATTRIBUTE: under ReparamModule they are views of the flat
