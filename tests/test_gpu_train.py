@@ -380,3 +380,45 @@ def test_g13_s2d_mtt_trainer_on_hip_vs_reference_golden():
     grand = tr.step(0, traj, start_epoch=0, index_chunks=chunks)
     print("G13 grand %.6f vs %.6f, d/dlr %.5e vs %.5e" % (float(grand), float(z["grand_loss"]), float(tr.last_grads[4]), float(z["grad_lr"])))
     check_s2d_mtt_against_g13(z, tr, grand, tol=5e-3)
+
+
+def test_atomic_accumulation_run_to_run_spread_is_bounded():
+    """Weight gradients, the classifier head, the hallucinator's parameter / memory gradients and match_loss accumulate
+    with fp32 atomics, so their summation order -- and the last bits -- change from run to run.  Bound the spread: five
+    repetitions of the same call stay within 2e-6 rel-L2 of each other (fp32 rounding of sums of a few thousand terms),
+    and the kernels without atomics (forward, input gradient) are bitwise reproducible."""
+    import types
+    from video_distillation_amd import networks, plan, train, utils
+    C, B = 5, 6
+    g = torch.Generator().manual_seed(606)
+    x = torch.randn(B, 8, 3, 64, 64, generator=g).cuda()
+    y = torch.tensor([0, 1, 2, 3, 4, 0]).cuda()
+    params = [p.cuda() for p in R.init_params(61, 3, C)]
+    te = train.TrainEngine(plan.NetGeometry(8, 64, 64), C, (2, 1, 1), "cuda:0", prec="f16x3", prec_bwd="f16x3")
+    runs = []
+    for _ in range(5):
+        loss, logits, grads = te.loss_and_grads(x, y, params, None)
+        runs.append((float(loss), logits.clone(), [t.clone() for t in grads]))
+    assert all(r[0] == runs[0][0] for r in runs) and all(torch.equal(r[1], runs[0][1]) for r in runs)     # forward: no atomics
+    spread = max(_rel(r[2][i], runs[0][2][i].cpu().double()) for r in runs[1:] for i in range(8))
+    # hallucinator: g_dyn / g_stat / g_w / g_b all via atomics
+    hal = utils.Conv3DNet(img_size=64).cuda()
+    st = torch.randn(4, 3, 64, 64, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(4, 8, 1, 64, 64, generator=g).cuda().requires_grad_(True)
+    up = torch.randn(4, 8, 3, 64, 64, generator=g).cuda()
+    hruns = []
+    for _ in range(5):
+        for t in (st, dy, hal.encoder.weight, hal.encoder.bias):
+            t.grad = None
+        out = hal(st, dy)
+        out.backward(up)
+        hruns.append((out.detach().clone(), st.grad.clone(), dy.grad.clone(), hal.encoder.weight.grad.clone()))
+    assert all(torch.equal(h[0], hruns[0][0]) for h in hruns)
+    hspread = max(_rel(h[i], hruns[0][i].cpu().double()) for h in hruns[1:] for i in (1, 2, 3))
+    # match_loss: 5 shared accumulators
+    gw = [torch.randn_like(p) for p in params]
+    gs = [torch.randn_like(p) for p in params]
+    vals = [float(utils.match_loss(gs, gw, types.SimpleNamespace(device="cuda", dis_metric="ours"))) for _ in range(5)]
+    mspread = max(abs(v / vals[0] - 1) for v in vals)
+    print("run-to-run spread: training gradients %.1e, hallucinator gradients %.1e, match_loss %.1e" % (spread, hspread, mspread))
+    assert spread < 2e-6 and hspread < 2e-6 and mspread < 2e-6
