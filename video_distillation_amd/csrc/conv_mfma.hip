@@ -358,74 +358,56 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
                 const int sc = (VD_DBG(p) & 32) ? 0 : ((st < S) ? st : S - 1);   // dbg 32: every step reads the same LDS rows
                 return lds_tap[2 * sc + half];
             };
+            // A fragments: AD + 1 = 2 register sets.  The set an M tile's MFMAs have just consumed is refilled AT ONCE with the
+            // fragment of TWO steps ahead, tile by tile, so an LDS read has ~1.75 K steps of matrix work to return instead
+            // of one (same registers, same K order per output, bitwise the same results): measured on the first layer, whose
+            // waves are often alone on their SIMD (partner workgroup in its DMA / epilogue phase), -4.7 %.
+            static_assert(AD == 1, "the refill scheme below is written for two register sets");
             uint4 A[AD + 1][MA];
 #pragma unroll
-            for (int d = 0; d < AD; ++d) {
+            for (int d = 0; d <= AD; ++d) {
                 const int tp = tap_of(d);
 #pragma unroll
                 for (int i = 0; i < MA; ++i) A[d][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
             }
-            int tp = tap_of(AD);
+            int tp = tap_of(AD + 1);          // tap offset of step s + 2
+            auto k_step = [&](const int u, const int s_abs) {
+                load_b(s_abs + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
+                const int tp_next = tap_of(s_abs + AD + 2);
+                VD_SCHED_BARRIER();
+                VD_PRIO(1);
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) {
+                    if (NTW == 2 && BAL == 0 && i == MTW - 1 && short_row) continue;
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+                        acc[j * MTW + i] = mfma16<PREC>(A[u % (AD + 1)][i], bqh[u][j], acc[j * MTW + i]);
+                    VD_SCHED_BARRIER();
+                    if (i > 0 && (VD_DBG(p) & 64)) A[u % (AD + 1)][i] = A[u % (AD + 1)][0];                 // dbg 64: one LDS read per step
+                    else A[u % (AD + 1)][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
+                    VD_SCHED_BARRIER();
+                }
+                if constexpr (BAL) {   // seventh M tile: this wave's single N tile of it (wave row picks which)
+                    uint4 bx = bqh[u][0];
+                    if (wm) bx = bqh[u][1];
+                    acc[MTW * NTW] = mfma16<PREC>(A[u % (AD + 1)][MTW], bx, acc[MTW * NTW]);
+                    VD_SCHED_BARRIER();
+                    A[u % (AD + 1)][MTW] = *reinterpret_cast<const uint4*>(smem + a_off[MTW] + tp);
+                }
+                VD_PRIO(0);
+                VD_SCHED_BARRIER();
+                tp = tp_next;
+            };
             int s = 0;
             for (; s + DB < S; s += DB + 1) {   // full groups of DB+1 steps: no bound checks in the hot loop
 #pragma unroll
-                for (int u = 0; u <= DB; ++u) {
-                    load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
-                    const int tp_next = tap_of(s + u + AD + 1);
-#pragma unroll
-                    for (int i = 0; i < MA; ++i) {
-                        if (i > 0 && (VD_DBG(p) & 64)) { A[(u + AD) % (AD + 1)][i] = A[(u + AD) % (AD + 1)][0]; continue; }   // dbg 64: one LDS read per step
-                        if (NTW == 2 && BAL == 0 && i == MTW - 1 && short_row) continue;
-                        A[(u + AD) % (AD + 1)][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
-                    }
-                    VD_SCHED_BARRIER();
-                    VD_PRIO(1);
-#pragma unroll
-                    for (int i = 0; i < MTW; ++i) {
-                        if (NTW == 2 && BAL == 0 && i == MTW - 1 && short_row) continue;
-#pragma unroll
-                        for (int j = 0; j < NTW; ++j)
-                            acc[j * MTW + i] = mfma16<PREC>(A[u % (AD + 1)][i], bqh[u][j], acc[j * MTW + i]);
-                    }
-                    if constexpr (BAL) {   // seventh M tile: this wave's single N tile of it (wave row picks which)
-                        uint4 bx = bqh[u][0];
-                        if (wm) bx = bqh[u][1];
-                        acc[MTW * NTW] = mfma16<PREC>(A[u % (AD + 1)][MTW], bx, acc[MTW * NTW]);
-                    }
-                    VD_PRIO(0);
-                    VD_SCHED_BARRIER();
-                    tp = tp_next;
-                }
+                for (int u = 0; u <= DB; ++u) k_step(u, s + u);
             }
             if (s < S) {                      // remaining 1..DB steps
 #pragma unroll
                 for (int u = 0; u <= DB; ++u) {
                     if (s + u >= S) break;
-                    load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
-                    const int tp_next = tap_of(s + u + AD + 1);
-#pragma unroll
-                    for (int i = 0; i < MA; ++i) {
-                        if (i > 0 && (VD_DBG(p) & 64)) { A[(u + AD) % (AD + 1)][i] = A[(u + AD) % (AD + 1)][0]; continue; }   // dbg 64: one LDS read per step
-                        if (NTW == 2 && BAL == 0 && i == MTW - 1 && short_row) continue;
-                        A[(u + AD) % (AD + 1)][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
-                    }
-                    VD_SCHED_BARRIER();
-                    VD_PRIO(1);
-#pragma unroll
-                    for (int i = 0; i < MTW; ++i) {
-                        if (NTW == 2 && BAL == 0 && i == MTW - 1 && short_row) continue;
-#pragma unroll
-                        for (int j = 0; j < NTW; ++j)
-                            acc[j * MTW + i] = mfma16<PREC>(A[u % (AD + 1)][i], bqh[u][j], acc[j * MTW + i]);
-                    }
-                    if constexpr (BAL) {   // seventh M tile: this wave's single N tile of it (wave row picks which)
-                        uint4 bx = bqh[u][0];
-                        if (wm) bx = bqh[u][1];
-                        acc[MTW * NTW] = mfma16<PREC>(A[u % (AD + 1)][MTW], bx, acc[MTW * NTW]);
-                    }
-                    VD_PRIO(0);
-                    VD_SCHED_BARRIER();
-                    tp = tp_next;
+                    k_step(u, s + u);
                 }
             }
         } else {
@@ -869,7 +851,7 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
                 asm volatile("" : "+s"(gi));
-                if (gi < ngroups) {
+                if (gi < ngroups && !(VD_DBG(p) & 4)) {
                     const uint32_t* gp = (off[u] != 0xFFFFFFFFu) ? csrc + off[u] : zslot;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                                      (__attribute__((address_space(3))) void*)(smem + gi * 1024), 16, 0, 0);
@@ -885,25 +867,36 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
         for (int i = 0; i < MTW; ++i)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+        // A fragments: two register sets; the set an MFMA has just consumed is refilled at once with the fragment of TWO steps
+        // ahead (tile by tile), so a read has ~1.75 K steps (224 matrix cycles) to return instead of one (128): with the
+        // partner workgroup of the CU in its DMA / epilogue phase this wave is alone on its SIMD and nothing else hides the
+        // LDS latency (same-box A/B: 1.71 -> 1.63 ms per 512 clips)
         uint4 A[2][MTW];
         {
-            const int tp0 = lds_tap[half];
+            {
+                const int tp0 = lds_tap[half], tp1 = lds_tap[2 + half];
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) A[0][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp0);
-        }
-        int tp = lds_tap[2 + half];
+                for (int i = 0; i < MTW; ++i) A[0][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp0);
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int tp_next = lds_tap[2 * ((s + 2 < S) ? s + 2 : S - 1) + half];
+                for (int i = 0; i < MTW; ++i) A[1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp1);
+            }
+            int tp2 = lds_tap[4 + half];                      // tap offset of step s + 2
+            if (!(VD_DBG(p) & 2))
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) A[(s + 1) & 1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < S; ++s) {
+                const int tp3 = lds_tap[2 * ((s + 3 < S) ? s + 3 : S - 1) + half];
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) acc[i] = mfma16<PREC>(A[s & 1][i], breg[s], acc[i]);
-            __builtin_amdgcn_sched_barrier(0);
-            tp = tp_next;
+                for (int i = 0; i < MTW; ++i) {
+                    acc[i] = mfma16<PREC>(A[s & 1][i], breg[s], acc[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 2 < S) A[s & 1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                tp2 = tp3;
+            }
         }
         VD_LDS_BARRIER();                // every wave is done reading the patch: the staging tile aliases it
+        if (VD_DBG(p) & 1) { if (acc[0][0] == 123.456f) reinterpret_cast<float*>(p.dst)[0] = 1.f; continue; }
         // ---- epilogue: bias + ReLU + (1,2,2) max-pool, staged through LDS, 16-byte slot stores ----
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {

@@ -102,7 +102,7 @@ class _DevPlan:
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.breg_ok and argmax is None and not p.dbg:
+        if self.breg_ok and argmax is None and (not p.dbg or os.environ.get("VD_BREG_DBG") == "1"):
             hip.check(hip.lib().vd_conv0_breg(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv0_breg(%s)" % self.plan.name)
         elif self.persistent_ok and argmax is None and not p.dbg:
             hip.check(hip.lib().vd_conv0_persistent(ctypes.byref(p), hip.stream_ptr(src.device)),

@@ -78,7 +78,7 @@ _lib: Optional[ctypes.CDLL] = None
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        path = LIB_PATH
+        path = os.environ.get("VD_LIB_PATH", LIB_PATH)           # (measurement tools: A/B of two builds on one box)
         if os.environ.get("VD_LIB_VARIANT") == "dbg":      # profiling tools: the build with the dbg hooks compiled in
             path = build(debug_hooks=True)
         if not os.path.exists(path):
@@ -88,6 +88,8 @@ def lib() -> ctypes.CDLL:
         L = ctypes.CDLL(path)
         for name in EXPORTS:
             if not hasattr(L, name):
+                if "VD_LIB_PATH" in os.environ:      # an older build loaded on purpose for an A/B measurement
+                    continue
                 raise RuntimeError("libvd_hip.so does not export %s" % name)
             getattr(L, name).restype = {"vd_program_info": ctypes.c_int64, "vd_program_free": None, "vd_blob_free": None, "vd_embed_free": None,
                                         "vd_embed_num_features": ctypes.c_int64, "vd_embed_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
