@@ -806,6 +806,9 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
     const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);
     int* lds_tap = reinterpret_cast<int*>(smem + plane_bytes);
     int* lds_otab = lds_tap + 2 * S;
+    // gather entries of the NEXT box, brought in by 4-byte LDS-DMA while the current box computes (no registers held
+    // across the K loop, no global-load latency at the start of a box): [LU][64 lanes] per wave
+    int* park = reinterpret_cast<int*>(smem + plane_bytes + 512) + wave * (LU * 64);
     for (int k = tid; k < 2 * S; k += 256) lds_tap[k] = t_tab[k];
     for (int k = tid; k < 32; k += 256) lds_otab[k] = o_tab[k];
     int a_off[MTW];
@@ -831,18 +834,27 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
     const int b_lo = wgid * boxes_per_wg;
     const int b_hi = (b_lo + boxes_per_wg < total) ? b_lo + boxes_per_wg : total;
     uint16_t* stg = reinterpret_cast<uint16_t*>(smem);
+    auto park_next = [&](int b) {      // this wave's LU x 64 gather entries of box b -> its park region (asynchronous)
+        const int32_t* gtab = p.gather + (int64_t)(b % p.nbox) * p.gather_stride + lane;
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int gi = wave + u * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gtab + ((gi < ngroups) ? gi : ngroups - 1) * 64),
+                                             (__attribute__((address_space(3))) void*)(park + u * 64), 4, 0, 0);
+        }
+    };
+    if (b_lo < b_hi) park_next(b_lo);
+    __syncthreads();                     // tables published, first entries landed
     asm volatile("" ::: "memory");
     for (int b = b_lo; b < b_hi; ++b) {
         const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
-        // ---- gather entries, then the patch DMA (all entries consumed before the first DMA) ----
+        // ---- gather entries (parked in LDS during the previous box), then the patch DMA ----
         {
-            const int32_t* gtab = p.gather + (int64_t)bi * p.gather_stride;
             const uint32_t* csrc = src + (p.clip_index != nullptr ? p.clip_index[clip0] : (int64_t)clip0) * p.src_clip_stride4;
             uint32_t off[LU];
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
-                const int gi = wave + u * 4;
-                const int e = gtab[((gi < ngroups) ? gi : ngroups - 1) * 64 + lane];
+                const int e = park[u * 64 + lane];
                 off[u] = (e >= 0) ? (uint32_t)(e & 0xFFFFFF) : 0xFFFFFFFFu;
             }
 #pragma unroll
@@ -858,6 +870,7 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
                 }
                 gi += 4;
             }
+            if (b + 1 < b_hi) park_next(b + 1);      // lands under this box's K loop; waited for (vmcnt) with the patch below
         }
         const int out_rel = p.boxes[bi * 8 + 3];
         __syncthreads();                 // patch landed (vmcnt(0) + barrier); also publishes the LDS tables
@@ -943,7 +956,7 @@ static int launch_conv0_breg(const VdConvParams& p, hipStream_t st) {
     static VdDevCache cache;
     int ncu = 0;
     if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
-    const size_t lds = (size_t)p.lds_plane_bytes + (2 * 32 + 32) * sizeof(int) + 16;
+    const size_t lds = (size_t)p.lds_plane_bytes + 512 + 4 * 14 * 64 * sizeof(int);
     if (lds > 80 * 1024) return -3;
     const int64_t slots = (int64_t)ncu * 2;
     const int gens = p.persist > 0 ? p.persist : 4;
