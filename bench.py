@@ -187,8 +187,11 @@ class Harness:
         return {"seconds": dt, "steps": n, "value": n / dt, "unit": "steps/s"}
 
 
-def roofline_from_profile(prof, device, kernel_labels):
-    """Aggregate the launch profile by tile program; the program with the largest total time is the dominant kernel."""
+def roofline_from_profile(prof, device, kernel_labels, only_prec=None):
+    """Aggregate the launch profile by tile program; the program with the largest total time is the dominant kernel.
+    ``only_prec``: rank only programs of that operand precision (DM / s2d: the real-clip stream -- the small synthetic-clip
+    launches run concurrently on a second stream, and their event-to-event times stretch to the length of the kernels
+    they share the CUs with, so their summed durations are not GPU time)."""
     from video_distillation_amd import hip
     agg = {}
     for name, prec, flop, e0, e1 in prof:
@@ -201,7 +204,8 @@ def roofline_from_profile(prof, device, kernel_labels):
     inv = {v: k for k, v in hip.PREC.items()}
     total = sum(v[0] for v in agg.values())
     ranked = sorted(agg.items(), key=lambda kv: -kv[1][0])
-    (name, prec), (secs, n, flop) = ranked[0]
+    first = [kv for kv in ranked if only_prec is None or kv[0][1] == hip.PREC[only_prec]] or ranked
+    (name, prec), (secs, n, flop) = first[0]
     achieved = flop / secs / 1e12
     x3 = hip.is_x3(prec)
     return {"bound": "mfma", "kernel": "%s, tile program '%s', operands %s" % (kernel_labels.get(name, "conv_mfma_kernel"), name, inv[prec]),
@@ -372,7 +376,7 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
         out["step_frac_of_mfma_peak"] = out["step_tflops"] / PEAK_TFLOPS
         labels = {"fwd1": "conv_mfma_kernel<PREC, 3, false, 2, 1> (balanced 7-tile layout; conv layer 1 forward, real clips)",
                   "fwd0": "conv0_breg_kernel<PREC> (conv layer 0 forward)"}
-        roof = roofline_from_profile(prof, device, labels)
+        roof = roofline_from_profile(prof, device, labels, only_prec=args.prec_real)
         if roof:
             clips = roof["flop_per_launch"] / (2.0 * macs[1]) if "fwd1" in roof["kernel"] else None
             roof["traffic"], roof["traffic_source"] = pmc_traffic("conv1_fwd_f16", clips) if clips else (None, None)
