@@ -217,13 +217,31 @@ def roofline_from_profile(prof, device, kernel_labels, only_prec=None):
                           "tflops": v[2] / v[0] / 1e12 if v[0] > 0 else None} for k, v in ranked[:8]]}
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """Everything that writes to fd 1 while the benchmark runs -- RCCL's version banner, evaluate_synset's progress
+    line -- is sent to stderr; the ONE JSON line is written to the real stdout at the very end (``finish``)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
 def finish(h, out, extra_rank0=None):
-    if h.rank == 0:
-        print(json.dumps(out))
-    if h.world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if h.rank == 0:
+        line = (json.dumps(out) + "\n").encode()
+        if _REAL_STDOUT is not None:
+            os.write(_REAL_STDOUT, line)
+        else:
+            sys.stdout.write(line.decode())
 
 
 def base_record(args, h, metric, dt, per_step, dtype, workload, parallelism, precision):
@@ -586,6 +604,7 @@ def bench_mtt(args, h, distill, geo):
 # ------------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    quiet_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -595,9 +614,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("VD_BENCH_FORCE_DIST") == "1":      # (the env: exercise the RCCL calls on a one-GPU box)
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
     if args.pool_per_class is None:
         args.pool_per_class = 1 if args.method == "mtt" else 93
 

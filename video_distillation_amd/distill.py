@@ -329,7 +329,8 @@ class DMTrainer:
             with on_syn():
                 f_syn, handle = be.embed_syn(self.image_syn, weights)
                 be.real_to_syn(f_real)
-                loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
+                f_real = self._exchange(f_real)      # (batch sharding) on the synthetic-clip stream: the real-clip stream is
+                loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)     # free to start the next iteration's forward meanwhile
                 grad = be.embed_backward(handle, g_syn)
                 be.sgd(self.image_syn, self.buf, grad, self.lr_img, self.momentum, first=(self.steps_done == 0))
                 loss = loss_c.sum()
@@ -338,7 +339,7 @@ class DMTrainer:
             self.steps_done += 1
             return loss
         be.set_weights(weights)
-        f_real = self._real_features(idx_t)
+        f_real = self._exchange(self._real_features(idx_t))
         f_syn, handle = be.embed_syn(self.image_syn, weights) if hasattr(be, "embed_syn") else be.embed_keep(self.image_syn)
         loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
         grad = be.embed_backward(handle, g_syn)
@@ -347,18 +348,23 @@ class DMTrainer:
         return loss_c.sum()
 
     def _real_features(self, idx_t: torch.Tensor) -> torch.Tensor:
-        """Features of the real clips this rank embeds, in the form dm_loss() consumes: all clips of
-        the owned classes (class sharding), or -- batch sharding -- the all-reduced per-class MEAN
-        feature of the owned classes (one row per class, i.e. a 'batch' of one)."""
+        """This rank's contribution to the real side: all clips' features of the owned classes (class sharding), or --
+        batch sharding -- the per-class sums of its 1/world slice of every class's batch, pre-scaled by 1/batch_real
+        (C x D fp32, 410 KB; ``_exchange`` all-reduces them)."""
         f = self.be.embed_pool(self.pool.clips, idx_t)
         if self.shard != "batch":
             return f
+        return self.be.group_sum(f, self.num_classes, self.batch_real // self.world, 1.0 / self.batch_real)
+
+    def _exchange(self, x: torch.Tensor) -> torch.Tensor:
+        """Batch sharding: the one data-path collective of a DM step -- all-reduce of the per-class feature sums; returns the
+        class MEANS of the owned classes in the form dm_loss() consumes (one row per class, a 'batch' of one)."""
+        if self.shard != "batch":
+            return x
         import torch.distributed as dist
-        per = self.batch_real // self.world
-        sums = self.be.group_sum(f, self.num_classes, per, 1.0 / self.batch_real)
         if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        return sums[self.c_lo:self.c_hi].contiguous()
+            dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        return x[self.c_lo:self.c_hi].contiguous()
 
     def global_loss(self, local_loss: torch.Tensor) -> torch.Tensor:
         """Sum of the per-rank losses (== the reference's ``loss`` before /num_classes)."""
