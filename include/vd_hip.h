@@ -246,6 +246,11 @@ int vd_head_second_order(const float* logits, const float* dlogits, const int32_
  * batch_hint > 0 clips per launch -- the latency-oriented decomposition exactly as the Python planner does, and
  * returns the serialised program (malloc'd; vd_blob_free) that vd_program_load consumes. */
 int vd_program_build(int layer, int frames, int height, int width, int prec, int batch_hint, void** blob, int64_t* nbytes);
+/* the INPUT-GRADIENT programs of a level: level 0 -> one program (parity_class 0) that merges the four stride-2 parity
+ * classes into the N dimension and writes fp32 pixels (T,3,H,W); levels 1, 2 -> one program per parity class
+ * (parity_class = ph * 2 + pw) writing fp32 [t][h][w][cin].  Source of all: dense dy slots (vd_unpool_relu_bwd). */
+int vd_program_build_dgrad(int layer, int parity_class, int frames, int height, int width, int batch_hint, void** blob,
+                           int64_t* nbytes);
 void vd_blob_free(void* blob);
 
 /* ---- ConvNet3D.embed (networks.py:747-751) as one handle: nothing but this header, the library and device pointers.
@@ -256,9 +261,22 @@ void vd_blob_free(void* blob);
  *                            (fp32 device vectors) are read by the launches and must stay alive
  *   vd_embed_forward         features[nclips][vd_embed_num_features] = embed(clips[(clip_index ? clip_index[b] : b)]),
  *                            clips (.,T,3,H,W) fp32 -- the reference's input layout; asynchronous on `stream`
- * Errors: -1 bad argument, -6 no weights set, -7 workspace too small, otherwise the failing call's code. */
+ * Errors: -1 bad argument, -6 no weights set, -7 workspace too small, otherwise the failing call's code.
+ * With the INPUT GRADIENT (the DM class term's backward to the synthetic pixels, distill_baseline.py:351-354):
+ *   vd_embed_create_ex       also plans + loads the input-gradient programs with operand precision prec_bwd (-1: none)
+ *   vd_embed_forward_keep    forward that also stores the pooling arg-max bytes of the three levels in `argmax`
+ *                            (vd_embed_argmax_bytes(e, nclips) bytes, caller-owned)
+ *   vd_embed_backward        g_clips (nclips,T,3,H,W) fp32 = d <g_features, features> / d clips for such a forward
+ *                            (vd_embed_backward_workspace_bytes of scratch); error -8 if created without prec_bwd */
 typedef struct VdEmbed VdEmbed;
 int vd_embed_create(int frames, int height, int width, int prec, int batch_hint, VdEmbed** out);
+int vd_embed_create_ex(int frames, int height, int width, int prec, int prec_bwd, int batch_hint, VdEmbed** out);
+int64_t vd_embed_argmax_bytes(const VdEmbed* e, int64_t nclips);
+int64_t vd_embed_backward_workspace_bytes(const VdEmbed* e, int64_t nclips);
+int vd_embed_forward_keep(VdEmbed* e, const float* clips, const int64_t* clip_index, int64_t nclips, void* workspace,
+                          int64_t workspace_bytes, float* features, uint8_t* argmax, void* stream);
+int vd_embed_backward(VdEmbed* e, const float* g_features, const uint8_t* argmax, int64_t nclips, void* workspace,
+                      int64_t workspace_bytes, float* g_clips, void* stream);
 int64_t vd_embed_num_features(const VdEmbed* e);
 int64_t vd_embed_workspace_bytes(const VdEmbed* e, int64_t nclips);
 int vd_embed_set_weights(VdEmbed* e, const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
@@ -292,6 +310,10 @@ int vd_program_load(const void* blob, int64_t nbytes, int prec, VdProgram** out)
 int vd_program_pack_weights(VdProgram* prog, const float* w, void* stream);
 int vd_program_run(VdProgram* prog, const void* src, int64_t src_plane_slots, const float* bias, void* dst,
                    int64_t dst_plane_stride, uint8_t* argmax, const int64_t* clip_index, int nclips, void* stream);
+/* the same with the fp32 epilogue scale of the input-gradient programs (out_scale[0] multiplies every output; NULL = 1) */
+int vd_program_run_scaled(VdProgram* prog, const void* src, int64_t src_plane_slots, const float* bias, void* dst,
+                          int64_t dst_plane_stride, uint8_t* argmax, const int64_t* clip_index, int nclips,
+                          const float* out_scale, void* stream);
 int64_t vd_program_info(const VdProgram* prog, int what);
 void vd_program_free(VdProgram* prog);
 

@@ -46,3 +46,25 @@ def test_cpp_planner_argument_errors():
     assert lib.vd_program_build(0, 16, 112, 112, 7, 0, ctypes.byref(blob), ctypes.byref(n)) == -1
     assert lib.vd_program_build(0, 16, 8, 8, 1, 0, ctypes.byref(blob), ctypes.byref(n)) == -2
     assert lib.vd_program_build(0, 16, 112, 112, 1, 0, None, ctypes.byref(n)) == -1
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libvd_hip.so not built")
+@pytest.mark.parametrize("dims,hint", [((16, 112, 112), None), ((16, 112, 112), 50), ((8, 64, 64), None), ((8, 64, 64), 8), ((8, 80, 96), 4)])
+def test_cpp_planner_emits_the_python_planner_s_input_gradient_programs(dims, hint):
+    lib = ctypes.CDLL(LIB)
+    lib.vd_blob_free.restype = None
+    geo = plan.NetGeometry(*dims)
+    net = plan.plan_network(geo, ntw=2, ntw0=1, balanced=True, batch_hint=hint)
+    for layer in range(3):
+        for cls, pl in enumerate(net["bwd"][layer]):
+            want = plan.export_program(pl)
+            blob, n = ctypes.c_void_p(), ctypes.c_int64()
+            rc = lib.vd_program_build_dgrad(layer, cls, geo.frames, geo.height, geo.width, hint or 0, ctypes.byref(blob), ctypes.byref(n))
+            assert rc == 0, (layer, cls, rc)
+            try:
+                got = ctypes.string_at(blob, n.value)
+            finally:
+                lib.vd_blob_free(blob)
+            assert got == want, "dgrad layer %d class %d differs" % (layer, cls)
+        blob, n = ctypes.c_void_p(), ctypes.c_int64()
+        assert lib.vd_program_build_dgrad(layer, len(net["bwd"][layer]), geo.frames, geo.height, geo.width, 0, ctypes.byref(blob), ctypes.byref(n)) == -3

@@ -1,4 +1,4 @@
-// Host-side planner of the forward tile programs, in C++: the C ABI needs no Python step.
+// Host-side planner of the forward and input-gradient tile programs, in C++: the C ABI needs no Python step.
 //
 // What video_distillation_amd/plan.py does for the three forward programs of one ConvNet3D geometry
 // (plan_forward_pix, plan_forward_cl, the wave-layout choice of plan_network and latency_variant), re-stated in C++ with
@@ -27,7 +27,7 @@
 namespace {
 
 constexpr int SLOT_BYTES = 16;
-constexpr int EPI_POOL_CL = 0, EPI_POOL_FEAT = 1;
+constexpr int EPI_POOL_CL = 0, EPI_POOL_FEAT = 1, EPI_ROWS = 2;
 constexpr int KT = 3, KH = 7, KW = 7;
 // ds_read_b128 services a wave in four 16-lane groups (two per lane half)
 const int B128_GROUPS[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
@@ -51,6 +51,7 @@ struct Plan {
     int64_t clip_stride4 = 0, chunk_stride4 = 0;
     int NTW = 1;
     int64_t rows_total = 0;
+    std::vector<int32_t> col_off;      // EPI_ROWS: element offset of output column n (empty: n * n_stride)
     int nbox() const { return (int)boxes.size(); }
     int64_t lds_slots() const {
         int64_t m = 0;
@@ -92,6 +93,60 @@ std::vector<std::array<int, 4>> perms4() {
 
 // One BoxType for a fixed enumeration order of the pool windows: searches the LDS pitches and, per MFMA tile, which
 // window sits in which lane-half / register-half, for the fewest ds_read_b128 bank conflicts.
+// plain-row programs (input-gradient passes): rows in (clip, a, b, c) order, 32 per MFMA tile, no tile assignment to search
+BoxType build_type_rows(const int box[3], const int row_stride[3], const std::vector<Tap>& taps, const int ext[3], int mt_pad,
+                        const OutFn& out_fn, const int valid[3], int ncl, int64_t slot_cap) {
+    const int na = box[0], nb = box[1], nc = box[2];
+    const int pf = ext[0], ph = ext[1], pw = ext[2];
+    std::vector<std::array<int64_t, 4>> rcoord;
+    std::vector<int64_t> rout;
+    for (int ci = 0; ci < ncl; ++ci)
+        for (int a = 0; a < na; ++a)
+            for (int b = 0; b < nb; ++b)
+                for (int c = 0; c < nc; ++c) {
+                    rcoord.push_back({ci, (int64_t)row_stride[0] * a, (int64_t)row_stride[1] * b, (int64_t)row_stride[2] * c});
+                    rout.push_back((a < valid[0] && b < valid[1] && c < valid[2]) ? out_fn(ci, a, b, c) : -1);
+                }
+    const int nrows = (int)rcoord.size();
+    const int ntile_used = (int)cdiv(nrows, 32);
+    bool have = false;
+    double best_cyc = 0.0;
+    int best_pitch_c = 0;
+    BoxType best;
+    for (int dph = 0; dph < 16; ++dph) {
+        const int pitch_h = pw + dph;
+        for (int dpf = 0; dpf < 16; ++dpf) {
+            const int pitch_f = ph * pitch_h + dpf;
+            const int pitch_c = pf * pitch_f;
+            if ((int64_t)pitch_c * ncl > slot_cap && have) continue;
+            std::vector<int64_t> a_off((size_t)mt_pad * 32, 0), out((size_t)mt_pad * 32, -1);
+            for (int r = 0; r < nrows; ++r) {
+                a_off[r] = rcoord[r][0] * pitch_c + rcoord[r][1] * pitch_f + rcoord[r][2] * pitch_h + rcoord[r][3];
+                out[r] = rout[r];
+            }
+            double cyc_sum = 0.0;
+            for (int t = 0; t < ntile_used; ++t) cyc_sum += conflict_cycles(&a_off[(size_t)t * 32]);
+            const double cyc = cyc_sum / ntile_used;
+            const double kc = round3(cyc);
+            if (!have || kc < best_cyc || (kc == best_cyc && pitch_c < best_pitch_c)) {
+                have = true; best_cyc = kc; best_pitch_c = pitch_c;
+                best = BoxType();
+                best.pf = pf; best.ph = ph; best.pw = pw; best.pitch_h = pitch_h; best.pitch_f = pitch_f; best.pitch_c = pitch_c;
+                best.mt = mt_pad; best.cyc = cyc;
+                best.a_off.resize(a_off.size()); best.out.resize(out.size());
+                for (size_t k = 0; k < a_off.size(); ++k) best.a_off[k] = (int32_t)(a_off[k] * SLOT_BYTES);
+                for (size_t k = 0; k < out.size(); ++k) best.out[k] = (int32_t)out[k];
+                best.tap_off.resize(taps.size());
+                for (size_t k = 0; k < taps.size(); ++k)
+                    best.tap_off[k] = (int32_t)((taps[k][0] * pitch_f + taps[k][1] * pitch_h + taps[k][2]) * SLOT_BYTES);
+            }
+            if (cyc <= 4.0 + 1e-9) break;
+        }
+        if (have && best_cyc <= 4.0 + 1e-9) break;
+    }
+    return best;
+}
+
 BoxType build_type_order(const int box[3], const int row_stride[3], const std::vector<Tap>& taps, const int ext[3], int mt_pad,
                          const OutFn& out_fn, const int valid[3], int ncl, int64_t slot_cap, const int order[3]) {
     static const std::vector<std::array<int, 4>> PERMS = perms4();
@@ -217,9 +272,10 @@ struct PlanSpec {
     int out_chunk_stride;
     int lds_budget;
     int ntw;
+    bool pooled = true;                // pool windows of 2x2x2 conv rows (forward) vs plain rows (input gradient)
 };
 
-// plan._make_plan for pooled programs (group = 2x2x2 conv rows per pool window)
+// plan._make_plan (pooled programs: group = 2x2x2 conv rows per pool window; plain-row programs: group = 1)
 bool make_plan(const PlanSpec& sp, Plan& pl) {
     const int ntaps = (int)sp.taps.size();
     const int S = (ntaps + 1) / 2;
@@ -240,7 +296,8 @@ bool make_plan(const PlanSpec& sp, Plan& pl) {
     for (int MTW : sp.mtw_options)
         for (int ncl : sp.ncl_options) {
             const int rows_max = (sp.MW * MTW * 32) / ncl;
-            if (rows_max < 8) continue;
+            const int G = sp.pooled ? 2 : 1;
+            if (rows_max < G * G * G) continue;
             const int waves = (sp.NT / sp.ntw) * sp.MW;
             const int64_t dma_cap = (int64_t)waves * (MTW * sp.ntw <= 4 ? 14 : 17) * 64;
             const int64_t budget = std::min<int64_t>(sp.lds_budget, dma_cap - 64);
@@ -248,10 +305,10 @@ bool make_plan(const PlanSpec& sp, Plan& pl) {
             bool hb = false;
             int64_t k_nbox = 0, k_slots = 0;
             int k_narrow = 0, cb[3] = {0, 0, 0};
-            for (int na = 2; na < RA + 2; na += 2)
-                for (int nb = 2; nb < RB + 2; nb += 2)
-                    for (int nc = 2; nc < RC + 2; nc += 2) {
-                        if (na > RA + 1 || nb > RB + 1 || nc > RC + 1) continue;
+            for (int na = G; na < RA + G; na += G)
+                for (int nb = G; nb < RB + G; nb += G)
+                    for (int nc = G; nc < RC + G; nc += G) {
+                        if (na > RA + G - 1 || nb > RB + G - 1 || nc > RC + G - 1) continue;
                         if (na * nb * nc > rows_max) continue;
                         int e[3];
                         ext(na, nb, nc, e);
@@ -289,7 +346,8 @@ bool make_plan(const PlanSpec& sp, Plan& pl) {
                     if (keys[k] == key) ty = (int)k;
                 if (ty < 0) {
                     const int valid[3] = {key[0], key[1], key[2]};
-                    pl.types.push_back(build_type(best_box, sp.row_stride, taps_p, e_box, mt_pad, sp.out_index, valid, ncl, slot_cap));
+                    pl.types.push_back(sp.pooled ? build_type(best_box, sp.row_stride, taps_p, e_box, mt_pad, sp.out_index, valid, ncl, slot_cap)
+                                                 : build_type_rows(best_box, sp.row_stride, taps_p, e_box, mt_pad, sp.out_index, valid, ncl, slot_cap));
                     keys.push_back(key);
                     ty = (int)keys.size() - 1;
                 }
@@ -301,7 +359,7 @@ bool make_plan(const PlanSpec& sp, Plan& pl) {
     pl.chunk_stride4 = (int64_t)pl.F * pl.H * pl.W * 4;
     pl.clip_stride4 = (int64_t)sp.CC * pl.F * pl.H * pl.W * 4;
     pl.NT = sp.NT; pl.MW = sp.MW; pl.MTW = MTW; pl.S = S; pl.ncl = ncl;
-    pl.epi = sp.epi; pl.pool_t = sp.pool_t; pl.relu = 1; pl.n_out = sp.n_out; pl.n_stride = sp.n_stride;
+    pl.epi = sp.epi; pl.pool_t = sp.pool_t; pl.relu = sp.pooled ? 1 : 0; pl.n_out = sp.n_out; pl.n_stride = sp.n_stride;
     pl.out_clip_stride = sp.out_clip_stride; pl.out_chunk_stride = sp.out_chunk_stride;
     pl.rows_total = (int64_t)pl.boxes.size() * mt_pad * 32 / ncl;
     pl.NTW = sp.ntw;
@@ -420,6 +478,141 @@ bool plan_forward_pix(int cout, int t_in, int h_in, int w_in, int lds_budget, in
     return true;
 }
 
+// plan.plan_dgrad: input gradient of Conv3d(cin->cout) for the input positions (t, 2b+ph, 2c+pw); source = dense dy on the
+// conv grid (channels-last chunks of cout); dx[t,h,w,ci] = sum dy[t+1-kt, (h+3-kh)/2, (w+3-kw)/2, n] * W[n,ci,kt,kh,kw]
+bool plan_dgrad(int cin, int cout, int t_in, int h_in, int w_in, int ph, int pw, int lds_budget, std::vector<int> mtw_options, Plan& pl) {
+    if (cout % 8) return false;
+    const int CC = cout / 8;
+    const int T = conv_out_dim(t_in, KT, 1, 1), OH = conv_out_dim(h_in, KH, 2, 3), OW = conv_out_dim(w_in, KW, 2, 3);
+    std::vector<Tap> tap_k;
+    for (int kt = 0; kt < KT; ++kt)
+        for (int kh = 0; kh < KH; ++kh) {
+            if ((ph + 3 - kh) % 2 != 0) continue;
+            for (int kw = 0; kw < KW; ++kw)
+                if ((pw + 3 - kw) % 2 == 0) tap_k.push_back({kt, kh, kw});
+        }
+    PlanSpec sp;
+    for (const auto& k : tap_k) {
+        // python floor division: (ph + 3 - kh) // 2 + 1 with possibly negative numerators
+        auto fdiv2 = [](int v) { return (v >= 0) ? v / 2 : -((-v + 1) / 2); };
+        sp.taps.push_back({2 - k[0], fdiv2(ph + 3 - k[1]) + 1, fdiv2(pw + 3 - k[2]) + 1});
+    }
+    sp.src_grid[0] = T; sp.src_grid[1] = OH; sp.src_grid[2] = OW;
+    sp.CC = CC;
+    sp.row_dims[0] = t_in; sp.row_dims[1] = (h_in - ph + 1) / 2; sp.row_dims[2] = (w_in - pw + 1) / 2;
+    sp.row_origin[0] = sp.row_origin[1] = sp.row_origin[2] = -1;
+    sp.row_stride[0] = sp.row_stride[1] = sp.row_stride[2] = 1;
+    const int n_pad = ((cin + 31) / 32) * 32;
+    sp.n_out = cin; sp.NT = n_pad / 32; sp.MW = std::max(1, 4 / sp.NT);
+    sp.mtw_options = mtw_options;
+    const int64_t rows_all = (int64_t)sp.row_dims[0] * sp.row_dims[1] * sp.row_dims[2];
+    const int max_ncl = (int)std::max<int64_t>(1, (8 * 32 * sp.MW) / std::max<int64_t>(rows_all, 1));
+    std::set<int> ncls = {1, max_ncl};
+    for (int n : {2, 4, 8}) if (n <= max_ncl) ncls.insert(n);
+    sp.ncl_options.assign(ncls.begin(), ncls.end());
+    sp.epi = EPI_ROWS; sp.pool_t = 0; sp.lds_budget = lds_budget; sp.ntw = 1; sp.pooled = false;
+    const int64_t clip_stride = (int64_t)t_in * h_in * w_in * cin;       // fp32 [t][h][w][cin]
+    sp.out_index = [=](int ci, int a, int b, int c) { return ci * clip_stride + (((int64_t)a * h_in + (2 * b + ph)) * w_in + 2 * c + pw) * cin; };
+    sp.n_stride = 1; sp.out_clip_stride = clip_stride; sp.out_chunk_stride = 0;
+    if (!make_plan(sp, pl)) return false;
+    const int S = pl.S, NT = pl.NT, ntaps = (int)tap_k.size();
+    pl.widx.assign((size_t)CC * S * NT * 64 * 8, -1);
+    for (int cc = 0; cc < CC; ++cc)
+        for (int s = 0; s < S; ++s)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int p = 2 * s + (lane >> 5);
+                    if (p >= ntaps) continue;
+                    const int64_t ci = nt * 32 + (lane & 31);
+                    if (ci >= cin) continue;
+                    for (int j = 0; j < 8; ++j) {
+                        const int64_t n = cc * 8 + j;
+                        pl.widx[((((size_t)cc * S + s) * NT + nt) * 64 + lane) * 8 + j] =
+                            (int32_t)((((n * cin + ci) * KT + tap_k[p][0]) * KH + tap_k[p][1]) * KW + tap_k[p][2]);
+                    }
+                }
+    return true;
+}
+
+// plan.plan_dgrad_pix: input gradient of the FIRST layer with the four stride-2 parity classes merged into N
+// (one output row = the 2x2 pixel block (t, 2b..2b+1, 2c..2c+1), columns n = c*4 + ph*2 + pw; K = 48 taps x cout)
+bool plan_dgrad_pix(int cin, int cout, int t_in, int h_in, int w_in, int lds_budget, Plan& pl) {
+    if (cin * 4 > 32 || cout % 8 || h_in % 2 || w_in % 2) return false;
+    const int CC = cout / 8;
+    const int T = conv_out_dim(t_in, KT, 1, 1), OH = conv_out_dim(h_in, KH, 2, 3), OW = conv_out_dim(w_in, KW, 2, 3);
+    PlanSpec sp;
+    for (int dt = 0; dt < 3; ++dt)
+        for (int dh = 0; dh < 4; ++dh)
+            for (int dw = 0; dw < 4; ++dw) sp.taps.push_back({dt, dh, dw});
+    sp.src_grid[0] = T; sp.src_grid[1] = OH; sp.src_grid[2] = OW;
+    sp.CC = CC;
+    sp.row_dims[0] = t_in; sp.row_dims[1] = h_in / 2; sp.row_dims[2] = w_in / 2;
+    sp.row_origin[0] = sp.row_origin[1] = sp.row_origin[2] = -1;
+    sp.row_stride[0] = sp.row_stride[1] = sp.row_stride[2] = 1;
+    sp.n_out = cin * 4; sp.NT = 1; sp.MW = 4;
+    sp.mtw_options = {7, 8};
+    sp.ncl_options = {1};
+    sp.epi = EPI_ROWS; sp.pool_t = 0; sp.lds_budget = lds_budget; sp.ntw = 1; sp.pooled = false;
+    const int64_t clip_stride = (int64_t)t_in * cin * h_in * w_in;
+    sp.out_index = [=](int ci, int a, int b, int c) { return ci * clip_stride + ((int64_t)a * cin * h_in + 2 * b) * w_in + 2 * c; };
+    sp.n_stride = 0; sp.out_clip_stride = clip_stride; sp.out_chunk_stride = 0;
+    if (!make_plan(sp, pl)) return false;
+    const int S = pl.S, ntaps = (int)sp.taps.size();
+    pl.widx.assign((size_t)CC * S * 64 * 8, -1);
+    for (int cc = 0; cc < CC; ++cc)
+        for (int s = 0; s < S; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int p = 2 * s + (lane >> 5);
+                if (p >= ntaps) continue;
+                const int dt = sp.taps[p][0], dh = sp.taps[p][1], dw = sp.taps[p][2];
+                const int kt = 2 - dt, n = lane & 31;
+                const int ci = n / 4, ph = (n / 2) % 2, pw = n % 2;
+                const int kh = ph + 5 - 2 * dh, kw = pw + 5 - 2 * dw;
+                if (ci >= cin || kh < 0 || kh >= KH || kw < 0 || kw >= KW) continue;
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t nn = cc * 8 + j;
+                    pl.widx[(((size_t)cc * S + s) * 64 + lane) * 8 + j] = (int32_t)((((nn * cin + ci) * KT + kt) * KH + kh) * KW + kw);
+                }
+            }
+    pl.col_off.assign(32, 0);
+    for (int n = 0; n < cin * 4; ++n) pl.col_off[n] = (n / 4) * h_in * w_in + ((n / 2) % 2) * w_in + (n % 2);
+    return true;
+}
+
+// input geometry (cin, t, h, w) of ConvNet3D level `layer`
+void layer_input(int layer, int frames, int height, int width, int& cin, int& t, int& h, int& w) {
+    const int widths[3] = {64, 128, 128}, pools_t[3] = {1, 2, 2};
+    cin = 3; t = frames; h = height; w = width;
+    for (int li = 0; li < layer; ++li) {
+        const int T = conv_out_dim(t, KT, 1, 1), OH = conv_out_dim(h, KH, 2, 3), OW = conv_out_dim(w, KW, 2, 3);
+        cin = widths[li]; t = T / pools_t[li]; h = OH / 2; w = OW / 2;
+    }
+}
+
+// the input-gradient programs of `layer` as plan.plan_network builds them: layer 0 -> one merged program (even H, W);
+// layers 1, 2 -> one program per stride-2 parity class (index = ph * 2 + pw), latency-oriented variant for small batches
+bool plan_dgrad_layer(int layer, int cls, int frames, int height, int width, int batch_hint, Plan& pl) {
+    int cin, t, h, w;
+    layer_input(layer, frames, height, width, cin, t, h, w);
+    const int widths[3] = {64, 128, 128};
+    const int cout = widths[layer], lds_budget = 3700;
+    if (layer == 0) return cls == 0 && h % 2 == 0 && w % 2 == 0 && plan_dgrad_pix(cin, cout, t, h, w, lds_budget, pl);   // (odd clip sizes: Python planner only)
+    const int nph = std::min(2, h), npw = std::min(2, w);
+    if (cls < 0 || cls >= nph * npw) return false;
+    const int ph = cls / npw, pw = cls % npw;
+    if (!plan_dgrad(cin, cout, t, h, w, ph, pw, lds_budget, {7, 8, 4, 2}, pl)) return false;
+    if (batch_hint > 0 && pl.grid(batch_hint) < 512) {
+        const Plan base = pl;
+        const std::vector<std::vector<int>> tries = {{2, 4, 7, 8}, {4}, {2}};
+        for (const auto& opts : tries) {
+            Plan alt;
+            if (!plan_dgrad(cin, cout, t, h, w, ph, pw, lds_budget, opts, alt)) continue;
+            if (alt.grid(batch_hint) > pl.grid(batch_hint) && (double)alt.rows_total <= (double)base.rows_total * 1.05) pl = alt;
+        }
+    }
+    return true;
+}
+
 // the forward program of `layer` as plan.plan_network + engine.EmbedEngine choose it for operand precision `prec`
 bool plan_layer(int layer, int frames, int height, int width, int prec, int batch_hint, Plan& pl) {
     const bool x3 = (prec == VD_PREC_BF16X3 || prec == VD_PREC_F16X3);
@@ -509,7 +702,7 @@ std::vector<uint8_t> export_program(const Plan& pl, int persist) {
                               (pl.NTW == 2 && mt_max < pl.MW * pl.MTW) ? mt_max : 0};
     memcpy(&h[1], head, sizeof(head));
     const int64_t sizes[7] = {(int64_t)desc.size(), (int64_t)tables.size(), (int64_t)boxes.size(), (int64_t)gt.size(),
-                              (int64_t)pl.widx.size(), 0, persist};
+                              (int64_t)pl.widx.size(), (int64_t)pl.col_off.size(), persist};
     memcpy(&h[28], sizes, sizeof(sizes));
     std::vector<uint8_t> blob(sizeof(h));
     memcpy(blob.data(), h, sizeof(h));
@@ -518,7 +711,7 @@ std::vector<uint8_t> export_program(const Plan& pl, int persist) {
         blob.resize(o + v.size() * sizeof(int32_t));
         if (!v.empty()) memcpy(blob.data() + o, v.data(), v.size() * sizeof(int32_t));
     };
-    append(desc); append(tables); append(boxes); append(gt); append(pl.widx);
+    append(desc); append(tables); append(boxes); append(gt); append(pl.widx); append(pl.col_off);
     return blob;
 }
 
@@ -529,6 +722,21 @@ extern "C" int vd_program_build(int layer, int frames, int height, int width, in
     if (frames < 2 || height < 16 || width < 16) return -2;
     Plan pl;
     if (!plan_layer(layer, frames, height, width, prec, batch_hint, pl)) return -3;
+    const std::vector<uint8_t> b = export_program(pl, 4);
+    void* out = malloc(b.size());
+    if (out == nullptr) return -5;
+    memcpy(out, b.data(), b.size());
+    *blob = out;
+    *nbytes = (int64_t)b.size();
+    return 0;
+}
+
+extern "C" int vd_program_build_dgrad(int layer, int parity_class, int frames, int height, int width, int batch_hint, void** blob,
+                                      int64_t* nbytes) {
+    if (blob == nullptr || nbytes == nullptr || layer < 0 || layer > 2) return -1;
+    if (frames < 2 || height < 16 || width < 16) return -2;
+    Plan pl;
+    if (!plan_dgrad_layer(layer, parity_class, frames, height, width, batch_hint, pl)) return -3;
     const std::vector<uint8_t> b = export_program(pl, 4);
     void* out = malloc(b.size());
     if (out == nullptr) return -5;

@@ -89,11 +89,17 @@ extern "C" int vd_program_pack_weights(VdProgram* g, const float* w, void* strea
 
 extern "C" int vd_program_run(VdProgram* g, const void* src, int64_t src_plane_slots, const float* bias, void* dst,
                               int64_t dst_plane_stride, uint8_t* argmax, const int64_t* clip_index, int nclips, void* stream) {
+    return vd_program_run_scaled(g, src, src_plane_slots, bias, dst, dst_plane_stride, argmax, clip_index, nclips, nullptr, stream);
+}
+
+extern "C" int vd_program_run_scaled(VdProgram* g, const void* src, int64_t src_plane_slots, const float* bias, void* dst,
+                                     int64_t dst_plane_stride, uint8_t* argmax, const int64_t* clip_index, int nclips,
+                                     const float* out_scale, void* stream) {
     if (g == nullptr || src == nullptr || dst == nullptr || nclips < 0) return -1;
     VdConvParams p = g->p;         // per-call copy: the handle may be used from several streams
     p.src = src; p.src_plane_stride4 = src_plane_slots * 4;
     p.bias = bias; p.dst = dst; p.dst_plane_stride = dst_plane_stride;
-    p.argmax = argmax; p.clip_index = clip_index; p.nclips = nclips;
+    p.argmax = argmax; p.clip_index = clip_index; p.nclips = nclips; p.out_scale = out_scale;
     // first-layer programs in the single-pass formats and the 2 x 2-wave layout run the kernel that keeps the layer's B
     // fragments in registers across its box walk (bitwise the same results; same rule as engine._DevPlan)
     const bool breg = p.prec < 2 && p.epi == VD_EPI_POOL_CL && p.pool_t == 1 && p.CC == 1 && p.ncl == 1 && p.NTW <= 1 &&
@@ -126,13 +132,18 @@ extern "C" void vd_program_free(VdProgram* g) {
 // ---- ConvNet3D.embed as ONE handle: planner (csrc/planner.cpp) + programs + launches -----------------------------------
 struct VdEmbed {
     VdProgram* prog[3];
-    int frames, height, width, prec, planes;
+    VdProgram* bwd[3][4];            // input-gradient programs per level (level 0: one merged program)
+    int nbwd[3];
+    int frames, height, width, prec, planes, prec_bwd, planes_bwd;
+    int dims[3][12];                 // cin, cout, t, h, w, T, OH, OW, To, Ho, Wo, pool_t per level (plan.NetGeometry.layer_dims)
     int64_t slots0_per_clip, slots1_per_clip, slots2_per_clip, nfeat;
     const float* bias[3];
     bool has_weights;
 };
 
-extern "C" int vd_embed_create(int frames, int height, int width, int prec, int batch_hint, VdEmbed** out) {
+static int conv_out(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
+
+extern "C" int vd_embed_create_ex(int frames, int height, int width, int prec, int prec_bwd, int batch_hint, VdEmbed** out) {
     if (out == nullptr) return -1;
     VdEmbed* e = static_cast<VdEmbed*>(calloc(1, sizeof(VdEmbed)));
     if (e == nullptr) return -5;
@@ -145,6 +156,32 @@ extern "C" int vd_embed_create(int frames, int height, int width, int prec, int 
     }
     e->frames = frames; e->height = height; e->width = width; e->prec = prec;
     e->planes = (prec == VD_PREC_BF16X3 || prec == VD_PREC_F16X3) ? 2 : 1;
+    e->prec_bwd = prec_bwd;
+    e->planes_bwd = (prec_bwd == VD_PREC_BF16X3 || prec_bwd == VD_PREC_F16X3) ? 2 : 1;
+    {
+        const int widths[3] = {64, 128, 128}, pools[3] = {1, 2, 2};
+        int cin = 3, t = frames, h = height, w = width;
+        for (int l = 0; l < 3; ++l) {
+            const int T = conv_out(t, 3, 1, 1), OH = conv_out(h, 7, 2, 3), OW = conv_out(w, 7, 2, 3);
+            const int d[12] = {cin, widths[l], t, h, w, T, OH, OW, T / pools[l], OH / 2, OW / 2, pools[l]};
+            memcpy(e->dims[l], d, sizeof(d));
+            cin = widths[l]; t = T / pools[l]; h = OH / 2; w = OW / 2;
+        }
+    }
+    if (prec_bwd >= 0) {
+        if (prec_bwd > 3) { vd_embed_free(e); return -1; }
+        for (int l = 0; l < 3; ++l) {
+            const int ncls = (l == 0) ? 1 : (e->dims[l][3] < 2 ? 1 : 2) * (e->dims[l][4] < 2 ? 1 : 2);
+            for (int c = 0; c < ncls; ++c) {
+                void* blob = nullptr;
+                int64_t n = 0;
+                int rc = vd_program_build_dgrad(l, c, frames, height, width, batch_hint, &blob, &n);
+                if (rc == 0) { rc = vd_program_load(blob, n, prec_bwd, &e->bwd[l][c]); vd_blob_free(blob); }
+                if (rc != 0) { vd_embed_free(e); return rc; }
+                e->nbwd[l] = c + 1;
+            }
+        }
+    }
     const int rowp = ((width + 8 + 7) / 8) * 8;
     e->slots0_per_clip = (int64_t)frames * 3 * height * (rowp / 8);
     e->slots1_per_clip = e->prog[0]->p.out_clip_stride;
@@ -154,6 +191,10 @@ extern "C" int vd_embed_create(int frames, int height, int width, int prec, int 
     return 0;
 }
 
+extern "C" int vd_embed_create(int frames, int height, int width, int prec, int batch_hint, VdEmbed** out) {
+    return vd_embed_create_ex(frames, height, width, prec, -1, batch_hint, out);
+}
+
 extern "C" int64_t vd_embed_num_features(const VdEmbed* e) { return e ? e->nfeat : -1; }
 
 extern "C" int64_t vd_embed_workspace_bytes(const VdEmbed* e, int64_t nclips) {
@@ -161,12 +202,32 @@ extern "C" int64_t vd_embed_workspace_bytes(const VdEmbed* e, int64_t nclips) {
     return (int64_t)e->planes * nclips * (e->slots0_per_clip + e->slots1_per_clip + e->slots2_per_clip) * 16 + 3 * 256;
 }
 
+extern "C" int64_t vd_embed_argmax_bytes(const VdEmbed* e, int64_t nclips) {
+    if (e == nullptr || nclips < 0) return -1;
+    return nclips * (e->slots1_per_clip * 8 + e->slots2_per_clip * 8 + e->nfeat) + 3 * 256;
+}
+
+static int64_t dy_slots(const VdEmbed* e, int l, int64_t nclips) {
+    const int* d = e->dims[l];
+    return nclips * (d[1] / 8) * (int64_t)d[5] * d[6] * d[7];
+}
+
+extern "C" int64_t vd_embed_backward_workspace_bytes(const VdEmbed* e, int64_t nclips) {
+    if (e == nullptr || nclips < 0 || e->prec_bwd < 0) return -1;
+    int64_t dy = 0;
+    for (int l = 0; l < 3; ++l) dy = dy > dy_slots(e, l, nclips) ? dy : dy_slots(e, l, nclips);
+    int64_t dx = 0;
+    for (int l = 1; l < 3; ++l) dx += nclips * (int64_t)e->dims[l][2] * e->dims[l][3] * e->dims[l][4] * e->dims[l][0] * 4;
+    return (int64_t)e->planes_bwd * dy * 16 + dx + 4 * 256;
+}
+
 extern "C" int vd_embed_set_weights(VdEmbed* e, const float* w0, const float* b0, const float* w1, const float* b1,
                                     const float* w2, const float* b2, void* stream) {
     if (e == nullptr || !w0 || !b0 || !w1 || !b1 || !w2 || !b2) return -1;
     const float* w[3] = {w0, w1, w2};
     for (int l = 0; l < 3; ++l) {
-        const int rc = vd_program_pack_weights(e->prog[l], w[l], stream);
+        int rc = vd_program_pack_weights(e->prog[l], w[l], stream);
+        for (int c = 0; rc == 0 && c < e->nbwd[l]; ++c) rc = vd_program_pack_weights(e->bwd[l][c], w[l], stream);
         if (rc != 0) return rc;
     }
     e->bias[0] = b0; e->bias[1] = b1; e->bias[2] = b2;       // read by the launches: the caller keeps them alive
@@ -174,27 +235,101 @@ extern "C" int vd_embed_set_weights(VdEmbed* e, const float* w0, const float* b0
     return 0;
 }
 
-extern "C" int vd_embed_forward(VdEmbed* e, const float* clips, const int64_t* clip_index, int64_t nclips, void* workspace,
-                                int64_t workspace_bytes, float* features, void* stream) {
+static char* align256(char* p) { return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~(uintptr_t)255); }
+
+static int embed_forward_impl(VdEmbed* e, const float* clips, const int64_t* clip_index, int64_t nclips, void* workspace,
+                              int64_t workspace_bytes, float* features, uint8_t* argmax, void* stream) {
     if (e == nullptr || clips == nullptr || features == nullptr || nclips < 0 || nclips > 0x7fffffff) return -1;
     if (!e->has_weights) return -6;
     if (nclips == 0) return 0;
     if (workspace == nullptr || workspace_bytes < vd_embed_workspace_bytes(e, nclips)) return -7;
-    auto align = [](char* p) { return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~(uintptr_t)255); };
     const int64_t n0 = nclips * e->slots0_per_clip, n1 = nclips * e->slots1_per_clip, n2 = nclips * e->slots2_per_clip;
-    char* rows = align(static_cast<char*>(workspace));
-    char* act1 = align(rows + (int64_t)e->planes * n0 * 16);
-    char* act2 = align(act1 + (int64_t)e->planes * n1 * 16);
+    char* rows = align256(static_cast<char*>(workspace));
+    char* act1 = align256(rows + (int64_t)e->planes * n0 * 16);
+    char* act2 = align256(act1 + (int64_t)e->planes * n1 * 16);
+    uint8_t *am0 = nullptr, *am1 = nullptr, *am2 = nullptr;
+    if (argmax != nullptr) {
+        am0 = reinterpret_cast<uint8_t*>(align256(reinterpret_cast<char*>(argmax)));
+        am1 = reinterpret_cast<uint8_t*>(align256(reinterpret_cast<char*>(am0) + n1 * 8));
+        am2 = reinterpret_cast<uint8_t*>(align256(reinterpret_cast<char*>(am1) + n2 * 8));
+    }
     int rc = vd_pix2rows(clips, clip_index, nclips, e->frames, e->height, e->width, rows, e->planes == 2 ? rows + n0 * 16 : nullptr,
                          e->prec, stream);
-    if (rc == 0) rc = vd_program_run(e->prog[0], rows, n0, e->bias[0], act1, n1, nullptr, nullptr, (int)nclips, stream);
-    if (rc == 0) rc = vd_program_run(e->prog[1], act1, n1, e->bias[1], act2, n2, nullptr, nullptr, (int)nclips, stream);
-    if (rc == 0) rc = vd_program_run(e->prog[2], act2, n2, e->bias[2], features, 0, nullptr, nullptr, (int)nclips, stream);
+    if (rc == 0) rc = vd_program_run(e->prog[0], rows, n0, e->bias[0], act1, n1, am0, nullptr, (int)nclips, stream);
+    if (rc == 0) rc = vd_program_run(e->prog[1], act1, n1, e->bias[1], act2, n2, am1, nullptr, (int)nclips, stream);
+    if (rc == 0) rc = vd_program_run(e->prog[2], act2, n2, e->bias[2], features, 0, am2, nullptr, (int)nclips, stream);
     return rc;
+}
+
+extern "C" int vd_embed_forward(VdEmbed* e, const float* clips, const int64_t* clip_index, int64_t nclips, void* workspace,
+                                int64_t workspace_bytes, float* features, void* stream) {
+    return embed_forward_impl(e, clips, clip_index, nclips, workspace, workspace_bytes, features, nullptr, stream);
+}
+
+extern "C" int vd_embed_forward_keep(VdEmbed* e, const float* clips, const int64_t* clip_index, int64_t nclips, void* workspace,
+                                     int64_t workspace_bytes, float* features, uint8_t* argmax, void* stream) {
+    if (argmax == nullptr) return -1;
+    return embed_forward_impl(e, clips, clip_index, nclips, workspace, workspace_bytes, features, argmax, stream);
+}
+
+// d <g_features, embed(clips)> / d clips for a vd_embed_forward_keep call (same weights): per level, last to first,
+// un-pool + ReLU backward into dense dy slots (power-of-two scaled for the fp16 formats), then the level's dgrad programs
+extern "C" int vd_embed_backward(VdEmbed* e, const float* g_features, const uint8_t* argmax, int64_t nclips, void* workspace,
+                                 int64_t workspace_bytes, float* g_clips, void* stream) {
+    if (e == nullptr || g_features == nullptr || argmax == nullptr || g_clips == nullptr || nclips < 0 || nclips > 0x7fffffff) return -1;
+    if (e->prec_bwd < 0) return -8;
+    if (!e->has_weights) return -6;
+    if (nclips == 0) return 0;
+    if (workspace == nullptr || workspace_bytes < vd_embed_backward_workspace_bytes(e, nclips)) return -7;
+    const int64_t n1 = nclips * e->slots1_per_clip, n2 = nclips * e->slots2_per_clip;
+    const uint8_t* am[3];
+    am[0] = reinterpret_cast<const uint8_t*>(align256(const_cast<char*>(reinterpret_cast<const char*>(argmax))));
+    am[1] = reinterpret_cast<const uint8_t*>(align256(const_cast<char*>(reinterpret_cast<const char*>(am[0])) + n1 * 8));
+    am[2] = reinterpret_cast<const uint8_t*>(align256(const_cast<char*>(reinterpret_cast<const char*>(am[1])) + n2 * 8));
+    int64_t dymax = 0;
+    for (int l = 0; l < 3; ++l) dymax = dymax > dy_slots(e, l, nclips) ? dymax : dy_slots(e, l, nclips);
+    char* dy = align256(static_cast<char*>(workspace));
+    char* dxbuf[3] = {nullptr, nullptr, nullptr};
+    char* cur = align256(dy + (int64_t)e->planes_bwd * dymax * 16);
+    for (int l = 1; l < 3; ++l) {
+        dxbuf[l] = cur;
+        cur = align256(cur + nclips * (int64_t)e->dims[l][2] * e->dims[l][3] * e->dims[l][4] * e->dims[l][0] * 4);
+    }
+    float* scale = reinterpret_cast<float*>(cur);
+    const bool scaled = (e->prec_bwd == VD_PREC_F16 || e->prec_bwd == VD_PREC_F16X3);
+    const float* grad = g_features;
+    int64_t grad_n = nclips * e->nfeat;
+    int layout = 0;
+    for (int l = 2; l >= 0; --l) {
+        const int* d = e->dims[l];
+        const int64_t nslots = dy_slots(e, l, nclips);
+        float* sc = nullptr;
+        int rc = 0;
+        if (scaled) {
+            sc = scale + 4 * l;
+            rc = vd_absmax_scale(grad, grad_n, 1024.0f, sc, stream);
+            if (rc) return rc;
+        }
+        rc = vd_unpool_relu_bwd(grad, am[l], nclips, d[1], d[8], d[9], d[10], d[11], d[5], d[6], d[7], layout, dy,
+                                e->planes_bwd == 2 ? dy + nslots * 16 : nullptr, e->prec_bwd, sc, stream);
+        if (rc) return rc;
+        float* outp = (l == 0) ? g_clips : reinterpret_cast<float*>(dxbuf[l]);
+        for (int c = 0; c < e->nbwd[l]; ++c) {
+            rc = vd_program_run_scaled(e->bwd[l][c], dy, nslots, nullptr, outp, 0, nullptr, nullptr, (int)nclips, sc ? sc + 1 : nullptr, stream);
+            if (rc) return rc;
+        }
+        grad = outp;
+        grad_n = nclips * (int64_t)d[2] * d[3] * d[4] * d[0];
+        layout = 1;
+    }
+    return 0;
 }
 
 extern "C" void vd_embed_free(VdEmbed* e) {
     if (e == nullptr) return;
-    for (int l = 0; l < 3; ++l) vd_program_free(e->prog[l]);
+    for (int l = 0; l < 3; ++l) {
+        vd_program_free(e->prog[l]);
+        for (int c = 0; c < 4; ++c) vd_program_free(e->bwd[l][c]);
+    }
     free(e);
 }
