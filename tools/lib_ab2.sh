@@ -7,3 +7,7 @@ for i in 1 2 3; do
 done
 echo -n "dc old: "; VD_LIB_PATH=$PWD/video_distillation_amd/libvd_hip_old.so run --method dc --classes 51 --ipc 5 --steps 3 --warmup 1
 echo -n "dc new: "; run --method dc --classes 51 --ipc 5 --steps 3 --warmup 1
+echo -n "mtt old: "; VD_LIB_PATH=$PWD/video_distillation_amd/libvd_hip_old.so run --method mtt --classes 400 --frames 8 --size 64 --steps 4 --warmup 2
+echo -n "mtt new: "; run --method mtt --classes 400 --frames 8 --size 64 --steps 4 --warmup 2
+echo -n "dc old: "; VD_LIB_PATH=$PWD/video_distillation_amd/libvd_hip_old.so run --method dc --classes 51 --ipc 5 --steps 3 --warmup 1
+echo -n "dc new: "; run --method dc --classes 51 --ipc 5 --steps 3 --warmup 1

@@ -411,12 +411,18 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
                 }
             }
         } else {
-            int tap_cur = lds_tap[half];
-            uint4 A0h[H0], A0l[H0], A1h[H1], A1l[H1];
+            // hi+lo formats: one register set of A fragments (hi and lo plane); the pair a tile's three MFMAs have just
+            // consumed is refilled at once with the next K step's, so a read has the other tiles' MFMAs (almost a whole step)
+            // to return -- the same idea as in the single-pass loop, same K order per output
+            int tap_next = lds_tap[2 * ((1 < S) ? 1 : 0) + half];
+            uint4 Ah[MTW], Al[MTW];
+            {
+                const int tap0 = lds_tap[half];
 #pragma unroll
-            for (int i = 0; i < H0; ++i) {
-                A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_cur);
-                A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_cur);
+                for (int i = 0; i < MTW; ++i) {
+                    Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap0);
+                    Al[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap0);
+                }
             }
             for (int s = 0; s < S; s += DB + 1) {
 #pragma unroll
@@ -426,41 +432,24 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
                     uint4 bh[NTW], bl[NTW];
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) { bh[j] = bqh[u][j]; bl[j] = bql[u][j]; }
-                    const int sn = (s + u + 1 < S) ? s + u + 1 : s + u;
-                    const int tap_next = lds_tap[2 * sn + half];
-#pragma unroll
-                    for (int i = 0; i < H1; ++i) {
-                        A1h[i] = *reinterpret_cast<const uint4*>(smem + a_off[H0 + i] + tap_cur);
-                        A1l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[H0 + i] + tap_cur);
-                    }
+                    const int sn2 = (s + u + 2 < S) ? s + u + 2 : S - 1;
+                    const int tap_next2 = lds_tap[2 * sn2 + half];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < H0; ++i)
+                    for (int i = 0; i < MTW; ++i) {
+                        if (NTW == 2 && BAL == 0 && i == MTW - 1 && short_row) continue;
 #pragma unroll
                         for (int j = 0; j < NTW; ++j) {
-                            acc[j * MTW + i] = mfma16<PREC>(A0l[i], bh[j], acc[j * MTW + i]);
-                            acc[j * MTW + i] = mfma16<PREC>(A0h[i], bl[j], acc[j * MTW + i]);
-                            acc[j * MTW + i] = mfma16<PREC>(A0h[i], bh[j], acc[j * MTW + i]);
+                            acc[j * MTW + i] = mfma16<PREC>(Al[i], bh[j], acc[j * MTW + i]);
+                            acc[j * MTW + i] = mfma16<PREC>(Ah[i], bl[j], acc[j * MTW + i]);
+                            acc[j * MTW + i] = mfma16<PREC>(Ah[i], bh[j], acc[j * MTW + i]);
                         }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < H0; ++i) {
-                        A0h[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
-                        A0l[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_next);
+                        __builtin_amdgcn_sched_barrier(0);
+                        Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
+                        Al[i] = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tap_next);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < H1; ++i) {
-                        if (NTW == 2 && BAL == 0 && i == H1 - 1 && short_row) continue;
-#pragma unroll
-                        for (int j = 0; j < NTW; ++j) {
-                            acc[j * MTW + H0 + i] = mfma16<PREC>(A1l[i], bh[j], acc[j * MTW + H0 + i]);
-                            acc[j * MTW + H0 + i] = mfma16<PREC>(A1h[i], bl[j], acc[j * MTW + H0 + i]);
-                            acc[j * MTW + H0 + i] = mfma16<PREC>(A1h[i], bh[j], acc[j * MTW + H0 + i]);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    tap_cur = tap_next;
+                    tap_next = tap_next2;
                 }
             }
         }
