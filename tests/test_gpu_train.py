@@ -311,6 +311,39 @@ def test_gm_trainer_hip_matches_oracle_trainer():
     assert torch.isfinite(got_s).all() and _rel(got_s, want_s.double()) < 5e-2
 
 
+def test_gm_trainer_class_lanes_match_serial(monkeypatch):
+    """GMTrainer's class lanes (class k on stream k % lanes with its own engine slot) against the one-stream path on the
+    same inputs: the per-class terms are independent, so loss and pixel update agree to the atomics' summation-order
+    noise.  Dropout off: the two paths draw their masks in a different order."""
+    from video_distillation_amd import distill, plan
+    C, ipc = 6, 2
+    geo = plan.NetGeometry(8, 64, 64)
+    g = torch.Generator().manual_seed(99)
+    clips = torch.randn(C * 4, 8, 3, 64, 64, generator=g).to("cuda:0")
+    syn0 = clips[[i for c in range(C) for i in (4 * c, 4 * c + 1)]].clone()
+    init = lambda it: R.init_params(900 + it, 3, C)       # noqa: E731
+
+    def run(lanes):
+        monkeypatch.setenv("VD_GM_LANES", str(lanes))
+        pool = distill.RealPool(clips, [4] * C, [4 * c for c in range(C)])
+        tr = distill.GMTrainer(distill.HipGMOps("cuda:0", "ours"), pool, geo, C, ipc, batch_real=3, lr_img=1e-3, image_syn=syn0.clone(),
+                               outer_loop=1, dropout_p=0.0, net_init=init)
+        out = []
+        for rep in range(3):                      # fresh trainer state each time: the same first step, three times
+            tr.image_syn.copy_(syn0); tr.buf.zero_(); tr.steps_done = 0
+            loss = float(tr.step(0))
+            out.append((loss, (tr.image_syn - syn0).cpu().double()))
+        return out
+    serial, laned = run(1), run(3)
+    noise = max(_rel(u, serial[0][1]) for _, u in serial[1:])
+    err = max(_rel(u, serial[0][1]) for _, u in laned)
+    print("GM lanes: loss serial %s lanes %s; update rel-l2 lanes-vs-serial %.2e (serial run-to-run %.2e)"
+          % (["%.6f" % l for l, _ in serial], ["%.6f" % l for l, _ in laned], err, noise))
+    for l, _ in laned:
+        assert abs(l - serial[0][0]) / serial[0][0] < 1e-4
+    assert err < max(1e-3, 5 * noise)
+
+
 @pytest.mark.parametrize("B,K,use_mask", [(1, 4, False), (3, 5, True)])
 def test_hessian_vector_product_matches_fp64(B, K, use_mask):
     """param_adjoint=True: d <v, dCE/dparams> / d params (H v, MTT's unrolled inner loop) vs fp64."""

@@ -548,8 +548,15 @@ class HipGMOps:
                 p.copy_(w)
         return net.train()
 
-    def param_grads(self, net, x, labels, create_graph: bool):
-        return net.param_grads(x, labels, create_graph=create_graph)[1]
+    def param_grads(self, net, x, labels, create_graph: bool, slot: int = 0):
+        return net.param_grads(x, labels, create_graph=create_graph, slot=slot)[1]
+
+    def lane_streams(self, n: int):
+        """Streams of the class lanes (GMTrainer): class terms are independent chains of ~150 small launches each, so several
+        run concurrently, each on its own stream with its own engine slot."""
+        if getattr(self, "_lanes", None) is None or len(self._lanes) != n:
+            self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(n)]
+        return self._lanes
 
     def param_grads_async(self, net, x, labels):
         """First-order parameter gradients of a REAL batch on a side stream: the real batch of the next class
@@ -639,29 +646,34 @@ class GMTrainer:
             idx = sample_real_indices(it * self.outer_loop + ol, self.pool.counts, self.pool.offsets, self.batch_real, self.classes)
             idx_t = torch.as_tensor(idx, device=dev).reshape(len(self.classes), -1)
             g_img = torch.zeros_like(self.image_syn)
-            overlap = hasattr(ops, "param_grads_async") and os.environ.get("VD_GM_OVERLAP", "1") == "1"
-
-            def real_side(k):
-                c = self.classes[k]
-                real = self.pool.clips[idx_t[k]]
-                lab_r = torch.full((real.shape[0],), c, dtype=torch.int64, device=dev)
-                if overlap:
-                    return ops.param_grads_async(net, real, lab_r)
-                return [t.detach() for t in ops.param_grads(net, real, lab_r, False)], None
-            pending = real_side(0) if self.classes else None
-            for k, c in enumerate(self.classes):
-                gw_real, ready = pending
-                if k + 1 < len(self.classes):
-                    pending = real_side(k + 1)          # runs under this class's synthetic-clip passes
-                if ready is not None:
-                    torch.cuda.current_stream(dev).wait_event(ready)
-                lab_s = torch.full((self.ipc,), c, dtype=torch.int64, device=dev)
-                syn = self.image_syn[k * self.ipc:(k + 1) * self.ipc].detach().clone().requires_grad_(True)
-                gw_syn = ops.param_grads(net, syn, lab_s, True)
-                loss = ops.match_loss(gw_syn, gw_real)
-                (g,) = torch.autograd.grad(loss, syn)
-                g_img[k * self.ipc:(k + 1) * self.ipc] = g
-                total = total + loss.detach()
+            nlanes = int(os.environ.get("VD_GM_LANES", "6")) if hasattr(ops, "lane_streams") else 1
+            if nlanes > 1 and len(self.classes) > 1:
+                # class lanes: class k runs on stream k % nlanes with engine slot k % nlanes; the chains only meet in g_img
+                # (disjoint rows) and in the loss sum
+                lanes = ops.lane_streams(nlanes)
+                main = torch.cuda.current_stream(dev)
+                totals = [torch.zeros((), device=dev) for _ in lanes]
+                for st in lanes:
+                    st.wait_stream(main)
+                for k, c in enumerate(self.classes):
+                    lane = k % nlanes
+                    with torch.cuda.stream(lanes[lane]):
+                        real = self.pool.clips[idx_t[k]]
+                        lab_r = torch.full((real.shape[0],), c, dtype=torch.int64, device=dev)
+                        gw_real = [t.detach() for t in ops.param_grads(net, real, lab_r, False, slot=lane)]
+                        lab_s = torch.full((self.ipc,), c, dtype=torch.int64, device=dev)
+                        syn = self.image_syn[k * self.ipc:(k + 1) * self.ipc].detach().clone().requires_grad_(True)
+                        gw_syn = ops.param_grads(net, syn, lab_s, True, slot=lane)
+                        loss = ops.match_loss(gw_syn, gw_real)
+                        (g,) = torch.autograd.grad(loss, syn)
+                        g_img[k * self.ipc:(k + 1) * self.ipc] = g
+                        totals[lane] = totals[lane] + loss.detach()
+                for st, tl in zip(lanes, totals):
+                    main.wait_stream(st)
+                    tl.record_stream(main)
+                total = total + torch.stack(totals).sum()
+            else:
+                total = total + self._class_terms_serial(ops, net, idx_t, g_img, dev)
             ops.sgd(self.image_syn, self.buf, g_img, self.lr_img, self.momentum, first=(self.steps_done == 0))
             self.steps_done += 1
             if ol == self.outer_loop - 1:
@@ -670,6 +682,35 @@ class GMTrainer:
             lab_all = torch.arange(self.num_classes, device=dev).repeat_interleave(self.ipc)
             for _ in range(self.inner_loop):
                 ops.train_epoch(net, syn_all, lab_all, opt_net, self.batch_train)
+        return total
+
+    def _class_terms_serial(self, ops, net, idx_t, g_img, dev):
+        """All class terms on the caller's stream; with a HIP backend the real batch of class k+1 is prefetched on a side
+        stream under the synthetic-clip passes of class k."""
+        total = torch.zeros((), device=dev)
+        overlap = hasattr(ops, "param_grads_async") and os.environ.get("VD_GM_OVERLAP", "1") == "1"
+
+        def real_side(k):
+            c = self.classes[k]
+            real = self.pool.clips[idx_t[k]]
+            lab_r = torch.full((real.shape[0],), c, dtype=torch.int64, device=dev)
+            if overlap:
+                return ops.param_grads_async(net, real, lab_r)
+            return [t.detach() for t in ops.param_grads(net, real, lab_r, False)], None
+        pending = real_side(0) if self.classes else None
+        for k, c in enumerate(self.classes):
+            gw_real, ready = pending
+            if k + 1 < len(self.classes):
+                pending = real_side(k + 1)          # runs under this class's synthetic-clip passes
+            if ready is not None:
+                torch.cuda.current_stream(dev).wait_event(ready)
+            lab_s = torch.full((self.ipc,), c, dtype=torch.int64, device=dev)
+            syn = self.image_syn[k * self.ipc:(k + 1) * self.ipc].detach().clone().requires_grad_(True)
+            gw_syn = ops.param_grads(net, syn, lab_s, True)
+            loss = ops.match_loss(gw_syn, gw_real)
+            (g,) = torch.autograd.grad(loss, syn)
+            g_img[k * self.ipc:(k + 1) * self.ipc] = g
+            total = total + loss.detach()
         return total
 
     def global_loss(self, local_loss: torch.Tensor) -> torch.Tensor:

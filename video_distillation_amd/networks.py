@@ -129,8 +129,8 @@ class _ParamGradFunction(torch.autograd.Function):
     """(loss, logits, dCE/dparams...) = f(x); backward = HIP second-order pass (train.GradMatchEngine.vjp)."""
 
     @staticmethod
-    def forward(ctx, x, labels, mask, net):
-        te = net._gm_engine(x)
+    def forward(ctx, x, labels, mask, net, slot=0):
+        te = net._gm_engine(x, slot)
         loss, logits, g, state = te.param_grads(x, labels, list(net.parameters()), mask)
         ctx.te, ctx.state, ctx.net = te, state, net
         ctx.wkey = tuple((p.data_ptr(), p._version) for p in net.parameters())
@@ -144,7 +144,7 @@ class _ParamGradFunction(torch.autograd.Function):
         net = ctx.net
         if tuple((p.data_ptr(), p._version) for p in net.parameters()) != ctx.wkey:
             raise RuntimeError("ConvNet3D parameters changed between param_grads() and backward()")
-        return ctx.te.vjp(ctx.state, v, list(net.parameters())), None, None, None
+        return ctx.te.vjp(ctx.state, v, list(net.parameters())), None, None, None, None
 
 
 def _zeros_like_or(t, ref):
@@ -400,11 +400,13 @@ class ConvNet3D(nn.Module):
         return (type(criterion) is nn.CrossEntropyLoss and criterion.weight is None and criterion.reduction == "mean"
                 and getattr(criterion, "label_smoothing", 0.0) == 0.0)
 
-    def _train_engine(self, x):
+    def _train_engine(self, x, slot: int = 0):
+        """``slot``: engines own workspaces and packed operands, so calls that run concurrently on different streams (the
+        class lanes of distill.GMTrainer) each use their own instance."""
         from . import train
         hint = _batch_hint(x.shape[0])
         key = ("train", x.shape[1], x.shape[3], x.shape[4], self.logit.weight.shape[0], hint, _PRECISION["train"], _PRECISION["train_bwd"],
-               x.device.index if x.device.index is not None else torch.cuda.current_device())
+               x.device.index if x.device.index is not None else torch.cuda.current_device(), slot)
         te = _ENGINES.get(key)
         if te is None:
             te = train.TrainEngine(P.NetGeometry(x.shape[1], x.shape[3], x.shape[4]), self.logit.weight.shape[0],
@@ -413,11 +415,11 @@ class ConvNet3D(nn.Module):
             _ENGINES[key] = te
         return te
 
-    def _gm_engine(self, x):
+    def _gm_engine(self, x, slot: int = 0):
         from . import train
         hint = _batch_hint(x.shape[0])
         key = ("gm", x.shape[1], x.shape[3], x.shape[4], self.logit.weight.shape[0], hint, _PRECISION["match"],
-               x.device.index if x.device.index is not None else torch.cuda.current_device())
+               x.device.index if x.device.index is not None else torch.cuda.current_device(), slot)
         te = _ENGINES.get(key)
         if te is None:
             te = train.GradMatchEngine(P.NetGeometry(x.shape[1], x.shape[3], x.shape[4]), self.logit.weight.shape[0],
@@ -431,7 +433,7 @@ class ConvNet3D(nn.Module):
             return torch.bernoulli(torch.full((x.shape[0], te.C, te.Tp), keep, device=x.device)) / keep
         return None
 
-    def param_grads(self, x, labels, create_graph: bool = False, mask=None):
+    def param_grads(self, x, labels, create_graph: bool = False, mask=None, slot: int = 0):
         """``torch.autograd.grad(CrossEntropyLoss()(net(x), labels), net.parameters(), create_graph=...)``
         on the HIP path (gradient matching: upstream DC loop).  Returns
         (loss, [8 gradients in parameters() order]).  With ``create_graph`` the gradients are
@@ -441,12 +443,12 @@ class ConvNet3D(nn.Module):
         if not (self._hip_ok and x.is_cuda):
             raise RuntimeError("ConvNet3D.param_grads: HIP tensors and the ConvNet3D of get_network only (no CPU path)")
         if create_graph:
-            te = self._gm_engine(x)
+            te = self._gm_engine(x, slot)
             if mask is None:
                 mask = self._dropout_mask(x, te)
-            out = _ParamGradFunction.apply(x, labels, mask, self)
+            out = _ParamGradFunction.apply(x, labels, mask, self, slot)
             return out[0], list(out[2:])
-        te = self._train_engine(x)
+        te = self._train_engine(x, slot)
         if mask is None:
             mask = self._dropout_mask(x, te)
         loss, _, g = te.loss_and_grads(x, labels, list(self.parameters()), mask)
