@@ -293,6 +293,14 @@ int vd_mfma_peak(int blocks, int iters, int shape, float* out, void* stream);
 int vd_sgd_momentum_wd(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, float wd, int first,
                        void* stream);
 
+/* Decoded frames -> clips, the device half of the dataset preload (replaces the per-frame host transform
+ * `ToTensor()` + `Normalize(mean, std)` of utils.py:171-173 and the per-step host->device copy of get_images,
+ * distill_baseline.py:84-90): src (nframes, H, W, 3) uint8 -> dst (nframes, 3, H, W) fp32,
+ * dst = (src / 255 - mean[c]) / std[c], each operation correctly rounded (bit-equal to the host transform).
+ * mean3 / std3 are HOST pointers to 3 floats; std must be non-zero.  HBM-bound: 15 bytes per pixel. */
+int vd_frames_normalize(const void* src_u8, float* dst, int64_t nframes, int height, int width, const float* mean3,
+                        const float* std3, void* stream);
+
 /* ---- Serialised tile programs: the torch-free, Python-free way to run a layer ------------------------------
  * A program blob is written offline by the planner (engine.export_program(plan) / tools/export_programs.py) for
  * one layer geometry; it replaces what nn.Conv3d/nn.ReLU/nn.MaxPool3d's constructors hold in the reference

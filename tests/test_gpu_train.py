@@ -455,3 +455,80 @@ def test_atomic_accumulation_run_to_run_spread_is_bounded():
     mspread = max(abs(v / vals[0] - 1) for v in vals)
     print("run-to-run spread: training gradients %.1e, hallucinator gradients %.1e, match_loss %.1e" % (spread, hspread, mspread))
     assert spread < 2e-6 and hspread < 2e-6 and mspread < 2e-6
+
+
+def test_expert_trajectories_match_the_oracle_loop(tmp_path):
+    """checkpoint.train_expert_trajectories (the buffer.py:64-95 producer on the HIP train step) against the same loop
+    written out on the oracle: fresh net, SGD(momentum, weight decay) over shuffled mini-batches, parameters recorded
+    before training and after every epoch, lr x0.1 with a fresh optimiser after epoch E//2+1; then the
+    replay_buffer_{n}.pt round trip."""
+    import argparse
+    from video_distillation_amd import checkpoint, networks, utils
+    C, n, batch, epochs, lr, mom, l2 = 3, 8, 4, 3, 0.02, 0.5, 1e-3
+    g = torch.Generator().manual_seed(515)
+    x = torch.randn(n, 8, 3, 64, 64, generator=g)
+    y = torch.arange(n) % C
+    p0 = R.init_params(808, 3, C)
+
+    def factory():
+        net = networks.ConvNet3D(3, C, 128, 3, 'relu', 'none', 'maxpooling', 8, (64, 64))
+        with torch.no_grad():
+            for p, q in zip(net.parameters(), p0):
+                p.copy_(q)
+        net.dropout.p = 0.0
+        return net
+    shuffle = torch.Generator()               # the loader's own generator: the net constructor draws from the global one
+    loader = torch.utils.data.DataLoader(utils.TensorDataset(x, y), batch_size=batch, shuffle=True, num_workers=0, generator=shuffle)
+    args = argparse.Namespace(device="cuda:0", model="ConvNet3D")
+    shuffle.manual_seed(99)
+    traj = checkpoint.train_expert_trajectories(factory, loader, args, num_experts=1, train_epochs=epochs, lr_teacher=lr,
+                                                mom=mom, l2=l2, decay=True)
+    assert len(traj) == 1 and len(traj[0]) == epochs + 1 and len(traj[0][0]) == 8
+    assert all(t.device.type == "cpu" for t in traj[0][-1])
+    # the oracle loop over the same shuffles
+    shuffle.manual_seed(99)
+    params = [p.detach().clone().requires_grad_(True) for p in p0]
+    bufs, cur_lr, want = [None] * 8, lr, [[p.detach().clone() for p in p0]]
+    for e in range(epochs):
+        for xb, yb in loader:
+            logits = R.convnet3d_logits(R.standardise_batch(xb), params, training=False)
+            grads = torch.autograd.grad(torch.nn.functional.cross_entropy(logits, yb), params)
+            with torch.no_grad():
+                for i, (p, gr) in enumerate(zip(params, grads)):
+                    gr = gr + l2 * p
+                    bufs[i] = gr.clone() if bufs[i] is None else bufs[i] * mom + gr
+                    p -= cur_lr * bufs[i]
+        want.append([p.detach().clone() for p in params])
+        if e == epochs // 2 + 1:
+            cur_lr *= 0.1
+            bufs = [None] * 8
+    for e in range(epochs + 1):
+        step = [_rel(a - s, (b - s).double()) if e else float((a - b).abs().max())
+                for a, b, s in zip(traj[0][e], want[e], p0)]
+        print("expert epoch %d: per-tensor error of the accumulated update" % e, ["%.1e" % v for v in step])
+        assert max(step) < (1e-3 if e else 1e-12)
+    path = checkpoint.save_expert_buffer(str(tmp_path), traj)
+    assert path.endswith("replay_buffer_0.pt")
+    back = checkpoint.load_expert_buffers(str(tmp_path))
+    assert len(back) == 1 and all(torch.equal(a, b) for a, b in zip(back[0][2], traj[0][2]))
+
+
+def test_buffer_driver_writes_reference_format_files(tmp_path):
+    """buffer.run on HBM-resident clips: replay_buffer_{n}.pt files of save_interval experts each, first timestamp = the
+    expert's initial parameters (8 tensors, parameters() order), and the files feed load_expert_buffers."""
+    from video_distillation_amd import buffer, checkpoint
+    C = 3
+    g = torch.Generator().manual_seed(61)
+    clips = torch.randn(7, 8, 3, 64, 64, generator=g).to("cuda:0")
+    labels = torch.arange(7) % C
+    args = buffer.build_parser().parse_args(["--num_experts", "3", "--train_epochs", "2", "--batch_train", "4", "--lr_teacher", "0.01",
+                                             "--save_interval", "2", "--buffer_path", str(tmp_path)])
+    files = buffer.run(args, train=(clips, labels), num_classes=C, log=lambda *_: None)
+    assert [os.path.basename(f) for f in files] == ["replay_buffer_0.pt"]           # the third expert stays pending, as upstream
+    back = checkpoint.load_expert_buffers(str(tmp_path))
+    assert len(back) == 2 and len(back[0]) == 3 and len(back[0][0]) == 8
+    from video_distillation_amd.distill import FULL_SHAPES
+    assert [tuple(t.shape) for t in back[1][2]] == [tuple(s) for s in FULL_SHAPES(C)]
+    moved = [float((a - b).abs().max()) for a, b in zip(back[0][0], back[0][2])]
+    assert min(moved) > 0 and all(np.isfinite(moved))
+    assert not torch.equal(back[0][0][0], back[1][0][0])                             # every expert starts from its own init

@@ -71,6 +71,14 @@ def main():
     t = timeit(lambda: L.vd_pix2rows(hip.ptr(xx), None, ctypes.c_int64(512), 16, 112, 112, hip.ptr(rows), None, 1, hip.stream_ptr(dev)))
     byt = xx.numel() * 4 + rows.numel() * 2
     out["pix2rows_f16"] = {"ms": t * 1e3, "GBps": byt / t / 1e9, "frac_hbm": byt / t / 1e9 / PEAK}
+    # decoded frames -> clips (dataset preload): 256 clips x 16 frames 112x112, 3 B read + 12 B written per pixel
+    from video_distillation_amd import dataset as D
+    del xx, rows
+    u8 = torch.randint(0, 256, (256 * 16, 112, 112, 3), dtype=torch.uint8, device=dev)
+    clips = torch.empty((256 * 16, 3, 112, 112), device=dev)
+    t = timeit(lambda: D.frames_normalize(u8, clips, D.IMAGENET_MEAN, D.IMAGENET_STD))
+    byt = u8.numel() * 5
+    out["frames_normalize"] = {"ms": t * 1e3, "GBps": byt / t / 1e9, "frac_hbm": byt / t / 1e9 / PEAK, "bytes": byt}
     print(json.dumps(out))
 
 

@@ -569,6 +569,132 @@ def g14(networks, utils):
     print("f4: reference-written files in %s; checkpoint.py's files load into the reference's modules" % d)
 
 
+def _install_transform_stubs():
+    """torchvision is absent here; the reference's dataset classes need ``transforms.Compose / ToTensor / Normalize`` and
+    ``transforms.functional.hflip``.  These four are restated from torchvision's documented behaviour (PIL RGB image ->
+    CHW float in [0, 1]; per-channel (x - mean) / std in place; left-right mirror) -- they are the fixture generator's,
+    not the reference's; what G15 pins is the reference's DATASET logic around them (index files, label numbering, frame
+    picks, generator order, flip-before-transform, stacking)."""
+    from PIL import Image
+    tv = sys.modules["torchvision.transforms"]
+
+    class Compose:
+        def __init__(self, ts): self.ts = ts
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToTensor:
+        def __call__(self, pic):
+            arr = np.asarray(pic.convert("RGB") if pic.mode != "RGB" else pic, dtype=np.uint8)
+            return torch.from_numpy(arr.copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+    class Normalize:
+        def __init__(self, mean, std): self.mean, self.std = mean, std
+        def __call__(self, t):
+            mean = torch.as_tensor(self.mean, dtype=t.dtype).view(-1, 1, 1)
+            std = torch.as_tensor(self.std, dtype=t.dtype).view(-1, 1, 1)
+            return t.clone().sub_(mean).div_(std)
+
+    fn = types.ModuleType("torchvision.transforms.functional")
+    fn.hflip = lambda img: img.transpose(Image.FLIP_LEFT_RIGHT)
+    tv.Compose, tv.ToTensor, tv.Normalize, tv.functional = Compose, ToTensor, Normalize, fn
+    sys.modules["torchvision.transforms.functional"] = fn
+    return tv
+
+
+def _write_frame_tree(root):
+    """A tiny UCF-style tree (5 videos, 33..64 frames of 112x112 JPEG) and a Kinetics-style one (3 videos x 8 frames 64x64)."""
+    from PIL import Image
+    rng = np.random.default_rng(2024)
+    yy, xx = np.mgrid[0:112, 0:112].astype(np.float32)
+
+    def frame(vid, t, size):
+        s = 112 // size
+        base = np.stack([(xx * (1 + vid) + 3 * t) % 256, (yy * 2 + 5 * vid) % 256, ((xx + yy) * 0.7 + 11 * t) % 256], -1)
+        x0 = (7 * t + 13 * vid) % 80
+        base[20 + vid * 5:50 + vid * 5, x0:x0 + 24] = (250 - 40 * vid, 30 + 20 * vid, 120)
+        base = base + rng.normal(0, 4, base.shape)
+        return Image.fromarray(np.clip(base, 0, 255).astype(np.uint8)[::s, ::s])
+    ucf = os.path.join(root, "UCF101")
+    vids = [("v_Archery_g01_c01", "Archery", "train", 64), ("v_Biking_g01_c01", "Biking", "train", 40),
+            ("v_Archery_g02_c01", "Archery", "train", 36), ("v_Biking_g02_c01", "Biking", "test", 33),
+            ("v_Archery_g03_c01", "Archery", "test", 34)]
+    for vi, (name, _, _, n) in enumerate(vids):
+        d = os.path.join(ucf, "jpegs_112", name)
+        os.makedirs(d, exist_ok=True)
+        for t in range(1, n + 1):
+            frame(vi, t, 112).save(os.path.join(d, "frame%06d.jpg" % t), quality=60)
+    for csv_name in ("ucf101_splits1.csv", "ucf50_splits1.csv", "hmdb51_splits.csv"):
+        with open(os.path.join(ucf, csv_name), "w") as fp:
+            fp.write("folder_name,label,split\n")
+            for name, label, split, _ in vids:
+                fp.write("%s,%s,%s\n" % (name, label, split))
+    kin = os.path.join(root, "kinetics_64x64x8")
+    kvids = [("aaaaaaaaaaa", 3, 13, "zumba", "train"), ("bbbbbbbbbbb", 10, 20, "abseiling", "train"),
+             ("ccccccccccc", 0, 10, "zumba", "train"), ("ddddddddddd", 5, 15, "abseiling", "val")]
+    for vi, (yt, a, b, label, split) in enumerate(kvids):
+        d = os.path.join(kin, split, "%s_%06d_%06d" % (yt, a, b))
+        os.makedirs(d, exist_ok=True)
+        for t in range(8 if vi != 2 else 5):               # the third clip is short: the reader must skip it
+            frame(vi, t, 56).resize((64, 64)).save(os.path.join(d, "img_%05d.jpg" % t), quality=60)
+    for split, csv_split in (("train", "train"), ("val", "validate")):
+        with open(os.path.join(kin, "%s.csv" % csv_split), "w") as fp:
+            fp.write("label,youtube_id,time_start,time_end,split\n")
+            for yt, a, b, label, sp in kvids:
+                if sp == split:
+                    fp.write("%s,%s,%d,%d,%s\n" % (label, yt, a, b, csv_split))
+
+
+def g15():
+    """Frame-folder datasets (distill_utils/dataset.py): a committed JPEG tree + what the reference's classes return for it
+    under fixed generator seeds.  Per item: the frame numbers picked, the label, a strided probe of the clip and two
+    whole-clip checksums."""
+    root = os.path.join(OUT, "frames")
+    if not os.path.exists(os.path.join(root, "UCF101")):
+        _write_frame_tree(root)
+    tv = _install_transform_stubs()
+    sys.path.insert(0, REF)
+    from distill_utils import dataset as RD
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    tf = tv.Compose([tv.ToTensor(), tv.Normalize(mean=mean, std=std)])
+    out = {}
+
+    def record(tag, ds, passes):
+        np.random.seed(5); random.seed(7); torch.manual_seed(3)
+        k = 0
+        for _ in range(passes):
+            for i in range(len(ds)):
+                x, y = ds[i]
+                out["%s_%d_probe" % (tag, k)] = x[:, :, ::16, ::16].numpy()
+                out["%s_%d_sums" % (tag, k)] = np.array([float(x.double().sum()), float((x.double() ** 2).sum())])
+                out["%s_%d_label" % (tag, k)] = np.int64(y)
+                if hasattr(ds, "frames"):
+                    out["%s_%d_frames" % (tag, k)] = np.array(ds.frames, dtype=np.int64)
+                k += 1
+        out["%s_count" % tag] = np.int64(k)
+        out["%s_labels" % tag] = np.array(ds.labels, dtype=np.int64)
+    ucf = os.path.join(root, "UCF101")
+    record("ucf_train", RD.UCF101(ucf, "train", tf), 2)          # second pass: kept start frames, fresh flips
+    record("ucf_test", RD.UCF101(ucf, "test", tf), 2)            # test items redraw the start every visit
+    record("hmdb_train", RD.HMDB51(ucf, "train", tf), 1)
+    record("mini_train", RD.miniUCF101(ucf, "train", tf), 1)
+    record("mini_seg", RD.miniUCF101(ucf, "train", tf, sample="split-random"), 1)
+    kin = os.path.join(root, "kinetics_64x64x8")
+    for split in ("train", "val"):
+        ds = RD.Kinetics400(kin, split, tf)
+        out["kin_%s_labels" % split] = np.array(ds.labels, dtype=np.int64)
+        out["kin_%s_dirs" % split] = np.array([os.path.basename(d) for d in ds.video_dirs])
+        for i in range(len(ds)):
+            x, y = ds[i]
+            names = os.listdir(ds.video_dirs[i])               # the order the reference stacked the frames in
+            out["kin_%s_%d_names" % (split, i)] = np.array(names)
+            out["kin_%s_%d_probe" % (split, i)] = x[:, :, ::8, ::8].numpy()
+            out["kin_%s_%d_sums" % (split, i)] = np.stack([x[t].double().sum().numpy() for t in range(x.shape[0])])
+    npz("g15_frame_datasets.npz", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -577,7 +703,7 @@ def main():
     for name, fn in (("g1", lambda: g1(networks)), ("g2", lambda: g2_g3(networks)), ("g4", lambda: g4_g5(networks, utils)),
                      ("g6", lambda: g6(networks, utils)), ("g7", lambda: g7(networks, utils)),
                      ("g9", lambda: g9(networks, utils)), ("g10", lambda: g10(networks, utils)),
-                     ("g11", lambda: g11(networks, utils)), ("g12", lambda: g12(networks)), ("g13", lambda: g13(networks, utils)), ("g14", lambda: g14(networks, utils))):
+                     ("g11", lambda: g11(networks, utils)), ("g12", lambda: g12(networks)), ("g13", lambda: g13(networks, utils)), ("g14", lambda: g14(networks, utils)), ("g15", g15)):
         if not only or name in only:
             fn()
 

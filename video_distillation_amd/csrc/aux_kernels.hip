@@ -1493,3 +1493,81 @@ extern "C" int vd_mfma_peak(int blocks, int iters, int shape, float* out, void* 
 }
 
 extern "C" int vd_abi_version(void) { return VD_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Decoded frames -> clips: HWC uint8 -> CHW fp32, (v / 255 - mean[c]) / std[c]  (torchvision ToTensor + Normalize as the
+// reference's datasets apply them per frame, utils.py:171-173; here once per preload, on the device).  HBM-bound: 3 bytes
+// read and 12 written per pixel.  Every operation is a correctly rounded fp32 one, so the result equals the host
+// transform's bit for bit.
+// ------------------------------------------------------------------------------------------------------------------------
+struct FrameNorm { float mean[3]; float std[3]; };
+
+__device__ __forceinline__ float frame_norm1(unsigned v, float mean, float sd) {
+    return __fdiv_rn(__fsub_rn(__fdiv_rn((float)v, 255.0f), mean), sd);
+}
+
+__global__ void frames_normalize_quad_kernel(const uint32_t* __restrict__ src, float* __restrict__ dst, int64_t nframes,
+                                             int64_t quads_per_frame, FrameNorm nm) {
+    const int64_t total = nframes * quads_per_frame;
+    const int64_t hw = quads_per_frame * 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / quads_per_frame, q = i - f * quads_per_frame;
+        const uint32_t* s = src + i * 3;                       // 4 pixels = 12 bytes
+        const uint32_t a = s[0], b = s[1], c = s[2];           // r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+        float4 r, g, bl;
+        r.x = frame_norm1(a & 255u, nm.mean[0], nm.std[0]);
+        g.x = frame_norm1((a >> 8) & 255u, nm.mean[1], nm.std[1]);
+        bl.x = frame_norm1((a >> 16) & 255u, nm.mean[2], nm.std[2]);
+        r.y = frame_norm1(a >> 24, nm.mean[0], nm.std[0]);
+        g.y = frame_norm1(b & 255u, nm.mean[1], nm.std[1]);
+        bl.y = frame_norm1((b >> 8) & 255u, nm.mean[2], nm.std[2]);
+        r.z = frame_norm1((b >> 16) & 255u, nm.mean[0], nm.std[0]);
+        g.z = frame_norm1(b >> 24, nm.mean[1], nm.std[1]);
+        bl.z = frame_norm1(c & 255u, nm.mean[2], nm.std[2]);
+        r.w = frame_norm1((c >> 8) & 255u, nm.mean[0], nm.std[0]);
+        g.w = frame_norm1((c >> 16) & 255u, nm.mean[1], nm.std[1]);
+        bl.w = frame_norm1(c >> 24, nm.mean[2], nm.std[2]);
+        float* d = dst + f * 3 * hw + q * 4;
+        *reinterpret_cast<float4*>(d) = r;
+        *reinterpret_cast<float4*>(d + hw) = g;
+        *reinterpret_cast<float4*>(d + 2 * hw) = bl;
+    }
+}
+
+__global__ void frames_normalize_scalar_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t nframes, int64_t hw,
+                                               FrameNorm nm) {
+    const int64_t total = nframes * hw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / hw, p = i - f * hw;
+        const uint8_t* s = src + i * 3;
+        float* d = dst + f * 3 * hw + p;
+        d[0] = frame_norm1(s[0], nm.mean[0], nm.std[0]);
+        d[hw] = frame_norm1(s[1], nm.mean[1], nm.std[1]);
+        d[2 * hw] = frame_norm1(s[2], nm.mean[2], nm.std[2]);
+    }
+}
+
+extern "C" int vd_frames_normalize(const void* src_u8, float* dst, int64_t nframes, int height, int width, const float* mean3,
+                                   const float* std3, void* stream) {
+    if (nframes < 0 || height < 0 || width < 0 || !mean3 || !std3) return -1;
+    const int64_t hw = (int64_t)height * width;
+    if (nframes == 0 || hw == 0) return 0;
+    if (!src_u8 || !dst) return -1;
+    FrameNorm nm;
+    for (int c = 0; c < 3; ++c) {
+        nm.mean[c] = mean3[c]; nm.std[c] = std3[c];
+        if (!(std3[c] != 0.f)) return -1;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool vec = (hw % 4 == 0) && (reinterpret_cast<uintptr_t>(src_u8) % 4 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
+    const int64_t items = vec ? nframes * (hw / 4) : nframes * hw;
+    int64_t blocks = (items + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (vec)
+        hipLaunchKernelGGL(frames_normalize_quad_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const uint32_t*>(src_u8), dst, nframes, hw / 4, nm);
+    else
+        hipLaunchKernelGGL(frames_normalize_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const uint8_t*>(src_u8), dst, nframes, hw, nm);
+    return (int)hipGetLastError();
+}

@@ -265,6 +265,22 @@ class RealPool:
             offsets[c] = k * per_class
         return RealPool(clips, counts, offsets)
 
+    @staticmethod
+    def from_dataset(dataset, num_classes: int, classes: Sequence[int], device, workers: int = 8):
+        """The ``--preload`` + ``indices_class`` bookkeeping of the reference (distill_baseline.py:36-45, 76-81) with the
+        clips left in HBM: the items of the owned ``classes`` of a frame-folder dataset (``dataset.FrameFolderVideos``)
+        are decoded once, class by class in dataset order, and normalised on the device (``dataset.preload``)."""
+        from . import dataset as D
+        per_class = D.indices_class(dataset.labels, num_classes)
+        order = [i for c in classes for i in per_class[c]]
+        clips, _ = D.preload(dataset, device, indices=order, workers=workers)
+        counts = [len(per_class[c]) for c in range(num_classes)]
+        offsets, o = [0] * num_classes, 0
+        for c in classes:
+            offsets[c] = o
+            o += counts[c]
+        return RealPool(clips, counts, offsets)
+
 
 class DMTrainer:
     """Baseline DM (distill_baseline.py DM branch, :292-361) over the classes owned by this rank."""

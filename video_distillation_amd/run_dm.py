@@ -5,9 +5,9 @@ distill_baseline.py:292-361, with its flag names for everything that branch read
     python -m video_distillation_amd.run_dm --dataset synthetic --ipc 1 --Iteration 100 --eval_it 50
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m video_distillation_amd.run_dm ...
 
-Data: ``--dataset synthetic`` (randn clips) or ``--data_file f.pt`` holding
-{"clips": (N,T,3,H,W), "labels": (N,), "test_clips", "test_labels"} (the reference's frame-folder
-datasets are out of scope).  Logging: JSON lines with the reference's wandb keys
+Data: ``--dataset synthetic`` (randn clips); ``--dataset miniUCF101|UCF101|HMDB51|Kinetics400 --data_path D``
+(the reference's frame folders, decoded once and kept in HBM: dataset.py); or ``--data_file f.pt`` holding
+{"clips": (N,T,3,H,W), "labels": (N,), "test_clips", "test_labels"}.  Logging: JSON lines with the reference's wandb keys
 (``Loss``, ``Accuracy/<model>``, ``Max_Accuracy/<model>``, ``Std/<model>``, ``Max_Std/<model>``).
 """
 from __future__ import annotations
@@ -26,6 +26,8 @@ def build_parser():
     p = argparse.ArgumentParser(description="DM distillation on MI355X")
     p.add_argument('--dataset', type=str, default='synthetic')
     p.add_argument('--data_file', type=str, default=None)
+    p.add_argument('--data_path', type=str, default='distill_utils/data')
+    p.add_argument('--num_workers', type=int, default=8, help='decode threads of the preload')
     p.add_argument('--method', type=str, default='DM', choices=['DM'])
     p.add_argument('--model', type=str, default='ConvNet3D')
     p.add_argument('--ipc', type=int, default=1)
@@ -54,6 +56,13 @@ def build_parser():
 def load_data(args, rank, world, geo, device):
     """-> (RealPool with this rank's classes resident on `device`, num_classes, (c_lo, c_hi), testloader)."""
     from . import distill
+    if args.data_file is None and args.dataset != 'synthetic':
+        from . import dataset as D
+        _, im_size, num_classes, _, _, _, dst_train, _, testloader = D.get_dataset(args.dataset, args.data_path,
+                                                                                   img_size=(args.im_size, args.im_size))
+        c_lo, c_hi = distill.class_range(num_classes, rank, world)
+        pool = distill.RealPool.from_dataset(dst_train, num_classes, list(range(c_lo, c_hi)), device, workers=args.num_workers)
+        return pool, num_classes, (c_lo, c_hi), testloader
     if args.data_file is None:
         c_lo, c_hi = distill.class_range(args.num_classes, rank, world)
         pool = distill.RealPool.synthetic(args.num_classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device)
