@@ -71,7 +71,8 @@ typedef struct VdConvParams {
     int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
     int32_t reserved1;
-    int32_t reserved0;
+    int32_t replica_stride;       /* atomic ROWS epilogue: dst += boxes[box][5] * replica_stride floats (weight-gradient programs spread their
+                                     boxes over copies of dW so that same-address atomics do not serialise); 0 = one target */
 } VdConvParams;
 
 int vd_abi_version(void);
@@ -292,6 +293,12 @@ void vd_embed_free(VdEmbed* e);
 int vd_mfma_peak(int blocks, int iters, int shape, float* out, void* stream);
 int vd_sgd_momentum_wd(float* x, float* buf, const float* g, int64_t n, float lr, float momentum, float wd, int first,
                        void* stream);
+
+/* Folds the accumulation copies of a weight-gradient tile program back into the gradient tensor:
+ * out[col][row] += sum over r of rep[r][row][col], rep = (replicas, rows = cin*147, cols = cout) fp32, out = dW (cout, cin, 3, 7, 7).
+ * The programs accumulate cout-minor (the 32 lanes of an atomic instruction share one 128-byte line) and spread their
+ * boxes over the copies (VdConvParams.replica_stride = rows*cols; box row word 5 = the copy). */
+int vd_replica_sum(const float* rep, int replicas, int rows, int cols, float* out, void* stream);
 
 /* Decoded frames -> clips, the device half of the dataset preload (replaces the per-frame host transform
  * `ToTensor()` + `Normalize(mean, std)` of utils.py:171-173 and the per-step host->device copy of get_images,

@@ -1571,3 +1571,33 @@ extern "C" int vd_frames_normalize(const void* src_u8, float* dst, int64_t nfram
                            reinterpret_cast<const uint8_t*>(src_u8), dst, nframes, hw, nm);
     return (int)hipGetLastError();
 }
+
+// Weight-gradient programs accumulate into scratch copies laid out [replica][cin*147 rows][cout cols] (cout minor, so the 32
+// lanes of an atomic instruction fall into one 128-byte line instead of 32 lines 441..18816 floats apart) and spread
+// their boxes over the copies.  This folds them back: out[col][row] += sum_r rep[r][row][col]  (out = dW, (cout, cin, 3, 7, 7)).
+__global__ void replica_sum_kernel(const float* __restrict__ rep, int replicas, int rows, int cols, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int64_t plane = (int64_t)rows * cols;
+    for (int dy = threadIdx.y; dy < 32; dy += blockDim.y) {
+        const int row = r0 + dy, col = c0 + threadIdx.x;
+        float sum = 0.f;
+        if (row < rows && col < cols)
+            for (int r = 0; r < replicas; ++r) sum += rep[r * plane + (int64_t)row * cols + col];
+        tile[dy][threadIdx.x] = sum;
+    }
+    __syncthreads();
+    for (int dy = threadIdx.y; dy < 32; dy += blockDim.y) {
+        const int col = c0 + dy, row = r0 + threadIdx.x;
+        if (row < rows && col < cols) out[(int64_t)col * rows + row] += tile[threadIdx.x][dy];
+    }
+}
+
+extern "C" int vd_replica_sum(const float* rep, int replicas, int rows, int cols, float* out, void* stream) {
+    if (replicas < 0 || rows < 0 || cols < 0) return -1;
+    if (replicas == 0 || rows == 0 || cols == 0) return 0;
+    if (!rep || !out) return -1;
+    hipLaunchKernelGGL(replica_sum_kernel, dim3((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32)), dim3(32, 8), 0,
+                       reinterpret_cast<hipStream_t>(stream), rep, replicas, rows, cols, out);
+    return (int)hipGetLastError();
+}

@@ -463,6 +463,7 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
 
     if (p.epi == VD_EPI_ROWS) {
         float* dst = reinterpret_cast<float*>(p.dst);
+        if constexpr (EXT) { if (p.atomic) dst += (int64_t)box[5] * p.replica_stride; }   // this box's copy of the accumulation target
         const float osc = (p.out_scale != nullptr) ? p.out_scale[0] : 1.f;
 #pragma unroll
       for (int j = 0; j < NTW + BAL; ++j) {

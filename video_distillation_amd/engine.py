@@ -324,7 +324,8 @@ class WgradOp:
         self.planes = 2 if hip.is_x3(self.prec) else 1
         self.device = torch.device(device)
         blk = os.environ.get("VD_WG_BLOCK")
-        self.plan = P.plan_wgrad("wgrad%dx%d" % (cin, cout), cin, cout, t, h, w, nclips, block=tuple(int(v) for v in blk.split(",")) if blk else None)
+        self.plan = P.plan_wgrad("wgrad%dx%d" % (cin, cout), cin, cout, t, h, w, nclips, block=tuple(int(v) for v in blk.split(",")) if blk else None,
+                                 planes=self.planes)
         self.dp = _DevPlan(self.plan, self.device, self.prec)
         self.T, self.OH, self.OW = self.plan.meta["grid"]
         self.CCb = self.plan.CC
@@ -332,6 +333,8 @@ class WgradOp:
         self.xT = torch.empty((self.planes, cin * self.CCb * self.npos_in, 8), dtype=torch.int16, device=self.device)
         self.bp_elems = self.plan.nbox * self.plan.w_box_stride
         self.bp = torch.empty((self.planes, self.bp_elems), dtype=torch.int16, device=self.device)
+        self.replicas = int(self.plan.meta["replicas"])
+        self.rep = torch.empty((self.replicas, cin * 147, cout), dtype=torch.float32, device=self.device)
 
     def run(self, x_src: torch.Tensor, x_is_pixels: bool, x_plane_slots: int, dy: torch.Tensor, dy_plane_slots: int,
             dw_out: torch.Tensor, out_scale: Optional[torch.Tensor] = None) -> None:
@@ -351,5 +354,9 @@ class WgradOp:
         nt, noh, now = self.plan.meta["box"]
         hip.check(L.vd_pack_dy(hip.ptr(dy), ctypes.c_int64(dy_plane_slots), self.planes, ctypes.c_int64(nb), self.cout, self.T,
                                self.OH, self.OW, nt, noh, now, hip.ptr(self.bp), ctypes.c_int64(self.bp_elems), st), "vd_pack_dy")
-        self.dp.run(self.xT, xT_plane, None, dw_out.data_ptr(), 0, None, self.cin, out_scale=out_scale, wpk=self.bp,
+        # boxes accumulate into `replicas` cout-minor copies (coalesced atomics, no same-address pile-up), folded into dw_out after
+        self.rep.zero_()
+        self.dp.params.replica_stride = dw_out.numel()
+        self.dp.run(self.xT, xT_plane, None, self.rep.data_ptr(), 0, None, self.cin, out_scale=out_scale, wpk=self.bp,
                     w_plane_elems=self.bp_elems)
+        hip.check(L.vd_replica_sum(hip.ptr(self.rep), self.replicas, self.cin * 147, self.cout, hip.ptr(dw_out), st), "vd_replica_sum")

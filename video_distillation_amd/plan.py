@@ -143,6 +143,7 @@ class ConvPlan:
         for bi, box in enumerate(self.boxes):
             ty = int(box[0])
             out[bi, :5] = (descs[ty][7], descs[ty][8], descs[ty][9], int(box[4]), ty)
+            out[bi, 5] = int(box[5])              # replica of the accumulation target (weight-gradient programs), else 0
         return out
 
     def flat_tables(self):
@@ -698,22 +699,31 @@ def plan_dgrad_pix(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: i
     return plan
 
 
-WGRAD_BLOCKS = ((8, 4, 4), (4, 4, 14), (8, 2, 14), (4, 7, 7), (2, 7, 14), (4, 2, 14), (2, 4, 14), (2, 2, 14), (1, 4, 14), (1, 2, 14))
+WGRAD_BLOCKS = ((8, 4, 4), (4, 4, 14), (8, 2, 14), (4, 7, 7), (2, 7, 14), (4, 2, 14), (2, 4, 14), (4, 4, 4), (2, 2, 14), (1, 4, 14), (2, 4, 4), (1, 2, 14))
 
 
 def plan_wgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, nclips: int,
-               lds_budget: int = 3700, block=None) -> ConvPlan:
+               lds_budget: int = 3700, block=None, planes: int = 1) -> ConvPlan:
     if block is None:
-        # the largest block of positions (= K steps per staged patch, and fewest atomic passes over dW) whose
-        # patch fits the LDS budget and the DMA-group budget of the workgroup (cout/32 waves x 17 groups of 64 slots)
+        # Among the blocks of positions whose patch fits the LDS budget and the DMA-group budget of the workgroup (cout/32
+        # waves x 17 groups of 64 slots), the one with the smallest  (K steps incl. the padding of partial blocks) /
+        # (resident waves per CU, counted up to 6 of the 8 the register budget allows -- 4 when the K loop is a single
+        # clip chunk): residency is limited by the patch (`planes` 16-bit planes in LDS) and by how many workgroups the
+        # launch has at all.  Ties: fewest boxes (atomic passes), longest K loop.  Measured per 64 clips 112x112x16,
+        # hi+lo formats: layer 1 (8,2,14) 1.45 -> (4,2,14) 1.23 ms; layer 0 (4,2,14) 0.79 -> (2,2,14) 0.65 ms; layer 2
+        # (8,4,4) 0.19 -> (2,4,4) 0.13 ms; 256 clips 64x64x8: layer 1 (2,7,8) 1.16 / (8,4,4) 0.82 / (4,4,4) 0.78 ms.
         best = None
+        wg_waves = cout // 32
+        want = 6 if nclips > 8 else 4
         for cand in WGRAD_BLOCKS:
             pl = _plan_wgrad(name, cin, cout, t_in, h_in, w_in, nclips, lds_budget, cand)
             bt = pl.types[0]
             groups = -(-bt.pitch_c // 64)
             if bt.pitch_c > lds_budget or groups > (cout // 32) * 17:
                 continue
-            key = (pl.nbox, -pl.S)
+            lds = planes * bt.pitch_c * SLOT_BYTES + 2048
+            resident = min(8, (160 * 1024 // lds) * wg_waves, cin * pl.nbox * wg_waves // 256)
+            key = (pl.nbox * pl.S / max(1, min(resident, want)), pl.nbox, -pl.S)
             if best is None or key < best[0]:
                 best = (key, pl)
         assert best is not None, "no weight-gradient block fits"
@@ -766,7 +776,7 @@ def _plan_wgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int,
             key = (round(cyc, 3), pitch_c)
             if best is None or key < best[0]:
                 out = -np.ones(MTW * 32, dtype=np.int64)
-                out[:len(rows_tap)] = np.arange(len(rows_tap))
+                out[:len(rows_tap)] = np.arange(len(rows_tap)) * cout      # accumulation target [cin][tap][cout]: cout minor
                 tap_off = np.array([(dt * pitch_f + 2 * doh * pitch_h + 2 * dow) * SLOT_BYTES for dt, doh, dow in positions])
                 best = (key, BoxType(pf, ph, pw, pitch_h, pitch_f, pitch_c, MTW, (a_off * SLOT_BYTES).astype(np.int32),
                                      out.astype(np.int32), tap_off.astype(np.int32), cyc))
@@ -781,15 +791,23 @@ def _plan_wgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int,
             for ow0 in range(0, OW, now):
                 boxes.append([0, t0 - 1, 2 * oh0 - 3, 2 * ow0 - 3, 0, 0])
                 blocks.append((t0, oh0, ow0))
+    # Every box of a channel adds into the same 147 x cout floats with fp32 atomics.  Two things make that affordable:
+    # the target is laid out [cin][tap][cout] (a wave's 32 output channels share one 128-byte line; in dW's own layout
+    # they are 441..18816 floats apart and the chip sustains only ~30 G scattered atomics/s: 0.4 ms of a 1.5 ms layer-1
+    # launch), and boxes are dealt round-robin to `replicas` copies (box row word 5; same-address atomics serialise).
+    # WgradOp folds the copies into dW afterwards (vd_replica_sum, a tiled transpose).
+    replicas = max(1, min(16, len(boxes) // 28))
+    for bi, box in enumerate(boxes):
+        box[5] = bi % replicas
     plan = ConvPlan(name=name, CC=CCb, F=t_in, H=h_in, W=w_in, row_pitch4=w_in * 4, chunk_stride4=t_in * h_in * w_in * 4,
                     clip_stride4=CCb * t_in * h_in * w_in * 4, NT=NT, MW=MW, MTW=MTW, S=S, ncl=1,
                     boxes=np.asarray(boxes, dtype=np.int32), types=[bt], widx=np.zeros((0,), dtype=np.int32),
-                    epi=EPI_ROWS, pool_t=0, relu=False, n_out=cout, n_stride=cin * KT * KH * KW,
-                    out_clip_stride=KT * KH * KW, out_chunk_stride=0, out_shape=(cout, cin, KT, KH, KW),
+                    epi=EPI_ROWS, pool_t=0, relu=False, n_out=cout, n_stride=1,
+                    out_clip_stride=KT * KH * KW * cout, out_chunk_stride=0, out_shape=(cin, KT, KH, KW, cout),
                     rows_total=len(boxes) * MTW * 32, rows_useful=len(boxes) * len(rows_tap), meta={"box": (nt, noh, now)})
     plan.atomic = True
     plan.w_box_stride = CCb * S * NT * 64 * 8
-    plan.meta.update({"blocks": blocks, "positions": positions, "grid": (T, OH, OW), "nclips": nclips, "cout": cout,
+    plan.meta.update({"blocks": blocks, "positions": positions, "grid": (T, OH, OW), "nclips": nclips, "cout": cout, "replicas": replicas,
                       "macs_per_unit": T * OH * OW * KT * KH * KW * cout * nclips})       # unit = one input channel
     return plan
 
