@@ -194,6 +194,12 @@ int vd_clip_minor_pix(const float* x, int64_t nclips, int T, int H, int W, void*
                       void* stream);
 int vd_pack_dy(const void* dy, int64_t dy_plane_slots, int planes, int64_t nclips, int N, int T, int OH, int OW,
                int nt, int noh, int now, void* dst, int64_t dst_plane_elems, void* stream);
+/* vd_unpool_relu_bwd followed by vd_pack_dy, fused for a layer whose dense dy has no other reader (the first layer when no
+ * pixel gradient is wanted): the packed B operand of the weight-gradient program straight from the pooled gradient and the
+ * arg-max bytes, bitwise what the two calls produce.  (nt, noh, now) = the program's block of positions. */
+int vd_unpool_relu_bwd_packed(const float* g, const uint8_t* argmax, int64_t nclips, int C, int To, int Ho, int Wo,
+                              int pool_t, int T, int OH, int OW, int g_layout, int nt, int noh, int now,
+                              void* dst_hi, void* dst_lo, int prec, const float* scale, void* stream);
 
 /* Conv3d bias gradient from the POOLED gradient and the arg-max bytes of the layer (layouts as in vd_unpool_relu_bwd):
  * db[n] += sum of g over clips and pooled positions whose window was alive (bit 7 clear); accumulates (fp32 atomics). */

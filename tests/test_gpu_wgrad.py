@@ -46,3 +46,39 @@ def test_wgrad_matches_autograd(prec, tol, cfg):
     err = float((dw.double().cpu() - want).norm() / want.norm())
     print(cfg, prec, "wgrad rel-l2 %.2e" % err)
     assert err < tol
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16", "bf16x3"])
+@pytest.mark.parametrize("cfg", [(64, 8, 32, 32, 1, 11, 1), (128, 8, 16, 16, 2, 5, 0), (64, 4, 14, 14, 1, 9, 1)])
+def test_fused_unpool_pack_is_bitwise_the_two_kernel_path(prec, cfg):
+    """vd_unpool_relu_bwd_packed == vd_unpool_relu_bwd followed by vd_pack_dy, bit for bit, for both gradient layouts,
+    both pool depths, ragged clip counts (not a multiple of 8) and grids the block does not divide."""
+    from video_distillation_amd import engine, hip
+    cout, T, OH, OW, pt, n, layout = cfg
+    To, Ho, Wo = T // pt, OH // 2, OW // 2
+    op = engine.WgradOp(64 if cout == 128 else 3, cout, T, 2 * OH, 2 * OW, n, prec, "cuda:0")
+    assert (op.T, op.OH, op.OW) == (T, OH, OW)
+    g = torch.Generator(device="cuda").manual_seed(cout + n)
+    npos = To * Ho * Wo
+    grad = torch.randn((n, cout, npos) if layout == 0 else (n, npos, cout), device="cuda", generator=g)
+    am = torch.randint(0, 4 * pt, (n * cout * npos,), device="cuda", generator=g).to(torch.uint8)
+    am[::13] = 128                                             # dead windows (ReLU): bit 7 set, never matches a position code
+    scale = torch.tensor([4.0, 0.25], device="cuda")
+    L, st = hip.lib(), hip.stream_ptr(op.device)
+    nslots = n * (cout // 8) * T * OH * OW
+    dy = torch.empty((op.planes, nslots, 8), dtype=torch.int16, device="cuda")
+    lo = dy[1] if op.planes == 2 else None
+    hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am), ctypes.c_int64(n), cout, To, Ho, Wo, pt, T, OH, OW, layout,
+                                   hip.ptr(dy[0]), hip.ptr(lo), op.prec, hip.ptr(scale), st), "unpool")
+    nt, noh, now = op.plan.meta["box"]
+    op.bp.fill_(-1)
+    hip.check(L.vd_pack_dy(hip.ptr(dy), ctypes.c_int64(nslots), op.planes, ctypes.c_int64(n), cout, T, OH, OW, nt, noh, now,
+                           hip.ptr(op.bp), ctypes.c_int64(op.bp_elems), st), "pack")
+    want = op.bp.clone()
+    op.bp.fill_(-1)
+    blo = op.bp[1] if op.planes == 2 else None
+    hip.check(L.vd_unpool_relu_bwd_packed(hip.ptr(grad), hip.ptr(am), ctypes.c_int64(n), cout, To, Ho, Wo, pt, T, OH, OW, layout,
+                                          nt, noh, now, hip.ptr(op.bp[0]), hip.ptr(blo), op.prec, hip.ptr(scale), st), "fused")
+    torch.cuda.synchronize()
+    assert torch.equal(op.bp, want)
+    assert int((want != 0).sum()) > 0

@@ -1028,6 +1028,74 @@ extern "C" int vd_pack_dy(const void* dy, int64_t dy_plane_slots, int planes, in
     return (int)hipGetLastError();
 }
 
+// vd_unpool_relu_bwd + vd_pack_dy in one pass, for a layer whose dense dy nobody else reads (the first layer when no pixel
+// gradient is asked for): one thread per packed B slot (box, cb, s, nt, lane) computes its 8 clips of dy[pos][n] straight
+// from the pooled gradient and the arg-max bytes.  Same arithmetic, so the packed operand is bitwise the one the two
+// kernels produce -- without writing and re-reading the dense slots (2 x 642 MB for 50 clips 112x112x16 in the hi+lo formats).
+__global__ void unpool_pack_kernel(const float* __restrict__ g, const uint8_t* __restrict__ amax, int64_t nclips, int N,
+                                   int To, int Ho, int Wo, int pool_t, int T, int OH, int OW, int g_layout,
+                                   int nt, int noh, int now, int S, int CCb, int NT, int nbh, int nbw,
+                                   uint4* __restrict__ hi, uint4* __restrict__ lo, int prec, const float* __restrict__ scale,
+                                   int64_t per_plane) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_plane) return;
+    const float sc = (scale != nullptr) ? scale[0] : 1.f;
+    int64_t r = i;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int ntile = (int)(r % NT); r /= NT;
+    const int s = (int)(r % S); r /= S;
+    const int cb = (int)(r % CCb); r /= CCb;
+    const int box = (int)r;
+    const int bw = box % nbw, bh = (box / nbw) % nbh, bt = box / (nbw * nbh);
+    const int pidx = 2 * s + (lane >> 5);
+    const int dow = pidx % now, doh = (pidx / now) % noh, dt = pidx / (now * noh);
+    const int t = bt * nt + dt, oh = bh * noh + doh, ow = bw * now + dow;
+    const int n = ntile * 32 + (lane & 31);
+    const int pt = t / pool_t, pr = oh >> 1, pc = ow >> 1;
+    const bool inside = (t < T) && (oh < OH) && (ow < OW) && (pt < To) && (pr < Ho) && (pc < Wo);
+    const int j = (pool_t == 2 ? ((t & 1) << 2) : 0) | ((oh & 1) << 1) | (ow & 1);
+    const int64_t npos = (int64_t)To * Ho * Wo;
+    const int64_t pos = ((int64_t)pt * Ho + pr) * Wo + pc;
+    const int CC = N >> 3, cc = n >> 3, e = n & 7;
+    uint16_t h16[8], l16[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t clip = (int64_t)cb * 8 + k;
+        float v = 0.f;
+        if (inside && clip < nclips) {
+            int64_t gi, ai;
+            if (g_layout == 0) { gi = (clip * N + n) * npos + pos; ai = gi; }
+            else { gi = (clip * npos + pos) * N + n; ai = ((clip * CC + cc) * npos + pos) * 8 + e; }
+            if (amax[ai] == (uint8_t)j) v = g[gi] * sc;
+        }
+        split16p(prec, v, h16[k], l16[k]);
+    }
+    uint4 vh, vl;
+    vh.x = h16[0] | ((uint32_t)h16[1] << 16); vh.y = h16[2] | ((uint32_t)h16[3] << 16);
+    vh.z = h16[4] | ((uint32_t)h16[5] << 16); vh.w = h16[6] | ((uint32_t)h16[7] << 16);
+    hi[i] = vh;
+    if (lo != nullptr) {
+        vl.x = l16[0] | ((uint32_t)l16[1] << 16); vl.y = l16[2] | ((uint32_t)l16[3] << 16);
+        vl.z = l16[4] | ((uint32_t)l16[5] << 16); vl.w = l16[6] | ((uint32_t)l16[7] << 16);
+        lo[i] = vl;
+    }
+}
+
+extern "C" int vd_unpool_relu_bwd_packed(const float* g, const uint8_t* argmax, int64_t nclips, int C, int To, int Ho, int Wo,
+                                         int pool_t, int T, int OH, int OW, int g_layout, int nt, int noh, int now,
+                                         void* dst_hi, void* dst_lo, int prec, const float* scale, void* stream) {
+    if (C % 32 != 0 || (pool_t != 1 && pool_t != 2) || ((nt * noh * now) & 1) || nt < 1 || noh < 1 || now < 1) return -2;
+    const int S = nt * noh * now / 2, CCb = (int)((nclips + 7) / 8), NT = C / 32;
+    const int nbt = (T + nt - 1) / nt, nbh = (OH + noh - 1) / noh, nbw = (OW + now - 1) / now;
+    const int64_t per_plane = (int64_t)nbt * nbh * nbw * CCb * S * NT * 64;
+    if (per_plane <= 0) return 0;
+    if (!g || !argmax || !dst_hi) return -1;
+    hipLaunchKernelGGL(unpool_pack_kernel, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       g, argmax, nclips, C, To, Ho, Wo, pool_t, T, OH, OW, g_layout, nt, noh, now, S, CCb, NT, nbh, nbw,
+                       (uint4*)dst_hi, (uint4*)dst_lo, prec, scale, per_plane);
+    return (int)hipGetLastError();
+}
+
 // Conv3d bias gradient: one workgroup per 8-channel chunk; threads stride (clip, position).
 __global__ __launch_bounds__(256) void bias_grad_kernel(const uint4* __restrict__ dy, int64_t plane_slots, int planes,
                                                          int64_t nclips, int CCh, int64_t npos, int prec,

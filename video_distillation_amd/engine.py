@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -336,27 +336,51 @@ class WgradOp:
         self.replicas = int(self.plan.meta["replicas"])
         self.rep = torch.empty((self.replicas, cin * 147, cout), dtype=torch.float32, device=self.device)
 
-    def run(self, x_src: torch.Tensor, x_is_pixels: bool, x_plane_slots: int, dy: torch.Tensor, dy_plane_slots: int,
-            dw_out: torch.Tensor, out_scale: Optional[torch.Tensor] = None) -> None:
-        """x_src: fp32 clips (B,T,3,H,W) if x_is_pixels else channels-last slots [planes][clip][C/8][npos][8];
-        dy: dense slots [planes][clip][N/8][T][OH][OW][8]; dw_out (cout,cin,3,7,7) fp32 is ACCUMULATED into."""
+    def _stage_x(self, x_src: torch.Tensor, x_is_pixels: bool, x_plane_slots: int) -> None:
         L, st = hip.lib(), hip.stream_ptr(self.device)
         nb = self.nclips
-        xT_plane = self.xT.shape[1]
         if x_is_pixels:
             lo = self.xT[1] if self.planes == 2 else None
             hip.check(L.vd_clip_minor_pix(hip.ptr(x_src), ctypes.c_int64(nb), self.t, self.h, self.w, hip.ptr(self.xT[0]),
                                           hip.ptr(lo), self.prec, st), "vd_clip_minor_pix")
         else:
             hip.check(L.vd_clip_minor_cl(hip.ptr(x_src), ctypes.c_int64(x_plane_slots), self.planes, ctypes.c_int64(nb), self.cin,
-                                         ctypes.c_int64(self.npos_in), hip.ptr(self.xT), ctypes.c_int64(xT_plane), st),
+                                         ctypes.c_int64(self.npos_in), hip.ptr(self.xT), ctypes.c_int64(self.xT.shape[1]), st),
                       "vd_clip_minor_cl")
-        nt, noh, now = self.plan.meta["box"]
-        hip.check(L.vd_pack_dy(hip.ptr(dy), ctypes.c_int64(dy_plane_slots), self.planes, ctypes.c_int64(nb), self.cout, self.T,
-                               self.OH, self.OW, nt, noh, now, hip.ptr(self.bp), ctypes.c_int64(self.bp_elems), st), "vd_pack_dy")
-        # boxes accumulate into `replicas` cout-minor copies (coalesced atomics, no same-address pile-up), folded into dw_out after
+
+    def _accumulate(self, dw_out: torch.Tensor, out_scale: Optional[torch.Tensor]) -> None:
+        """The tile program over the staged x and the packed dy: boxes accumulate into `replicas` cout-minor copies
+        (coalesced atomics, no same-address pile-up), which are then folded into dw_out."""
+        L, st = hip.lib(), hip.stream_ptr(self.device)
         self.rep.zero_()
         self.dp.params.replica_stride = dw_out.numel()
-        self.dp.run(self.xT, xT_plane, None, self.rep.data_ptr(), 0, None, self.cin, out_scale=out_scale, wpk=self.bp,
+        self.dp.run(self.xT, self.xT.shape[1], None, self.rep.data_ptr(), 0, None, self.cin, out_scale=out_scale, wpk=self.bp,
                     w_plane_elems=self.bp_elems)
         hip.check(L.vd_replica_sum(hip.ptr(self.rep), self.replicas, self.cin * 147, self.cout, hip.ptr(dw_out), st), "vd_replica_sum")
+
+    def run(self, x_src: torch.Tensor, x_is_pixels: bool, x_plane_slots: int, dy: torch.Tensor, dy_plane_slots: int,
+            dw_out: torch.Tensor, out_scale: Optional[torch.Tensor] = None) -> None:
+        """x_src: fp32 clips (B,T,3,H,W) if x_is_pixels else channels-last slots [planes][clip][C/8][npos][8];
+        dy: dense slots [planes][clip][N/8][T][OH][OW][8]; dw_out (cout,cin,3,7,7) fp32 is ACCUMULATED into."""
+        L, st = hip.lib(), hip.stream_ptr(self.device)
+        self._stage_x(x_src, x_is_pixels, x_plane_slots)
+        nt, noh, now = self.plan.meta["box"]
+        hip.check(L.vd_pack_dy(hip.ptr(dy), ctypes.c_int64(dy_plane_slots), self.planes, ctypes.c_int64(self.nclips), self.cout, self.T,
+                               self.OH, self.OW, nt, noh, now, hip.ptr(self.bp), ctypes.c_int64(self.bp_elems), st), "vd_pack_dy")
+        self._accumulate(dw_out, out_scale)
+
+    def run_pooled(self, x_src: torch.Tensor, x_is_pixels: bool, x_plane_slots: int, g_pooled: torch.Tensor, argmax: torch.Tensor,
+                   g_layout: int, pooled: Tuple[int, int, int, int], scale: Optional[torch.Tensor], dw_out: torch.Tensor,
+                   out_scale: Optional[torch.Tensor] = None) -> None:
+        """As ``run`` for a layer whose dense dy has no other reader: dy = backward of ReLU + max-pool of the POOLED gradient
+        ``g_pooled`` (layout / arg-max bytes as vd_unpool_relu_bwd takes them; ``pooled`` = (To, Ho, Wo, pool_t)) goes
+        straight into the packed B operand (vd_unpool_relu_bwd_packed), bitwise what unpool + pack produce."""
+        L, st = hip.lib(), hip.stream_ptr(self.device)
+        self._stage_x(x_src, x_is_pixels, x_plane_slots)
+        nt, noh, now = self.plan.meta["box"]
+        To, Ho, Wo, pt = pooled
+        lo = self.bp[1] if self.planes == 2 else None
+        hip.check(L.vd_unpool_relu_bwd_packed(hip.ptr(g_pooled), hip.ptr(argmax), ctypes.c_int64(self.nclips), self.cout, To, Ho, Wo, pt,
+                                              self.T, self.OH, self.OW, g_layout, nt, noh, now, hip.ptr(self.bp[0]), hip.ptr(lo),
+                                              self.prec, hip.ptr(scale), st), "vd_unpool_relu_bwd_packed")
+        self._accumulate(dw_out, out_scale)

@@ -119,11 +119,13 @@ class TrainEngine:
         return g_feat
 
     def feat_backward(self, x: torch.Tensor, nb: int, am, g_feat: torch.Tensor, g: Optional[Sequence[torch.Tensor]],
-                      dx: Optional[torch.Tensor] = None) -> None:
+                      dx: Optional[torch.Tensor] = None, keep_dense: bool = False) -> None:
         """Backward of the three conv levels for the feature gradient ``g_feat`` (nb, num_feat): per layer, last to
         first, un-pool + ReLU backward, bias gradient, weight gradient (accumulated into g[0..5], zeroed by the caller;
         skipped when ``g`` is None) and the input-gradient passes (down to the pixels, into ``dx``, when given).  The
-        engine's weights / packed dgrad operands must be current; activations are read from the engine workspace."""
+        engine's weights / packed dgrad operands must be current; activations are read from the engine workspace.
+        ``keep_dense``: a second-order sweep will read the first layer's dense gradient slots (workspace ``dy0``); without
+        it and without ``dx`` they are never materialised (``WgradOp.run_pooled``)."""
         eng, L, st = self.eng, hip.lib(), hip.stream_ptr(self.device)
         acts, act_plane = self._acts(nb)
         grad, layout = g_feat, 0
@@ -131,25 +133,30 @@ class TrainEngine:
         for li in (2, 1, 0):
             cin, cout, t, h, w, T, OH, OW, To, Ho, Wo, pt = eng.dims[li]
             nslots = nb * (cout // 8) * T * OH * OW
-            dy = eng._buf("dy%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)
-            lo = dy[1] if eng.planes_bwd == 2 else None
+            dense = li > 0 or dx is not None or keep_dense   # the first layer's dense dy: pixel-gradient and second-order passes only
+            if not dense and g is None:
+                break
             sc = inv = None
             if scaled:
                 scb = eng._buf("gscale%d" % li, (4,), torch.float32)
                 hip.check(L.vd_absmax_scale(hip.ptr(grad), ctypes.c_int64(grad.numel()), ctypes.c_float(1024.0),
                                             hip.ptr(scb), st), "vd_absmax_scale")
                 sc, inv = scb, scb[1:]
-            hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout, To, Ho, Wo, pt, T, OH, OW,
-                                           layout, hip.ptr(dy[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(sc), st),
-                      "vd_unpool_relu_bwd")
+            if dense:
+                dy = eng._buf("dy%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)
+                lo = dy[1] if eng.planes_bwd == 2 else None
+                hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout, To, Ho, Wo, pt, T, OH, OW,
+                                               layout, hip.ptr(dy[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(sc), st),
+                          "vd_unpool_relu_bwd")
             if g is not None:
                 # bias gradient from the pooled gradient (the dense dy has one non-zero per live pool window)
                 hip.check(L.vd_bias_grad_pooled(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout,
                                                 ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(g[2 * li + 1]), st),
                           "vd_bias_grad_pooled")
                 op = self._wgrad(li, nb)
-                if li == 0:
-                    op.run(x, True, 0, dy, nslots, g[0], out_scale=inv)
+                if li == 0:     # pooled gradient -> packed B operand of the weight-gradient program in one pass (4x fewer bytes
+                    #             than re-reading the dense slots, which are not even written when nobody else needs them)
+                    op.run_pooled(x, True, 0, grad, am[0], layout, (To, Ho, Wo, pt), sc, g[0], out_scale=inv)
                 else:
                     op.run(acts[li], False, act_plane[li], dy, nslots, g[2 * li], out_scale=inv)
             if li > 0 or dx is not None:
@@ -181,7 +188,7 @@ class TrainEngine:
         self.gflat.zero_()
         g = self.grads()
         g_feat = self.head_backward(hs, dlog, g[6], g[7])
-        self.feat_backward(x, nb, am, g_feat, g)
+        self.feat_backward(x, nb, am, g_feat, g, keep_dense=state is not None)
         if state is not None:
             _, act_plane = self._acts(nb)
             state.update(nb=nb, am=am, dropped=hs["dropped"], logits=logits, dlog=dlog, amt=hs["amt"], mask=hs["mask"],
@@ -447,7 +454,7 @@ class GradMatchEngine(TrainEngine):
             geo = self.geo
             dx = torch.empty((fs["nb"], geo.frames, geo.channel, geo.height, geo.width), dtype=torch.float32,
                              device=self.device) if need_dx else None
-            self.feat_backward(fs["x"], fs["nb"], fs["am"], g_feat.detach().to(torch.float32).contiguous(), g, dx)
+            self.feat_backward(fs["x"], fs["nb"], fs["am"], g_feat.detach().to(torch.float32).contiguous(), g, dx, keep_dense=keep)
         finally:
             eng._ws = keep_ws
         if not keep:
