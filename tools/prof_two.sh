@@ -5,3 +5,6 @@ prof() { local name=$1; shift
 VD_SKIP_TORCH=1 prof train python3 $ROOT/tools/train_host_time.py 50
 VD_GM_LANES=1 prof dc1 python3 $ROOT/bench.py --method dc --classes 8 --ipc 5 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0
 ls $OUT
+cd /tmp
+prof mtt python3 $ROOT/bench.py --method mtt --classes 400 --frames 8 --size 64 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0
+ls $OUT

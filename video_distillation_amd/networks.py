@@ -34,19 +34,24 @@ from . import plan as P
 _PRECISION = {"real": os.environ.get("VD_PREC_REAL", "f16"), "syn": os.environ.get("VD_PREC_SYN", "f16x3"),
               "bwd": os.environ.get("VD_PREC_BWD", "f16"),
               "train": os.environ.get("VD_PREC_TRAIN", "f16x3"), "train_bwd": os.environ.get("VD_PREC_TRAIN_BWD", "f16x3"),
-              "match": os.environ.get("VD_PREC_MATCH", "bf16x3")}
+              "match": os.environ.get("VD_PREC_MATCH", "bf16x3"), "match_real_bwd": os.environ.get("VD_PREC_MATCH_REAL_BWD", "f16")}
 _ENGINES: Dict[Tuple, object] = {}
 
 
 def set_precision(real: str = None, syn: str = None, bwd: str = None, train: str = None, train_bwd: str = None,
-                  match: str = None) -> None:
+                  match: str = None, match_real_bwd: str = None) -> None:
     """Operand precision of the MFMA contraction: ``real`` for the forward of inputs without
     gradient, ``syn`` for the forward of inputs that need d/dx (its arg-max decisions steer the
     gradient), ``bwd`` for the input-gradient passes (no discrete decisions: single-pass fp16 with
     per-layer power-of-two scaling is the default); ``train`` / ``train_bwd`` for the forward and
-    the gradient passes of ``hip_train_step``.  One of 'bf16', 'f16', 'bf16x3', 'f16x3'."""
+    the gradient passes of ``hip_train_step``; ``match`` for the twice-differentiable passes of gradient / trajectory
+    matching and ``match_real_bwd`` for the gradient passes of ``param_grads(create_graph=False)`` -- the DETACHED real-batch
+    side of gradient matching, whose forward stays in ``train`` precision (its arg-max decisions route the gradient) while
+    the backward, which decides nothing, runs single-pass with the power-of-two scaling.  One of 'bf16', 'f16', 'bf16x3',
+    'f16x3'."""
     from . import hip
-    for k, v in (("real", real), ("syn", syn), ("bwd", bwd), ("train", train), ("train_bwd", train_bwd), ("match", match)):
+    for k, v in (("real", real), ("syn", syn), ("bwd", bwd), ("train", train), ("train_bwd", train_bwd), ("match", match),
+                 ("match_real_bwd", match_real_bwd)):
         if v is not None:
             if v not in hip.PREC:
                 raise ValueError("unknown precision %r" % v)
@@ -400,18 +405,19 @@ class ConvNet3D(nn.Module):
         return (type(criterion) is nn.CrossEntropyLoss and criterion.weight is None and criterion.reduction == "mean"
                 and getattr(criterion, "label_smoothing", 0.0) == 0.0)
 
-    def _train_engine(self, x, slot: int = 0):
+    def _train_engine(self, x, slot: int = 0, prec_bwd: str = None):
         """``slot``: engines own workspaces and packed operands, so calls that run concurrently on different streams (the
-        class lanes of distill.GMTrainer) each use their own instance."""
+        class lanes of distill.GMTrainer) each use their own instance.  ``prec_bwd`` overrides the ``train_bwd`` precision."""
         from . import train
         hint = _batch_hint(x.shape[0])
-        key = ("train", x.shape[1], x.shape[3], x.shape[4], self.logit.weight.shape[0], hint, _PRECISION["train"], _PRECISION["train_bwd"],
+        prec_bwd = prec_bwd or _PRECISION["train_bwd"]
+        key = ("train", x.shape[1], x.shape[3], x.shape[4], self.logit.weight.shape[0], hint, _PRECISION["train"], prec_bwd,
                x.device.index if x.device.index is not None else torch.cuda.current_device(), slot)
         te = _ENGINES.get(key)
         if te is None:
             te = train.TrainEngine(P.NetGeometry(x.shape[1], x.shape[3], x.shape[4]), self.logit.weight.shape[0],
                                    self.avg_pool.kernel_size, x.device, prec=_PRECISION["train"],
-                                   prec_bwd=_PRECISION["train_bwd"], batch_hint=hint)
+                                   prec_bwd=prec_bwd, batch_hint=hint)
             _ENGINES[key] = te
         return te
 
@@ -448,7 +454,7 @@ class ConvNet3D(nn.Module):
                 mask = self._dropout_mask(x, te)
             out = _ParamGradFunction.apply(x, labels, mask, self, slot)
             return out[0], list(out[2:])
-        te = self._train_engine(x, slot)
+        te = self._train_engine(x, slot, _PRECISION["match_real_bwd"])
         if mask is None:
             mask = self._dropout_mask(x, te)
         loss, _, g = te.loss_and_grads(x, labels, list(self.parameters()), mask)

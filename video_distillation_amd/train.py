@@ -154,11 +154,12 @@ class TrainEngine:
                                                 ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(g[2 * li + 1]), st),
                           "vd_bias_grad_pooled")
                 op = self._wgrad(li, nb)
-                if li == 0:     # pooled gradient -> packed B operand of the weight-gradient program in one pass (4x fewer bytes
-                    #             than re-reading the dense slots, which are not even written when nobody else needs them)
+                # pooled gradient -> packed B operand of the weight-gradient program in one pass (4-8x fewer bytes than
+                # re-reading the dense slots, which for the first layer are not even written when nobody else needs them)
+                if li == 0:
                     op.run_pooled(x, True, 0, grad, am[0], layout, (To, Ho, Wo, pt), sc, g[0], out_scale=inv)
                 else:
-                    op.run(acts[li], False, act_plane[li], dy, nslots, g[2 * li], out_scale=inv)
+                    op.run_pooled(acts[li], False, act_plane[li], grad, am[li], layout, (To, Ho, Wo, pt), sc, g[2 * li], out_scale=inv)
             if li > 0 or dx is not None:
                 out = dx if li == 0 else eng._buf("dx%d" % li, (nb, t, h, w, cin), torch.float32)
                 for dp in eng.bwd[li]:
