@@ -49,12 +49,15 @@ def test_wgrad_matches_autograd(prec, tol, cfg):
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "f16", "bf16x3"])
-@pytest.mark.parametrize("cfg", [(64, 8, 32, 32, 1, 11, 1), (128, 8, 16, 16, 2, 5, 0), (64, 4, 14, 14, 1, 9, 1)])
-def test_fused_unpool_pack_is_bitwise_the_two_kernel_path(prec, cfg):
+@pytest.mark.parametrize("cfg", [(64, 8, 32, 32, 1, 11, 1, None), (128, 8, 16, 16, 2, 5, 0, None), (64, 4, 14, 14, 1, 9, 1, None),
+                                 (128, 8, 14, 14, 2, 9, 1, "4,7,7"), (64, 6, 14, 14, 1, 3, 0, "4,4,14"), (128, 8, 8, 8, 2, 16, 1, "1,2,2")])
+def test_fused_unpool_pack_is_bitwise_the_two_kernel_path(prec, cfg, monkeypatch):
     """vd_unpool_relu_bwd_packed == vd_unpool_relu_bwd followed by vd_pack_dy, bit for bit, for both gradient layouts,
     both pool depths, ragged clip counts (not a multiple of 8) and grids the block does not divide."""
     from video_distillation_amd import engine, hip
-    cout, T, OH, OW, pt, n, layout = cfg
+    cout, T, OH, OW, pt, n, layout, block = cfg
+    if block:           # odd blocks take the one-slot-per-thread kernel, even ones the 2x2-window kernel; partial blocks at the grid edge
+        monkeypatch.setenv("VD_WG_BLOCK", block)
     To, Ho, Wo = T // pt, OH // 2, OW // 2
     op = engine.WgradOp(64 if cout == 128 else 3, cout, T, 2 * OH, 2 * OW, n, prec, "cuda:0")
     assert (op.T, op.OH, op.OW) == (T, OH, OW)

@@ -1081,6 +1081,72 @@ __global__ void unpool_pack_kernel(const float* __restrict__ g, const uint8_t* _
     }
 }
 
+// The same for blocks with even height and width: one thread per 2x2 spatial pool window (box, cb, dt, doh/2, dow/2, nt, n%32)
+// reads the 8 clips' pooled values and arg-max bytes ONCE and writes the window's four slots (4x fewer load instructions;
+// the four stores of a wave's 32 channels are 512 contiguous bytes each).
+__global__ void unpool_pack_win_kernel(const float* __restrict__ g, const uint8_t* __restrict__ amax, int64_t nclips, int N,
+                                       int To, int Ho, int Wo, int pool_t, int T, int OH, int OW, int g_layout,
+                                       int nt, int noh, int now, int S, int CCb, int NT, int nbh, int nbw,
+                                       uint4* __restrict__ hi, uint4* __restrict__ lo, int prec, const float* __restrict__ scale,
+                                       int64_t nthreads) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nthreads) return;
+    const float sc = (scale != nullptr) ? scale[0] : 1.f;
+    const int hw = now >> 1, hh = noh >> 1;
+    int64_t r = i;
+    const int l32 = (int)(r & 31); r >>= 5;
+    const int ntile = (int)(r % NT); r /= NT;
+    const int wc = (int)(r % hw); r /= hw;
+    const int wr = (int)(r % hh); r /= hh;
+    const int dt = (int)(r % nt); r /= nt;
+    const int cb = (int)(r % CCb); r /= CCb;
+    const int box = (int)r;
+    const int bw = box % nbw, bh = (box / nbw) % nbh, bt = box / (nbw * nbh);
+    const int t = bt * nt + dt, oh0 = bh * noh + 2 * wr, ow0 = bw * now + 2 * wc;
+    const int n = ntile * 32 + l32;
+    const int pt = t / pool_t, pr = oh0 >> 1, pc = ow0 >> 1;
+    const bool live = (t < T) && (pt < To) && (pr < Ho) && (pc < Wo);
+    const int jt = (pool_t == 2) ? ((t & 1) << 2) : 0;
+    const int64_t npos = (int64_t)To * Ho * Wo;
+    const int64_t pos = ((int64_t)pt * Ho + pr) * Wo + pc;
+    const int CC = N >> 3, cc = n >> 3, e = n & 7;
+    float gv[8];
+    int code[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t clip = (int64_t)cb * 8 + k;
+        gv[k] = 0.f; code[k] = -1;
+        if (live && clip < nclips) {
+            int64_t gi, ai;
+            if (g_layout == 0) { gi = (clip * N + n) * npos + pos; ai = gi; }
+            else { gi = (clip * npos + pos) * N + n; ai = ((clip * CC + cc) * npos + pos) * 8 + e; }
+            code[k] = (int)amax[ai];
+            gv[k] = g[gi] * sc;
+        }
+    }
+    const int64_t box_base = ((int64_t)box * CCb + cb) * S;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int dr = q >> 1, dc = q & 1;
+        const int pidx = (dt * noh + 2 * wr + dr) * now + 2 * wc + dc;
+        const bool inside = (oh0 + dr < OH) && (ow0 + dc < OW);
+        const int j = jt | (dr << 1) | dc;
+        uint16_t h16[8], l16[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) split16p(prec, (inside && code[k] == j) ? gv[k] : 0.f, h16[k], l16[k]);
+        const int64_t o = ((box_base + (pidx >> 1)) * NT + ntile) * 64 + (pidx & 1) * 32 + l32;
+        uint4 vh, vl;
+        vh.x = h16[0] | ((uint32_t)h16[1] << 16); vh.y = h16[2] | ((uint32_t)h16[3] << 16);
+        vh.z = h16[4] | ((uint32_t)h16[5] << 16); vh.w = h16[6] | ((uint32_t)h16[7] << 16);
+        hi[o] = vh;
+        if (lo != nullptr) {
+            vl.x = l16[0] | ((uint32_t)l16[1] << 16); vl.y = l16[2] | ((uint32_t)l16[3] << 16);
+            vl.z = l16[4] | ((uint32_t)l16[5] << 16); vl.w = l16[6] | ((uint32_t)l16[7] << 16);
+            lo[o] = vl;
+        }
+    }
+}
+
 extern "C" int vd_unpool_relu_bwd_packed(const float* g, const uint8_t* argmax, int64_t nclips, int C, int To, int Ho, int Wo,
                                          int pool_t, int T, int OH, int OW, int g_layout, int nt, int noh, int now,
                                          void* dst_hi, void* dst_lo, int prec, const float* scale, void* stream) {
@@ -1090,6 +1156,13 @@ extern "C" int vd_unpool_relu_bwd_packed(const float* g, const uint8_t* argmax, 
     const int64_t per_plane = (int64_t)nbt * nbh * nbw * CCb * S * NT * 64;
     if (per_plane <= 0) return 0;
     if (!g || !argmax || !dst_hi) return -1;
+    if ((noh & 1) == 0 && (now & 1) == 0) {
+        const int64_t nthreads = per_plane / 4;          // four slots per thread
+        hipLaunchKernelGGL(unpool_pack_win_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           g, argmax, nclips, C, To, Ho, Wo, pool_t, T, OH, OW, g_layout, nt, noh, now, S, CCb, NT, nbh, nbw,
+                           (uint4*)dst_hi, (uint4*)dst_lo, prec, scale, nthreads);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(unpool_pack_kernel, dim3((unsigned)((per_plane + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        g, argmax, nclips, C, To, Ho, Wo, pool_t, T, OH, OW, g_layout, nt, noh, now, S, CCb, NT, nbh, nbw,
                        (uint4*)dst_hi, (uint4*)dst_lo, prec, scale, per_plane);
