@@ -25,4 +25,4 @@ for it in range(2, 5):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print("lanes %s: host issue %.1f ms, total %.1f ms" % (os.environ.get("VD_GM_LANES", "6"), (t1 - t0) * 1e3, (t2 - t0) * 1e3))
+    print("lanes %s: host issue %.1f ms, total %.1f ms" % (os.environ.get("VD_GM_LANES", "8"), (t1 - t0) * 1e3, (t2 - t0) * 1e3))

@@ -662,7 +662,7 @@ class GMTrainer:
             idx = sample_real_indices(it * self.outer_loop + ol, self.pool.counts, self.pool.offsets, self.batch_real, self.classes)
             idx_t = torch.as_tensor(idx, device=dev).reshape(len(self.classes), -1)
             g_img = torch.zeros_like(self.image_syn)
-            nlanes = int(os.environ.get("VD_GM_LANES", "6")) if hasattr(ops, "lane_streams") else 1
+            nlanes = int(os.environ.get("VD_GM_LANES", "8")) if hasattr(ops, "lane_streams") else 1
             if nlanes > 1 and len(self.classes) > 1:
                 # class lanes: class k runs on stream k % nlanes with engine slot k % nlanes; the chains only meet in g_img
                 # (disjoint rows) and in the loss sum
