@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
     constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
     constexpr int H1 = MTW - H0;
     constexpr int AD = 1;                               // x1: A-fragment prefetch distance (K-steps)
-    constexpr int DB = X3 ? 2 : VD_DB_X1;               // B-fragment prefetch distance; (DB+1) % (AD+1) == 0
+    constexpr int DB = X3 ? (TILES <= 2 ? 5 : 2) : VD_DB_X1;   // B-fragment prefetch distance (K steps); x1: (DB+1) % (AD+1) == 0
     static_assert(X3 || (DB + 1) % (AD + 1) == 0, "ring sizes must divide the unroll factor");
     constexpr int LU = (TILES <= 4) ? 14 : 17;   // DMA groups per wave (4 waves x LU x 64 slots >= the plan's patch)
     extern __shared__ __attribute__((aligned(16))) char smem[];
