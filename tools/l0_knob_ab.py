@@ -1,4 +1,4 @@
-"""A/B of conv0_breg_kernel variants selected by VD_L0_KNOB (p.reserved1) on one box: bitwise comparison + timing."""
+"""First-layer forward program (conv0_breg_kernel) stand-alone: time per launch and a bitwise comparison of the features between the runs of one call (tools/lib_ab.sh runs it once per library build, VD_LIB_PATH)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
