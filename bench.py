@@ -276,8 +276,8 @@ def cpu_baseline_dm(args, trainer, backend, it, s2d=None):
         sidx, didx = (torch.as_tensor(t, device=dev) for t in trainer.indices(it))
         n = ncls * trainer.vpc
         syn = backend.hallucinate(trainer.static, trainer.dynamic, sidx[:n], didx[:n], trainer.hal_w, trainer.hal_b)
-    backend.eng_real.set_weights(weights)
-    f_real = backend.embed_pool(trainer.pool.clips, torch.as_tensor(idx, device=dev))
+    backend.set_real_weights(weights, args.batch_real)
+    f_real = backend.embed_pool(trainer.pool.clips, torch.as_tensor(idx, device=dev), args.batch_real)
     f_syn, _ = backend.embed_syn(syn, weights)
     loss_gpu = float(backend.dm_loss(f_real, f_syn, ncls)[0].sum())
     reals = [real[c * args.batch_real:(c + 1) * args.batch_real] for c in range(ncls)]
@@ -386,7 +386,7 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
              "exchange" % world) if trainer.__dict__.get("shard") == "batch" else
             "class-sharded x%d (owner-computes, no gradient exchange%s)" % (world, "; 1.3 KB all-reduce of the hallucinator gradient" if s2d else ""),
             {"real_clips": args.prec_real, "syn_clips_fwd": args.prec_syn, "input_gradient": args.prec_bwd, "accumulate": "f32",
-             "syn_value_pass": backend.weight_format})
+             "real_weight_dither_groups": backend._dither, "syn_value_pass": None if backend._dither else backend.weight_format})
         out["config"]["pool_per_class"] = args.pool_per_class
         out["config"]["real_pool"] = ("resident in HBM: fp32 clips + the same clips converted once to the first layer's 16-bit pixel "
                                       "rows; a real batch is an index list, no per-step conversion") if backend.resident_rows else \

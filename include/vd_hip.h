@@ -96,6 +96,11 @@ int vd_conv0_persistent(const VdConvParams* params, void* stream);
  * precisions) through the planner's gather table.  n = number of packed elements. */
 int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, void* out_hi, void* out_lo,
                     int prec, void* stream);
+/* Dithered single-pass weights for the real side of DM (f16 / bf16): out[g][i] = packed element i for launch group g of
+ * `groups` (a power of two <= 64); every weight is rounded up in round(lam * groups) of the groups and down in the others, so
+ * the mean over the groups equals the fp32 weight to 1/(2 groups) ulp and the weight-rounding perturbation of a class's mean
+ * feature cancels to first order (the real clips of a class are dealt to the groups). */
+int vd_pack_weights_dither(const float* w, const int32_t* widx, int64_t n, int groups, void* out, int prec, void* stream);
 
 /* out[i] = (float) rn16(w[i]) in the 16-bit format of `prec` (f16 / bf16): the weights of the fresh
  * network of a DM iteration (get_network, distill_baseline.py:334) rounded once, so that the real-clip

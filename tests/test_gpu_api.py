@@ -385,18 +385,20 @@ def test_g12_late_regime_dm_run(golden_dir):
     seeds = {it: int(z["net_seed0"]) + it for it in range(steps)}
     pool = types.SimpleNamespace(clips=pool_t.reshape(C * NP, 8, 3, 64, 64).cuda(), counts=[NP] * C, offsets=[0, NP])
 
-    def trainer(mode, value_pass=True):
+    def trainer(mode, dither=True, value_pass=True):
         inner = distill.HipBackend(geo, "cuda:0", **MODES[mode])
+        inner.dither_enabled = dither
         if not value_pass:
             inner.weight_format = None
         return distill.DMTrainer(_FixedNetBackend(inner, seeds), pool, C, 1, B, lr_img=float(z["lr"]), momentum=mu,
                                  image_syn=pool_t[:, 0].clone().cuda())
-    ta, tb, tc = trainer("x3"), trainer("mixed"), trainer("mixed", value_pass=False)
-    assert tb.be.weight_format == "f16" and tc.be.weight_format is None and ta.be.weight_format is None
+    # shipped: dithered real-side weights; the two older remedies for comparison: value pass, nothing
+    ta, tb, tv, tc = trainer("x3"), trainer("mixed"), trainer("mixed", dither=False), trainer("mixed", dither=False, value_pass=False)
+    assert tv.be.weight_format == "f16" and tc.be.weight_format is None and ta.be.weight_format is None
     sub = lambda t: t.cpu()[:, ::2, :, ::4, ::4]       # noqa: E731
     orig = D.sample_real_indices
     rec = {"x3_vs_reference": {"loss": [], "grad": []}, "mixed_vs_x3": {"loss": [], "grad": []},
-           "mixed_novaluepass_vs_x3": {"loss": [], "grad": []}}
+           "mixed_valuepass_vs_x3": {"loss": [], "grad": []}, "mixed_plain_vs_x3": {"loss": [], "grad": []}}
     try:
         for it in range(steps):
             D.sample_real_indices = lambda it_, counts, offsets, b, classes, it=it: np.concatenate(
@@ -406,7 +408,7 @@ def test_g12_late_regime_dm_run(golden_dir):
             ga = ta.buf - mu * state[1] if it > 0 else ta.buf.clone()       # buf = mu*buf + g
             rec["x3_vs_reference"]["loss"].append(abs(la / float(z["losses"][it]) - 1))
             rec["x3_vs_reference"]["grad"].append(_rel(sub(ga), z["grads"][it]))
-            for tr, key in ((tb, "mixed_vs_x3"), (tc, "mixed_novaluepass_vs_x3")):
+            for tr, key in ((tb, "mixed_vs_x3"), (tv, "mixed_valuepass_vs_x3"), (tc, "mixed_plain_vs_x3")):
                 tr.image_syn.copy_(state[0]); tr.buf.copy_(state[1]); tr.steps_done = state[2]
                 lt = float(tr.step(it))
                 gt = tr.buf - mu * state[1] if it > 0 else tr.buf.clone()
@@ -416,14 +418,17 @@ def test_g12_late_regime_dm_run(golden_dir):
         D.sample_real_indices = orig
     rec["feature_diff_over_norm"] = [float(v) for v in z["rel_diff"].mean(1)]
     _record("g12", rec)
-    for k in ("x3_vs_reference", "mixed_vs_x3", "mixed_novaluepass_vs_x3"):
+    assert tb.be.inner._dither == 8 and tv.be.inner._dither == 0
+    for k in ("x3_vs_reference", "mixed_vs_x3", "mixed_valuepass_vs_x3", "mixed_plain_vs_x3"):
         print("G12 %s: max loss rel %.2e, grad rel-l2 max %.2e median %.2e" % (k, max(rec[k]["loss"]), max(rec[k]["grad"]),
                                                                               float(np.median(rec[k]["grad"]))))
     assert max(rec["x3_vs_reference"]["loss"]) < 1e-3
     assert max(rec["x3_vs_reference"]["grad"][:6]) < 1e-3
     assert max(rec["mixed_vs_x3"]["loss"]) < 1e-3
-    assert max(rec["mixed_vs_x3"]["grad"]) < 3e-3
-    assert np.median(rec["mixed_novaluepass_vs_x3"]["grad"]) > 1.5 * np.median(rec["mixed_vs_x3"]["grad"])   # the value pass earns its cost
+    assert max(rec["mixed_vs_x3"]["grad"]) < 2e-3
+    # the dithered weights beat the value pass they replace, which beat doing nothing
+    assert np.median(rec["mixed_valuepass_vs_x3"]["grad"]) > 1.3 * np.median(rec["mixed_vs_x3"]["grad"])
+    assert np.median(rec["mixed_plain_vs_x3"]["grad"]) > 1.5 * np.median(rec["mixed_valuepass_vs_x3"]["grad"])
 
 
 def test_two_gpu_bench_matches_single_gpu_loss():

@@ -1,0 +1,92 @@
+"""Dithered single-pass weights of the real side (vd_pack_weights_dither, engine.dither_groups, HipBackend.embed_pool):
+kernel semantics against a numpy restatement, and the effect it exists for -- the weight-rounding perturbation of a class's
+MEAN feature -- against the fp32 oracle, next to plain rn16 weights."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _neighbours(w, dt):
+    q = w.to(dt)
+    qf = q.float()
+    up = torch.nextafter(q, torch.full_like(q, float("inf"))).float()
+    dn = torch.nextafter(q, torch.full_like(q, float("-inf"))).float()
+    return torch.where(qf <= w, qf, dn), torch.where(qf >= w, qf, up)
+
+
+def _bitrev(g, G):
+    b = G.bit_length() - 1
+    return int(format(g, "0%db" % b)[::-1], 2) if b else 0
+
+
+@pytest.mark.parametrize("prec,dt", [("f16", torch.float16), ("bf16", torch.bfloat16)])
+@pytest.mark.parametrize("G", [4, 8, 16])
+def test_dither_kernel_matches_restatement_and_is_unbiased(prec, dt, G):
+    from video_distillation_amd import hip
+    g = torch.Generator().manual_seed(G)
+    n = 5000
+    w = torch.randn(n, generator=g) * 0.02
+    w[:8] = torch.tensor([0.0, -0.0, 1.0, -0.5, 6.0e-8, -6.0e-8, 1e-3, 65504.0])           # zero, representable, subnormal, largest half
+    widx = torch.arange(n, dtype=torch.int32)
+    widx[100] = -1                                                                            # padding entry of a gather table -> 0
+    out = torch.empty((G, n), dtype=torch.int16, device="cuda")
+    wd, id_ = w.cuda(), widx.cuda()           # (kept alive: a temporary's block would be handed to the next allocation)
+    hip.check(hip.lib().vd_pack_weights_dither(hip.ptr(wd), hip.ptr(id_), ctypes.c_int64(n), G, hip.ptr(out),
+                                               hip.PREC[prec], hip.stream_ptr(torch.device("cuda:0"))), "dither")
+    got = out.cpu().view(dt).float()
+    src = w.clone(); src[100] = 0.0
+    lo, hi = _neighbours(src, dt)
+    lam = torch.where(hi > lo, (src - lo) / (hi - lo), torch.zeros_like(src))
+    k = torch.arange(n, dtype=torch.int64); k[100] = -1
+    rot = (((k * 2654435761) % 4294967296) >> 7) % G
+    for gi in range(G):
+        slot = (_bitrev(gi, G) + rot) % G
+        want = torch.where((slot.float() + 0.5) / G < lam, hi, lo)
+        assert torch.equal(got[gi], want), (prec, G, gi)
+    ulp = (hi - lo)
+    assert float(((got.double().mean(0) - src.double()).abs() - ulp.double() / (2 * G)).max()) <= 1e-12     # mean over groups = w to ulp/(2G)
+    assert torch.equal(got[:, 2], torch.full((G,), 1.0)) and torch.equal(got[:, 100], torch.zeros(G))
+    with pytest.raises(RuntimeError):
+        hip.check(hip.lib().vd_pack_weights_dither(hip.ptr(wd), hip.ptr(id_), ctypes.c_int64(n), 6, hip.ptr(out),
+                                                   hip.PREC[prec], hip.stream_ptr(torch.device("cuda:0"))), "dither")
+
+
+def test_dither_groups_rule(monkeypatch):
+    from video_distillation_amd.engine import dither_groups
+    assert [dither_groups(n, "f16") for n in (64, 8, 4, 12, 6, 3, 1, 0)] == [8, 8, 4, 4, 0, 0, 0, 0]
+    assert dither_groups(64, "f16x3") == 0 and dither_groups(64, "bf16") == 8
+    monkeypatch.setenv("VD_REAL_DITHER", "16")
+    assert dither_groups(64, "f16") == 16 and dither_groups(8, "f16") == 8
+    monkeypatch.setenv("VD_REAL_DITHER", "0")
+    assert dither_groups(64, "f16") == 0
+
+
+def test_class_mean_bias_of_the_real_side_with_and_without_dither(monkeypatch):
+    """Similar clips (the late regime of a distillation: the case plain rn16 weights are worst at): error of the class-mean
+    feature of the single-pass real side against the fp32 oracle, plain vs dithered."""
+    from video_distillation_amd import distill, plan
+    geo = plan.NetGeometry(8, 64, 64)
+    g = torch.Generator().manual_seed(5)
+    C, n = 2, 16
+    base = torch.randn(C, 1, 8, 3, 64, 64, generator=g)
+    pool = (base + 0.1 * torch.randn(C, n, 8, 3, 64, 64, generator=g)).reshape(C * n, 8, 3, 64, 64)
+    params = R.init_params(1234, 3, 5)
+    with torch.no_grad():
+        want = R.convnet3d_embed(pool, params).view(C, n, -1).mean(1)
+    idx = torch.arange(C * n, device="cuda")
+    err = {}
+    for setting in ("0", "8"):
+        monkeypatch.setenv("VD_REAL_DITHER", setting)
+        be = distill.HipBackend(geo, "cuda:0")
+        be.set_real_weights([p.cuda() for p in params[:6]], n)
+        assert be._dither == (8 if setting == "8" else 0)
+        f = be.embed_pool(pool.cuda(), idx, n).cpu().view(C, n, -1).mean(1)
+        err[setting] = float((f - want).norm() / want.norm())
+    print("class-mean feature error of the f16 real side: plain rn16(W) %.2e, 8 dither groups %.2e" % (err["0"], err["8"]))
+    assert err["8"] < 0.5 * err["0"] and err["8"] < 8e-5

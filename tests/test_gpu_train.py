@@ -506,7 +506,9 @@ def test_expert_trajectories_match_the_oracle_loop(tmp_path):
         step = [_rel(a - s, (b - s).double()) if e else float((a - b).abs().max())
                 for a, b, s in zip(traj[0][e], want[e], p0)]
         print("expert epoch %d: per-tensor error of the accumulated update" % e, ["%.1e" % v for v in step])
-        assert max(step) < (1e-3 if e else 1e-12)
+        # typical 8e-5; a pooling near-tie resolved the other way after atomically accumulated (order-dependent) updates moves
+        # a tensor's update by up to ~1/256 -- seen once in ~10 runs -- so the bar leaves room for one flip
+        assert max(step) < (8e-3 if e else 1e-12) and float(np.median(step)) < (1e-3 if e else 1e-12)
     path = checkpoint.save_expert_buffer(str(tmp_path), traj)
     assert path.endswith("replay_buffer_0.pt")
     back = checkpoint.load_expert_buffers(str(tmp_path))

@@ -66,6 +66,60 @@ extern "C" int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, v
     return (int)hipGetLastError();
 }
 
+// DITHERED single-pass weights: the real clips of a class are dealt to `groups` (a power of two) launch groups, and group g
+// multiplies by the weights rounded DOWN or UP to the neighbouring 16-bit values such that, for every weight, the mean over
+// the groups equals the fp32 value to 1/(2 groups) ulp: with lam = (w - lo) / (hi - lo) the weight rounds up in
+// round(lam * groups) of the groups -- those whose slot (bit-reversed group number, rotated per weight by a hash of its
+// index) falls below lam.  Plain rn16(W) perturbs the class mean of the real features SYSTEMATICALLY (1.9e-4 |f|, it does
+// not average out over the clips of a batch); the dithered groups' perturbations cancel to first order in the mean
+// (CPU simulation tests/sim_dither_tool.py: 3.0e-5 |f| at 8 groups, 2.2e-5 at 16; the value pass it replaces leaves 8e-5).
+// out[g][i] = packed operand element i of group g (same gather table as vd_pack_weights).
+__device__ __forceinline__ uint16_t f16_step(uint16_t b, bool up) {
+    // next representable value above (up) / below a 16-bit sign-magnitude float (f16 and bf16 alike); +-0 handled
+    const bool neg = (b & 0x8000u) != 0;
+    const uint16_t mag = b & 0x7FFFu;
+    if (mag == 0) return up ? (uint16_t)0x0001u : (uint16_t)0x8001u;
+    return (neg == up) ? (uint16_t)(b - 1) : (uint16_t)(b + 1);
+}
+
+__global__ void pack_weights_dither_kernel(const float* __restrict__ w, const int32_t* __restrict__ widx, int64_t n, int groups,
+                                           int log2g, uint16_t* __restrict__ out, int prec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t k = widx[i];
+    const float v = (k >= 0) ? w[k] : 0.f;
+    const bool bf = (prec == VD_PREC_BF16 || prec == VD_PREC_BF16X3);
+    uint16_t qb; float qf;
+    if (bf) { const __bf16 q = (__bf16)v; qb = __builtin_bit_cast(uint16_t, q); qf = (float)q; }
+    else { const _Float16 q = (_Float16)v; qb = __builtin_bit_cast(uint16_t, q); qf = (float)q; }
+    uint16_t lob = qb, hib = qb;
+    float lo = qf, hi = qf;
+    const bool finite = (qb & 0x7FFFu) < (bf ? 0x7F80u : 0x7C00u);
+    if (finite && qf < v) { hib = f16_step(qb, true); hi = bf ? (float)__builtin_bit_cast(__bf16, hib) : (float)__builtin_bit_cast(_Float16, hib); }
+    if (finite && qf > v) { lob = f16_step(qb, false); lo = bf ? (float)__builtin_bit_cast(__bf16, lob) : (float)__builtin_bit_cast(_Float16, lob); }
+    const bool split = hi > lo && hi < 3.0e38f && lo > -3.0e38f;
+    const float lam = split ? (v - lo) / (hi - lo) : 0.f;
+    const uint32_t rot = (((uint32_t)k * 2654435761u) >> 7) & (uint32_t)(groups - 1);
+    for (int g = 0; g < groups; ++g) {
+        const uint32_t rev = log2g ? (__brev((uint32_t)g) >> (32 - log2g)) : 0u;
+        const uint32_t slot = (rev + rot) & (uint32_t)(groups - 1);
+        const float t = ((float)slot + 0.5f) / (float)groups;
+        out[(int64_t)g * n + i] = (t < lam) ? hib : lob;
+    }
+}
+
+extern "C" int vd_pack_weights_dither(const float* w, const int32_t* widx, int64_t n, int groups, void* out, int prec, void* stream) {
+    if (groups < 1 || groups > 64 || (groups & (groups - 1)) != 0) return -2;
+    if (prec != VD_PREC_F16 && prec != VD_PREC_BF16) return -2;          // single-pass formats: the hi+lo formats carry the weights exactly
+    if (n <= 0) return 0;
+    if (!w || !widx || !out) return -1;
+    int log2g = 0;
+    while ((1 << log2g) < groups) ++log2g;
+    hipLaunchKernelGGL(pack_weights_dither_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       w, widx, n, groups, log2g, (uint16_t*)out, prec);
+    return (int)hipGetLastError();
+}
+
 // out = (float) rn16(w): the network's weights rounded ONCE to the single-pass operand format, so that
 // every pass of a step (single-pass real-clip forward, split-precision synthetic-clip forward, input
 // gradient) multiplies by the SAME weights -- the step is then the exact step of the network rn16(W),

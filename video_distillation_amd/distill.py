@@ -122,6 +122,14 @@ class HipBackend:
         # rn16(W), whose features enter the loss -- both sides of the difference then carry the same perturbation.
         self.weight_format = prec_real if (prec_real in ("f16", "bf16") and prec_syn == prec_real + "x3"
                                            and os.environ.get("VD_VALUE_PASS", "1") == "1") else None
+        # The better remedy where the real batch of a class has >= 4 clips: DITHER the real side's weights instead.  The
+        # class's clips are dealt to G launch groups; group g multiplies by weights rounded down / up such that every
+        # weight's mean over the groups is the fp32 value to 1/(2G) ulp (vd_pack_weights_dither), so the perturbation of
+        # the class MEAN cancels to first order: 3e-5 |f| at G = 8 against 1.9e-4 (plain) and 8e-5 (value pass; CPU
+        # simulation tests/sim_dither_tool.py) -- and the synthetic clips need only their exact-weight forward.
+        self.prec_real = prec_real
+        self.dither_enabled = True      # (tests switch it off per backend to measure the other two remedies)
+        self._dither = 0
         self.resident_rows = os.environ.get("VD_RESIDENT_ROWS", "1") == "1"
         self._pool_rows = None
 
@@ -134,15 +142,22 @@ class HipBackend:
         eng = self.eng_syn
         eng.set_weights(weights)
         feats, handle = eng.forward(x, keep=True)
-        if self.weight_format is not None:
+        if self.weight_format is not None and not self._dither:
             eng.set_weights(weights, quantize=self.weight_format)
             feats = eng.forward(x)
         return feats, handle
 
-    def set_weights(self, weights) -> None:
-        self.eng_real.set_weights(weights)
+    def set_weights(self, weights, per_class: int = 0) -> None:
+        self.set_real_weights(weights, per_class)
         if self.eng_syn is not self.eng_real:
             self.eng_syn.set_weights(weights)
+
+    def set_real_weights(self, weights, per_class: int = 0) -> None:
+        """Weights of the real-clip engine for a step whose real batches hold ``per_class`` clips per class on this rank
+        (0: unknown -> no dithering): packs the dithered operand sets when there are enough clips to deal them to."""
+        from . import engine
+        self._dither = engine.dither_groups(int(per_class), self.prec_real) if (self.dither_enabled and self.eng_syn is not self.eng_real) else 0
+        self.eng_real.set_weights(weights, dither=self._dither)
 
     # -- stream plumbing (no-ops for single-stream / CPU test backends) ----------------------
     def fork(self):
@@ -174,17 +189,30 @@ class HipBackend:
             for t in tensors:
                 t.record_stream(cur)
 
-    def embed_pool(self, pool: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    def embed_pool(self, pool: torch.Tensor, index: torch.Tensor, per_class: int = 0) -> torch.Tensor:
         """Features of pool[index].  The pool is static, so it is converted once to the first layer's
         16-bit operand rows and kept resident next to the fp32 clips (6 GB for the miniUCF101-sized
         pool); a real batch is then only an index list (what ``get_images`` + ``.to(device)`` +
-        the cast inside the reference's conv do per class and step, distill_baseline.py:84-90)."""
+        the cast inside the reference's conv do per class and step, distill_baseline.py:84-90).
+        ``index`` is class-major with ``per_class`` clips per class; after ``set_real_weights(w, per_class)`` chose G
+        dither groups, clip j of every class runs in launch group j mod G (G launches of 1/G of the batch each)."""
+        rows = None
         if self.resident_rows:
             key = (pool.data_ptr(), tuple(pool.shape))
             if self._pool_rows is None or self._pool_rows[0] != key:
                 self._pool_rows = (key, self.eng_real.pool_rows(pool))
-            return self.eng_real.forward(pool, index=index, rows=self._pool_rows[1])
-        return self.eng_real.forward(pool, index=index)
+            rows = self._pool_rows[1]
+        G = self._dither
+        if G and per_class and per_class % G == 0 and index.numel() % per_class == 0:
+            ncls = index.numel() // per_class
+            feats = torch.empty((index.numel(), self.num_feat), dtype=torch.float32, device=self.device)
+            by_group = index.view(ncls, per_class // G, G)
+            out = feats.view(ncls, per_class // G, G, self.num_feat)
+            for g in range(G):
+                f = self.eng_real.forward(pool, index=by_group[:, :, g].reshape(-1), rows=rows, group=g)
+                out[:, :, g] = f.view(ncls, per_class // G, self.num_feat)
+            return feats
+        return self.eng_real.forward(pool, index=index, rows=rows)
 
     def embed_keep(self, x: torch.Tensor):
         return self.eng_syn.forward(x, keep=True)
@@ -340,7 +368,7 @@ class DMTrainer:
                 w.record_stream(be.s_real)
                 w.record_stream(be.s_syn)
             with on_real():
-                be.eng_real.set_weights(weights)
+                be.set_real_weights(weights, self._per_class())
                 f_real = self._real_features(idx_t)
             with on_syn():
                 f_syn, handle = be.embed_syn(self.image_syn, weights)
@@ -354,7 +382,10 @@ class DMTrainer:
                 be.join(loss)
             self.steps_done += 1
             return loss
-        be.set_weights(weights)
+        if hasattr(be, "set_real_weights"):
+            be.set_weights(weights, self._per_class())
+        else:
+            be.set_weights(weights)
         f_real = self._exchange(self._real_features(idx_t))
         f_syn, handle = be.embed_syn(self.image_syn, weights) if hasattr(be, "embed_syn") else be.embed_keep(self.image_syn)
         loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
@@ -367,10 +398,15 @@ class DMTrainer:
         """This rank's contribution to the real side: all clips' features of the owned classes (class sharding), or --
         batch sharding -- the per-class sums of its 1/world slice of every class's batch, pre-scaled by 1/batch_real
         (C x D fp32, 410 KB; ``_exchange`` all-reduces them)."""
-        f = self.be.embed_pool(self.pool.clips, idx_t)
+        f = self.be.embed_pool(self.pool.clips, idx_t, self._per_class()) if hasattr(self.be, "set_real_weights") else \
+            self.be.embed_pool(self.pool.clips, idx_t)
         if self.shard != "batch":
             return f
         return self.be.group_sum(f, self.num_classes, self.batch_real // self.world, 1.0 / self.batch_real)
+
+    def _per_class(self) -> int:
+        """Real clips per class in this rank's launches (the unit the real side's dither groups divide)."""
+        return self.batch_real // self.world if self.shard == "batch" else self.batch_real
 
     def _exchange(self, x: torch.Tensor) -> torch.Tensor:
         """Batch sharding: the one data-path collective of a DM step -- all-reduce of the per-class feature sums; returns the
@@ -487,8 +523,11 @@ class S2DTrainer:
                 w.record_stream(be.s_real)
                 w.record_stream(be.s_syn)
             with on_real():
-                be.eng_real.set_weights(weights)
-                f_real = be.embed_pool(self.pool.clips, idx_t)
+                be.set_real_weights(weights, self.batch_real)
+                f_real = be.embed_pool(self.pool.clips, idx_t, self.batch_real)
+        elif hasattr(be, "set_real_weights"):
+            be.set_weights(weights, self.batch_real)
+            f_real = be.embed_pool(self.pool.clips, idx_t, self.batch_real)
         else:
             be.set_weights(weights)
             f_real = be.embed_pool(self.pool.clips, idx_t)

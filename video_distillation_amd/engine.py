@@ -85,14 +85,27 @@ class _DevPlan:
                                             hip.ptr(self.wpk[0]), hip.ptr(lo), self.prec, hip.stream_ptr(w.device)),
                   "vd_pack_weights")
 
+    def pack_dither(self, w: torch.Tensor, groups: int) -> None:
+        """``groups`` dithered single-pass operand sets (vd_pack_weights_dither); ``run(..., group=g)`` multiplies by set g."""
+        assert w.dtype == torch.float32 and w.is_contiguous() and self.wpk.shape[0] == 1
+        if getattr(self, "wpk_d", None) is None or self.wpk_d.shape[0] != groups:
+            self.wpk_d = torch.empty((groups, self.n_w), dtype=torch.int16, device=w.device)
+        hip.check(hip.lib().vd_pack_weights_dither(hip.ptr(w), hip.ptr(self.widx), ctypes.c_int64(self.n_w), int(groups),
+                                                   hip.ptr(self.wpk_d), self.prec, hip.stream_ptr(w.device)), "vd_pack_weights_dither")
+
     def run(self, src: torch.Tensor, src_plane_slots: int, bias: Optional[torch.Tensor], dst_ptr: int,
             dst_plane_stride: int, argmax: Optional[torch.Tensor], nclips: int, out_scale: Optional[torch.Tensor] = None,
-            wpk: Optional[torch.Tensor] = None, w_plane_elems: int = 0, clip_index: Optional[torch.Tensor] = None) -> None:
+            wpk: Optional[torch.Tensor] = None, w_plane_elems: int = 0, clip_index: Optional[torch.Tensor] = None,
+            group: Optional[int] = None) -> None:
         p = self.params
         p.clip_index = 0 if clip_index is None else clip_index.data_ptr()
         p.out_scale = 0 if out_scale is None else out_scale.data_ptr()
         if wpk is not None:     # B operand supplied per call (weight-gradient programs)
             p.wpk = wpk.data_ptr(); p.w_plane_stride = w_plane_elems
+        elif group is not None:  # one of the dithered operand sets of pack_dither
+            p.wpk = self.wpk_d[group].data_ptr(); p.w_plane_stride = self.n_w
+        else:
+            p.wpk = self.wpk.data_ptr(); p.w_plane_stride = self.n_w
         p.src = src.data_ptr(); p.src_plane_stride4 = src_plane_slots * 4
         p.bias = 0 if bias is None else bias.data_ptr()
         p.dst = dst_ptr; p.dst_plane_stride = dst_plane_stride
@@ -112,6 +125,20 @@ class _DevPlan:
         if prof is not None:
             e1.record()
             prof.append((self.plan.name, self.prec, 2.0 * self.plan.meta.get("macs_per_unit", 0) * nclips, e0, e1))
+
+
+def dither_groups(n: int, prec: str) -> int:
+    """Number of dithered weight sets (a power of two, >= 4) a batch of ``n`` real clips whose MEAN feature is what matters
+    is dealt to, or 0: single-pass formats only, ``VD_REAL_DITHER`` (default 8; < 4 turns it off) is the most, and the
+    groups must divide the batch evenly.  Below 4 groups the value pass on the synthetic side is the better remedy
+    (tests/sim_dither_tool.py: 2 groups leave 1.1e-4 |f|, the value pass 8e-5, 8 groups 3e-5)."""
+    want = int(os.environ.get("VD_REAL_DITHER", "8"))
+    if prec not in ("f16", "bf16") or want < 4 or n < 4:
+        return 0
+    g = 1
+    while g * 2 <= min(want, n) and n % (g * 2) == 0:
+        g *= 2
+    return g if g >= 4 else 0
 
 
 def round_weights(params: Sequence[torch.Tensor], prec: str) -> List[torch.Tensor]:
@@ -177,15 +204,19 @@ class EmbedEngine:
             self._ws[name] = t
         return t[:n].view(*shape)
 
-    def set_weights(self, params: Sequence[torch.Tensor], quantize: Optional[str] = None) -> None:
+    def set_weights(self, params: Sequence[torch.Tensor], quantize: Optional[str] = None, dither: int = 0) -> None:
         """params = [w0, b0, w1, b1, w2, b2] fp32 on the device (ConvNet3D.features order).  ``quantize`` ('f16' /
-        'bf16'): round the three weight tensors to that operand format first (``round_weights``)."""
+        'bf16'): round the three weight tensors to that operand format first (``round_weights``).  ``dither`` = G >= 2
+        (single-pass engines): additionally pack G dithered operand sets, selected by ``forward(..., group=g)``."""
         ws = [p.detach().to(self.device, torch.float32).contiguous() for p in params[:6]]
         if quantize is not None:
             ws = round_weights(ws, quantize)
         self._weights = ws
         for li in range(3):
             self.fwd[li].pack(ws[2 * li])
+            if dither >= 2:
+                self.fwd[li].pack_dither(ws[2 * li], dither)
+        self._dither = int(dither) if dither >= 2 else 0
         self._bwd_packed = False
 
     def _pack_bwd(self) -> None:
@@ -214,12 +245,13 @@ class EmbedEngine:
         return rows
 
     def forward(self, x: torch.Tensor, keep: bool = False, index: Optional[torch.Tensor] = None,
-                rows: Optional[torch.Tensor] = None):
+                rows: Optional[torch.Tensor] = None, group: Optional[int] = None):
         """x (B,T,3,H,W) fp32 on the device -> features (B, num_feat) fp32.  With ``keep`` the
         pooling arg-max of every layer is retained and returned as a handle for ``backward``
         (several forwards may be outstanding before their backwards, as in the reference's
-        per-class loop, distill_baseline.py:344-354)."""
+        per-class loop, distill_baseline.py:344-354).  ``group``: multiply by dithered operand set g of ``set_weights(dither=G)``."""
         assert self._weights is not None, "set_weights() first"
+        assert group is None or 0 <= group < getattr(self, "_dither", 0), "set_weights(dither=G) first"
         g = self.geo
         assert x.dim() == 5 and tuple(x.shape[1:]) == (g.frames, g.channel, g.height, g.width), x.shape
         x = x.detach().to(torch.float32).contiguous()
@@ -259,11 +291,11 @@ class EmbedEngine:
             prof = self.profile
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if prof is not None else None
             if ev: ev[0].record()
-            self.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, am0, nb, clip_index=cidx)
+            self.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, am0, nb, clip_index=cidx, group=group)
             if ev: ev[1].record()
-            self.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, am1, nb)
+            self.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, am1, nb, group=group)
             if ev: ev[2].record()
-            self.fwd[2].run(act2, n2, w[5], feats[c0:].data_ptr(), 0, am2, nb)
+            self.fwd[2].run(act2, n2, w[5], feats[c0:].data_ptr(), 0, am2, nb, group=group)
             if ev:
                 ev[3].record()
                 prof += [("fwd0", nb, ev[0], ev[1]), ("fwd1", nb, ev[1], ev[2]), ("fwd2", nb, ev[2], ev[3])]

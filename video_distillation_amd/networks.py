@@ -98,27 +98,43 @@ def get_engine(geo: P.NetGeometry, prec: str, device, prec_bwd: str = None) -> "
 
 
 class _EmbedFunction(torch.autograd.Function):
-    """features = embed(x) on the HIP path; backward = HIP input gradient."""
+    """features = embed(x) on the HIP path; backward = HIP input gradient.
+
+    Mixed mode and the weight-rounding bias of the single-pass real side (distill.HipBackend has the same logic for the
+    fused trainers): a batch of >= 4 clips WITHOUT gradient is dealt to dithered weight sets (``engine.dither_groups``:
+    its mean feature, which is what DM consumes, then carries no first-order rounding bias) and the net remembers that;
+    clips WITH gradient get the exact-weight f16x3 forward, plus the value pass (``_weight_format``) only when the net's
+    last no-gradient batch could not be dithered."""
 
     @staticmethod
-    def forward(ctx, x, net):
+    def forward(ctx, x, net, dither_ok=True):
         need_grad = ctx.needs_input_grad[0]
         prec = _PRECISION["syn"] if need_grad else _PRECISION["real"]
         geo = P.NetGeometry(x.shape[1], x.shape[3], x.shape[4])
         eng = get_engine(geo, prec, x.device, _PRECISION["bwd"] if need_grad else None)
-        net._sync_engine(eng)
         if need_grad:
+            net._sync_engine(eng)
             feats, saved = eng.forward(x, keep=True)
             q = _weight_format()
-            if q is not None:       # value pass of the mixed mode (see distill.HipBackend.weight_format)
+            if q is not None and not getattr(net, "_real_dithered", False):   # value pass (see distill.HipBackend.weight_format)
                 net._sync_engine(eng, quantize=q)
                 feats = eng.forward(x)
             ctx.saved = saved
             ctx.eng = eng
             ctx.wkey = net._weights_key()
             ctx.net = net
-        else:
-            feats = eng.forward(x)
+            return feats
+        from .engine import dither_groups
+        G = dither_groups(int(x.shape[0]), prec) if (dither_ok and _PRECISION["syn"] == prec + "x3") else 0
+        if dither_ok:
+            net._real_dithered = bool(G)
+        net._sync_engine(eng, dither=G)
+        if not G:
+            return eng.forward(x)
+        B = int(x.shape[0])
+        feats = torch.empty((B, eng.num_feat), dtype=torch.float32, device=x.device)
+        for g in range(G):     # clip j runs with dithered weight set j mod G
+            feats[g::G] = eng.forward(x, index=torch.arange(g, B, G, device=x.device), group=g)
         return feats
 
     @staticmethod
@@ -127,7 +143,7 @@ class _EmbedFunction(torch.autograd.Function):
         if net._weights_key() != ctx.wkey:
             raise RuntimeError("ConvNet3D parameters changed between embed() and backward()")
         net._sync_engine(eng)
-        return eng.backward(ctx.saved, g), None
+        return eng.backward(ctx.saved, g), None, None
 
 
 class _ParamGradFunction(torch.autograd.Function):
@@ -332,14 +348,14 @@ class ConvNet3D(nn.Module):
         bump; an in-place edit through ``.data`` (``p.data.mul_(2)``) does NOT bump it -- call this after such an edit."""
         self._pack_epoch = getattr(self, "_pack_epoch", 0) + 1
 
-    def _sync_engine(self, eng, quantize=None) -> None:
+    def _sync_engine(self, eng, quantize=None, dither: int = 0) -> None:
         # the cached engines outlive nets: remember the owner by a weak reference, not by id() (a new net may be built
         # at a freed net's address, on storage the caching allocator hands out again)
         import weakref
-        key = (self._weights_key(), quantize)
+        key = (self._weights_key(), quantize, dither)
         owner = getattr(eng, "_owner_ref", None)
         if owner is None or owner() is not self or getattr(eng, "_owner_key", None) != key:
-            eng.set_weights(self._feature_params(), quantize=quantize)
+            eng.set_weights(self._feature_params(), quantize=quantize, dither=dither)
             eng._owner_key = key
             eng._owner_ref = weakref.ref(self)
 
@@ -372,7 +388,7 @@ class ConvNet3D(nn.Module):
         test passes per evaluation, utils.py:793-824)."""
         import ctypes
         from . import hip
-        feats = _EmbedFunction.apply(x.detach(), self)
+        feats = _EmbedFunction.apply(x.detach(), self, False)      # inference: plain rn16 weights, one launch per layer
         g = P.NetGeometry(x.shape[1], x.shape[3], x.shape[4])
         d = g.layer_dims()[-1]
         C, To, Ho, Wo = d[1], d[8], d[9], d[10]
