@@ -70,7 +70,8 @@ typedef struct VdConvParams {
     int32_t mt_valid;             /* NTW = 2: M tiles per box that carry rows (< MW*MTW: the last wave row skips its padding tile); 0 = all */
     int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
-    int32_t reserved1;
+    int32_t w_set_clips;          /* single-pass forward programs: > 0 = the B operand holds several sets, w_plane_stride elements apart; the box's
+                                     first clip / w_set_clips picks the set (dithered real-side weights); 0 = one set */
     int32_t replica_stride;       /* atomic ROWS epilogue: dst += boxes[box][5] * replica_stride floats (weight-gradient programs spread their
                                      boxes over copies of dW so that same-address atomics do not serialise); 0 = one target */
 } VdConvParams;

@@ -90,3 +90,30 @@ def test_class_mean_bias_of_the_real_side_with_and_without_dither(monkeypatch):
         err[setting] = float((f - want).norm() / want.norm())
     print("class-mean feature error of the f16 real side: plain rn16(W) %.2e, 8 dither groups %.2e" % (err["0"], err["8"]))
     assert err["8"] < 0.5 * err["0"] and err["8"] < 8e-5
+
+
+@pytest.mark.parametrize("geom,n", [((8, 64, 64), 8), ((16, 112, 112), 16)])
+def test_one_launch_with_set_selection_equals_one_launch_per_group(geom, n):
+    """EmbedEngine.forward_sets (layers 1 and 2: ONE launch, the operand set picked per box from the clip number) against G
+    separate forwards with ``group=g``: bitwise the same features; resident 16-bit rows and fp32 clips as the source."""
+    from video_distillation_amd import distill, plan
+    geo = plan.NetGeometry(*geom)
+    g = torch.Generator().manual_seed(n)
+    C = 3
+    pool = torch.randn(C * n + 5, geom[0], 3, geom[1], geom[2], generator=g).cuda()
+    params = [p.cuda() for p in R.init_params(77, 3, 5)[:6]]
+    be = distill.HipBackend(geo, "cuda:0")
+    be.set_real_weights(params, n)
+    G = be._dither
+    assert G == 8
+    idx = torch.randperm(C * n + 5, generator=g)[:C * n].cuda()
+    for resident in (True, False):
+        be.resident_rows = resident
+        got = be.embed_pool(pool, idx, n)
+        want = torch.empty_like(got)
+        for gi in range(G):
+            sel = idx.view(C, n // G, G)[:, :, gi].reshape(-1)
+            want.view(C, n // G, G, -1)[:, :, gi] = be.eng_real.forward(pool, index=sel, group=gi).view(C, n // G, -1)
+        assert torch.equal(got, want)
+    plain = be.eng_real.forward(pool, index=idx)
+    assert not torch.equal(plain, got) and float((plain - got).norm() / plain.norm()) < 1e-3

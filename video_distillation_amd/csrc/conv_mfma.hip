@@ -256,7 +256,10 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
         // first B fragments of this chunk: issued before the patch DMA so both latencies overlap
         // (per-box B operands and atomic accumulation exist only in the weight-gradient (MTW 5) and
         //  second-order instantiations: two scalar registers the hot programs do not pay for)
-        const uint4* wp = wbase + (EXT ? (((int64_t)bi * p.w_box_stride) >> 3) : (int64_t)0) + ((int64_t)cc * S * p.NT + wn * NTW) * 64 + lane;
+        // (single-pass programs: w_set_clips > 0 selects one of several operand sets, w_plane_stride apart, by the box's first
+        //  clip -- the dithered weights of the real side, distill.HipBackend.embed_pool)
+        const int64_t wset = (!X3 && !EXT && p.w_set_clips > 0) ? (int64_t)(clip0 / p.w_set_clips) * w_lo : (int64_t)0;
+        const uint4* wp = wbase + wset + (EXT ? (((int64_t)bi * p.w_box_stride) >> 3) : (int64_t)0) + ((int64_t)cc * S * p.NT + wn * NTW) * 64 + lane;
         auto load_b = [&](int s, uint4* bh, uint4* bl) {
             const int sc = (VD_DBG(p) & 16) ? 0 : ((s < S) ? s : S - 1);   // dbg 16: always the same (cached) B fragment
 #pragma unroll

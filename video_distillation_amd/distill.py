@@ -204,14 +204,10 @@ class HipBackend:
             rows = self._pool_rows[1]
         G = self._dither
         if G and per_class and per_class % G == 0 and index.numel() % per_class == 0:
-            ncls = index.numel() // per_class
-            feats = torch.empty((index.numel(), self.num_feat), dtype=torch.float32, device=self.device)
-            by_group = index.view(ncls, per_class // G, G)
-            out = feats.view(ncls, per_class // G, G, self.num_feat)
-            for g in range(G):
-                f = self.eng_real.forward(pool, index=by_group[:, :, g].reshape(-1), rows=rows, group=g)
-                out[:, :, g] = f.view(ncls, per_class // G, self.num_feat)
-            return feats
+            ncls, q = index.numel() // per_class, per_class // G
+            # group-major launch order [g][class][q]: the clips of one weight set are consecutive (EmbedEngine.forward_sets)
+            f = self.eng_real.forward_sets(pool, index.view(ncls, q, G).permute(2, 0, 1).reshape(-1), rows=rows)
+            return f.view(G, ncls, q, self.num_feat).permute(1, 2, 0, 3).reshape(index.numel(), self.num_feat)
         return self.eng_real.forward(pool, index=index, rows=rows)
 
     def embed_keep(self, x: torch.Tensor):

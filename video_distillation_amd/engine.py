@@ -96,14 +96,18 @@ class _DevPlan:
     def run(self, src: torch.Tensor, src_plane_slots: int, bias: Optional[torch.Tensor], dst_ptr: int,
             dst_plane_stride: int, argmax: Optional[torch.Tensor], nclips: int, out_scale: Optional[torch.Tensor] = None,
             wpk: Optional[torch.Tensor] = None, w_plane_elems: int = 0, clip_index: Optional[torch.Tensor] = None,
-            group: Optional[int] = None) -> None:
+            group: Optional[int] = None, set_clips: int = 0) -> None:
         p = self.params
         p.clip_index = 0 if clip_index is None else clip_index.data_ptr()
         p.out_scale = 0 if out_scale is None else out_scale.data_ptr()
+        p.w_set_clips = 0
         if wpk is not None:     # B operand supplied per call (weight-gradient programs)
             p.wpk = wpk.data_ptr(); p.w_plane_stride = w_plane_elems
         elif group is not None:  # one of the dithered operand sets of pack_dither
             p.wpk = self.wpk_d[group].data_ptr(); p.w_plane_stride = self.n_w
+        elif set_clips > 0:      # all dithered sets in one launch: clips [s * set_clips, (s+1) * set_clips) multiply by set s
+            assert set_clips % self.plan.ncl == 0
+            p.wpk = self.wpk_d.data_ptr(); p.w_plane_stride = self.n_w; p.w_set_clips = int(set_clips)
         else:
             p.wpk = self.wpk.data_ptr(); p.w_plane_stride = self.n_w
         p.src = src.data_ptr(); p.src_plane_stride4 = src_plane_slots * 4
@@ -303,6 +307,48 @@ class EmbedEngine:
                 saved.append((c0, nb, am0, am1, am2))
         if keep:
             return feats, saved
+        return feats
+
+    def forward_sets(self, x: torch.Tensor, index: torch.Tensor, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Features of x[index] with the clips in G = ``set_weights(dither=G)`` consecutive blocks of len(index) / G, block s
+        multiplying by dithered operand set s (single-pass engines).  The first layer -- whose kernel keeps its B fragments
+        in registers for a workgroup's whole walk -- runs one launch per block; layers 1 and 2 run ONE launch each and pick
+        the set per box (VdConvParams.w_set_clips)."""
+        G = getattr(self, "_dither", 0)
+        B = int(index.numel())
+        assert G >= 2 and B % G == 0 and self.planes == 1, "set_weights(dither=G) on a single-pass engine first"
+        g = self.geo
+        per = B // G
+        index = index.to(self.device, torch.int64).contiguous()
+        feats = torch.empty((B, self.num_feat), dtype=torch.float32, device=self.device)
+        rowp = P.pix_row_pitch(g.width)
+        per1 = int(np.prod(self.fwd[0].plan.out_shape[:-1]))
+        per2 = int(np.prod(self.fwd[1].plan.out_shape[:-1]))
+        n1, n2 = B * per1, B * per2
+        act1 = self._buf("act1", (1, n1, 8), torch.int16)
+        act2 = self._buf("act2", (1, n2, 8), torch.int16)
+        w = self._weights
+        if rows is None:
+            n_slots0 = B * g.frames * 3 * g.height * (rowp // 8)
+            slots0 = self._buf("slots0", (1, n_slots0, 8), torch.int16)
+            hip.check(hip.lib().vd_pix2rows(hip.ptr(x.detach().to(torch.float32).contiguous()), hip.ptr(index), ctypes.c_int64(B),
+                                            g.frames, g.height, g.width, hip.ptr(slots0[0]), hip.ptr(None), self.prec,
+                                            hip.stream_ptr(self.device)), "vd_pix2rows")
+        for s in range(G):
+            if rows is not None:
+                self.fwd[0].run(rows, int(rows.shape[1]), w[1], act1.data_ptr() + s * per * per1 * 16, n1, None, per,
+                                clip_index=index[s * per:], group=s)
+            else:
+                per0 = g.frames * 3 * g.height * (rowp // 8)
+                self.fwd[0].run(slots0[:, s * per * per0:], n_slots0, w[1], act1.data_ptr() + s * per * per1 * 16, n1, None, per, group=s)
+        for li, (src, n_src, per_src, dst_ptr, n_dst, per_dst_bytes) in enumerate((
+                (act1, n1, per1, act2.data_ptr(), n2, per2 * 16), (act2, n2, per2, feats.data_ptr(), 0, self.num_feat * 4)), start=1):
+            if per % self.fwd[li].plan.ncl == 0:       # a box never spans two sets: one launch
+                self.fwd[li].run(src, n_src, w[2 * li + 1], dst_ptr, n_dst, None, B, set_clips=per)
+            else:
+                for s in range(G):
+                    self.fwd[li].run(src[:, s * per * per_src:], n_src, w[2 * li + 1], dst_ptr + s * per * per_dst_bytes, n_dst, None,
+                                     per, group=s)
         return feats
 
     def backward(self, saved, g_feat: torch.Tensor) -> torch.Tensor:
