@@ -808,11 +808,14 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
 #pragma unroll
     for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
     uint4 breg[S];
-    {
-        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)wn * 64 + lane;
+    // (w_set_clips > 0: several operand sets, w_plane_stride apart, picked by the clip number -- the dithered weights of the real
+    //  side; a workgroup's boxes are consecutive, so it reloads its fragments at most once or twice in its walk)
+    auto load_breg = [&](int set) {
+        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)set * (p.w_plane_stride >> 3) + (int64_t)wn * 64 + lane;
 #pragma unroll
         for (int s = 0; s < S; ++s) breg[s] = wp[(int64_t)s * 128];
-    }
+    };
+    int cur_set = 0;
     const int n = wn * 32 + (lane & 31);
     const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
     const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
@@ -837,10 +840,16 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
         }
     };
     if (b_lo < b_hi) park_next(b_lo);
+    if (p.w_set_clips > 0 && b_lo < b_hi) cur_set = (b_lo / p.nbox) / p.w_set_clips;
+    load_breg(cur_set);
     __syncthreads();                     // tables published, first entries landed
     asm volatile("" ::: "memory");
     for (int b = b_lo; b < b_hi; ++b) {
         const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
+        if (p.w_set_clips > 0) {
+            const int set = clip0 / p.w_set_clips;
+            if (set != cur_set) { cur_set = set; load_breg(set); }
+        }
         // ---- gather entries (parked in LDS during the previous box), then the patch DMA ----
         {
             const uint32_t* csrc = src + (p.clip_index != nullptr ? p.clip_index[clip0] : (int64_t)clip0) * p.src_clip_stride4;

@@ -311,9 +311,9 @@ class EmbedEngine:
 
     def forward_sets(self, x: torch.Tensor, index: torch.Tensor, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Features of x[index] with the clips in G = ``set_weights(dither=G)`` consecutive blocks of len(index) / G, block s
-        multiplying by dithered operand set s (single-pass engines).  The first layer -- whose kernel keeps its B fragments
-        in registers for a workgroup's whole walk -- runs one launch per block; layers 1 and 2 run ONE launch each and pick
-        the set per box (VdConvParams.w_set_clips)."""
+        multiplying by dithered operand set s (single-pass engines): ONE launch per layer, the set picked per box from the clip
+        number (VdConvParams.w_set_clips; the first layer's register-resident-B kernel reloads its fragments when a
+        workgroup's walk crosses into the next block)."""
         G = getattr(self, "_dither", 0)
         B = int(index.numel())
         assert G >= 2 and B % G == 0 and self.planes == 1, "set_weights(dither=G) on a single-pass engine first"
@@ -334,13 +334,19 @@ class EmbedEngine:
             hip.check(hip.lib().vd_pix2rows(hip.ptr(x.detach().to(torch.float32).contiguous()), hip.ptr(index), ctypes.c_int64(B),
                                             g.frames, g.height, g.width, hip.ptr(slots0[0]), hip.ptr(None), self.prec,
                                             hip.stream_ptr(self.device)), "vd_pix2rows")
-        for s in range(G):
+        if self.fwd[0].breg_ok:       # register-resident-B kernel: reloads its fragments when a workgroup's walk crosses into the next set
             if rows is not None:
-                self.fwd[0].run(rows, int(rows.shape[1]), w[1], act1.data_ptr() + s * per * per1 * 16, n1, None, per,
-                                clip_index=index[s * per:], group=s)
+                self.fwd[0].run(rows, int(rows.shape[1]), w[1], act1.data_ptr(), n1, None, B, clip_index=index, set_clips=per)
             else:
-                per0 = g.frames * 3 * g.height * (rowp // 8)
-                self.fwd[0].run(slots0[:, s * per * per0:], n_slots0, w[1], act1.data_ptr() + s * per * per1 * 16, n1, None, per, group=s)
+                self.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, None, B, set_clips=per)
+        else:
+            for s in range(G):
+                if rows is not None:
+                    self.fwd[0].run(rows, int(rows.shape[1]), w[1], act1.data_ptr() + s * per * per1 * 16, n1, None, per,
+                                    clip_index=index[s * per:], group=s)
+                else:
+                    per0 = g.frames * 3 * g.height * (rowp // 8)
+                    self.fwd[0].run(slots0[:, s * per * per0:], n_slots0, w[1], act1.data_ptr() + s * per * per1 * 16, n1, None, per, group=s)
         for li, (src, n_src, per_src, dst_ptr, n_dst, per_dst_bytes) in enumerate((
                 (act1, n1, per1, act2.data_ptr(), n2, per2 * 16), (act2, n2, per2, feats.data_ptr(), 0, self.num_feat * 4)), start=1):
             if per % self.fwd[li].plan.ncl == 0:       # a box never spans two sets: one launch
