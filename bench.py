@@ -633,7 +633,10 @@ def main():
     c_lo, c_hi = distill.class_range(args.classes, rank, world)
     shard = args.shard
     if shard == "auto":
-        shard = "batch" if (world > 1 and args.batch_real % world == 0 and args.method == "dm") else "class"
+        # class blocks (50 -> 7,7,6,...: no data-path collective) beat the balanced batch split (+ one 410 KB all-reduce)
+        # in the single-GPU proxy of a rank's step at every N: 17.0 / 8.9 / 5.0 ms vs 17.1 / 8.7 / 5.3 ms at N = 2 / 4 / 8
+        # (tools/rank_proxy.py; the exchange is not even in those numbers) -- `--shard batch` remains available
+        shard = "class"
     if shard == "batch":   # every rank holds the whole pool (11 GB) and embeds its slice of each class batch
         pool = distill.RealPool.synthetic(args.classes, list(range(args.classes)), args.pool_per_class, geo, device, seed=1234)
     else:
