@@ -264,6 +264,12 @@ int vd_program_build(int layer, int frames, int height, int width, int prec, int
  * (parity_class = ph * 2 + pw) writing fp32 [t][h][w][cin].  Source of all: dense dy slots (vd_unpool_relu_bwd). */
 int vd_program_build_dgrad(int layer, int parity_class, int frames, int height, int width, int batch_hint, void** blob,
                            int64_t* nbytes);
+/* The weight-gradient program of ConvNet3D level `layer` for batches of `nclips` clips whose operands have `planes` 16-bit
+ * planes (1: f16 / bf16, 2: the hi+lo formats) -- plan.plan_wgrad in C++ (byte-identical blob, tests/test_cplanner.py).
+ * block3 receives the block of positions (nt, noh, now) vd_pack_dy / vd_unpool_relu_bwd_packed must pack dy for, *replicas
+ * the number of accumulation copies ([copy][cin*147][cout] fp32, VdConvParams.replica_stride) vd_replica_sum folds into dW. */
+int vd_program_build_wgrad(int layer, int frames, int height, int width, int nclips, int planes, void** blob, int64_t* nbytes,
+                           int* block3, int* replicas);
 void vd_blob_free(void* blob);
 
 /* ---- ConvNet3D.embed (networks.py:747-751) as one handle: nothing but this header, the library and device pointers.
@@ -341,6 +347,13 @@ int vd_program_run(VdProgram* prog, const void* src, int64_t src_plane_slots, co
 int vd_program_run_scaled(VdProgram* prog, const void* src, int64_t src_plane_slots, const float* bias, void* dst,
                           int64_t dst_plane_stride, uint8_t* argmax, const int64_t* clip_index, int nclips,
                           const float* out_scale, void* stream);
+/* Run a weight-gradient program (vd_program_build_wgrad + vd_program_load): source = x in the clip-minor layout of
+ * vd_clip_minor_cl / _pix, B operand = the packed dy of vd_pack_dy / vd_unpool_relu_bwd_packed for the program's block,
+ * `copies` = [replicas][cin*147][cout] fp32 zeroed by the caller (copy_elems = cin*147*cout), accumulated into with fp32
+ * atomics and folded into dW by vd_replica_sum.  out_scale: device float multiplied into the result (NULL = 1). */
+int vd_program_run_wgrad(VdProgram* prog, const void* x_clip_minor, int64_t x_plane_slots, const void* packed_dy,
+                         int64_t packed_plane_elems, float* copies, int64_t copy_elems, int cin, const float* out_scale,
+                         void* stream);
 int64_t vd_program_info(const VdProgram* prog, int what);
 void vd_program_free(VdProgram* prog);
 

@@ -68,3 +68,33 @@ def test_cpp_planner_emits_the_python_planner_s_input_gradient_programs(dims, hi
             assert got == want, "dgrad layer %d class %d differs" % (layer, cls)
         blob, n = ctypes.c_void_p(), ctypes.c_int64()
         assert lib.vd_program_build_dgrad(layer, len(net["bwd"][layer]), geo.frames, geo.height, geo.width, 0, ctypes.byref(blob), ctypes.byref(n)) == -3
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libvd_hip.so not built")
+@pytest.mark.parametrize("dims,nclips,planes", [((16, 112, 112), 64, 2), ((16, 112, 112), 64, 1), ((16, 112, 112), 5, 2), ((8, 64, 64), 256, 2),
+                                                ((8, 64, 64), 50, 1), ((8, 80, 96), 7, 2), ((4, 64, 64), 3, 1)])
+def test_cpp_planner_emits_the_python_planner_s_weight_gradient_programs(dims, nclips, planes):
+    """vd_program_build_wgrad == plan.plan_wgrad: the same block of positions, the same accumulation copies, byte-identical
+    serialised programs, for every layer of the benchmark geometries and an odd one, both operand-plane counts, batch sizes
+    from a ragged handful to 256."""
+    lib = ctypes.CDLL(LIB)
+    lib.vd_blob_free.restype = None
+    geo = plan.NetGeometry(*dims)
+    for layer, (cin, cout, t, h, w) in enumerate([d[:5] for d in geo.layer_dims()]):
+        pl = plan.plan_wgrad("wgrad%dx%d" % (cin, cout), cin, cout, t, h, w, nclips, planes=planes)
+        want = plan.export_program(pl)
+        blob, n = ctypes.c_void_p(), ctypes.c_int64()
+        block, reps = (ctypes.c_int * 3)(), ctypes.c_int()
+        rc = lib.vd_program_build_wgrad(layer, geo.frames, geo.height, geo.width, nclips, planes, ctypes.byref(blob), ctypes.byref(n),
+                                        block, ctypes.byref(reps))
+        assert rc == 0, rc
+        try:
+            got = ctypes.string_at(blob, n.value)
+        finally:
+            lib.vd_blob_free(blob)
+        assert tuple(block) == tuple(pl.meta["box"]) and reps.value == pl.meta["replicas"], (layer, tuple(block), pl.meta["box"])
+        assert len(got) == len(want) and got == want, "layer %d differs" % layer
+    blob, n, block, reps = ctypes.c_void_p(), ctypes.c_int64(), (ctypes.c_int * 3)(), ctypes.c_int()
+    assert lib.vd_program_build_wgrad(3, 16, 112, 112, 8, 1, ctypes.byref(blob), ctypes.byref(n), block, ctypes.byref(reps)) == -1
+    assert lib.vd_program_build_wgrad(0, 16, 112, 112, 0, 1, ctypes.byref(blob), ctypes.byref(n), block, ctypes.byref(reps)) == -2
+    assert lib.vd_program_build_wgrad(0, 16, 112, 112, 8, 3, ctypes.byref(blob), ctypes.byref(n), block, ctypes.byref(reps)) == -2

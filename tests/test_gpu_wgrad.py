@@ -85,3 +85,68 @@ def test_fused_unpool_pack_is_bitwise_the_two_kernel_path(prec, cfg, monkeypatch
     torch.cuda.synchronize()
     assert torch.equal(op.bp, want)
     assert int((want != 0).sum()) > 0
+
+
+@pytest.mark.parametrize("layer,n,prec", [(1, 11, "f16x3"), (0, 9, "f16"), (2, 50, "bf16x3")])
+def test_weight_gradient_through_the_c_abi_alone(layer, n, prec):
+    """vd_program_build_wgrad (C++ planner) -> vd_program_load -> vd_clip_minor_* / vd_pack_dy -> vd_program_run_wgrad ->
+    vd_replica_sum: the weight gradient of a layer without the Python planner or engine, against engine.WgradOp (same
+    program, so equal to the atomics' summation order) and against autograd."""
+    from video_distillation_amd import engine, hip, plan
+    geo = plan.NetGeometry(8, 64, 64)
+    cin, cout, t, h, w = geo.layer_dims()[layer][:5]
+    g = torch.Generator().manual_seed(layer + n)
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    wgt = torch.zeros(cout, cin, 3, 7, 7, dtype=torch.double, requires_grad=True)
+    y = F.conv3d(x.double(), wgt, None, stride=(1, 2, 2), padding=(1, 3, 3))
+    dy = torch.randn(y.shape, generator=g)
+    (want,) = torch.autograd.grad(y, wgt, dy.double())
+    planes = 2 if prec.endswith("x3") else 1
+    L, st, dev = hip.lib(), hip.stream_ptr(torch.device("cuda:0")), "cuda:0"
+    blob, nb, block, reps = ctypes.c_void_p(), ctypes.c_int64(), (ctypes.c_int * 3)(), ctypes.c_int()
+    hip.check(L.vd_program_build_wgrad(layer, 8, 64, 64, n, planes, ctypes.byref(blob), ctypes.byref(nb), block, ctypes.byref(reps)), "build")
+    prog = ctypes.c_void_p()
+    hip.check(L.vd_program_load(blob, nb, hip.PREC[prec], ctypes.byref(prog)), "load")
+    L.vd_blob_free(blob)
+    try:
+        T, OH, OW = y.shape[2:]
+        CCb, npos = (n + 7) // 8, t * h * w
+        xT = torch.empty((planes, cin * CCb * npos, 8), dtype=torch.int16, device=dev)
+        if layer == 0:
+            xs = x.permute(0, 2, 1, 3, 4).contiguous().cuda()
+            hip.check(L.vd_clip_minor_pix(hip.ptr(xs), ctypes.c_int64(n), t, h, w, hip.ptr(xT[0]), hip.ptr(xT[1] if planes == 2 else None),
+                                          hip.PREC[prec], st), "clip_minor_pix")
+        else:
+            xs = _slots_from_dense(x, prec, planes).cuda()
+            hip.check(L.vd_clip_minor_cl(hip.ptr(xs), ctypes.c_int64(xs[0].numel() // 8), planes, ctypes.c_int64(n), cin, ctypes.c_int64(npos),
+                                         hip.ptr(xT), ctypes.c_int64(xT.shape[1]), st), "clip_minor_cl")
+        dys = _slots_from_dense(dy, prec, planes).cuda()
+        nt, noh, now = block
+        S = nt * noh * now // 2
+        nbox = -(-T // nt) * -(-OH // noh) * -(-OW // now)
+        bp_elems = nbox * CCb * S * (cout // 32) * 64 * 8
+        bp = torch.empty((planes, bp_elems), dtype=torch.int16, device=dev)
+        hip.check(L.vd_pack_dy(hip.ptr(dys), ctypes.c_int64(dys[0].numel() // 8), planes, ctypes.c_int64(n), cout, T, OH, OW, nt, noh, now,
+                               hip.ptr(bp), ctypes.c_int64(bp_elems), st), "pack_dy")
+        copies = torch.zeros((reps.value, cin * 147, cout), dtype=torch.float32, device=dev)
+        hip.check(L.vd_program_run_wgrad(prog, hip.ptr(xT), ctypes.c_int64(xT.shape[1]), hip.ptr(bp), ctypes.c_int64(bp_elems), hip.ptr(copies),
+                                         ctypes.c_int64(cin * 147 * cout), cin, None, st), "run_wgrad")
+        dw = torch.zeros(cout, cin, 3, 7, 7, device=dev)
+        hip.check(L.vd_replica_sum(hip.ptr(copies), reps.value, cin * 147, cout, hip.ptr(dw), st), "replica_sum")
+        torch.cuda.synchronize()
+        assert L.vd_program_run_wgrad(prog, hip.ptr(xT), ctypes.c_int64(xT.shape[1]), hip.ptr(bp), ctypes.c_int64(bp_elems), hip.ptr(copies),
+                                      ctypes.c_int64(7), cin, None, st) == -2          # wrong size of the accumulation copies
+    finally:
+        L.vd_program_free(prog)
+    op = engine.WgradOp(cin, cout, t, h, w, n, prec, dev)
+    assert tuple(op.plan.meta["box"]) == tuple(block) and op.replicas == reps.value
+    ref = torch.zeros_like(dw)
+    if layer == 0:
+        op.run(xs, True, 0, dys, int(dys[0].numel() // 8), ref)
+    else:
+        op.run(xs, False, int(xs[0].numel() // 8), dys, int(dys[0].numel() // 8), ref)
+    torch.cuda.synchronize()
+    same = float((dw - ref).norm() / ref.norm())
+    err = float((dw.double().cpu() - want).norm() / want.norm())
+    print("C-ABI wgrad layer %d %s: vs engine %.1e, vs autograd %.1e" % (layer, prec, same, err))
+    assert same < 1e-6 and err < (2e-3 if prec == "f16" else 1e-4)

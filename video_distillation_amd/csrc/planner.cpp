@@ -50,6 +50,8 @@ struct Plan {
     int w_step4 = 4, row_pitch4 = 0;
     int64_t clip_stride4 = 0, chunk_stride4 = 0;
     int NTW = 1;
+    int atomic = 0;                    // EPI_ROWS: accumulate with fp32 atomics (weight-gradient programs)
+    int64_t w_box_stride = 0;          // per-box B operand (packed dy), elements
     int64_t rows_total = 0;
     std::vector<int32_t> col_off;      // EPI_ROWS: element offset of output column n (empty: n * n_stride)
     int nbox() const { return (int)boxes.size(); }
@@ -649,6 +651,96 @@ bool plan_layer(int layer, int frames, int height, int width, int prec, int batc
     return true;
 }
 
+// plan._plan_wgrad: weight gradient of Conv3d(cin->cout, k(3,7,7), s(1,2,2), p(1,3,3)) as a tile program with the operand
+// roles rotated -- a program "clip" is an input channel, its 147 output rows the taps, K runs over (position of a block) x
+// (8 clips per slot); boxes of positions accumulate, fp32 atomics, into [copy][cin][tap][cout] scratch.
+void plan_wgrad_block(int cin, int cout, int t_in, int h_in, int w_in, int nclips, int lds_budget, int bt0, int bh0, int bw0, Plan& pl) {
+    const int T = conv_out_dim(t_in, KT, 1, 1), OH = conv_out_dim(h_in, KH, 2, 3), OW = conv_out_dim(w_in, KW, 2, 3);
+    int nt = std::min(bt0, T), noh = std::min(bh0, OH), now = std::min(bw0, OW);
+    if ((nt * noh * now) % 2) now += 1;
+    const int CCb = (nclips + 7) / 8, NT = cout / 32, MTW = 5;
+    const int pf = nt + 2, ph = 2 * (noh - 1) + 7, pw = 2 * (now - 1) + 7;
+    std::vector<std::array<int, 3>> positions;
+    for (int dt = 0; dt < nt; ++dt) for (int doh = 0; doh < noh; ++doh) for (int dow = 0; dow < now; ++dow) positions.push_back({dt, doh, dow});
+    const int S = (int)positions.size() / 2;
+    const int ntaps = KT * KH * KW;
+    bool have = false;
+    double best_cyc = 0.0; int best_pc = 0;
+    BoxType best;
+    for (int dph = 0; dph < 16; ++dph) {
+        const int pitch_h = pw + dph;
+        for (int dpf = 0; dpf < 16; ++dpf) {
+            const int pitch_f = ph * pitch_h + dpf, pitch_c = pf * pitch_f;
+            if ((double)pitch_c > lds_budget * 1.12 && have) continue;
+            std::vector<int64_t> a_off((size_t)MTW * 32, 0);
+            int r = 0;
+            for (int kt = 0; kt < KT; ++kt) for (int kh = 0; kh < KH; ++kh) for (int kw = 0; kw < KW; ++kw) a_off[r++] = (int64_t)kt * pitch_f + kh * pitch_h + kw;
+            double cyc = 0.0;
+            for (int t = 0; t < MTW; ++t) cyc += conflict_cycles(a_off.data() + t * 32);
+            cyc /= MTW;
+            const double rc = std::nearbyint(cyc * 1000.0) / 1000.0;          // Python round(cyc, 3) (half-even, like nearbyint's default mode)
+            if (!have || rc < best_cyc || (rc == best_cyc && pitch_c < best_pc)) {
+                have = true; best_cyc = rc; best_pc = pitch_c;
+                best = BoxType();
+                best.pf = pf; best.ph = ph; best.pw = pw; best.pitch_h = pitch_h; best.pitch_f = pitch_f; best.pitch_c = pitch_c; best.mt = MTW;
+                best.cyc = cyc;
+                best.a_off.resize((size_t)MTW * 32); best.out.assign((size_t)MTW * 32, -1);
+                for (int i = 0; i < MTW * 32; ++i) best.a_off[i] = (int32_t)(a_off[i] * 16);
+                for (int i = 0; i < ntaps; ++i) best.out[i] = i * cout;
+                best.tap_off.resize(positions.size());
+                for (size_t i = 0; i < positions.size(); ++i)
+                    best.tap_off[i] = (int32_t)(((int64_t)positions[i][0] * pitch_f + 2 * positions[i][1] * pitch_h + 2 * positions[i][2]) * 16);
+            }
+            if (cyc <= 4.0 + 1e-9) break;
+        }
+        if (best_cyc <= 4.0 + 1e-9) break;
+    }
+    pl = Plan();
+    pl.types.push_back(best);
+    for (int t0 = 0; t0 < T; t0 += nt) for (int oh0 = 0; oh0 < OH; oh0 += noh) for (int ow0 = 0; ow0 < OW; ow0 += now)
+        pl.boxes.push_back({0, (int64_t)t0 - 1, (int64_t)2 * oh0 - 3, (int64_t)2 * ow0 - 3, 0, 0});
+    const int replicas = std::max(1, std::min(16, pl.nbox() / 28));
+    for (int bi = 0; bi < pl.nbox(); ++bi) pl.boxes[bi][5] = bi % replicas;
+    pl.CC = CCb; pl.F = t_in; pl.H = h_in; pl.W = w_in; pl.row_pitch4 = w_in * 4; pl.w_step4 = 4;
+    pl.chunk_stride4 = (int64_t)t_in * h_in * w_in * 4; pl.clip_stride4 = (int64_t)CCb * t_in * h_in * w_in * 4;
+    pl.NT = NT; pl.MW = 1; pl.MTW = MTW; pl.S = S; pl.ncl = 1; pl.NTW = 1;
+    pl.epi = EPI_ROWS; pl.pool_t = 0; pl.relu = 0; pl.n_out = cout; pl.n_stride = 1;
+    pl.out_clip_stride = (int64_t)ntaps * cout; pl.out_chunk_stride = 0; pl.out_t_stride = 0;
+    pl.atomic = 1; pl.w_box_stride = (int64_t)CCb * S * NT * 64 * 8;
+    pl.rows_total = (int64_t)pl.nbox() * MTW * 32;
+}
+
+// plan.plan_wgrad: the block of positions with the fewest K steps (incl. padding of partial blocks) per resident wave
+bool plan_wgrad(int cin, int cout, int t_in, int h_in, int w_in, int nclips, int planes, Plan& out, int block[3], int& replicas) {
+    static const int BLOCKS[12][3] = {{8, 4, 4}, {4, 4, 14}, {8, 2, 14}, {4, 7, 7}, {2, 7, 14}, {4, 2, 14}, {2, 4, 14}, {4, 4, 4},
+                                      {2, 2, 14}, {1, 4, 14}, {2, 4, 4}, {1, 2, 14}};
+    const int lds_budget = 3700, wg_waves = cout / 32, want = nclips > 8 ? 6 : 4;
+    bool have = false;
+    double best_score = 0.0; int best_nbox = 0, best_S = 0;
+    for (const auto& b : BLOCKS) {
+        Plan pl;
+        plan_wgrad_block(cin, cout, t_in, h_in, w_in, nclips, lds_budget, b[0], b[1], b[2], pl);
+        const BoxType& bt = pl.types[0];
+        const int64_t groups = cdiv(bt.pitch_c, 64);
+        if (bt.pitch_c > lds_budget || groups > (int64_t)wg_waves * 17) continue;
+        const int64_t lds = (int64_t)planes * bt.pitch_c * 16 + 2048;
+        const int64_t resident = std::min<int64_t>(std::min<int64_t>(8, (160 * 1024 / lds) * wg_waves), (int64_t)cin * pl.nbox() * wg_waves / 256);
+        const double score = (double)((int64_t)pl.nbox() * pl.S) / (double)std::max<int64_t>(1, std::min<int64_t>(resident, want));
+        const bool better = !have || score < best_score || (score == best_score && (pl.nbox() < best_nbox || (pl.nbox() == best_nbox && -pl.S < -best_S)));
+        if (better) {
+            have = true; best_score = score; best_nbox = pl.nbox(); best_S = pl.S;
+            out = pl;
+            const int T = conv_out_dim(t_in, KT, 1, 1), OH = conv_out_dim(h_in, KH, 2, 3), OW = conv_out_dim(w_in, KW, 2, 3);
+            block[0] = std::min(b[0], T); block[1] = std::min(b[1], OH); block[2] = std::min(b[2], OW);
+            if ((block[0] * block[1] * block[2]) % 2) block[2] += 1;
+        }
+    }
+    if (!have) return false;
+    replicas = 1;
+    for (int bi = 0; bi < out.nbox(); ++bi) replicas = std::max(replicas, (int)out.boxes[bi][5] + 1);
+    return true;
+}
+
 // plan.export_program: 40 int64 header words + int32 arrays type_desc | tables | boxes | gather | widx | col_off
 std::vector<uint8_t> export_program(const Plan& pl, int persist) {
     std::vector<int32_t> desc, tables;
@@ -673,6 +765,7 @@ std::vector<uint8_t> export_program(const Plan& pl, int persist) {
         boxes[(size_t)bi * 8 + 2] = desc[(size_t)ty * 16 + 9];
         boxes[(size_t)bi * 8 + 3] = (int32_t)pl.boxes[bi][4];
         boxes[(size_t)bi * 8 + 4] = ty;
+        boxes[(size_t)bi * 8 + 5] = (int32_t)pl.boxes[bi][5];      // copy of the accumulation target (weight-gradient programs)
     }
     // gather table: for every LDS slot of a box's patch the source slot it is filled from (dword offset inside the
     // (clip, chunk) block, box-local clip index in bits 24..30); -1 = zero fill
@@ -698,7 +791,7 @@ std::vector<uint8_t> export_program(const Plan& pl, int persist) {
     memcpy(&h[0], "VDPROG01", 8);
     const int64_t head[27] = {pl.CC, pl.S, pl.NT, pl.MW, pl.MTW, pl.NTW, pl.epi, pl.pool_t, pl.relu, pl.n_out, pl.n_stride,
                               pl.out_clip_stride, pl.out_chunk_stride, pl.out_t_stride, gstride * 16, (int64_t)pl.types.size(),
-                              desc[7], desc[8], desc[9], 0, 0, pl.ncl, nbox, gstride, pl.clip_stride4, pl.chunk_stride4,
+                              desc[7], desc[8], desc[9], pl.atomic, pl.w_box_stride, pl.ncl, nbox, gstride, pl.clip_stride4, pl.chunk_stride4,
                               (pl.NTW == 2 && mt_max < pl.MW * pl.MTW) ? mt_max : 0};
     memcpy(&h[1], head, sizeof(head));
     const int64_t sizes[7] = {(int64_t)desc.size(), (int64_t)tables.size(), (int64_t)boxes.size(), (int64_t)gt.size(),
@@ -737,6 +830,24 @@ extern "C" int vd_program_build_dgrad(int layer, int parity_class, int frames, i
     if (frames < 2 || height < 16 || width < 16) return -2;
     Plan pl;
     if (!plan_dgrad_layer(layer, parity_class, frames, height, width, batch_hint, pl)) return -3;
+    const std::vector<uint8_t> b = export_program(pl, 4);
+    void* out = malloc(b.size());
+    if (out == nullptr) return -5;
+    memcpy(out, b.data(), b.size());
+    *blob = out;
+    *nbytes = (int64_t)b.size();
+    return 0;
+}
+
+extern "C" int vd_program_build_wgrad(int layer, int frames, int height, int width, int nclips, int planes, void** blob,
+                                      int64_t* nbytes, int* block3, int* replicas) {
+    if (blob == nullptr || nbytes == nullptr || block3 == nullptr || replicas == nullptr || layer < 0 || layer > 2) return -1;
+    if (frames < 2 || height < 16 || width < 16 || nclips < 1 || planes < 1 || planes > 2) return -2;
+    int cin, t, h, w;
+    layer_input(layer, frames, height, width, cin, t, h, w);
+    const int cout = layer == 0 ? 64 : 128;
+    Plan pl;
+    if (!plan_wgrad(cin, cout, t, h, w, nclips, planes, pl, block3, *replicas)) return -3;
     const std::vector<uint8_t> b = export_program(pl, 4);
     void* out = malloc(b.size());
     if (out == nullptr) return -5;

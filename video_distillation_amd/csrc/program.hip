@@ -108,6 +108,23 @@ extern "C" int vd_program_run_scaled(VdProgram* g, const void* src, int64_t src_
     return breg ? vd_conv0_breg(&p, stream) : vd_conv_mfma(&p, stream);
 }
 
+// A weight-gradient program (vd_program_build_wgrad): x re-laid out clip-minor (vd_clip_minor_cl / _pix) is the source, the
+// packed dy of the program's blocks (vd_pack_dy / vd_unpool_relu_bwd_packed) the per-call B operand, and the boxes ACCUMULATE
+// (fp32 atomics) into `copies` = [replicas][cin*147][cout] floats, zeroed by the caller and folded into dW by vd_replica_sum.
+extern "C" int vd_program_run_wgrad(VdProgram* g, const void* x_clip_minor, int64_t x_plane_slots, const void* packed_dy,
+                                    int64_t packed_plane_elems, float* copies, int64_t copy_elems, int cin, const float* out_scale,
+                                    void* stream) {
+    if (g == nullptr || x_clip_minor == nullptr || packed_dy == nullptr || copies == nullptr || cin <= 0) return -1;
+    if (!g->p.atomic || g->p.w_box_stride == 0 || g->p.epi != VD_EPI_ROWS) return -2;      // not a weight-gradient program
+    if (copy_elems != (int64_t)cin * g->p.out_clip_stride || copy_elems > 0x7fffffff) return -2;
+    VdConvParams p = g->p;
+    p.src = x_clip_minor; p.src_plane_stride4 = x_plane_slots * 4;
+    p.wpk = packed_dy; p.w_plane_stride = packed_plane_elems;
+    p.bias = nullptr; p.dst = copies; p.dst_plane_stride = 0; p.replica_stride = (int32_t)copy_elems;
+    p.argmax = nullptr; p.clip_index = nullptr; p.nclips = cin; p.out_scale = out_scale;
+    return vd_conv_mfma(&p, stream);
+}
+
 extern "C" int64_t vd_program_info(const VdProgram* g, int what) {
     if (g == nullptr) return -1;
     switch (what) {
