@@ -357,6 +357,24 @@ int vd_program_run_wgrad(VdProgram* prog, const void* x_clip_minor, int64_t x_pl
 int64_t vd_program_info(const VdProgram* prog, int what);
 void vd_program_free(VdProgram* prog);
 
+/* ---- One evaluate_synset training step (utils.py:765-792, 852-853) behind one handle, no Python ---------------------------
+ * forward with kept activations, classifier head (AvgPool3d, dropout mask, 1x1x1 conv, max over frames), CrossEntropyLoss,
+ * backward (bias / weight / input gradients per level) and torch.optim.SGD(momentum, weight_decay) on the 8 parameter tensors.
+ * prec / prec_bwd: operand formats of the forward and the gradient passes (same 16-bit family; the gradient passes read the
+ * forward's kept activations, so prec_bwd may not have more planes than prec).  nclips is fixed at creation (the programs are
+ * planned for it).  The caller owns all tensors and the workspace (vd_train_workspace_bytes).
+ * vd_train_step: params[8] / momentum[8] device fp32 in parameters() order, updated in place; `first` != 0 initialises the
+ * momentum buffers with the gradient (SGD's first step); clips (nclips, T, 3, H, W) already standardised (vd_standardize);
+ * labels int64; dropout_mask (nclips, 128, T') of 0 or 1/(1-p), or NULL; loss_per_clip (nclips) / logits (nclips, K) optional.
+ * Errors: -1 arguments, -2 precisions do not combine, -7 workspace too small, -9 runtime. */
+typedef struct VdTrain VdTrain;
+int vd_train_create(int frames, int height, int width, int num_classes, int prec, int prec_bwd, int64_t nclips, VdTrain** out);
+int64_t vd_train_workspace_bytes(const VdTrain* t);
+int vd_train_step(VdTrain* t, float* const* params, float* const* momentum, const float* clips, const int64_t* labels,
+                  const float* dropout_mask, float lr, float momentum_coef, float weight_decay, int first, void* workspace,
+                  int64_t workspace_bytes, float* loss_per_clip, float* logits, void* stream);
+void vd_train_free(VdTrain* t);
+
 #ifdef __cplusplus
 }
 #endif

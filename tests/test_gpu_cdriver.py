@@ -101,3 +101,65 @@ def test_c_driver_dm_class_term_forward_backward_sgd(tmp_path):
     assert rel_l < 1e-3 and rel_g < 2e-3
     want_after, _ = R.sgd_momentum_step(syn, grad, None, 0.5, 0.5)                  # first step: buf = g
     np.testing.assert_allclose(syn_after.numpy(), want_after.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("geom,B,K,prec,prec_bwd", [((8, 64, 64), 6, 5, "f16x3", "f16x3"), ((8, 64, 64), 9, 4, "f16x3", "f16"),
+                                                   ((16, 112, 112), 4, 3, "bf16x3", "bf16x3")])
+def test_training_step_through_the_c_handle(geom, B, K, prec, prec_bwd):
+    """vd_train_create / vd_train_step (planners, programs, head, loss, gradients, SGD -- all behind the C ABI) against
+    ConvNet3D.hip_train_step for two consecutive steps (momentum, weight decay): per-clip losses, logits and the 8 updated
+    parameter tensors."""
+    import ctypes
+    import torch
+    from video_distillation_amd import hip, networks
+    T, H, W = geom
+    g = torch.Generator().manual_seed(B * 10 + K)
+    x = torch.randn(B, T, 3, H, W, generator=g).cuda()
+    y = torch.randint(0, K, (B,), generator=g).cuda()
+    lr, mom, wd = 0.05, 0.9, 5e-4
+    torch.manual_seed(5)
+    net = networks.ConvNet3D(3, K, 128, 3, 'relu', 'none', 'maxpooling', T, (H, W)).cuda().train()
+    net.dropout.p = 0.0
+    p0 = [p.detach().clone() for p in net.parameters()]
+    old = networks.get_precision()
+    networks.set_precision(train=prec, train_bwd=prec_bwd)
+    try:
+        opt = torch.optim.SGD(net.parameters(), lr=lr, momentum=mom, weight_decay=wd)
+        crit = torch.nn.CrossEntropyLoss().cuda()
+        assert net.hip_trainable(x, opt, crit)
+        ref = [net.hip_train_step(x, y, opt) for _ in range(2)]
+    finally:
+        networks.set_precision(train=old["train"], train_bwd=old["train_bwd"])
+    L, st = hip.lib(), hip.stream_ptr(torch.device("cuda:0"))
+    tr = ctypes.c_void_p()
+    hip.check(L.vd_train_create(T, H, W, K, hip.PREC[prec], hip.PREC[prec_bwd], ctypes.c_int64(B), ctypes.byref(tr)), "vd_train_create")
+    try:
+        nbytes = L.vd_train_workspace_bytes(tr)
+        assert nbytes > 0
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device="cuda")
+        params = [p.clone().contiguous() for p in p0]
+        bufs = [torch.zeros_like(p) for p in params]
+        P8 = (ctypes.c_void_p * 8)(*[p.data_ptr() for p in params])
+        M8 = (ctypes.c_void_p * 8)(*[b.data_ptr() for b in bufs])
+        loss_c = torch.empty(B, device="cuda")
+        logits = torch.empty(B, K, device="cuda")
+        got = []
+        for step in range(2):
+            hip.check(L.vd_train_step(tr, P8, M8, hip.ptr(x), hip.ptr(y), None, ctypes.c_float(lr), ctypes.c_float(mom), ctypes.c_float(wd),
+                                      int(step == 0), hip.ptr(ws), ctypes.c_int64(nbytes + 256), hip.ptr(loss_c), hip.ptr(logits), st), "vd_train_step")
+            torch.cuda.synchronize()
+            got.append((logits.clone(), float(loss_c.mean())))
+        assert L.vd_train_step(tr, P8, M8, hip.ptr(x), hip.ptr(y), None, ctypes.c_float(lr), ctypes.c_float(mom), ctypes.c_float(wd), 0,
+                               hip.ptr(ws), ctypes.c_int64(1024), None, None, st) == -7
+    finally:
+        L.vd_train_free(tr)
+    for step in range(2):
+        ref_logits, ref_loss = ref[step]
+        assert abs(got[step][1] - float(ref_loss)) <= 2e-5 * abs(float(ref_loss)) + 1e-6, (step, got[step][1], float(ref_loss))
+        assert float((got[step][0] - ref_logits).abs().max()) <= 2e-4 * float(ref_logits.abs().max()) + 1e-6
+    errs = [float((a - b.detach()).norm() / (b.detach() - q).norm().clamp_min(1e-30)) for a, b, q in zip(params, net.parameters(), p0)]
+    print("C train step %s/%s: losses %s, per-tensor error of the two-step update %s" % (prec, prec_bwd, [v for _, v in got], ["%.1e" % v for v in errs]))
+    assert max(errs) < 2e-4
+    tr2 = ctypes.c_void_p()
+    assert L.vd_train_create(T, H, W, K, hip.PREC["f16"], hip.PREC["f16x3"], ctypes.c_int64(B), ctypes.byref(tr2)) == -2
+    assert L.vd_train_create(T, H, W, K, hip.PREC["f16x3"], hip.PREC["bf16x3"], ctypes.c_int64(B), ctypes.byref(tr2)) == -2

@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "../../include/vd_hip.h"
 
 struct VdProgram {
@@ -349,4 +351,200 @@ extern "C" void vd_embed_free(VdEmbed* e) {
         for (int c = 0; c < 4; ++c) vd_program_free(e->bwd[l][c]);
     }
     free(e);
+}
+
+// ---- One evaluate_synset training step (utils.py:765-792, 852-853) as ONE handle ------------------------------------------
+// forward with kept activations -> head -> CrossEntropy -> head backward -> per level: bias gradient, weight gradient (the
+// program of vd_program_build_wgrad), input gradient -> torch.optim.SGD(momentum, weight_decay) on the 8 tensors.  The same
+// call sequence as train.TrainEngine.loss_and_grads + sgd_step, from C: no Python, no torch.
+struct VdTrain {
+    VdEmbed* e;
+    VdProgram* wg[3];
+    int block[3][3], replicas[3];
+    int K, kt, kh, kw, Tp;
+    int64_t nclips;
+};
+
+static int64_t a256(int64_t n) { return (n + 255) & ~(int64_t)255; }
+
+extern "C" void vd_train_free(VdTrain* t) {
+    if (t == nullptr) return;
+    vd_embed_free(t->e);
+    for (int l = 0; l < 3; ++l) vd_program_free(t->wg[l]);
+    free(t);
+}
+
+extern "C" int vd_train_create(int frames, int height, int width, int num_classes, int prec, int prec_bwd, int64_t nclips, VdTrain** out) {
+    if (out == nullptr || num_classes < 1 || nclips < 1 || nclips > 0x7fffffff || prec < 0 || prec > 3 || prec_bwd < 0 || prec_bwd > 3) return -1;
+    const int planes = prec >= 2 ? 2 : 1, planes_bwd = prec_bwd >= 2 ? 2 : 1;
+    // the gradient passes read the forward's 16-bit activations: same 16-bit family, no more planes than the forward kept
+    if (planes_bwd > planes || ((prec & 1) != (prec_bwd & 1))) return -2;
+    VdTrain* t = static_cast<VdTrain*>(calloc(1, sizeof(VdTrain)));
+    if (t == nullptr) return -5;
+    int hint = 1;
+    while (hint < nclips && hint < 512) hint *= 2;
+    int rc = vd_embed_create_ex(frames, height, width, prec, prec_bwd, nclips > 512 ? 0 : hint, &t->e);
+    for (int l = 0; rc == 0 && l < 3; ++l) {
+        void* blob = nullptr;
+        int64_t n = 0;
+        rc = vd_program_build_wgrad(l, frames, height, width, (int)nclips, planes_bwd, &blob, &n, t->block[l], &t->replicas[l]);
+        if (rc == 0) { rc = vd_program_load(blob, n, prec_bwd, &t->wg[l]); vd_blob_free(blob); }
+    }
+    if (rc != 0) { vd_train_free(t); return rc; }
+    t->K = num_classes; t->nclips = nclips;
+    t->kt = 2; t->kh = height > 64 ? 2 : 1; t->kw = height > 64 ? 2 : 1;            // networks.py:733
+    t->Tp = t->e->dims[2][8] - t->kt + 1;
+    *out = t;
+    return 0;
+}
+
+struct TrainLayout {      // byte offsets into the caller's workspace
+    int64_t fwd, argmax, bwd, xT, bp, copies, feats, g_feat, dropped, logits, amt, loss, dlog, grads, scale, total;
+    int64_t gofs[8], gsz[8];
+};
+
+static TrainLayout train_layout(const VdTrain* t) {
+    const VdEmbed* e = t->e;
+    const int64_t B = t->nclips;
+    TrainLayout L;
+    int64_t o = 256;
+    auto take = [&](int64_t bytes) { const int64_t at = o; o += a256(bytes); return at; };
+    L.fwd = take(vd_embed_workspace_bytes(e, B));
+    L.argmax = take(vd_embed_argmax_bytes(e, B));
+    L.bwd = take(vd_embed_backward_workspace_bytes(e, B));
+    int64_t xT = 0, bp = 0, cp = 0;
+    for (int l = 0; l < 3; ++l) {
+        const int* d = e->dims[l];
+        const int64_t CCb = (B + 7) / 8;
+        xT = std::max<int64_t>(xT, (int64_t)e->planes_bwd * d[0] * CCb * d[2] * d[3] * d[4] * 16);
+        const int nt = t->block[l][0], noh = t->block[l][1], now = t->block[l][2];
+        const int64_t nbox = (int64_t)((d[5] + nt - 1) / nt) * ((d[6] + noh - 1) / noh) * ((d[7] + now - 1) / now);
+        bp = std::max<int64_t>(bp, (int64_t)e->planes_bwd * nbox * CCb * (nt * noh * now / 2) * (d[1] / 32) * 64 * 16);
+        cp = std::max<int64_t>(cp, (int64_t)t->replicas[l] * d[0] * 147 * d[1] * 4);
+    }
+    L.xT = take(xT); L.bp = take(bp); L.copies = take(cp);
+    L.feats = take(B * e->nfeat * 4); L.g_feat = take(B * e->nfeat * 4);
+    L.dropped = take(B * (int64_t)t->Tp * 128 * 4);
+    L.logits = take(B * (int64_t)t->K * 4); L.amt = take(B * (int64_t)t->K * 4);
+    L.loss = take(B * 4); L.dlog = take(B * (int64_t)t->K * 4);
+    const int64_t sizes[8] = {64 * 3 * 147, 64, 128 * 64 * 147, 128, 128 * 128 * 147, 128, (int64_t)t->K * 128, t->K};
+    L.grads = o;
+    for (int i = 0; i < 8; ++i) { L.gsz[i] = sizes[i]; L.gofs[i] = take(sizes[i] * 4); }
+    L.scale = take(16 * 4);
+    L.total = o;
+    return L;
+}
+
+extern "C" int64_t vd_train_workspace_bytes(const VdTrain* t) { return t ? train_layout(t).total : -1; }
+
+// params[8] / momentum[8]: device fp32 tensors in parameters() order (features.0.weight, .bias, features.3.*, features.6.*,
+// logit.weight (K,128,1,1,1), logit.bias), updated IN PLACE; `first` != 0: the momentum buffers are initialised with the
+// gradient (torch.optim.SGD's first step).  clips (nclips, T, 3, H, W) fp32 -- already standardised (vd_standardize) as
+// epoch() does; labels int64; dropout_mask (nclips, 128, T') holding 0 or 1/(1-p), or NULL (eval-style, p = 0).
+// Outputs (device, optional): loss_per_clip (nclips), logits (nclips, K).
+extern "C" int vd_train_step(VdTrain* t, float* const* params, float* const* momentum, const float* clips, const int64_t* labels,
+                             const float* dropout_mask, float lr, float mom, float weight_decay, int first, void* workspace,
+                             int64_t workspace_bytes, float* loss_per_clip, float* logits_out, void* stream) {
+    if (t == nullptr || params == nullptr || momentum == nullptr || clips == nullptr || labels == nullptr) return -1;
+    for (int i = 0; i < 8; ++i) if (params[i] == nullptr || momentum[i] == nullptr) return -1;
+    const TrainLayout L = train_layout(t);
+    if (workspace == nullptr || workspace_bytes < L.total) return -7;
+    VdEmbed* e = t->e;
+    const int64_t B = t->nclips;
+    char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* feats = reinterpret_cast<float*>(ws + L.feats);
+    float* g_feat = reinterpret_cast<float*>(ws + L.g_feat);
+    float* dropped = reinterpret_cast<float*>(ws + L.dropped);
+    float* logits = reinterpret_cast<float*>(ws + L.logits);
+    int32_t* amt = reinterpret_cast<int32_t*>(ws + L.amt);
+    float* loss_c = reinterpret_cast<float*>(ws + L.loss);
+    float* dlog = reinterpret_cast<float*>(ws + L.dlog);
+    float* g[8];
+    for (int i = 0; i < 8; ++i) g[i] = reinterpret_cast<float*>(ws + L.gofs[i]);
+    uint8_t* argmax = reinterpret_cast<uint8_t*>(ws + L.argmax);
+    int rc = vd_embed_set_weights(e, params[0], params[1], params[2], params[3], params[4], params[5], stream);
+    if (rc == 0) rc = vd_embed_forward_keep(e, clips, nullptr, B, ws + L.fwd, vd_embed_workspace_bytes(e, B), feats, argmax, stream);
+    const int* d2 = e->dims[2];
+    if (rc == 0) rc = vd_head_train_fwd(feats, dropout_mask, params[6], params[7], B, d2[1], d2[8], d2[9], d2[10], t->kt, t->kh, t->kw, t->K,
+                                        dropped, logits, amt, stream);
+    if (rc == 0) rc = vd_ce_loss(logits, labels, (int)B, t->K, loss_c, dlog, stream);
+    if (rc) return rc;
+    if (hipMemsetAsync(ws + L.grads, 0, (size_t)(L.scale - L.grads), st) != hipSuccess) return -9;
+    rc = vd_head_train_bwd(dlog, amt, dropped, dropout_mask, params[6], B, d2[1], d2[8], d2[9], d2[10], t->kt, t->kh, t->kw, t->K,
+                           g[6], g[7], g_feat, stream);
+    if (rc) return rc;
+    // kept activations and arg-max bytes: the layout of embed_forward_impl
+    const int64_t n0 = B * e->slots0_per_clip, n1 = B * e->slots1_per_clip, n2 = B * e->slots2_per_clip;
+    char* rows = align256(ws + L.fwd);
+    char* act[3] = {nullptr, align256(rows + (int64_t)e->planes * n0 * 16), nullptr};
+    act[2] = align256(act[1] + (int64_t)e->planes * n1 * 16);
+    const int64_t act_plane[3] = {0, n1, n2};
+    const uint8_t* am[3];
+    am[0] = reinterpret_cast<const uint8_t*>(align256(reinterpret_cast<char*>(argmax)));
+    am[1] = reinterpret_cast<const uint8_t*>(align256(const_cast<char*>(reinterpret_cast<const char*>(am[0])) + n1 * 8));
+    am[2] = reinterpret_cast<const uint8_t*>(align256(const_cast<char*>(reinterpret_cast<const char*>(am[1])) + n2 * 8));
+    // dense dy + dx buffers: the layout of vd_embed_backward
+    int64_t dymax = 0;
+    for (int l = 0; l < 3; ++l) dymax = std::max(dymax, dy_slots(e, l, B));
+    char* dy = align256(ws + L.bwd);
+    char* dxbuf[3] = {nullptr, nullptr, nullptr};
+    char* cur = align256(dy + (int64_t)e->planes_bwd * dymax * 16);
+    for (int l = 1; l < 3; ++l) {
+        dxbuf[l] = cur;
+        cur = align256(cur + B * (int64_t)e->dims[l][2] * e->dims[l][3] * e->dims[l][4] * e->dims[l][0] * 4);
+    }
+    float* scale = reinterpret_cast<float*>(ws + L.scale);
+    const bool scaled = (e->prec_bwd == VD_PREC_F16 || e->prec_bwd == VD_PREC_F16X3);
+    char* xT = ws + L.xT;
+    char* bp = ws + L.bp;
+    float* copies = reinterpret_cast<float*>(ws + L.copies);
+    const float* grad = g_feat;
+    int64_t grad_n = B * e->nfeat;
+    int layout = 0;
+    for (int l = 2; l >= 0; --l) {
+        const int* d = e->dims[l];
+        const int cin = d[0], cout = d[1];
+        const int64_t nslots = dy_slots(e, l, B), CCb = (B + 7) / 8, npos_in = (int64_t)d[2] * d[3] * d[4];
+        float* sc = nullptr;
+        if (scaled) {
+            sc = scale + 4 * l;
+            if ((rc = vd_absmax_scale(grad, grad_n, 1024.0f, sc, stream))) return rc;
+        }
+        if (l > 0) {
+            rc = vd_unpool_relu_bwd(grad, am[l], B, cout, d[8], d[9], d[10], d[11], d[5], d[6], d[7], layout, dy,
+                                    e->planes_bwd == 2 ? dy + nslots * 16 : nullptr, e->prec_bwd, sc, stream);
+            if (rc) return rc;
+        }
+        if ((rc = vd_bias_grad_pooled(grad, am[l], B, cout, (int64_t)d[8] * d[9] * d[10], layout, g[2 * l + 1], stream))) return rc;
+        // weight gradient: x clip-minor, dy packed straight from the pooled gradient, boxes accumulate into copies
+        const int64_t xT_plane = (int64_t)cin * CCb * npos_in;
+        if (l == 0) rc = vd_clip_minor_pix(clips, B, d[2], d[3], d[4], xT, e->planes_bwd == 2 ? xT + xT_plane * 16 : nullptr, e->prec_bwd, stream);
+        else rc = vd_clip_minor_cl(act[l], act_plane[l], e->planes_bwd, B, cin, npos_in, xT, xT_plane, stream);
+        if (rc) return rc;
+        const int nt = t->block[l][0], noh = t->block[l][1], now = t->block[l][2];
+        const int64_t nbox = (int64_t)((d[5] + nt - 1) / nt) * ((d[6] + noh - 1) / noh) * ((d[7] + now - 1) / now);
+        const int64_t bp_elems = nbox * CCb * (nt * noh * now / 2) * (cout / 32) * 64 * 8;
+        rc = vd_unpool_relu_bwd_packed(grad, am[l], B, cout, d[8], d[9], d[10], d[11], d[5], d[6], d[7], layout, nt, noh, now, bp,
+                                       e->planes_bwd == 2 ? bp + bp_elems * 2 : nullptr, e->prec_bwd, sc, stream);
+        if (rc) return rc;
+        const int64_t copy_elems = (int64_t)cin * 147 * cout;
+        if (hipMemsetAsync(copies, 0, (size_t)t->replicas[l] * copy_elems * 4, st) != hipSuccess) return -9;
+        rc = vd_program_run_wgrad(t->wg[l], xT, xT_plane, bp, bp_elems, copies, copy_elems, cin, sc ? sc + 1 : nullptr, stream);
+        if (rc == 0) rc = vd_replica_sum(copies, t->replicas[l], cin * 147, cout, g[2 * l], stream);
+        if (rc) return rc;
+        if (l > 0) {
+            float* outp = reinterpret_cast<float*>(dxbuf[l]);
+            for (int c = 0; c < e->nbwd[l]; ++c)
+                if ((rc = vd_program_run_scaled(e->bwd[l][c], dy, nslots, nullptr, outp, 0, nullptr, nullptr, (int)B, sc ? sc + 1 : nullptr, stream))) return rc;
+            grad = outp;
+            grad_n = B * npos_in * cin;
+            layout = 1;
+        }
+    }
+    for (int i = 0; i < 8; ++i)
+        if ((rc = vd_sgd_momentum_wd(params[i], momentum[i], g[i], L.gsz[i], lr, mom, weight_decay, first, stream))) return rc;
+    if (loss_per_clip != nullptr && hipMemcpyAsync(loss_per_clip, loss_c, (size_t)B * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return -9;
+    if (logits_out != nullptr && hipMemcpyAsync(logits_out, logits, (size_t)B * t->K * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return -9;
+    return 0;
 }
