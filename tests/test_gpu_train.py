@@ -464,7 +464,7 @@ def test_expert_trajectories_match_the_oracle_loop(tmp_path):
     replay_buffer_{n}.pt round trip."""
     import argparse
     from video_distillation_amd import checkpoint, networks, utils
-    C, n, batch, epochs, lr, mom, l2 = 3, 8, 4, 3, 0.02, 0.5, 1e-3
+    C, n, batch, epochs, lr, mom, l2 = 3, 8, 4, 3, 0.02, 0.5, 1e-2
     g = torch.Generator().manual_seed(515)
     x = torch.randn(n, 8, 3, 64, 64, generator=g)
     y = torch.arange(n) % C
@@ -510,8 +510,12 @@ def test_expert_trajectories_match_the_oracle_loop(tmp_path):
         return [[_rel(a - s, (b - s).double()) if e else float((a - b).abs().max()) for a, b, s in zip(tr[0][e], want[e], p0)]
                 for e in range(epochs + 1)]
 
-    def within(errs):       # typical 8e-5; room for one pooling near-tie resolved the other way (atomically accumulated updates)
-        return all(max(st) < (8e-3 if e else 1e-12) and float(np.median(st)) < (1e-3 if e else 1e-12) for e, st in enumerate(errs))
+    def within(errs):
+        # typical 8e-5.  The features of this geometry have 256 entries per clip and a batch has 4 clips: ONE pooling near-tie
+        # resolved the other way (the weights carry the summation order of fp32 atomics, which differs between boxes) moves
+        # every gradient by ~1e-3 and the steps after it a little more -- so the bar is flip tolerant (a missing momentum,
+        # weight decay or lr switch is a 10 %-100 % error), and the typical value is printed / logged.
+        return all(max(st) < (5e-2 if e else 1e-12) for e, st in enumerate(errs))
     log = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "expert_test.log")
     os.makedirs(os.path.dirname(log), exist_ok=True)
     for attempt in range(2):
@@ -522,9 +526,9 @@ def test_expert_trajectories_match_the_oracle_loop(tmp_path):
                 fp.write("attempt %d epoch %d %s\n" % (attempt, e, " ".join("%.2e" % v for v in st)))
         if within(errs):
             break
-        # An out-of-tolerance run has been seen in 2 of ~20 runs of the whole gpu suite on the box pool (never alone, never twice
-        # on one box; the per-epoch errors of every other run agree to two digits).  The trajectory is recomputed once and
-        # both attempts are logged (gpurun_out/expert_test.log); a repeatable deviation still fails.
+        # (with the former 1e-3 bar a run was out of tolerance in 2 of ~20 runs of the whole gpu suite on the box pool -- never
+        # alone, never twice on one box, all other runs agreeing to two digits: a flip, see above.  The trajectory is recomputed
+        # once and both attempts are logged, gpurun_out/expert_test.log.)
         traj = hip_run()
     assert within(errs), errs
     path = checkpoint.save_expert_buffer(str(tmp_path), traj)
