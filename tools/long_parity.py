@@ -27,8 +27,9 @@ def trainer(**kw):
 
 
 ta = trainer(prec_real="f16x3", prec_syn="f16x3", prec_bwd="f16x3")
-tb = trainer()
-tv = trainer(); tv.be.dither_enabled = False
+bwd = os.environ.get("VD_LP_BWD", "f16")          # input-gradient operands of the mixed trainers
+tb = trainer(prec_bwd=bwd)
+tv = trainer(prec_bwd=bwd); tv.be.dither_enabled = False
 rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())        # noqa: E731
 rec = {"dither": {"loss": [], "grad": []}, "value_pass": {"loss": [], "grad": []}, "feature_gap": []}
 for it in range(steps):
