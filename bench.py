@@ -138,15 +138,18 @@ class Harness:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(self, step, sync, mark, profile_sink=None):
-        """W untimed + K timed steps; -> (wall seconds [max over ranks], per-step ms list, launch profile)."""
+    def run(self, step, sync, mark, profile=True):
+        """W untimed + K timed steps; -> (wall seconds [max over ranks], per-step ms list, launch profile).  ``profile``:
+        record two HIP events around every tile-program launch INSIDE the timed region (DM / s2d: ~25 launches per step,
+        this is where `roofline.achieved` comes from).  The loops that issue thousands of small launches per step (DC, MTT)
+        are host-issue sensitive: they are timed with the hook off and profiled in extra untimed steps (``profile_steps``)."""
         from video_distillation_amd import engine
         a = self.args
         for it in range(a.warmup):
             step(it)
         sync()
         self.barrier()
-        engine.LAUNCH_PROFILE = []
+        engine.LAUNCH_PROFILE = [] if profile else None
         marks = [mark()]
         t0 = time.perf_counter()
         losses = []
@@ -156,7 +159,7 @@ class Harness:
         sync()
         self.barrier()
         dt = time.perf_counter() - t0
-        prof, engine.LAUNCH_PROFILE = engine.LAUNCH_PROFILE, None
+        prof, engine.LAUNCH_PROFILE = engine.LAUNCH_PROFILE or [], None
         if self.world > 1:
             import torch.distributed as dist
             tmax = torch.tensor([dt], device=self.device, dtype=torch.float64)
@@ -164,6 +167,21 @@ class Harness:
             dt = float(tmax)
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
         return dt, per_step, prof, losses
+
+    def profile_steps(self, step, sync, first_it, n=1):
+        """``n`` extra untimed steps with the launch hook on, on EVERY rank (a step may contain collectives)."""
+        from video_distillation_amd import engine
+        sync()
+        torch.cuda.synchronize()
+        engine.LAUNCH_PROFILE = []
+        try:
+            for k in range(n):
+                step(first_it + k)
+            sync()
+            torch.cuda.synchronize()
+        finally:
+            prof, engine.LAUNCH_PROFILE = engine.LAUNCH_PROFILE, None
+        return prof
 
     def sustained(self, step, sync, first_it):
         a = self.args
@@ -471,8 +489,20 @@ def bench_dc(args, h, distill, geo, pool):
 
     def step(it):
         return trainer.global_loss(trainer.step(it))
-    dt, per_step, prof, losses = h.run(step, lambda: None, mark)
+    dt, per_step, _, losses = h.run(step, lambda: None, mark, profile=False)
     sustained = h.sustained(step, lambda: None, args.warmup + args.steps)
+    # per-program times: under the class lanes every launch shares the GPU with seven others, so its event-to-event time is
+    # not GPU time; one extra step on ONE lane (outside the timed region, on every rank: the step ends in a collective)
+    # attributes the conv time to the programs
+    lanes_env = os.environ.get("VD_GM_LANES")
+    os.environ["VD_GM_LANES"] = "1"
+    try:
+        prof1 = h.profile_steps(step, lambda: None, args.warmup + args.steps)
+    finally:
+        if lanes_env is None:
+            del os.environ["VD_GM_LANES"]
+        else:
+            os.environ["VD_GM_LANES"] = lanes_env
     out = None
     if rank == 0:
         macs = sum(conv_layer_macs(geo))
@@ -488,22 +518,6 @@ def bench_dc(args, h, distill, geo, pool):
         out["loss_last"] = float(losses[-1]) / args.classes
         out["step_tflops"] = step_flop / (dt / args.steps) / 1e12
         out["step_frac_of_mfma_peak"] = out["step_tflops"] / PEAK_TFLOPS
-        # per-program times: under the class lanes every launch shares the GPU with seven others, so its event-to-event time is
-        # not GPU time; one extra step on ONE lane (outside the timed region) attributes the conv time to the programs
-        from video_distillation_amd import engine
-        lanes_env = os.environ.get("VD_GM_LANES")
-        os.environ["VD_GM_LANES"] = "1"
-        try:
-            torch.cuda.synchronize()
-            engine.LAUNCH_PROFILE = []
-            step(args.warmup + args.steps)
-            torch.cuda.synchronize()
-            prof1, engine.LAUNCH_PROFILE = engine.LAUNCH_PROFILE, None
-        finally:
-            if lanes_env is None:
-                del os.environ["VD_GM_LANES"]
-            else:
-                os.environ["VD_GM_LANES"] = lanes_env
         roof = roofline_from_profile(prof1, device, {})
         if roof:
             roof["traffic"], roof["traffic_source"] = None, None
@@ -588,8 +602,9 @@ def bench_mtt(args, h, distill, geo):
 
     def step(it):
         return tr.step(it, traj)
-    dt, per_step, prof, losses = h.run(step, lambda: None, mark)
+    dt, per_step, _, losses = h.run(step, lambda: None, mark, profile=False)
     sustained = h.sustained(step, lambda: None, args.warmup + args.steps)
+    prof = h.profile_steps(step, lambda: None, args.warmup + args.steps)
     out = None
     if rank == 0:
         macs = sum(conv_layer_macs(geo))
@@ -612,6 +627,7 @@ def bench_mtt(args, h, distill, geo):
         if roof:
             roof["traffic"], roof["traffic_source"] = None, None
             roof["peak_measured"] = mfma_peak(device)
+            roof["measured_on"] = "one extra untimed step with the launch hook on (the timed steps run without it)"
             out["roofline"] = roof
         if sustained:
             out["sustained"] = sustained

@@ -34,25 +34,30 @@ def dither(w, g, G):
     return torch.where(t < lam, hi, lo)
 
 
-for name in ("similar", "independent"):
-    g = torch.Generator().manual_seed(5)
-    nreal = 32
-    if name == "similar":
-        base = torch.randn(8, 3, 64, 64, generator=g)
-        x = base + 0.1 * torch.randn(nreal + 1, 8, 3, 64, 64, generator=g)
-    else:
-        x = torch.randn(nreal + 1, 8, 3, 64, 64, generator=g)
-    params = R.init_params(1234)
-    f0 = R.convnet3d_embed(x, params)
-    fn = float(f0[0].norm())
-    p_rn = [p.half().float() if p.dim() == 5 else p for p in params[:6]]
-    d_rn = R.convnet3d_embed(x, p_rn) - f0
-    print("%-12s rn16:      |mean d|/|f| %.2e   value pass |mean d - d_syn|/|f| %.2e" % (
-        name, float(d_rn[:nreal].mean(0).norm()) / fn, float((d_rn[:nreal].mean(0) - d_rn[nreal]).norm()) / fn))
-    for G in (2, 4, 8, 16, 32):
-        d = torch.zeros(nreal, f0.shape[1])
-        for gi in range(G):
-            pg = [dither(p, gi, G) if p.dim() == 5 else p for p in params[:6]]
-            sel = torch.arange(gi, nreal, G)
-            d[sel] = R.convnet3d_embed(x[sel], pg) - f0[sel]
-        print("%-12s dither G=%-2d |mean d|/|f| %.2e" % (name, G, float(d.mean(0).norm()) / fn))
+def main():
+    for name in ("similar", "independent"):
+        g = torch.Generator().manual_seed(5)
+        nreal = 32
+        if name == "similar":
+            base = torch.randn(8, 3, 64, 64, generator=g)
+            x = base + 0.1 * torch.randn(nreal + 1, 8, 3, 64, 64, generator=g)
+        else:
+            x = torch.randn(nreal + 1, 8, 3, 64, 64, generator=g)
+        params = R.init_params(1234)
+        f0 = R.convnet3d_embed(x, params)
+        fn = float(f0[0].norm())
+        p_rn = [p.half().float() if p.dim() == 5 else p for p in params[:6]]
+        d_rn = R.convnet3d_embed(x, p_rn) - f0
+        print("%-12s rn16:      |mean d|/|f| %.2e   value pass |mean d - d_syn|/|f| %.2e" % (
+            name, float(d_rn[:nreal].mean(0).norm()) / fn, float((d_rn[:nreal].mean(0) - d_rn[nreal]).norm()) / fn))
+        for G in (2, 4, 8, 16, 32):
+            d = torch.zeros(nreal, f0.shape[1])
+            for gi in range(G):
+                pg = [dither(p, gi, G) if p.dim() == 5 else p for p in params[:6]]
+                sel = torch.arange(gi, nreal, G)
+                d[sel] = R.convnet3d_embed(x[sel], pg) - f0[sel]
+            print("%-12s dither G=%-2d |mean d|/|f| %.2e" % (name, G, float(d.mean(0).norm()) / fn))
+
+
+if __name__ == "__main__":
+    main()

@@ -136,7 +136,10 @@ def test_training_step_through_the_c_handle(geom, B, K, prec, prec_bwd):
     try:
         nbytes = L.vd_train_workspace_bytes(tr)
         assert nbytes > 0
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device="cuda")
+        # an UNALIGNED workspace pointer of exactly the queried size, with a canary behind it: the handle rounds the pointer up
+        # itself and must stay inside [ptr, ptr + nbytes)
+        ws_all = torch.full((nbytes + 200 + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+        ws = ws_all[200:]
         params = [p.clone().contiguous() for p in p0]
         bufs = [torch.zeros_like(p) for p in params]
         P8 = (ctypes.c_void_p * 8)(*[p.data_ptr() for p in params])
@@ -146,8 +149,9 @@ def test_training_step_through_the_c_handle(geom, B, K, prec, prec_bwd):
         got = []
         for step in range(2):
             hip.check(L.vd_train_step(tr, P8, M8, hip.ptr(x), hip.ptr(y), None, ctypes.c_float(lr), ctypes.c_float(mom), ctypes.c_float(wd),
-                                      int(step == 0), hip.ptr(ws), ctypes.c_int64(nbytes + 256), hip.ptr(loss_c), hip.ptr(logits), st), "vd_train_step")
+                                      int(step == 0), hip.ptr(ws), ctypes.c_int64(nbytes), hip.ptr(loss_c), hip.ptr(logits), st), "vd_train_step")
             torch.cuda.synchronize()
+            assert bool((ws_all[200 + nbytes:] == 0xA5).all()) and bool((ws_all[:200] == 0xA5).all()), "vd_train_step wrote outside its workspace"
             got.append((logits.clone(), float(loss_c.mean())))
         assert L.vd_train_step(tr, P8, M8, hip.ptr(x), hip.ptr(y), None, ctypes.c_float(lr), ctypes.c_float(mom), ctypes.c_float(wd), 0,
                                hip.ptr(ws), ctypes.c_int64(1024), None, None, st) == -7

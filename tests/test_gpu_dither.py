@@ -118,3 +118,47 @@ def test_one_launch_with_set_selection_equals_one_launch_per_group(geom, n):
         assert torch.equal(got, want)
     plain = be.eng_real.forward(pool, index=idx)
     assert not torch.equal(plain, got) and float((plain - got).norm() / plain.norm()) < 1e-3
+
+
+def test_module_embed_value_pass_follows_real_dither_and_the_weights():
+    """networks.ConvNet3D.embed in the mixed mode: which forward the gradient-carrying clips' FEATURES come from --
+    exact weights (the real side they meet was dithered) or rn16 weights (the value pass) -- follows ``net.real_dither``:
+    "auto" remembers a dithered no-gradient batch only for the weights it ran with and is not disturbed by inference passes;
+    True / False state it explicitly (call orders other than the reference's real-then-synthetic)."""
+    from video_distillation_amd import engine, networks, plan
+    torch.manual_seed(3)
+    net = networks.ConvNet3D(3, 5, 128, 3, 'relu', 'none', 'maxpooling', 8, (64, 64)).cuda().train()
+    for p in net.parameters():
+        p.requires_grad = False
+    g = torch.Generator().manual_seed(4)
+    real = torch.randn(8, 8, 3, 64, 64, generator=g).cuda()
+    syn = torch.randn(1, 8, 3, 64, 64, generator=g).cuda()
+    eng = engine.EmbedEngine(plan.NetGeometry(8, 64, 64), prec="f16x3")
+
+    def expect(quantize):
+        eng.set_weights(net._feature_params(), quantize=quantize)
+        return eng.forward(syn)
+
+    def syn_feats():
+        return net.embed(syn.clone().requires_grad_(True)).detach()
+    assert net.real_dither == "auto"
+    assert torch.equal(syn_feats(), expect("f16"))                 # nothing dithered yet: value pass
+    net.embed(real)                                                # 8 clips without gradient: 8 dither groups
+    assert torch.equal(syn_feats(), expect(None))
+    with torch.no_grad():
+        net.eval(); net(real[:2]); net.train()                     # an inference pass in between does not disturb it
+    assert torch.equal(syn_feats(), expect(None))
+    net.embed(real[:3])                                            # a real batch too small to dither: value pass again
+    assert torch.equal(syn_feats(), expect("f16"))
+    net.embed(real)
+    with torch.no_grad():
+        net.features[0].weight.mul_(1.5)                           # a weight update forgets the dithered batch
+    assert torch.equal(syn_feats(), expect("f16"))
+    net.real_dither = True                                         # synthetic clips first, real clips afterwards
+    assert torch.equal(syn_feats(), expect(None))
+    net.real_dither = False
+    f_plain = net.embed(real)
+    eng16 = engine.EmbedEngine(plan.NetGeometry(8, 64, 64), prec="f16")
+    eng16.set_weights(net._feature_params())
+    assert torch.equal(f_plain, eng16.forward(real))               # never dithered
+    assert torch.equal(syn_feats(), expect("f16"))

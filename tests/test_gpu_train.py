@@ -480,15 +480,30 @@ def test_expert_trajectories_match_the_oracle_loop(tmp_path):
     shuffle = torch.Generator()               # the loader's own generator: the net constructor draws from the global one
     loader = torch.utils.data.DataLoader(utils.TensorDataset(x, y), batch_size=batch, shuffle=True, num_workers=0, generator=shuffle)
     args = argparse.Namespace(device="cuda:0", model="ConvNet3D")
-    def hip_run():
+    # every HIP train step records the state it started from, its gradients and its pooling decisions
+    from video_distillation_amd import train
+    steps_rec, orig_lg, orig_fw = [], train.TrainEngine.loss_and_grads, train.TrainEngine._forward
+
+    def spy_forward(self, xx, params):
+        feats, nb, am = orig_fw(self, xx, params)
+        steps_rec[-1]["am"] = [a.clone() for a in am]
+        return feats, nb, am
+
+    def spy_loss_and_grads(self, xx, labels, params, mask=None, state=None):
+        steps_rec.append({"x": xx.detach().clone(), "labels": labels.detach().clone(), "params": [q.detach().clone() for q in params]})
+        out = orig_lg(self, xx, labels, params, mask, state)
+        steps_rec[-1]["grads"] = [gq.detach().clone() for gq in out[2]]
+        return out
+    train.TrainEngine.loss_and_grads, train.TrainEngine._forward = spy_loss_and_grads, spy_forward
+    try:
         torch.cuda.synchronize()
         shuffle.manual_seed(99)
-        tr = checkpoint.train_expert_trajectories(factory, loader, args, num_experts=1, train_epochs=epochs, lr_teacher=lr,
-                                                  mom=mom, l2=l2, decay=True)
-        assert len(tr) == 1 and len(tr[0]) == epochs + 1 and len(tr[0][0]) == 8
-        assert all(t.device.type == "cpu" for t in tr[0][-1])
-        return tr
-    traj = hip_run()
+        traj = checkpoint.train_expert_trajectories(factory, loader, args, num_experts=1, train_epochs=epochs, lr_teacher=lr,
+                                                    mom=mom, l2=l2, decay=True)
+    finally:
+        train.TrainEngine.loss_and_grads, train.TrainEngine._forward = orig_lg, orig_fw
+    assert len(traj) == 1 and len(traj[0]) == epochs + 1 and len(traj[0][0]) == 8
+    assert all(t.device.type == "cpu" for t in traj[0][-1])
     # the oracle loop over the same shuffles
     shuffle.manual_seed(99)
     params = [p.detach().clone().requires_grad_(True) for p in p0]
@@ -506,31 +521,40 @@ def test_expert_trajectories_match_the_oracle_loop(tmp_path):
         if e == epochs // 2 + 1:
             cur_lr *= 0.1
             bufs = [None] * 8
-    def errors(tr):
-        return [[_rel(a - s, (b - s).double()) if e else float((a - b).abs().max()) for a, b, s in zip(tr[0][e], want[e], p0)]
-                for e in range(epochs + 1)]
-
-    def within(errs):
-        # typical 8e-5.  The features of this geometry have 256 entries per clip and a batch has 4 clips: ONE pooling near-tie
-        # resolved the other way (the weights carry the summation order of fp32 atomics, which differs between boxes) moves
-        # every gradient by ~1e-3 and the steps after it a little more -- so the bar is flip tolerant (a missing momentum,
-        # weight decay or lr switch is a 10 %-100 % error), and the typical value is printed / logged.
-        return all(max(st) < (5e-2 if e else 1e-12) for e, st in enumerate(errs))
+    errs = [[_rel(a - s, (b - s).double()) if e else float((a - b).abs().max()) for a, b, s in zip(traj[0][e], want[e], p0)]
+            for e in range(epochs + 1)]
+    # ---- per step, against the fp64 oracle on the state the HIP step started from (no accumulation, no second attempt) ----
+    # A step is CLEAN when all 8 parameter gradients are within 1e-3 rel-L2 of the fp64 oracle's.  Anything above that must be a
+    # pooling near-tie: at 256 features per clip and 4 clips per batch ONE last-level window routed the other way moves every
+    # gradient by 1e-3 .. 3e-2 -- then the step's recorded arg-max bytes must differ from the fp64 oracle's max_pool3d decisions,
+    # and ONLY in windows whose two largest entries the oracle itself separates by < 2e-5 of the level's rms (the HIP forward's
+    # own rounding is 4e-6).  An outlier without such a window is a hazard (stale workspace, stream race), and fails.
+    from tests import argmax_tools
     log = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "expert_test.log")
     os.makedirs(os.path.dirname(log), exist_ok=True)
-    for attempt in range(2):
-        errs = errors(traj)
-        for e, st in enumerate(errs):
-            print("expert (attempt %d) epoch %d: per-tensor error of the accumulated update" % (attempt, e), ["%.1e" % v for v in st])
-            with open(log, "a") as fp:
-                fp.write("attempt %d epoch %d %s\n" % (attempt, e, " ".join("%.2e" % v for v in st)))
-        if within(errs):
-            break
-        # (with the former 1e-3 bar a run was out of tolerance in 2 of ~20 runs of the whole gpu suite on the box pool -- never
-        # alone, never twice on one box, all other runs agreeing to two digits: a flip, see above.  The trajectory is recomputed
-        # once and both attempts are logged, gpurun_out/expert_test.log.)
-        traj = hip_run()
-    assert within(errs), errs
+    assert len(steps_rec) == epochs * (n // batch)
+    flips, report = 0, []
+    for k, st in enumerate(steps_rec):
+        p64 = [q.double().cpu().requires_grad_(True) for q in st["params"]]
+        logits = R.convnet3d_logits(st["x"].double().cpu(), p64, training=False)
+        want_g = torch.autograd.grad(torch.nn.functional.cross_entropy(logits, st["labels"].cpu()), p64)
+        gerr = [_rel(a, b) for a, b in zip(st["grads"], want_g)]
+        dec = argmax_tools.compare_decisions(st["x"], st["params"], st["am"])
+        line = "step %d: max gradient error vs fp64 %.2e; arg-max mismatches / not near-tie / worst margin per level: %s" % (
+            k, max(gerr), ["%d/%d/%.1e" % (d["mismatch"], d["not_near_tie"], d["worst_margin"]) for d in dec])
+        report.append(line)
+        print(line)
+        assert all(d["not_near_tie"] == 0 for d in dec), line              # every differing decision is a genuine near-tie
+        if max(gerr) >= 1e-3:
+            flips += 1
+            assert max(gerr) < 5e-2 and sum(d["mismatch"] for d in dec[1:]) > 0, "outlier without a flipped window: " + line
+    for e, st in enumerate(errs):
+        print("expert epoch %d: per-tensor error of the accumulated update" % e, ["%.1e" % v for v in st])
+    with open(log, "a") as fp:
+        fp.write("\n".join(report + ["epoch %d %s" % (e, " ".join("%.2e" % v for v in st)) for e, st in enumerate(errs)]) + "\n")
+    assert max(errs[0]) < 1e-12
+    bar = 1e-3 if flips == 0 else 5e-2          # typical 8e-5; after an identified flip the trajectories legitimately part
+    assert all(max(st) < bar for st in errs[1:]), (flips, errs)
     path = checkpoint.save_expert_buffer(str(tmp_path), traj)
     assert path.endswith("replay_buffer_0.pt")
     back = checkpoint.load_expert_buffers(str(tmp_path))

@@ -237,7 +237,7 @@ extern "C" int64_t vd_embed_backward_workspace_bytes(const VdEmbed* e, int64_t n
     for (int l = 0; l < 3; ++l) dy = dy > dy_slots(e, l, nclips) ? dy : dy_slots(e, l, nclips);
     int64_t dx = 0;
     for (int l = 1; l < 3; ++l) dx += nclips * (int64_t)e->dims[l][2] * e->dims[l][3] * e->dims[l][4] * e->dims[l][0] * 4;
-    return (int64_t)e->planes_bwd * dy * 16 + dx + 4 * 256;
+    return (int64_t)e->planes_bwd * dy * 16 + dx + 5 * 256;       // four 256-byte alignments + the 12 scale floats behind the last one
 }
 
 extern "C" int vd_embed_set_weights(VdEmbed* e, const float* w0, const float* b0, const float* w1, const float* b1,
@@ -407,7 +407,7 @@ static TrainLayout train_layout(const VdTrain* t) {
     const VdEmbed* e = t->e;
     const int64_t B = t->nclips;
     TrainLayout L;
-    int64_t o = 256;
+    int64_t o = 0;        // offsets are relative to the workspace pointer rounded UP to 256 bytes: the slack is added to `total` below
     auto take = [&](int64_t bytes) { const int64_t at = o; o += a256(bytes); return at; };
     L.fwd = take(vd_embed_workspace_bytes(e, B));
     L.argmax = take(vd_embed_argmax_bytes(e, B));
@@ -431,7 +431,7 @@ static TrainLayout train_layout(const VdTrain* t) {
     L.grads = o;
     for (int i = 0; i < 8; ++i) { L.gsz[i] = sizes[i]; L.gofs[i] = take(sizes[i] * 4); }
     L.scale = take(16 * 4);
-    L.total = o;
+    L.total = o + 256;    // room for rounding an arbitrary caller pointer up to the next 256-byte boundary
     return L;
 }
 

@@ -102,9 +102,16 @@ class _EmbedFunction(torch.autograd.Function):
 
     Mixed mode and the weight-rounding bias of the single-pass real side (distill.HipBackend has the same logic for the
     fused trainers): a batch of >= 4 clips WITHOUT gradient is dealt to dithered weight sets (``engine.dither_groups``:
-    its mean feature, which is what DM consumes, then carries no first-order rounding bias) and the net remembers that;
-    clips WITH gradient get the exact-weight f16x3 forward, plus the value pass (``_weight_format``) only when the net's
-    last no-gradient batch could not be dithered."""
+    its mean feature, which is what DM consumes, then carries no first-order rounding bias); clips WITH gradient get the
+    exact-weight f16x3 forward, plus the value pass (``_weight_format``) when the real side they are compared with is NOT
+    dithered.  Which of the two holds is ``net.real_dither``:
+
+      * ``"auto"`` (default, the reference's call order ``embed(real).detach(); embed(syn)``, distill_baseline.py:344-349):
+        the net remembers whether its latest no-gradient batch WITH THE CURRENT WEIGHTS was dithered; inference passes
+        (``_infer_hip``) never touch that memory, and a weight update forgets it;
+      * ``True`` / ``False``: the caller states it -- dither every no-gradient batch of >= 4 clips and never run the value pass /
+        never dither and always run it -- for loops that embed the synthetic clips BEFORE the real ones or interleave
+        other no-gradient batches."""
 
     @staticmethod
     def forward(ctx, x, net, dither_ok=True):
@@ -116,7 +123,9 @@ class _EmbedFunction(torch.autograd.Function):
             net._sync_engine(eng)
             feats, saved = eng.forward(x, keep=True)
             q = _weight_format()
-            if q is not None and not getattr(net, "_real_dithered", False):   # value pass (see distill.HipBackend.weight_format)
+            mode = getattr(net, "real_dither", "auto")
+            dithered = (getattr(net, "_real_dithered_key", None) == net._weights_key()) if mode == "auto" else bool(mode)
+            if q is not None and not dithered:   # value pass (see distill.HipBackend.weight_format)
                 net._sync_engine(eng, quantize=q)
                 feats = eng.forward(x)
             ctx.saved = saved
@@ -125,9 +134,10 @@ class _EmbedFunction(torch.autograd.Function):
             ctx.net = net
             return feats
         from .engine import dither_groups
-        G = dither_groups(int(x.shape[0]), prec) if (dither_ok and _PRECISION["syn"] == prec + "x3") else 0
-        if dither_ok:
-            net._real_dithered = bool(G)
+        mode = getattr(net, "real_dither", "auto")
+        G = dither_groups(int(x.shape[0]), prec) if (dither_ok and mode is not False and _PRECISION["syn"] == prec + "x3") else 0
+        if dither_ok:       # (remembered per weight state: stale after an update, untouched by inference passes)
+            net._real_dithered_key = net._weights_key() if G else None
         net._sync_engine(eng, dither=G)
         if not G:
             return eng.forward(x)
@@ -277,6 +287,9 @@ class ConvNet3D(nn.Module):
         self._hip_ok = (channel == 3 and net_width == 128 and net_depth == 3 and net_act == 'relu'
                         and net_norm == 'none' and net_pooling == 'maxpooling')
         self._engine_keys: Dict[int, Tuple] = {}
+        # mixed-precision DM: how embed() reconciles the single-pass real side with the hi+lo synthetic side ("auto" /
+        # True / False; see _EmbedFunction).  Not part of the reference's surface; the default needs no caller change.
+        self.real_dither = "auto"
 
     # -- construction (same layer sequence / naming as networks.py:792-814) ------------------
     @staticmethod
