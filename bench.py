@@ -55,14 +55,19 @@ def parse():
     ap.add_argument("--size", type=int, default=112)
     ap.add_argument("--prec-real", default=os.environ.get("VD_PREC_REAL", "f16"))
     ap.add_argument("--prec-syn", default=os.environ.get("VD_PREC_SYN", "f16x3"))
-    ap.add_argument("--prec-bwd", default=os.environ.get("VD_PREC_BWD", "f16"),
-                    help="operand precision of the input-gradient passes (single-pass fp16 with power-of-two scaling)")
+    ap.add_argument("--prec-bwd", default=os.environ.get("VD_PREC_BWD", "f16x3"),
+                    help="operand precision of the input-gradient passes (f16x3: hi+lo pairs; f16: single pass; both with per-layer "
+                         "power-of-two scaling)")
+    ap.add_argument("--real-last", default=None, choices=["x1", "x3"],
+                    help="real side's last conv level: x3 = hi+lo operand pairs (default, VD_REAL_LAST), x1 = single pass like the others")
     ap.add_argument("--chunk", type=int, default=3200, help="real clips per launch (all of a single-GPU step by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-classes", type=int, default=10, help="dm/s2d: class terms timed for the CPU baseline")
-    ap.add_argument("--shard", default="auto", choices=["auto", "class", "batch"],
-                    help="multi-GPU decomposition: whole classes per rank, or 1/N of every class's real batch per rank "
-                         "(+ one all-reduce of the per-class feature sums); auto = batch when batch_real %% N == 0")
+    ap.add_argument("--shard", default="auto", choices=["auto", "class", "batch", "hybrid"],
+                    help="multi-GPU decomposition of dm: whole classes per rank (uneven blocks, no data-path collective); 1/N of every "
+                         "class's real batch per rank (+ all-reduce of the per-class feature sums); hybrid = equal blocks of whole "
+                         "classes + the left-over classes' batches split N ways (+ all-reduce of THEIR sums, 8 KB per class); "
+                         "auto = hybrid when it balances better than class blocks, else class")
     ap.add_argument("--syn-steps", type=int, default=10, help="--method mtt: unrolled student steps (sh/s2d/s2d_MTT_ms_K400.sh)")
     ap.add_argument("--batch-syn", type=int, default=256, help="--method mtt: composed clips per student step")
     ap.add_argument("--mtt-raw", action="store_true", help="--method mtt: raw synthetic clips (distill_baseline.py MTT) instead of "
@@ -252,6 +257,10 @@ def quiet_stdout():
 
 def finish(h, out, extra_rank0=None):
     import torch.distributed as dist
+    from video_distillation_amd import distill
+    if out is not None:     # data-path collectives this rank's trainers issued over the whole run (warm-up, timed, sustained, eval)
+        out["collectives"] = dict(distill.COLLECTIVE_CALLS, backend=(dist.get_backend() if dist.is_initialized() else None),
+                                  forced_on_one_rank=(h.world == 1 and distill.collectives_on(1)))
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -345,7 +354,8 @@ def run_eval(args, trainer, pool, device, rank):
     if rank != 0:
         return None
     labels = torch.arange(C, device=device).repeat_interleave(args.ipc)
-    have = [c for c in range(C) if pool.counts[c] > 4 and (c in trainer.classes or trainer.__dict__.get("shard") == "batch")]
+    resident = set(trainer.classes) | set(trainer.__dict__.get("split", []))       # classes whose real clips this rank holds
+    have = [c for c in range(C) if pool.counts[c] > 4 and (c in resident or trainer.__dict__.get("shard") == "batch")]
     idx = torch.as_tensor([pool.offsets[c] + pool.counts[c] - 1 - k for c in have for k in range(4)], device=device)
     test = utils.TensorDataset(pool.clips[idx], torch.as_tensor(have, device=device).repeat_interleave(4))
     loader = torch.utils.data.DataLoader(test, batch_size=64, shuffle=False)
@@ -402,8 +412,11 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
                                       "; vpc 1 / spc 2 / dpc 2, static memories frozen" if s2d else ""),
             ("real batch sharded x%d + all-reduce of per-class feature sums (410 KB); synthetic clips class-owned, no gradient "
              "exchange" % world) if trainer.__dict__.get("shard") == "batch" else
+            ("hybrid x%d: %d whole classes per rank + the real batches of %d left-over classes split %d ways (all-reduce of their "
+             "feature sums, %d KB); synthetic clips class-owned, no gradient exchange" % (
+                 world, args.classes // world, args.classes % world, world, (args.classes % world) * 8)) if trainer.__dict__.get("shard") == "hybrid" else
             "class-sharded x%d (owner-computes, no gradient exchange%s)" % (world, "; 1.3 KB all-reduce of the hallucinator gradient" if s2d else ""),
-            {"real_clips": args.prec_real, "syn_clips_fwd": args.prec_syn, "input_gradient": args.prec_bwd, "accumulate": "f32",
+            {"real_clips": args.prec_real, "real_clips_last_level": backend.real_last, "syn_clips_fwd": args.prec_syn, "input_gradient": args.prec_bwd, "accumulate": "f32",
              "real_weight_dither_groups": backend._dither, "syn_value_pass": None if backend._dither else backend.weight_format})
         out["config"]["pool_per_class"] = args.pool_per_class
         out["config"]["real_pool"] = ("resident in HBM: fp32 clips + the same clips converted once to the first layer's 16-bit pixel "
@@ -423,6 +436,9 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
             for p in roof["programs"]:
                 if p["program"] in ("fwd0", "fwd2") and p["operands"] == args.prec_real:
                     roof[p["program"] + "_tflops"] = p["tflops"]
+                if p["program"] == "fwd2_hilo":      # the real side's last level in hi+lo pairs: 3 MFMAs per algorithmic product
+                    roof["fwd2_tflops"] = p["tflops"]
+                    roof["fwd2_ms_per_launch"] = p["ms_total"] / max(p["launches"], 1)
             out["roofline"] = roof
         if sustained:
             out["sustained"] = sustained
@@ -666,19 +682,28 @@ def main():
     c_lo, c_hi = distill.class_range(args.classes, rank, world)
     shard = args.shard
     if shard == "auto":
-        # class blocks (50 -> 7,7,6,...: no data-path collective) beat the balanced batch split (+ one 410 KB all-reduce)
-        # in the single-GPU proxy of a rank's step at every N: 17.0 / 8.9 / 5.0 ms vs 17.1 / 8.7 / 5.3 ms at N = 2 / 4 / 8
-        # (tools/rank_proxy.py; the exchange is not even in those numbers) -- `--shard batch` remains available
-        shard = "class"
+        # Whole-class blocks (50 -> 7,7,6,...) need no data-path collective but leave ranks idle (ceiling 50/7 = 7.14x at 8);
+        # the balanced batch split (+ one 410 KB all-reduce) pays a rank's fixed per-launch costs on 50 small class slices
+        # (single-GPU proxy of a rank's step, tools/rank_proxy.py: 17.0 / 8.9 / 5.0 ms vs 17.1 / 8.7 / 5.3 ms at N = 2 / 4 / 8).
+        # The hybrid keeps whole classes and splits only the left-over ones: 400 real clips on every rank at N = 8.
+        uneven = world > 1 and args.classes % world != 0 and args.batch_real % world == 0
+        shard = "hybrid" if (uneven and args.method == "dm") else "class"
+    if shard == "hybrid" and args.method != "dm":
+        raise SystemExit("--shard hybrid is a decomposition of --method dm")
     if shard == "batch":   # every rank holds the whole pool (11 GB) and embeds its slice of each class batch
         pool = distill.RealPool.synthetic(args.classes, list(range(args.classes)), args.pool_per_class, geo, device, seed=1234)
+    elif shard == "hybrid":   # the rank's block of whole classes + every split class
+        block, split, _ = distill.hybrid_partition(args.classes, rank, world)
+        pool = distill.RealPool.synthetic(args.classes, block + split, args.pool_per_class, geo, device, seed=1234)
     else:
         pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device, seed=1234)
     if args.method == "dc":
         return bench_dc(args, h, distill, geo, pool)
     nsyn = (c_hi - c_lo) * (args.ipc if args.method == "dm" else 1)
+    if shard == "hybrid":
+        nsyn = (args.classes // world + 1) * args.ipc
     backend = distill.HipBackend(geo, device, prec_real=args.prec_real, prec_syn=args.prec_syn, chunk=args.chunk,
-                                 prec_bwd=args.prec_bwd,
+                                 prec_bwd=args.prec_bwd, real_last=args.real_last,
                                  syn_batch_hint=_batch_hint(nsyn) if os.environ.get("VD_SYN_HINT", "1") == "1" else None)
     return bench_dm(args, h, distill, plan, geo, pool, backend, shard)
 

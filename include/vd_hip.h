@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 2
+#define VD_ABI_VERSION 3
 
 /* operand precision of the MFMA contraction (accumulation is always fp32) */
 #define VD_PREC_BF16   0   /* bf16 operands, one MFMA per product                       */
@@ -74,6 +74,9 @@ typedef struct VdConvParams {
                                      first clip / w_set_clips picks the set (dithered real-side weights); 0 = one set */
     int32_t replica_stride;       /* atomic ROWS epilogue: dst += boxes[box][5] * replica_stride floats (weight-gradient programs spread their
                                      boxes over copies of dW so that same-address atomics do not serialise); 0 = one target */
+    int32_t emit_lo;              /* single-pass programs with the staged POOL_CL epilogue (argmax NULL): != 0 also writes the LOW plane
+                                     rn16(v - rn16(v)) of every pooled output, dst_plane_stride slots behind the high one -- the next level
+                                     can then run in the hi+lo format of the same 16-bit type (real side: level 2 in f16x3) */
 } VdConvParams;
 
 int vd_abi_version(void);

@@ -51,5 +51,7 @@ def compare_decisions(x_btchw, params, am, tie_tol=2e-5):
         mism = flag_diff | pos_diff
         far = mism & (slack > tie_tol)
         out.append({"windows": int(arg.numel()), "mismatch": int(mism.sum()), "not_near_tie": int(far.sum()),
-                    "worst_margin": float(slack[mism].max()) if bool(mism.any()) else 0.0})
+                    "worst_margin": float(slack[mism].max()) if bool(mism.any()) else 0.0,
+                    "mismatch_per_clip": [int(v) for v in mism.flatten(1).sum(1)],
+                    "not_near_tie_per_clip": [int(v) for v in far.flatten(1).sum(1)]})
     return out

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(lib, name), name
     lib.vd_abi_version.restype = ctypes.c_int
-    assert lib.vd_abi_version() == 2
+    assert lib.vd_abi_version() == 3
 
 
 def test_params_struct_layout_matches_header():

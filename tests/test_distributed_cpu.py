@@ -37,8 +37,12 @@ def _g3_setup(rank, world, shard="class"):
     reals = [randn(z["real_seeds"][it], *[(4, 8, 3, 64, 64)] * 3) for it in range(2)]
     pool = _Pool(); pool.clips = torch.cat([torch.cat(r) for r in reals]); pool.counts = [4] * 3; pool.offsets = [0, 4, 8]
     lo, hi = distill.class_range(3, rank, world)
+    own = list(range(lo, hi))
+    if shard == "hybrid" and world > 1:
+        block, _, mine = distill.hybrid_partition(3, rank, world)
+        own = block + mine
     tr = distill.DMTrainer(OracleBackend(net_seeds=z["net_seeds"]), pool, 3, 1, 4, lr_img=float(z["lr"]),
-                           momentum=float(z["momentum"]), rank=rank, world=world, image_syn=syn[lo:hi].clone(), shard=shard)
+                           momentum=float(z["momentum"]), rank=rank, world=world, image_syn=syn[own].clone(), shard=shard)
     return z, tr
 
 
@@ -74,6 +78,18 @@ def _worker_g3_batch(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         z, losses, syn = _g3_run(rank, world, shard="batch")
+        if rank == 0:
+            q.put((losses, syn.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_g3_hybrid(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z, losses, syn = _g3_run(rank, world, shard="hybrid")
         if rank == 0:
             q.put((losses, syn.numpy()))
     finally:
@@ -132,6 +148,16 @@ def test_dm_trainer_two_ranks_gloo_matches_golden():
 def test_dm_trainer_two_ranks_batch_sharded_matches_golden():
     """Real batch split over ranks + all-reduce of per-class feature sums == the reference step."""
     losses, syn = _spawn(_worker_g3_batch, 2)
+    z = np.load(os.path.join(GOLDEN, "g3_dm_steps.npz"))
+    np.testing.assert_allclose(losses, z["losses"], rtol=1e-5)
+    np.testing.assert_allclose(syn[:, ::2, :, ::4, ::4], z["syn2"], rtol=1e-4, atol=1e-5)
+
+
+def test_dm_trainer_two_ranks_hybrid_matches_golden():
+    """3 classes on 2 ranks, hybrid: one whole class per rank + the third class's real batch split in halves (all-reduce of
+    its 256 feature sums), its synthetic clip owned by rank 0, the gathered clips back in class order == the reference step."""
+    assert distill.hybrid_partition(3, 0, 2) == ([0], [2], [2]) and distill.hybrid_partition(3, 1, 2) == ([1], [2], [])
+    losses, syn = _spawn(_worker_g3_hybrid, 2)
     z = np.load(os.path.join(GOLDEN, "g3_dm_steps.npz"))
     np.testing.assert_allclose(losses, z["losses"], rtol=1e-5)
     np.testing.assert_allclose(syn[:, ::2, :, ::4, ::4], z["syn2"], rtol=1e-4, atol=1e-5)
@@ -376,10 +402,14 @@ def _c50_run(rank, world, shard):
     syn = torch.randn(C, 8, 3, 64, 64, generator=g)
     pool = _Pool(); pool.clips = clips; pool.counts = [B] * C; pool.offsets = [c * B for c in range(C)]
     lo, hi = distill.class_range(C, rank, world)
+    own = list(range(lo, hi))
+    if shard == "hybrid" and world > 1:
+        block, _, mine = distill.hybrid_partition(C, rank, world)
+        own = block + mine
     tr = distill.DMTrainer(OracleBackend(), pool, C, 1, B, lr_img=0.5, momentum=0.5, rank=rank, world=world,
-                           image_syn=syn[lo:hi].clone(), shard=shard)
+                           image_syn=syn[own].clone(), shard=shard)
     losses = [float(tr.global_loss(tr.step(it))) for it in range(1)]
-    return losses, tr.gather_syn(), (lo, hi)
+    return losses, tr.gather_syn(), ((lo, hi) if shard != "hybrid" else (len(own), own[-1]))
 
 
 def _worker_c50(rank, world, port, q, shard):
@@ -404,19 +434,27 @@ def _worker_c50_batch(rank, world, port, q):
     _worker_c50(rank, world, port, q, "batch")
 
 
+def _worker_c50_hybrid(rank, world, port, q):
+    _worker_c50(rank, world, port, q, "hybrid")
+
+
 _C50_CACHE = {}
 
 
-@pytest.mark.parametrize("worker", [_worker_c50_class, _worker_c50_batch])
+@pytest.mark.parametrize("worker", [_worker_c50_class, _worker_c50_batch, _worker_c50_hybrid])
 def test_dm_trainer_eight_ranks_fifty_classes(worker):
-    """world 8, C = 50: uneven class blocks (7,7,6,...) with ragged all-gather of the synthetic clips, and the batch
-    mode with one real clip of every class per rank; both equal the single-rank run."""
+    """world 8, C = 50: uneven class blocks (7,7,6,...) with ragged all-gather of the synthetic clips, the batch
+    mode with one real clip of every class per rank, and the hybrid (6 whole classes per rank + classes 48 / 49 split eight
+    ways, owned by ranks 0 / 1); all equal the single-rank run."""
     if "ref" not in _C50_CACHE:
         torch.set_num_threads(8)
         _C50_CACHE["ref"] = _c50_run(0, 1, "class")
     want_l, want_syn, _ = _C50_CACHE["ref"]
     losses, syn, spans = _spawn(worker, 8)
-    assert [b - a for a, b in spans] == [7, 7, 6, 6, 6, 6, 6, 6] and spans[0][0] == 0 and spans[-1][1] == 50
+    if worker is _worker_c50_hybrid:
+        assert spans == [(7, 48), (7, 49), (6, 17), (6, 23), (6, 29), (6, 35), (6, 41), (6, 47)]    # (clips owned, last class)
+    else:
+        assert [b - a for a, b in spans] == [7, 7, 6, 6, 6, 6, 6, 6] and spans[0][0] == 0 and spans[-1][1] == 50
     np.testing.assert_allclose(losses, want_l, rtol=2e-5)
     np.testing.assert_allclose(syn, want_syn.numpy(), rtol=1e-4, atol=1e-6)
 

@@ -271,17 +271,20 @@ def test_g11_evaluate_synset_multi_static_on_hip(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------
-# The SHIPPED precision mode (real f16 / syn f16x3 / input gradient f16): what bench.py times.
-# Measured errors are appended to gpurun_out/r02_parity.json (copied to profiles/ by hand).
+# The SHIPPED precision mode = HipBackend's defaults = what bench.py times: real clips single-pass f16 with dithered weights and
+# the last conv level in hi+lo pairs, synthetic clips f16 hi+lo pairs, input gradient f16 hi+lo pairs.  "fast" is round 2's
+# mode (single pass on every real level and in the input gradient).  Against the ORACLE at every step of the late regime:
+# tests/test_gpu_parity_late.py.  Measured errors are appended to gpurun_out/r03_parity.json (copied to profiles/ by hand).
 # ------------------------------------------------------------------------------------------------
-MODES = {"mixed": dict(prec_real="f16", prec_syn="f16x3", prec_bwd="f16"),
+MODES = {"mixed": dict(),
+         "fast": dict(prec_real="f16", prec_syn="f16x3", prec_bwd="f16", real_last="x1"),
          "x3": dict(prec_real="f16x3", prec_syn="f16x3", prec_bwd="f16x3")}
 
 
 def _record(key, value):
     import json
     path = os.environ.get("VD_PARITY_LOG", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                        "gpurun_out", "r02_parity.json"))
+                                                        "gpurun_out", "r03_parity.json"))
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         data = json.load(open(path)) if os.path.exists(path) else {}
@@ -298,8 +301,9 @@ def _rel(a, b):
 
 def test_g3_two_dm_steps_shipped_mixed_mode(golden_dir):
     """G3 (two reference DM iterations incl. momentum) in the mode bench.py times.  Bars: loss 1e-3 (north_star);
-    pixel gradient / update rel-L2 2e-3 (single-pass f16 input gradient: 5e-4 operand rounding + the arg-max
-    flips the fp32 reference itself shows against fp64, 3.9e-4)."""
+    pixel gradient / update rel-L2 1.5e-3 (four real clips per class only: G = 4 dither groups and a class mean over 4 clips
+    leave more of the single-pass rounding than the 64-clip batches of the real configurations do; + the arg-max flips the
+    fp32 reference itself shows against fp64, 3.9e-4)."""
     from video_distillation_amd import distill, plan
     import video_distillation_amd.distill as D
     z = np.load(os.path.join(golden_dir, "g3_dm_steps.npz"))
@@ -326,7 +330,7 @@ def test_g3_two_dm_steps_shipped_mixed_mode(golden_dir):
     _record("g3_mixed", {"loss_rel": lerr, "update_rel_l2": upd})
     print("G3 mixed: loss rel", lerr, "update rel-l2", upd)
     assert max(lerr) < 1e-3
-    assert max(upd) < 2e-3
+    assert max(upd) < 1.5e-3
 
 
 def test_g5_s2d_step_shipped_mixed_mode(golden_dir):
@@ -368,12 +372,12 @@ def test_g12_late_regime_dm_run(golden_dir):
         gradient of the first six steps within 1e-3 (measured 4e-5).  Later steps are recorded, not asserted: a single
         pooling near-tie resolved the other way in the last layer moves 1/2048 of the gradient (3e-2 rel-L2) and, at
         lr 50, the trajectories part from there on -- the fp32 reference is as arbitrary at such a tie as we are.
-    (b) the SHIPPED mixed mode, teacher-forced onto the f16x3 trainer's states (same synthetic clips and momentum before
-        every step; the routing of the gradient comes from the same exact-weight forward in both, so no tie can differ):
-        loss within 1e-3, gradient within 3e-3 rel-L2 of the f16x3 gradient at every step (measured 1.7e-3 .. 2.3e-3:
-        what is left of the real side's weight-rounding perturbation, ~8e-5 |f| on the class mean, over a feature
-        difference of 4e-2 |f|; it scales as 1/difference, so 3e-4 at a 25 % difference, 1e-4 at a random start).
-    (c) the same without the value pass (synthetic features from the exact-weight forward): recorded as the ablation."""
+    (b) HIP-vs-HIP ablation of the real side's remedies, teacher-forced onto the f16x3 trainer's states (same synthetic clips
+        and momentum before every step; the routing of the gradient comes from the same exact-weight forward in all, so no tie
+        can differ): the shipped mode (dithered weights, last level hi+lo, hi+lo input gradient), round 2's "fast" mode
+        (dithered weights, single pass everywhere else), the value pass it replaced, and nothing.  Asserted: the order, and
+        loss within 1e-3 of the f16x3 step for the shipped mode.  The shipped mode against the ORACLE at every step:
+        tests/test_gpu_parity_late.py (measured there: 0.73e-3 median; fast 1.09e-3)."""
     from video_distillation_amd import distill, plan
     import video_distillation_amd.distill as D
     z = np.load(os.path.join(golden_dir, "g12_dm_late.npz"))
@@ -392,12 +396,14 @@ def test_g12_late_regime_dm_run(golden_dir):
             inner.weight_format = None
         return distill.DMTrainer(_FixedNetBackend(inner, seeds), pool, C, 1, B, lr_img=float(z["lr"]), momentum=mu,
                                  image_syn=pool_t[:, 0].clone().cuda())
-    # shipped: dithered real-side weights; the two older remedies for comparison: value pass, nothing
-    ta, tb, tv, tc = trainer("x3"), trainer("mixed"), trainer("mixed", dither=False), trainer("mixed", dither=False, value_pass=False)
+    # shipped; round 2's fast mode (dithered real-side weights only); the two older remedies: value pass, nothing
+    ta, tb, tf = trainer("x3"), trainer("mixed"), trainer("fast")
+    tv, tc = trainer("fast", dither=False), trainer("fast", dither=False, value_pass=False)
     assert tv.be.weight_format == "f16" and tc.be.weight_format is None and ta.be.weight_format is None
+    assert tb.be.inner.real_last == "x3" and tf.be.inner.real_last == "x1"
     sub = lambda t: t.cpu()[:, ::2, :, ::4, ::4]       # noqa: E731
     orig = D.sample_real_indices
-    rec = {"x3_vs_reference": {"loss": [], "grad": []}, "mixed_vs_x3": {"loss": [], "grad": []},
+    rec = {"x3_vs_reference": {"loss": [], "grad": []}, "mixed_vs_x3": {"loss": [], "grad": []}, "fast_vs_x3": {"loss": [], "grad": []},
            "mixed_valuepass_vs_x3": {"loss": [], "grad": []}, "mixed_plain_vs_x3": {"loss": [], "grad": []}}
     try:
         for it in range(steps):
@@ -408,7 +414,7 @@ def test_g12_late_regime_dm_run(golden_dir):
             ga = ta.buf - mu * state[1] if it > 0 else ta.buf.clone()       # buf = mu*buf + g
             rec["x3_vs_reference"]["loss"].append(abs(la / float(z["losses"][it]) - 1))
             rec["x3_vs_reference"]["grad"].append(_rel(sub(ga), z["grads"][it]))
-            for tr, key in ((tb, "mixed_vs_x3"), (tv, "mixed_valuepass_vs_x3"), (tc, "mixed_plain_vs_x3")):
+            for tr, key in ((tb, "mixed_vs_x3"), (tf, "fast_vs_x3"), (tv, "mixed_valuepass_vs_x3"), (tc, "mixed_plain_vs_x3")):
                 tr.image_syn.copy_(state[0]); tr.buf.copy_(state[1]); tr.steps_done = state[2]
                 lt = float(tr.step(it))
                 gt = tr.buf - mu * state[1] if it > 0 else tr.buf.clone()
@@ -419,15 +425,17 @@ def test_g12_late_regime_dm_run(golden_dir):
     rec["feature_diff_over_norm"] = [float(v) for v in z["rel_diff"].mean(1)]
     _record("g12", rec)
     assert tb.be.inner._dither == 8 and tv.be.inner._dither == 0
-    for k in ("x3_vs_reference", "mixed_vs_x3", "mixed_valuepass_vs_x3", "mixed_plain_vs_x3"):
+    for k in ("x3_vs_reference", "mixed_vs_x3", "fast_vs_x3", "mixed_valuepass_vs_x3", "mixed_plain_vs_x3"):
         print("G12 %s: max loss rel %.2e, grad rel-l2 max %.2e median %.2e" % (k, max(rec[k]["loss"]), max(rec[k]["grad"]),
                                                                               float(np.median(rec[k]["grad"]))))
     assert max(rec["x3_vs_reference"]["loss"]) < 1e-3
     assert max(rec["x3_vs_reference"]["grad"][:6]) < 1e-3
     assert max(rec["mixed_vs_x3"]["loss"]) < 1e-3
-    assert max(rec["mixed_vs_x3"]["grad"]) < 2e-3
-    # the dithered weights beat the value pass they replace, which beat doing nothing
-    assert np.median(rec["mixed_valuepass_vs_x3"]["grad"]) > 1.3 * np.median(rec["mixed_vs_x3"]["grad"])
+    assert np.median(rec["mixed_vs_x3"]["grad"]) < 1e-3
+    # hi+lo last level and input gradient beat the single-pass ones; the dithered weights beat the value pass they replaced,
+    # which beat doing nothing
+    assert np.median(rec["fast_vs_x3"]["grad"]) > 1.2 * np.median(rec["mixed_vs_x3"]["grad"])
+    assert np.median(rec["mixed_valuepass_vs_x3"]["grad"]) > 1.3 * np.median(rec["fast_vs_x3"]["grad"])
     assert np.median(rec["mixed_plain_vs_x3"]["grad"]) > 1.5 * np.median(rec["mixed_valuepass_vs_x3"]["grad"])
 
 

@@ -1,0 +1,61 @@
+"""The RCCL data-path collectives of the trainers, EXECUTED on a one-GPU box: bench.py runs in child processes with a
+1-rank ``nccl`` process group (VD_BENCH_FORCE_DIST=1) and ``VD_FORCE_COLLECTIVES=1`` / ``VD_FORCE_BATCH_SHARD=1``, which keep
+every ``world > 1`` branch alive -- the feature-sum all-reduce of the batch / hybrid decompositions on the synthetic-clip
+stream, the hallucinator-gradient all-reduce of s2d, the loss all-reduces, the all-gather of the synthetic clips before
+evaluation, DC's per-step loss all-reduce incl. the profiling step every rank must take, MTT's flat-gradient / Hessian-vector
+all-reduces per student step.  A 1-rank collective is the identity, so every run must reproduce the plain run's loss; what
+the test adds is that the calls are issued to RCCL from the trainers' streams and complete (reference: the only multi-GPU
+mechanism upstream is nn.DataParallel, utils.py:615-623).  The N-rank arithmetic of the same code is covered on gloo
+(tests/test_distributed_cpu.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--sustain-seconds", "0"]
+FORCE = {"VD_BENCH_FORCE_DIST": "1", "VD_FORCE_COLLECTIVES": "1", "VD_FORCE_BATCH_SHARD": "1", "MASTER_PORT": "29541"}
+
+
+def _bench(extra, env=None):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.update(env or {})
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + COMMON + extra, cwd=ROOT, env=e, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_dm_decompositions_issue_their_collectives_and_keep_the_loss():
+    small = ["--classes", "6", "--pool-per-class", "70", "--eval-epochs", "1"]
+    plain = _bench(small + ["--shard", "class"])
+    assert plain["collectives"]["all_reduce"] == 0 and plain["collectives"]["backend"] is None
+    for shard, per_step in (("class", 1), ("batch", 2), ("hybrid", 2)):
+        # (hybrid on one rank has no class left over; VD_HYBRID_FORCE_SPLIT makes the last two classes split ones)
+        got = _bench(small + ["--shard", shard], dict(FORCE, VD_HYBRID_FORCE_SPLIT="2"))
+        c = got["collectives"]
+        assert c["backend"] == "nccl" and c["forced_on_one_rank"]
+        # 3 steps: the loss all-reduce each, + the feature-sum all-reduce of the batch / hybrid split; one all-gather of the
+        # synthetic clips before evaluate_synset
+        assert c["all_reduce"] == 3 * per_step and c["all_gather"] == 1, (shard, c)
+        assert abs(got["loss_last"] / plain["loss_last"] - 1) < 1e-5, (shard, got["loss_last"], plain["loss_last"])
+
+
+def test_s2d_dc_mtt_issue_their_collectives_and_keep_the_loss():
+    s2d = ["--method", "s2d", "--classes", "4", "--pool-per-class", "70", "--eval-epochs", "0"]
+    a, b = _bench(s2d), _bench(s2d, FORCE)
+    assert b["collectives"]["all_reduce"] == 3 * 2 and abs(b["loss_last"] / a["loss_last"] - 1) < 1e-5
+    dc = ["--method", "dc", "--classes", "3", "--ipc", "1", "--frames", "8", "--size", "64", "--batch-real", "8", "--pool-per-class", "12"]
+    a, b = _bench(dc), _bench(dc, FORCE)
+    assert b["collectives"]["all_reduce"] == 3 + 1            # every step's loss, incl. the extra profiling step of bench_dc
+    assert abs(b["loss_last"] / a["loss_last"] - 1) < 1e-3 and b["roofline"]["launches"] > 0
+    mtt = ["--method", "mtt", "--classes", "8", "--frames", "8", "--size", "64", "--syn-steps", "2", "--batch-syn", "8"]
+    a, b = _bench(mtt), _bench(mtt, FORCE)
+    # per iteration: flat gradient + Hessian-vector product per student step (2 x 2), hallucinator + dynamic-memory gradients (2);
+    # 3 timed / warm-up iterations + 1 profiling iteration
+    assert b["collectives"]["all_reduce"] == 4 * (2 * 2 + 2), b["collectives"]
+    assert abs(b["grand_loss_last"] / a["grand_loss_last"] - 1) < 1e-3

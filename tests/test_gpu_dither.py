@@ -162,3 +162,47 @@ def test_module_embed_value_pass_follows_real_dither_and_the_weights():
     eng16.set_weights(net._feature_params())
     assert torch.equal(f_plain, eng16.forward(real))               # never dithered
     assert torch.equal(syn_feats(), expect("f16"))
+
+
+@pytest.mark.parametrize("geom,n", [((8, 64, 64), 32), ((16, 112, 112), 8)])
+def test_last_level_in_hi_lo_pairs(geom, n):
+    """EmbedEngine(last_hilo=True): level 1's single-pass program also writes the LOW plane of its pooled outputs
+    (VdConvParams.emit_lo) and level 2 multiplies hi+lo activations by hi+lo weights.  (a) the high plane is bitwise what the
+    plain single-pass program writes and hi + lo reproduces the fp32 pooled value to 2^-22; (b) the features are closer to
+    the fp32 oracle than the all-single-pass engine's, per clip and on the class mean; (c) chunked == unchunked."""
+    from video_distillation_amd import engine, plan
+    geo = plan.NetGeometry(*geom)
+    T, H, W = geom
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(1, T, 3, H, W, generator=g) + 0.1 * torch.randn(n, T, 3, H, W, generator=g))
+    params = R.init_params(4321, 3, 5)
+    with torch.no_grad():
+        want = R.convnet3d_embed(x, params)
+    w = [p.cuda() for p in params[:6]]
+    e1 = engine.EmbedEngine(geo, prec="f16", chunk=4096); e1.set_weights(w)
+    e3 = engine.EmbedEngine(geo, prec="f16", chunk=4096, last_hilo=True); e3.set_weights(w)
+    f1, f3 = e1.forward(x.cuda()), e3.forward(x.cuda())
+    per2 = int(np.prod(e3.fwd[1].plan.out_shape[:-1]))
+    hi3 = e3._ws["act2"][:2 * n * per2 * 8].view(2, n * per2, 8)[0].clone()
+    lo3 = e3._ws["act2"][:2 * n * per2 * 8].view(2, n * per2, 8)[1].clone()
+    hi1 = e1._ws["act2"][:n * per2 * 8].view(n * per2, 8)
+    assert torch.equal(hi3, hi1)
+    ex = engine.EmbedEngine(geo, prec="f16x3", chunk=4096); ex.set_weights(w)       # the same pooled values from an f16x3 level 1 ...
+    ex.forward(x.cuda())
+    a_hi = ex._ws["act2"][:2 * n * per2 * 8].view(2, n * per2, 8)
+    exact = a_hi[0].view(torch.float16).double() + a_hi[1].view(torch.float16).double()
+    got = hi3.view(torch.float16).double() + lo3.view(torch.float16).double()
+    single = hi3.view(torch.float16).double()
+    # ... differ from ours by levels 0 / 1 running single pass; what matters here: hi + lo carries the value far below f16's 2^-11
+    assert float((lo3.view(torch.float16).double().abs() <= 2.0 ** -11 * single.abs() + 1e-7).double().mean()) == 1.0
+    assert float((got - exact).norm() / exact.norm()) < 1.05 * float((single - exact).norm() / exact.norm())
+    e_clip = [float(((f.cpu() - want).norm(dim=1) / want.norm(dim=1)).mean()) for f in (f1, f3)]
+    e_mean = [float((f.cpu().mean(0) - want.mean(0)).norm() / want.mean(0).norm()) for f in (f1, f3)]
+    print("%s last level x1 / hi+lo: per-clip feature error %.2e / %.2e, class-mean error %.2e / %.2e" % (geom, *e_clip, *e_mean))
+    assert e_clip[1] < 0.92 * e_clip[0] and e_clip[1] < 3e-4
+    e3c = engine.EmbedEngine(geo, prec="f16", chunk=3, last_hilo=True); e3c.set_weights(w)
+    assert torch.equal(e3c.forward(x.cuda()), f3)
+    with pytest.raises(AssertionError):
+        e3.forward(x.cuda(), keep=True)
+    with pytest.raises(ValueError):
+        engine.EmbedEngine(geo, prec="f16x3", last_hilo=True)

@@ -8,10 +8,14 @@ gradient per ``MODES``); at EVERY step the CPU oracle (``oracle.ref_cpu.dm_loss_
 the HIP step starts from -- same synthetic clips, same fresh network, same real batch -- in fp32 (what the reference
 computes) and in fp64 (what it approximates), and the HIP loss and pixel gradient are compared with both.
 
-Gradient criterion (flip tolerant, as tests/test_gpu_embed._grad_check): a max-pool window whose two largest entries tie
-to within rounding routes its gradient elsewhere depending on summation order -- the fp32 oracle differs from the fp64
-one for exactly that reason, measured below per step (`oracle32_vs_64`).  Per synthetic clip the rel-L2 error against fp64
-is asserted at the MEDIAN over (step, class) and at a high quantile; single (step, class) entries may exceed it by a flip.
+Gradient criterion (flip tolerant): a max-pool window whose two largest entries tie to within rounding routes its gradient
+elsewhere depending on summation order -- the fp32 oracle differs from the fp64 one for exactly that reason (`oracle32_vs_64`
+below), and in this regime it happens in roughly one step out of five.  So every (step, class) entry is classified by the
+pooling decisions the HIP forward of that synthetic clip RECORDED (its arg-max bytes) against the fp64 oracle's max_pool3d
+decisions (tests/argmax_tools.py): an entry with no differing window in levels 1 / 2 is CLEAN and must meet the bar; an entry
+above the bar must show a differing window, every differing window must be a near-tie of the fp64 oracle itself (margin below
+2e-5 of the level's rms), and the error stays below the 5e-2 a last-level flip can cause.  The median over ALL entries meets
+the bar as well.
 
 Measured values go to gpurun_out/r03_parity.json (copied to profiles/)."""
 import json
@@ -23,6 +27,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu as R
+from tests import argmax_tools
 
 pytestmark = pytest.mark.gpu
 
@@ -76,11 +81,22 @@ def late_regime_run(geom, C, NP, B, steps, lr, seed, modes=("shipped",), backend
     for m in modes:
         kw = {k: v for k, v in MODES[m].items() if v is not None}
         kw.update(backend_kw or {})
+        if m == "shipped" and os.environ.get("VD_PARITY_BWD"):      # (experiments: another input-gradient format for the lead trainer)
+            kw["prec_bwd"] = os.environ["VD_PARITY_BWD"]
         be = distill.HipBackend(geo, dev, chunk=4096, **kw)
         trainers[m] = distill.DMTrainer(be, pool, C, 1, B, lr_img=lr, momentum=mu, image_syn=syn0.clone())
     lead = trainers[modes[0]]
+    captured = {}
+    orig_embed_syn = lead.be.embed_syn
+
+    def spy_embed_syn(x, weights):          # the pooling decisions of the lead trainer's synthetic-clip forward
+        f, handle = orig_embed_syn(x, weights)
+        captured["am"] = [a.clone() for a in handle[0][2:5]]
+        return f, handle
+    lead.be.embed_syn = spy_embed_syn
     rec = {m: {"loss_vs_fp32": [], "loss_vs_fp64": [], "grad_vs_fp32": [], "grad_vs_fp64": [], "grad_vs_fp64_per_class": [],
                "flipped_frac": []} for m in modes}
+    rec["decisions"] = {"mismatch_upper_levels_per_class": [], "not_near_tie_per_class": [], "mismatch_level0": []}
     rec.update({"oracle32_vs_64": {"loss": [], "grad": [], "grad_per_class": []}, "feature_gap_over_norm": [], "oracle_seconds": []})
     for it in range(steps):
         state = (lead.image_syn.clone(), lead.buf.clone(), lead.steps_done)
@@ -116,12 +132,26 @@ def late_regime_run(geom, C, NP, B, steps, lr, seed, modes=("shipped",), backend
             r["grad_vs_fp64_per_class"].append([_rel(gt[c], g64[c]) for c in range(C)])
             d = (gt.double() - g64).abs()
             r["flipped_frac"].append(float((d > 1e-2 * g64.abs().max()).double().mean()))
+            if tr is lead:
+                dec = argmax_tools.compare_decisions(syn, weights, captured["am"])
+                rec["decisions"]["mismatch_upper_levels_per_class"].append(
+                    [a + b for a, b in zip(dec[1]["mismatch_per_clip"], dec[2]["mismatch_per_clip"])])
+                rec["decisions"]["not_near_tie_per_class"].append(
+                    [sum(v) for v in zip(*[d_["not_near_tie_per_clip"] for d_ in dec])])
+                rec["decisions"]["mismatch_level0"].append(dec[0]["mismatch"])
+    flipped = np.asarray(rec["decisions"]["mismatch_upper_levels_per_class"]).reshape(-1) > 0
     for m in modes:
         per = np.asarray(rec[m]["grad_vs_fp64_per_class"]).reshape(-1)
+        rec[m]["summary_clean"] = {"entries": int((~flipped).sum()), "of": int(flipped.size),
+                                   "grad_vs_fp64_median": float(np.median(per[~flipped])) if (~flipped).any() else None,
+                                   "grad_vs_fp64_max": float(per[~flipped].max()) if (~flipped).any() else None}
         rec[m]["summary"] = {"loss_vs_fp32_max": max(rec[m]["loss_vs_fp32"]), "loss_vs_fp64_max": max(rec[m]["loss_vs_fp64"]),
                              "grad_vs_fp64_median": float(np.median(per)), "grad_vs_fp64_p90": float(np.quantile(per, 0.9)),
                              "grad_vs_fp64_max": float(per.max()), "grad_vs_fp32_median": float(np.median(rec[m]["grad_vs_fp32"])),
-                             "dither_groups": int(getattr(trainers[m].be, "_dither", 0))}
+                             "dither_groups": int(getattr(trainers[m].be, "_dither", 0)),
+                             "real_last": getattr(trainers[m].be, "real_last", None),
+                             "prec_bwd": trainers[m].be.eng_syn.prec_name if trainers[m].be.eng_syn.prec_bwd == trainers[m].be.eng_syn.prec
+                             else [k for k, v in trainers[m].be.hip.PREC.items() if v == trainers[m].be.eng_syn.prec_bwd][0]}
     per = np.asarray(rec["oracle32_vs_64"]["grad_per_class"]).reshape(-1)
     rec["oracle32_vs_64"]["summary"] = {"loss_max": max(rec["oracle32_vs_64"]["loss"]), "grad_median": float(np.median(per)),
                                         "grad_p90": float(np.quantile(per, 0.9)), "grad_max": float(per.max())}
@@ -136,26 +166,39 @@ def _report(name, rec, modes):
     print("  fp32 oracle vs fp64 oracle:", rec["oracle32_vs_64"]["summary"])
     for m in modes:
         print("  %-8s vs oracle:" % m, rec[m]["summary"])
+        print("  %-8s clean entries (no differing pooling decision in levels 1 / 2):" % m, rec[m]["summary_clean"])
+    up = np.asarray(rec["decisions"]["mismatch_upper_levels_per_class"])
+    print("  (step, class) entries with a differing near-tie window in levels 1 / 2: %d of %d; level-0 mismatches per step: %s" % (
+        int((up > 0).sum()), up.size, rec["decisions"]["mismatch_level0"]))
     print("  oracle seconds per step (fp32, fp64): %.1f %.1f" % tuple(np.mean(rec["oracle_seconds"], axis=0)))
 
 
-# bars of the shipped mode: loss 1e-3 (north_star); pixel gradient per synthetic clip vs the fp64 oracle
-GRAD_MEDIAN_BAR = float(os.environ.get("VD_PARITY_GRAD_BAR", "1e-3"))
+# bars of the shipped mode: loss 1e-3 (north_star); pixel gradient per synthetic clip vs the fp64 oracle 1e-3
+GRAD_BAR = float(os.environ.get("VD_PARITY_GRAD_BAR", "1e-3"))
 
 
 def _assert_shipped(rec):
     s = rec["shipped"]["summary"]
-    assert s["dither_groups"] == 8
+    assert s["dither_groups"] == 8 and s["real_last"] == "x3" and s["prec_bwd"] == "f16x3"        # what bench.py times
     assert s["loss_vs_fp32_max"] < 1e-3 and s["loss_vs_fp64_max"] < 1e-3
-    assert s["grad_vs_fp64_median"] < GRAD_MEDIAN_BAR, s
-    # single (step, class) entries: a flipped last-layer window moves ~1/2048 of that clip's gradient (3e-2)
-    assert s["grad_vs_fp64_p90"] < 2 * GRAD_MEDIAN_BAR and s["grad_vs_fp64_max"] < 5e-2, s
+    assert s["grad_vs_fp64_median"] < GRAD_BAR, s
+    per = np.asarray(rec["shipped"]["grad_vs_fp64_per_class"])
+    upper = np.asarray(rec["decisions"]["mismatch_upper_levels_per_class"])
+    far = np.asarray(rec["decisions"]["not_near_tie_per_class"])
+    assert int(far.sum()) == 0, "a pooling decision differs from the fp64 oracle's in a window that is no near-tie: %s" % far.tolist()
+    for it in range(per.shape[0]):
+        for c in range(per.shape[1]):
+            if upper[it, c] == 0:          # same routing as the fp64 oracle in levels 1 and 2: the bar holds at this very step
+                assert per[it, c] < GRAD_BAR, (it, c, per[it, c])
+            else:                          # a near-tie routed the other way (the fp32 oracle does the same, oracle32_vs_64)
+                assert per[it, c] < 5e-2, (it, c, per[it, c], int(upper[it, c]))
 
 
 def test_late_regime_shipped_mode_vs_oracle_64():
     """The G12 configuration (2 classes x 64 real clips 64x64x8, 24 steps at lr 50)."""
     modes = ("shipped", "x3")
-    rec = late_regime_run((8, 64, 64), C=2, NP=80, B=64, steps=24, lr=50.0, seed=1201, modes=modes)
+    steps = int(os.environ.get("VD_PARITY_STEPS", "24"))
+    rec = late_regime_run((8, 64, 64), C=2, NP=80, B=64, steps=steps, lr=50.0, seed=1201, modes=modes)
     _report("late regime 64x64x8", rec, modes)
     _record("late_64x64x8", rec)
     _assert_shipped(rec)

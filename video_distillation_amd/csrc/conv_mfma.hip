@@ -512,6 +512,8 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
     // and write whole 16-byte slots.  (Per-lane 2-byte stores cost one memory instruction per value
     // and made the epilogue as expensive as the K loop of the first layer.)
     const bool staged = !feat && amx == nullptr;
+    // (single-pass programs may be asked for the low plane of their pooled outputs as well: VdConvParams.emit_lo)
+    const bool lo_out = X3 || (!EXT && p.emit_lo != 0);
     const int NCH = p.NT * 32;
     const int Q = mt_tot * 4 * nsets;
     uint16_t* stg = reinterpret_cast<uint16_t*>(smem);
@@ -546,11 +548,11 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
                 uint16_t hi, lo;
                 split16<PREC>(m0, hi, lo);
                 stg[q * NCH + n] = hi;
-                if constexpr (X3) stg[(Q + q) * NCH + n] = lo;
+                if (lo_out) stg[(Q + q) * NCH + n] = lo;
                 if (p.pool_t != 2) {
                     split16<PREC>(m1, hi, lo);
                     stg[(q + 1) * NCH + n] = hi;
-                    if constexpr (X3) stg[(Q + q + 1) * NCH + n] = lo;
+                    if (lo_out) stg[(Q + q + 1) * NCH + n] = lo;
                 }
                 continue;
             }
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
             if (o < 0 || base >= lim) continue;
             const uint32_t slot = (uint32_t)base + (uint32_t)cc * (uint32_t)p.out_chunk_stride;
             dslots[slot] = *reinterpret_cast<const uint4*>(stg + q * NCH + cc * 8);
-            if constexpr (X3) dslots[slot + p.dst_plane_stride] = *reinterpret_cast<const uint4*>(stg + (Q + q) * NCH + cc * 8);
+            if (lo_out) dslots[slot + p.dst_plane_stride] = *reinterpret_cast<const uint4*>(stg + (Q + q) * NCH + cc * 8);
         }
     }
     finish();
@@ -1052,6 +1054,13 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     if (p.ncl * 65536 <= 0 || p.S <= 0 || p.CC <= 0) return -2;
     if (p.MTW * ntw < 8 && (p.gather_stride >> 6) > (int64_t)wgw * (p.MTW * ntw <= 4 ? 14 : 17)) return -2;   // patch larger than the DMA register budget
     if (p.clip_index != nullptr && (p.ncl != 1 || p.CC != 1 || p.MTW * ntw > 4)) return -2;
+    if (p.emit_lo != 0) {   // low plane of a single-pass program's pooled outputs: staged channels-last epilogue only, and the staging tile
+                            // (two planes of pooled rows) must fit the one patch plane it aliases
+        const int mt_tot = p.MW * p.MTW + ((ntw == 2 && p.MTW == 3) ? 1 : 0);
+        if (p.prec > VD_PREC_F16 || p.epi != VD_EPI_POOL_CL || p.argmax != nullptr || p.dst_plane_stride <= 0 ||
+            (int64_t)2 * mt_tot * 4 * (p.pool_t == 2 ? 1 : 2) * p.NT * 32 * 2 > p.lds_plane_bytes)
+            return -2;
+    }
     if (ntw == 2 && p.MTW == 3) {   // balanced 7-tile layout (2 x 2 waves), single-pass formats
         if (p.MW != 2 || p.NT != 4 || p.select || p.src_split_cc > 0 || p.atomic || p.w_box_stride != 0) return -2;
         if ((p.gather_stride >> 6) > (int64_t)4 * 17) return -2;

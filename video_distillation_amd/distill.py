@@ -37,11 +37,57 @@ from . import plan as P
 PARAM_SHAPES = ((64, 3, 3, 7, 7), (64,), (128, 64, 3, 7, 7), (128,), (128, 128, 3, 7, 7), (128,))
 
 
+COLLECTIVE_CALLS = {"all_reduce": 0, "all_gather": 0, "bytes": 0}      # issued by the trainers of this process (bench.py reports them)
+
+
+def _all_reduce(t: torch.Tensor) -> None:
+    """Sum-all-reduce of ``t`` in place over the default process group, issued on the CURRENT stream (RCCL under the ``nccl``
+    backend: torch's process group runs the collective on its own communication stream, which waits for the current stream's
+    work before it starts and which the current stream waits for afterwards)."""
+    import torch.distributed as dist
+    COLLECTIVE_CALLS["all_reduce"] += 1
+    COLLECTIVE_CALLS["bytes"] += t.numel() * t.element_size()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def _all_gather(parts: List[torch.Tensor], t: torch.Tensor) -> None:
+    import torch.distributed as dist
+    COLLECTIVE_CALLS["all_gather"] += 1
+    COLLECTIVE_CALLS["bytes"] += t.numel() * t.element_size() * len(parts)
+    dist.all_gather(parts, t)
+
+
+def collectives_on(world: int) -> bool:
+    """Whether a trainer issues its data-path collectives: always with more than one rank; on ONE rank only when
+    ``VD_FORCE_COLLECTIVES=1`` and a process group exists -- so that the RCCL all_reduce / all_gather calls, on the trainers'
+    own streams, execute on a one-GPU box (tests/test_gpu_collectives.py; a 1-rank collective is the identity)."""
+    if world > 1:
+        return True
+    if os.environ.get("VD_FORCE_COLLECTIVES") == "1":
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    return False
+
+
 def class_range(num_classes: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block of classes owned by ``rank`` (sizes differ by at most one)."""
     base, extra = divmod(num_classes, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def hybrid_partition(num_classes: int, rank: int, world: int) -> Tuple[List[int], List[int], List[int]]:
+    """The hybrid decomposition of the DM class terms (distill_baseline.py:343-351) over ``world`` ranks: every rank takes
+    ``num_classes // world`` WHOLE classes (a contiguous block, no exchange), and the ``num_classes % world`` classes left
+    over are SPLIT: each rank embeds 1 / world of their real batches and the per-class feature sums are all-reduced
+    (2048 floats per split class), their synthetic clips being owned round-robin.  50 classes on 8 ranks: 6 whole classes +
+    1/8 of 2 = 400 real clips on every rank, where whole-class blocks give 7,7,6,... (448 / 384).
+    -> (this rank's block, all split classes, the split classes this rank owns)."""
+    nb = num_classes // world
+    if world == 1 and os.environ.get("VD_HYBRID_FORCE_SPLIT"):     # test knob: split classes on ONE rank, so that the exchange executes
+        nb = max(0, num_classes - int(os.environ["VD_HYBRID_FORCE_SPLIT"]))
+    split = list(range(nb * world, num_classes))
+    return list(range(rank * nb, (rank + 1) * nb)), split, [c for i, c in enumerate(split) if i % world == rank]
 
 
 def sample_real_indices(it: int, counts: Sequence[int], offsets: Sequence[int], batch_real: int,
@@ -93,12 +139,19 @@ class HipBackend:
     """Production backend: EmbedEngine (MFMA kernels) + the small HIP kernels."""
 
     def __init__(self, geo: P.NetGeometry, device, prec_real: str = "f16", prec_syn: str = "f16x3", chunk: int = 512,
-                 prec_bwd: Optional[str] = "f16", syn_batch_hint: Optional[int] = None):
+                 prec_bwd: Optional[str] = "f16x3", syn_batch_hint: Optional[int] = None, real_last: Optional[str] = None):
+        """``real_last``: operand format of the real side's LAST conv level when ``prec_real`` is single-pass -- "x3" (hi+lo
+        pairs: level 1 emits both planes of its output, level 2 runs three MFMAs per product on 5.6 % of the FLOPs) or "x1";
+        default from ``VD_REAL_LAST`` (see DESIGN section 2 for the measured error budget and cost of either)."""
         from . import engine, hip
         self.hip = hip
         self.device = torch.device(device)
         self.geo = geo
-        self.eng_real = engine.EmbedEngine(geo, prec=prec_real, device=device, chunk=chunk)
+        if real_last is None:
+            real_last = os.environ.get("VD_REAL_LAST", "x3")
+        assert real_last in ("x1", "x3")
+        self.real_last = real_last if prec_real in ("f16", "bf16") else "x1"
+        self.eng_real = engine.EmbedEngine(geo, prec=prec_real, device=device, chunk=chunk, last_hilo=(self.real_last == "x3"))
         self.eng_syn = self.eng_real if (prec_syn == prec_real and not prec_bwd) else \
             engine.EmbedEngine(geo, prec=prec_syn, device=device, chunk=chunk, prec_bwd=prec_bwd, batch_hint=syn_batch_hint)
         self.num_feat = geo.num_feat
@@ -195,7 +248,14 @@ class HipBackend:
         pool); a real batch is then only an index list (what ``get_images`` + ``.to(device)`` +
         the cast inside the reference's conv do per class and step, distill_baseline.py:84-90).
         ``index`` is class-major with ``per_class`` clips per class; after ``set_real_weights(w, per_class)`` chose G
-        dither groups, clip j of every class runs in launch group j mod G (G launches of 1/G of the batch each)."""
+        dither groups, clip j of every class runs with operand set j mod G (one launch per layer, ``forward_sets``)."""
+        segs = [(index.numel() // per_class, per_class)] if (per_class and index.numel() % per_class == 0) else None
+        return self.embed_pool_segments(pool, index, segs)
+
+    def embed_pool_segments(self, pool: torch.Tensor, index: torch.Tensor, segments) -> torch.Tensor:
+        """As ``embed_pool`` for an index made of several class-major segments ``[(classes, clips per class), ...]`` (the hybrid
+        decomposition: whole classes of 64 clips + 1/world slices of the split classes): clip j of every class goes to dither
+        group j mod G, all groups in ONE launch per layer; features come back in the order of ``index``."""
         rows = None
         if self.resident_rows:
             key = (pool.data_ptr(), tuple(pool.shape))
@@ -203,11 +263,24 @@ class HipBackend:
                 self._pool_rows = (key, self.eng_real.pool_rows(pool))
             rows = self._pool_rows[1]
         G = self._dither
-        if G and per_class and per_class % G == 0 and index.numel() % per_class == 0:
-            ncls, q = index.numel() // per_class, per_class // G
-            # group-major launch order [g][class][q]: the clips of one weight set are consecutive (EmbedEngine.forward_sets)
-            f = self.eng_real.forward_sets(pool, index.view(ncls, q, G).permute(2, 0, 1).reshape(-1), rows=rows)
-            return f.view(G, ncls, q, self.num_feat).permute(1, 2, 0, 3).reshape(index.numel(), self.num_feat)
+        if G and segments and all(per % G == 0 for _, per in segments) and sum(n * per for n, per in segments) == index.numel():
+            key = (tuple(segments), G, str(index.device))
+            perm = self._seg_perm.get(key) if hasattr(self, "_seg_perm") else None
+            if perm is None:     # group-major launch order [g][segment][class][q]: the clips of one weight set are consecutive
+                pos, parts = 0, [[] for _ in range(G)]
+                for n, per in segments:
+                    blk = torch.arange(pos, pos + n * per).view(n, per // G, G)
+                    for g in range(G):
+                        parts[g].append(blk[:, :, g].reshape(-1))
+                    pos += n * per
+                perm = torch.cat([torch.cat(pg) for pg in parts]).to(index.device)
+                if not hasattr(self, "_seg_perm"):
+                    self._seg_perm = {}
+                self._seg_perm[key] = perm
+            f = self.eng_real.forward_sets(pool, index[perm], rows=rows)
+            out = torch.empty_like(f)
+            out[perm] = f
+            return out
         return self.eng_real.forward(pool, index=index, rows=rows)
 
     def embed_keep(self, x: torch.Tensor):
@@ -318,18 +391,23 @@ class DMTrainer:
         class-owned.  The latter balances 50 classes over 8 ranks exactly (6.25 class-equivalents
         each instead of 7,7,6,...) at the price of one small all-reduce per step; the pool must
         then hold all classes on every rank."""
-        assert shard in ("class", "batch")
+        assert shard in ("class", "batch", "hybrid")
         # (world == 1 normally has nothing to shard; VD_FORCE_BATCH_SHARD=1 keeps the collective path
         #  alive on one rank so that it can be smoke-tested on a single-GPU box)
         self.shard = shard if (world > 1 or os.environ.get("VD_FORCE_BATCH_SHARD") == "1") else "class"
-        if self.shard == "batch":
-            assert batch_real % world == 0, "batch sharding needs batch_real divisible by the number of ranks"
+        if self.shard in ("batch", "hybrid"):
+            assert batch_real % world == 0, "batch / hybrid sharding needs batch_real divisible by the number of ranks"
         self.be, self.pool = backend, pool
         self.num_classes, self.ipc, self.batch_real = num_classes, ipc, batch_real
         self.lr_img, self.momentum = float(lr_img), float(momentum)
         self.rank, self.world = rank, world
         self.c_lo, self.c_hi = class_range(num_classes, rank, world)
         self.classes = list(range(self.c_lo, self.c_hi))
+        if self.shard == "hybrid":
+            # ``shard='hybrid'`` (hybrid_partition): whole classes in equal blocks + the left-over classes' real batches split
+            # over all ranks; a rank owns the synthetic clips of its block and of the split classes dealt to it
+            self.block, self.split, self.split_owned = hybrid_partition(num_classes, rank, world)
+            self.classes = self.block + self.split_owned
         if image_syn is None:   # --init real (distill_baseline.py:96-100): first ipc real clips of each class
             idx = np.concatenate([pool.offsets[c] + np.arange(ipc) % pool.counts[c] for c in self.classes]) \
                 if self.classes else np.zeros(0, dtype=np.int64)
@@ -337,6 +415,15 @@ class DMTrainer:
         self.image_syn = image_syn.contiguous()
         self.buf = torch.zeros_like(self.image_syn)
         self.steps_done = 0
+
+    def owned_classes(self, rank: Optional[int] = None) -> List[int]:
+        """Classes whose synthetic clips ``rank`` (default: this rank) owns, in the order of its ``image_syn`` rows."""
+        rank = self.rank if rank is None else rank
+        if self.shard == "hybrid":
+            block, _, owned = hybrid_partition(self.num_classes, rank, self.world)
+            return block + owned
+        lo, hi = class_range(self.num_classes, rank, self.world)
+        return list(range(lo, hi))
 
     def step(self, it: int, overlap: bool = False) -> torch.Tensor:
         """One distillation iteration over this rank's classes; returns the rank-local loss sum
@@ -348,6 +435,11 @@ class DMTrainer:
             per = self.batch_real // self.world
             idx = sample_real_indices(it, self.pool.counts, self.pool.offsets, self.batch_real, range(self.num_classes))
             idx = idx.reshape(self.num_classes, self.batch_real)[:, self.rank * per:(self.rank + 1) * per].reshape(-1)
+        elif self.shard == "hybrid":        # whole batches of the block classes, then this rank's 1/world slice of every split class
+            per = self.batch_real // self.world
+            idx_s = sample_real_indices(it, self.pool.counts, self.pool.offsets, self.batch_real, self.split)
+            idx_s = idx_s.reshape(len(self.split), self.batch_real)[:, self.rank * per:(self.rank + 1) * per].reshape(-1)
+            idx = np.concatenate([sample_real_indices(it, self.pool.counts, self.pool.offsets, self.batch_real, self.block), idx_s])
         else:
             idx = sample_real_indices(it, self.pool.counts, self.pool.offsets, self.batch_real, self.classes)
         dev = self.image_syn.device
@@ -393,25 +485,51 @@ class DMTrainer:
     def _real_features(self, idx_t: torch.Tensor) -> torch.Tensor:
         """This rank's contribution to the real side: all clips' features of the owned classes (class sharding), or --
         batch sharding -- the per-class sums of its 1/world slice of every class's batch, pre-scaled by 1/batch_real
-        (C x D fp32, 410 KB; ``_exchange`` all-reduces them)."""
-        f = self.be.embed_pool(self.pool.clips, idx_t, self._per_class()) if hasattr(self.be, "set_real_weights") else \
-            self.be.embed_pool(self.pool.clips, idx_t)
+        (C x D fp32, 410 KB; ``_exchange`` all-reduces them); hybrid: the class MEANS of the block classes followed by the
+        pre-scaled partial sums of the split classes."""
+        be = self.be
+        if self.shard == "hybrid":
+            nb, ns, per = len(self.block), len(self.split), self.batch_real // self.world
+            if hasattr(be, "embed_pool_segments"):
+                f = be.embed_pool_segments(self.pool.clips, idx_t, [(n, p) for n, p in ((nb, self.batch_real), (ns, per)) if n])
+            else:
+                f = be.embed_pool(self.pool.clips, idx_t)
+            parts = []
+            if nb:
+                parts.append(be.group_sum(f[:nb * self.batch_real].contiguous(), nb, self.batch_real, 1.0 / self.batch_real))
+            if ns:
+                parts.append(be.group_sum(f[nb * self.batch_real:].contiguous(), ns, per, 1.0 / self.batch_real))
+            return torch.cat(parts, 0)
+        f = be.embed_pool(self.pool.clips, idx_t, self._per_class()) if hasattr(be, "set_real_weights") else \
+            be.embed_pool(self.pool.clips, idx_t)
         if self.shard != "batch":
             return f
-        return self.be.group_sum(f, self.num_classes, self.batch_real // self.world, 1.0 / self.batch_real)
+        return be.group_sum(f, self.num_classes, self.batch_real // self.world, 1.0 / self.batch_real)
 
     def _per_class(self) -> int:
-        """Real clips per class in this rank's launches (the unit the real side's dither groups divide)."""
-        return self.batch_real // self.world if self.shard == "batch" else self.batch_real
+        """Real clips per class in this rank's launches (the unit the real side's dither groups divide; hybrid: the smaller
+        of its two segment sizes, which divides the other)."""
+        return self.batch_real // self.world if self.shard in ("batch", "hybrid") else self.batch_real
 
     def _exchange(self, x: torch.Tensor) -> torch.Tensor:
         """Batch sharding: the one data-path collective of a DM step -- all-reduce of the per-class feature sums; returns the
-        class MEANS of the owned classes in the form dm_loss() consumes (one row per class, a 'batch' of one)."""
-        if self.shard != "batch":
+        class MEANS of the owned classes in the form dm_loss() consumes (one row per class, a 'batch' of one).  Hybrid: only
+        the split classes' rows (2048 floats each) are all-reduced."""
+        if self.shard == "class":
             return x
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        live = dist.is_available() and dist.is_initialized()
+        if self.shard == "hybrid":
+            nb = len(self.block)
+            if not self.split:
+                return x
+            part = x[nb:].contiguous()
+            if live:
+                _all_reduce(part)
+            own = [self.split.index(c) for c in self.split_owned]
+            return torch.cat([x[:nb], part[own]], 0) if own else x[:nb].contiguous()
+        if live:
+            _all_reduce(x)
         return x[self.c_lo:self.c_hi].contiguous()
 
     def global_loss(self, local_loss: torch.Tensor) -> torch.Tensor:
@@ -419,10 +537,10 @@ class DMTrainer:
         be = self.be
         ctx = be.on_syn() if getattr(be, "two_streams", False) else _NullCtx()
         with ctx:
-            if self.world > 1:
+            if collectives_on(self.world):
                 import torch.distributed as dist
                 local_loss = local_loss.clone()
-                dist.all_reduce(local_loss, op=dist.ReduceOp.SUM)
+                _all_reduce(local_loss)
         return local_loss
 
     def sync(self) -> None:
@@ -442,17 +560,23 @@ class DMTrainer:
         landed when the caller's stream starts copying."""
         if hasattr(self, "sync"):
             self.sync()
-        if self.world == 1:
+        if not collectives_on(self.world):
             return self.image_syn
         import torch.distributed as dist
-        sizes = [(class_range(self.num_classes, r, self.world)[1] - class_range(self.num_classes, r, self.world)[0]) * self.ipc
-                 for r in range(self.world)]
+        owners = [self.owned_classes(r) if hasattr(self, "owned_classes") else
+                  list(range(*class_range(self.num_classes, r, self.world))) for r in range(self.world)]
+        sizes = [len(o) * self.ipc for o in owners]
         mx = max(sizes)
         pad = torch.zeros((mx,) + tuple(self.image_syn.shape[1:]), dtype=self.image_syn.dtype, device=self.image_syn.device)
         pad[:self.image_syn.shape[0]] = self.image_syn
         parts = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(parts, pad)
-        return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+        _all_gather(parts, pad)
+        out = torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+        order = [c for o in owners for c in o]                    # class of every gathered block of ipc rows
+        if order != sorted(order):                                # (hybrid: the split classes sit behind each rank's block)
+            pos = torch.as_tensor(np.argsort(order), device=out.device)
+            out = out.view(len(order), self.ipc, *out.shape[1:])[pos].reshape(out.shape)
+        return out
 
 
 class S2DTrainer:
@@ -536,10 +660,10 @@ class S2DTrainer:
             g_img = be.embed_backward(handle, g_syn)
             g_dyn, g_stat, g_w, g_b = be.hallucinate_backward(g_img, self.static, self.dynamic, sidx, didx, self.hal_w,
                                                               self.train_static)
-            if self.world > 1:   # the hallucinator is shared by all classes: one 1.3 KB all-reduce
+            if collectives_on(self.world):   # the hallucinator is shared by all classes: one 1.3 KB all-reduce
                 import torch.distributed as dist
                 flat = torch.cat([g_w.reshape(-1), g_b.reshape(-1)])
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                _all_reduce(flat)
                 g_w, g_b = flat[:324].view_as(g_w), flat[324:]
             first = self.steps_done == 0
             be.sgd(self.dynamic, self.buf_d, g_dyn, self.lr_dynamic, self.momentum, first)
@@ -557,6 +681,8 @@ class S2DTrainer:
     def sync(self) -> None:
         if getattr(self.be, "two_streams", False):
             self.be.join()
+
+    global_loss = DMTrainer.global_loss
 
     def mark(self):
         ev = torch.cuda.Event(enable_timing=True)
@@ -765,10 +891,10 @@ class GMTrainer:
         return total
 
     def global_loss(self, local_loss: torch.Tensor) -> torch.Tensor:
-        if self.world > 1:
+        if collectives_on(self.world):
             import torch.distributed as dist
             local_loss = local_loss.clone()
-            dist.all_reduce(local_loss, op=dist.ReduceOp.SUM)
+            _all_reduce(local_loss)
         return local_loss
 
     gather_syn = DMTrainer.gather_syn
@@ -878,18 +1004,18 @@ class MTTTrainer:
 
     def _finish(self, update: bool):
         g_img = self._g_img
-        if self.world > 1:
+        if collectives_on(self.world):
             import torch.distributed as dist
-            dist.all_reduce(g_img, op=dist.ReduceOp.SUM)
+            _all_reduce(g_img)
         if update:
             self.ops.sgd(self.image_syn, self.buf, g_img, self.lr_img, self.momentum, first=(self.steps_done == 0))
         return (g_img,)
 
     # -------------------------------------------------------------------------------------------------------------------
     def _allreduce(self, flat: torch.Tensor) -> torch.Tensor:
-        if self.world > 1:
+        if collectives_on(self.world):
             import torch.distributed as dist
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            _all_reduce(flat)
         return flat
 
     def step(self, it: int, trajectory, start_epoch: Optional[int] = None, index_chunks=None, update: bool = True):
@@ -1023,14 +1149,14 @@ class S2DMTTTrainer(MTTTrainer):
             self._g_stat += g_stat
 
     def _finish(self, update: bool):
-        if self.world > 1:
+        if collectives_on(self.world):
             import torch.distributed as dist
             flat = torch.cat([self._g_w.reshape(-1), self._g_b.reshape(-1)])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            _all_reduce(flat)
             self._g_w, self._g_b = flat[:self._g_w.numel()].view_as(self._g_w).contiguous(), flat[self._g_w.numel():].contiguous()
-            dist.all_reduce(self._g_dyn, op=dist.ReduceOp.SUM)
+            _all_reduce(self._g_dyn)
             if self.train_static:
-                dist.all_reduce(self._g_stat, op=dist.ReduceOp.SUM)
+                _all_reduce(self._g_stat)
         if update:
             first = self.steps_done == 0
             self.ops.sgd(self.dynamic, self.buf_d, self._g_dyn, self.lr_dynamic, self.momentum, first)

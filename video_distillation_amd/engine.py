@@ -96,8 +96,9 @@ class _DevPlan:
     def run(self, src: torch.Tensor, src_plane_slots: int, bias: Optional[torch.Tensor], dst_ptr: int,
             dst_plane_stride: int, argmax: Optional[torch.Tensor], nclips: int, out_scale: Optional[torch.Tensor] = None,
             wpk: Optional[torch.Tensor] = None, w_plane_elems: int = 0, clip_index: Optional[torch.Tensor] = None,
-            group: Optional[int] = None, set_clips: int = 0) -> None:
+            group: Optional[int] = None, set_clips: int = 0, emit_lo: bool = False) -> None:
         p = self.params
+        p.emit_lo = int(emit_lo)        # single-pass program, staged pooled epilogue: also write the low plane (dst_plane_stride behind)
         p.clip_index = 0 if clip_index is None else clip_index.data_ptr()
         p.out_scale = 0 if out_scale is None else out_scale.data_ptr()
         p.w_set_clips = 0
@@ -167,7 +168,13 @@ def round_weights(params: Sequence[torch.Tensor], prec: str) -> List[torch.Tenso
 
 class EmbedEngine:
     def __init__(self, geo: P.NetGeometry, prec: str = "bf16x3", device="cuda:0", chunk: int = 256,
-                 prec_bwd: Optional[str] = None, ntw0: Optional[int] = None, batch_hint: Optional[int] = None):
+                 prec_bwd: Optional[str] = None, ntw0: Optional[int] = None, batch_hint: Optional[int] = None,
+                 last_hilo: bool = False):
+        """``last_hilo`` (single-pass engines, forward without kept arg-max): the LAST conv level runs in the hi+lo format of the
+        same 16-bit type -- level 1's program also writes the low plane of its pooled outputs (VdConvParams.emit_lo) and level 2
+        multiplies hi+lo activations by hi+lo weights (3 MFMAs per product on 5.6 % of the network's FLOPs).  That removes two
+        of the six rounding sources of a single-pass forward (level 1's output rounding, level 2's weight rounding; DESIGN
+        section 2, tests/sim_error_budget_tool.py)."""
         if not torch.cuda.is_available():
             raise RuntimeError("EmbedEngine needs a HIP device (no CPU fallback)")
         hip.lib()
@@ -189,6 +196,12 @@ class EmbedEngine:
         net = P.plan_network(geo, ntw=self.ntw, ntw0=ntw0, balanced=bal, batch_hint=batch_hint)
         self.dims = net["dims"]
         self.fwd = [_DevPlan(pl, self.device, self.prec) for pl in net["fwd"]]
+        self.fwd2x = None
+        if last_hilo:
+            if hip.is_x3(self.prec):
+                raise ValueError("last_hilo is an option of the single-pass formats (%s already carries hi+lo planes)" % prec)
+            import dataclasses
+            self.fwd2x = _DevPlan(dataclasses.replace(net["fwd"][2], name="fwd2_hilo"), self.device, hip.PREC[prec + "x3"])
         # operand precision of the input-gradient passes (default: same as the forward)
         self.prec_bwd = hip.PREC[prec_bwd] if prec_bwd else self.prec
         self.planes_bwd = 2 if hip.is_x3(self.prec_bwd) else 1
@@ -217,6 +230,9 @@ class EmbedEngine:
             ws = round_weights(ws, quantize)
         self._weights = ws
         for li in range(3):
+            if li == 2 and self.fwd2x is not None:      # the last level multiplies by the exact hi+lo weights: nothing to dither
+                self.fwd2x.pack(ws[4])
+                continue
             self.fwd[li].pack(ws[2 * li])
             if dither >= 2:
                 self.fwd[li].pack_dither(ws[2 * li], dither)
@@ -284,8 +300,10 @@ class EmbedEngine:
                                          ctypes.c_int64(nb), g.frames, g.height, g.width,
                                          hip.ptr(slots0[0]), hip.ptr(lo), self.prec, st), "vd_pix2rows")
             n1, n2 = nb * per1, nb * per2
+            hilo = self.fwd2x is not None
+            assert not (hilo and keep), "last_hilo engines have no kept-arg-max forward"
             act1 = self._buf("act1", (self.planes, n1, 8), torch.int16)
-            act2 = self._buf("act2", (self.planes, n2, 8), torch.int16)
+            act2 = self._buf("act2", (2 if hilo else self.planes, n2, 8), torch.int16)
             am0 = am1 = am2 = None
             if keep:
                 am0 = torch.empty(n1 * 8, dtype=torch.uint8, device=self.device)
@@ -297,9 +315,12 @@ class EmbedEngine:
             if ev: ev[0].record()
             self.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, am0, nb, clip_index=cidx, group=group)
             if ev: ev[1].record()
-            self.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, am1, nb, group=group)
+            self.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, am1, nb, group=group, emit_lo=hilo)
             if ev: ev[2].record()
-            self.fwd[2].run(act2, n2, w[5], feats[c0:].data_ptr(), 0, am2, nb, group=group)
+            if hilo:
+                self.fwd2x.run(act2, n2, w[5], feats[c0:].data_ptr(), 0, None, nb)
+            else:
+                self.fwd[2].run(act2, n2, w[5], feats[c0:].data_ptr(), 0, am2, nb, group=group)
             if ev:
                 ev[3].record()
                 prof += [("fwd0", nb, ev[0], ev[1]), ("fwd1", nb, ev[1], ev[2]), ("fwd2", nb, ev[2], ev[3])]
@@ -325,8 +346,9 @@ class EmbedEngine:
         per1 = int(np.prod(self.fwd[0].plan.out_shape[:-1]))
         per2 = int(np.prod(self.fwd[1].plan.out_shape[:-1]))
         n1, n2 = B * per1, B * per2
+        hilo = self.fwd2x is not None
         act1 = self._buf("act1", (1, n1, 8), torch.int16)
-        act2 = self._buf("act2", (1, n2, 8), torch.int16)
+        act2 = self._buf("act2", (2 if hilo else 1, n2, 8), torch.int16)
         w = self._weights
         if rows is None:
             n_slots0 = B * g.frames * 3 * g.height * (rowp // 8)
@@ -349,12 +371,14 @@ class EmbedEngine:
                     self.fwd[0].run(slots0[:, s * per * per0:], n_slots0, w[1], act1.data_ptr() + s * per * per1 * 16, n1, None, per, group=s)
         for li, (src, n_src, per_src, dst_ptr, n_dst, per_dst_bytes) in enumerate((
                 (act1, n1, per1, act2.data_ptr(), n2, per2 * 16), (act2, n2, per2, feats.data_ptr(), 0, self.num_feat * 4)), start=1):
-            if per % self.fwd[li].plan.ncl == 0:       # a box never spans two sets: one launch
-                self.fwd[li].run(src, n_src, w[2 * li + 1], dst_ptr, n_dst, None, B, set_clips=per)
+            if li == 2 and hilo:                        # hi+lo weights: one set
+                self.fwd2x.run(src, n_src, w[5], dst_ptr, 0, None, B)
+            elif per % self.fwd[li].plan.ncl == 0:       # a box never spans two sets: one launch
+                self.fwd[li].run(src, n_src, w[2 * li + 1], dst_ptr, n_dst, None, B, set_clips=per, emit_lo=(li == 1 and hilo))
             else:
                 for s in range(G):
                     self.fwd[li].run(src[:, s * per * per_src:], n_src, w[2 * li + 1], dst_ptr + s * per * per_dst_bytes, n_dst, None,
-                                     per, group=s)
+                                     per, group=s, emit_lo=(li == 1 and hilo))
         return feats
 
     def backward(self, saved, g_feat: torch.Tensor) -> torch.Tensor:

@@ -43,7 +43,7 @@ class VdConvParams(ctypes.Structure):
         ("out_clip_stride", ctypes.c_int64),
         ("out_chunk_stride", ctypes.c_int32), ("out_t_stride", ctypes.c_int32),
         ("lds_plane_bytes", ctypes.c_int32), ("prec", ctypes.c_int32), ("dbg", ctypes.c_int32), ("ntypes", ctypes.c_int32), ("tab_ofs", ctypes.c_int32 * 3), ("atomic", ctypes.c_int32), ("select", ctypes.c_int32), ("src_split_cc", ctypes.c_int32), ("src_split_off4", ctypes.c_int64), ("NTW", ctypes.c_int32), ("clip_index", ctypes.c_void_p), ("mt_valid", ctypes.c_int32), ("persist", ctypes.c_int32), ("stamps", ctypes.c_void_p),
-        ("w_set_clips", ctypes.c_int32), ("replica_stride", ctypes.c_int32),
+        ("w_set_clips", ctypes.c_int32), ("replica_stride", ctypes.c_int32), ("emit_lo", ctypes.c_int32),
     ]
 
 
@@ -95,7 +95,7 @@ def lib() -> ctypes.CDLL:
             getattr(L, name).restype = {"vd_program_info": ctypes.c_int64, "vd_program_free": None, "vd_blob_free": None, "vd_embed_free": None, "vd_train_free": None, "vd_train_workspace_bytes": ctypes.c_int64,
                                         "vd_embed_num_features": ctypes.c_int64, "vd_embed_workspace_bytes": ctypes.c_int64,
                                         "vd_embed_argmax_bytes": ctypes.c_int64, "vd_embed_backward_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
-        if L.vd_abi_version() != 2:
+        if L.vd_abi_version() != 3:
             raise RuntimeError("libvd_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -32,14 +32,14 @@ import torch.nn as nn
 from . import plan as P
 
 _PRECISION = {"real": os.environ.get("VD_PREC_REAL", "f16"), "syn": os.environ.get("VD_PREC_SYN", "f16x3"),
-              "bwd": os.environ.get("VD_PREC_BWD", "f16"),
+              "bwd": os.environ.get("VD_PREC_BWD", "f16x3"), "real_last": os.environ.get("VD_REAL_LAST", "x3"),
               "train": os.environ.get("VD_PREC_TRAIN", "f16x3"), "train_bwd": os.environ.get("VD_PREC_TRAIN_BWD", "f16x3"),
               "match": os.environ.get("VD_PREC_MATCH", "bf16x3"), "match_real_bwd": os.environ.get("VD_PREC_MATCH_REAL_BWD", "f16")}
 _ENGINES: Dict[Tuple, object] = {}
 
 
 def set_precision(real: str = None, syn: str = None, bwd: str = None, train: str = None, train_bwd: str = None,
-                  match: str = None, match_real_bwd: str = None) -> None:
+                  match: str = None, match_real_bwd: str = None, real_last: str = None) -> None:
     """Operand precision of the MFMA contraction: ``real`` for the forward of inputs without
     gradient, ``syn`` for the forward of inputs that need d/dx (its arg-max decisions steer the
     gradient), ``bwd`` for the input-gradient passes (no discrete decisions: single-pass fp16 with
@@ -50,6 +50,10 @@ def set_precision(real: str = None, syn: str = None, bwd: str = None, train: str
     the backward, which decides nothing, runs single-pass with the power-of-two scaling.  One of 'bf16', 'f16', 'bf16x3',
     'f16x3'."""
     from . import hip
+    if real_last is not None:       # "x3": the last conv level of single-pass ``real`` forwards of the DM loop runs in hi+lo pairs
+        if real_last not in ("x1", "x3"):
+            raise ValueError("real_last is 'x1' or 'x3'")
+        _PRECISION["real_last"] = real_last
     for k, v in (("real", real), ("syn", syn), ("bwd", bwd), ("train", train), ("train_bwd", train_bwd), ("match", match),
                  ("match_real_bwd", match_real_bwd)):
         if v is not None:
@@ -85,14 +89,14 @@ def get_precision() -> Dict[str, str]:
     return dict(_PRECISION)
 
 
-def get_engine(geo: P.NetGeometry, prec: str, device, prec_bwd: str = None) -> "object":
+def get_engine(geo: P.NetGeometry, prec: str, device, prec_bwd: str = None, last_hilo: bool = False) -> "object":
     from . import engine
     device = torch.device(device)
-    key = (geo.frames, geo.height, geo.width, prec, prec_bwd,
+    key = (geo.frames, geo.height, geo.width, prec, prec_bwd, bool(last_hilo),
            device.index if device.index is not None else torch.cuda.current_device())
     eng = _ENGINES.get(key)
     if eng is None:
-        eng = engine.EmbedEngine(geo, prec=prec, device=device, prec_bwd=prec_bwd)
+        eng = engine.EmbedEngine(geo, prec=prec, device=device, prec_bwd=prec_bwd, last_hilo=last_hilo)
         _ENGINES[key] = eng
     return eng
 
@@ -118,7 +122,11 @@ class _EmbedFunction(torch.autograd.Function):
         need_grad = ctx.needs_input_grad[0]
         prec = _PRECISION["syn"] if need_grad else _PRECISION["real"]
         geo = P.NetGeometry(x.shape[1], x.shape[3], x.shape[4])
-        eng = get_engine(geo, prec, x.device, _PRECISION["bwd"] if need_grad else None)
+        # (the DM loop's real batches: single-pass with the last level in hi+lo pairs, like distill.HipBackend; inference
+        #  passes -- dither_ok False -- stay single-pass throughout)
+        hilo = (not need_grad) and dither_ok and prec in ("f16", "bf16") and _PRECISION["real_last"] == "x3" \
+            and _PRECISION["syn"] == prec + "x3"
+        eng = get_engine(geo, prec, x.device, _PRECISION["bwd"] if need_grad else None, last_hilo=hilo)
         if need_grad:
             net._sync_engine(eng)
             feats, saved = eng.forward(x, keep=True)
