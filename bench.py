@@ -73,6 +73,11 @@ def parse():
     ap.add_argument("--mtt-raw", action="store_true", help="--method mtt: raw synthetic clips (distill_baseline.py MTT) instead of "
                                                            "the static/dynamic composition of config 5")
     ap.add_argument("--method", default="dm", choices=["dm", "s2d", "dc", "mtt"])
+    ap.add_argument("--pool-kind", default="templates", choices=["templates", "randn"],
+                    help="synthetic real pool: class template + noise (learnable: eval top-1 is informative) or plain randn clips "
+                         "(SURVEY 8(d); top-1 is chance by construction).  Same value statistics, same timings.")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="dm: skip the two short extra timed legs (parity_mode = all hi+lo pairs, fast_mode = round 2's single-pass mode)")
     ap.add_argument("--eval-epochs", type=int, default=10,
                     help="dm: after the timed steps run evaluate_synset on the synthetic clips for this many epochs (0 = skip)")
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="length of the sustained leg (0 = skip)")
@@ -345,8 +350,9 @@ def cpu_baseline_dm(args, trainer, backend, it, s2d=None):
 
 def run_eval(args, trainer, pool, device, rank):
     """evaluate_synset (utils.py:848-886) on the current synthetic clips: a fresh ConvNet3D trained for --eval-epochs
-    epochs with the HIP train step, tested (3 passes, HIP inference) on 4 held-out pool clips per class.  The pool is
-    synthetic noise, so the accuracy is chance level by construction; it is reported because the metric names it."""
+    epochs with the HIP train step, tested (3 passes, HIP inference) on 4 held-out pool clips per class (never drawn as
+    initial synthetic clips; they may occur in real batches, as any pool clip).  On the default template pool the accuracy is
+    informative; on --pool-kind randn it is chance level by construction."""
     import types
     from video_distillation_amd import utils
     C = args.classes
@@ -371,7 +377,8 @@ def run_eval(args, trainer, pool, device, rank):
     dt = time.perf_counter() - t0
     return {"top1": float(acc_test), "acc_train": float(acc_train), "epochs": args.eval_epochs + 1, "seconds": dt,
             "ms_per_epoch": dt / (args.eval_epochs + 1) * 1e3, "test_clips": int(idx.numel()),
-            "note": "synthetic noise pool: top-1 is chance (%.3f) by construction" % (1.0 / C)}
+            "note": ("class template + noise pool: chance is %.3f" % (1.0 / C)) if args.pool_kind == "templates" else
+                    ("synthetic noise pool: top-1 is chance (%.3f) by construction" % (1.0 / C))}
 
 
 def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
@@ -399,6 +406,37 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
     ev = None
     if args.eval_epochs > 0 and not s2d:
         ev = run_eval(args, trainer, pool, device, rank)
+    # Two short extra legs of the same workload, on record next to the headline: the fp32-grade mode (every operand a hi+lo pair)
+    # and round 2's fast mode (single pass on every real level and in the input gradient).  Every rank runs them.
+    legs = {}
+    if not s2d and not args.no_extra_legs:
+        from video_distillation_amd.networks import _batch_hint
+        for name, kw in (("parity_mode", dict(prec_real=args.prec_syn, prec_syn=args.prec_syn, prec_bwd=args.prec_syn)),
+                         ("fast_mode", dict(prec_real=args.prec_real, prec_syn=args.prec_syn, prec_bwd=args.prec_real, real_last="x1"))):
+            be2 = distill.HipBackend(geo, device, chunk=args.chunk, syn_batch_hint=_batch_hint(len(trainer.classes) * args.ipc), **kw)
+            tr2 = distill.DMTrainer(be2, pool, args.classes, args.ipc, args.batch_real, lr_img=1.0, momentum=0.5, rank=rank, world=world,
+                                    shard=shard)
+            n_leg, warm = (5, 2)
+            for it in range(warm):
+                tr2.global_loss(tr2.step(it, overlap=True))
+            tr2.sync(); h.barrier()
+            t0 = time.perf_counter()
+            for it in range(warm, warm + n_leg):
+                last = tr2.global_loss(tr2.step(it, overlap=True))
+            tr2.sync(); h.barrier()
+            dt2 = time.perf_counter() - t0
+            if world > 1:
+                import torch.distributed as dist
+                tmax = torch.tensor([dt2], device=device, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt2 = float(tmax)
+            legs[name] = {"value": n_leg / dt2, "unit": "steps/s", "ms_per_step": dt2 / n_leg * 1e3, "steps": n_leg, "warmup": warm,
+                          "precision": {"real_clips": kw["prec_real"], "real_clips_last_level": be2.real_last,
+                                        "syn_clips_fwd": kw["prec_syn"], "input_gradient": kw["prec_bwd"],
+                                        "real_weight_dither_groups": be2._dither},
+                          "loss_last": float(last) / args.classes}
+            del tr2, be2
+            torch.cuda.empty_cache()
     out = None
     if rank == 0:
         macs = conv_layer_macs(geo)
@@ -419,6 +457,7 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
             {"real_clips": args.prec_real, "real_clips_last_level": backend.real_last, "syn_clips_fwd": args.prec_syn, "input_gradient": args.prec_bwd, "accumulate": "f32",
              "real_weight_dither_groups": backend._dither, "syn_value_pass": None if backend._dither else backend.weight_format})
         out["config"]["pool_per_class"] = args.pool_per_class
+        out["config"]["pool_kind"] = args.pool_kind
         out["config"]["real_pool"] = ("resident in HBM: fp32 clips + the same clips converted once to the first layer's 16-bit pixel "
                                       "rows; a real batch is an index list, no per-step conversion") if backend.resident_rows else \
             "resident in HBM as fp32, converted per step"
@@ -444,6 +483,8 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
             out["sustained"] = sustained
         if ev:
             out["eval"] = ev
+        for name, leg in legs.items():
+            out[name] = leg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_dm(args, trainer, backend, args.warmup + args.steps, s2d if s2d else None)
     finish(h, out)
@@ -691,12 +732,14 @@ def main():
     if shard == "hybrid" and args.method != "dm":
         raise SystemExit("--shard hybrid is a decomposition of --method dm")
     if shard == "batch":   # every rank holds the whole pool (11 GB) and embeds its slice of each class batch
-        pool = distill.RealPool.synthetic(args.classes, list(range(args.classes)), args.pool_per_class, geo, device, seed=1234)
+        pool = distill.RealPool.synthetic(args.classes, list(range(args.classes)), args.pool_per_class, geo, device, seed=1234,
+                                          kind=args.pool_kind)
     elif shard == "hybrid":   # the rank's block of whole classes + every split class
         block, split, _ = distill.hybrid_partition(args.classes, rank, world)
-        pool = distill.RealPool.synthetic(args.classes, block + split, args.pool_per_class, geo, device, seed=1234)
+        pool = distill.RealPool.synthetic(args.classes, block + split, args.pool_per_class, geo, device, seed=1234, kind=args.pool_kind)
     else:
-        pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device, seed=1234)
+        pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device, seed=1234,
+                                          kind=args.pool_kind)
     if args.method == "dc":
         return bench_dc(args, h, distill, geo, pool)
     nsyn = (c_hi - c_lo) * (args.ipc if args.method == "dm" else 1)

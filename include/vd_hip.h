@@ -378,6 +378,26 @@ int vd_train_step(VdTrain* t, float* const* params, float* const* momentum, cons
                   int64_t workspace_bytes, float* loss_per_clip, float* logits, void* stream);
 void vd_train_free(VdTrain* t);
 
+/* ---- Exchange steps of the sharded loops (one process per GPU), over RCCL / xGMI -------------------------------------------
+ * Replaces what nn.DataParallel does for the reference (utils.py:615-623: scatter the batch, replicate the module, gather the
+ * outputs over PCIe through GPU 0) by explicit collectives on device buffers; the Python trainers issue the same ones through
+ * torch.distributed (distill.py `_all_reduce` / `_all_gather`).  Per DM step the only data-path exchange is the all-reduce of
+ * the per-class feature sums of split classes (hybrid / batch decompositions: 2048 floats per class; pre-scale them with
+ * vd_group_sum's `scale`); s2d adds the 327 hallucinator gradients; MTT the flat parameter gradient and the Hessian-vector
+ * product per student step; vd_comm_allgather_f32 brings the class-owned synthetic clips together before evaluate_synset.
+ * librccl.so is resolved at the first call (dlopen): -10 = not available on this box, -11 = RCCL reported an error.
+ * vd_comm_unique_id: rank 0 creates the id and passes its 128 bytes to the other ranks over any host channel; every rank then
+ * calls vd_comm_create with ITS HIP device current.  Collectives are asynchronous on `stream`; send == recv is allowed. */
+typedef struct VdComm VdComm;
+typedef struct { char internal[128]; } VdCommId;
+int vd_comm_unique_id(VdCommId* id);
+int vd_comm_create(const VdCommId* id, int nranks, int rank, VdComm** out);
+int vd_comm_size(const VdComm* c);
+int vd_comm_rank(const VdComm* c);
+int vd_comm_allreduce_f32(VdComm* c, const float* send, float* recv, int64_t n, void* stream);
+int vd_comm_allgather_f32(VdComm* c, const float* send, float* recv, int64_t n_per_rank, void* stream);
+void vd_comm_free(VdComm* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -449,7 +449,7 @@ def test_two_gpu_bench_matches_single_gpu_loss():
     if torch.cuda.device_count() < 2:          # (device_count does not initialise the GPU)
         pytest.skip("needs two visible GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--eval-epochs", "0", "--sustain-seconds", "0",
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--eval-epochs", "0", "--sustain-seconds", "0", "--no-extra-legs",
               "--classes", "10", "--pool-per-class", "70"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
 
@@ -458,7 +458,7 @@ def test_two_gpu_bench_matches_single_gpu_loss():
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     one = run([sys.executable, "bench.py", "--gpus", "1"] + common)
-    for shard in ("class", "batch"):
+    for shard in ("class", "batch", "hybrid"):
         two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                    "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--shard", shard] + common)
         assert two["n_gpus"] == 2

@@ -1,0 +1,87 @@
+"""End to end on a LEARNABLE synthetic problem (class = smooth random template + noise; no dataset ships): N DM iterations and
+an ``evaluate_synset`` on the HIP path in the shipped precision mode, against the SAME loop on the oracle ops (the trainer
+logic over tests/cpu_backend.OracleBackend, then oracle.ref_cpu.train_epochs and a batch-standardised test pass) -- north_star:
+"outputs (synthetic tensors, matching loss, eval accuracy) must agree with the reference CPU path".  Reference loop:
+distill_baseline.py:334-355 (DM iteration), utils.py:848-886 (evaluate_synset), utils.py:752-844 (epoch)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from tests.cpu_backend import OracleBackend
+
+pytestmark = pytest.mark.gpu
+
+
+class _SeededNets:
+    """A backend whose fresh network of iteration ``it`` is the reference-initialised net of seed 100 + it (on both sides)."""
+
+    def __init__(self, inner, to_device):
+        self.inner, self.to_device = inner, to_device
+
+    def __getattr__(self, k):
+        return getattr(self.inner, k)
+
+    def new_network(self, seed):
+        return [self.to_device(p) for p in R.init_params(100 + int(seed))[:6]]
+
+
+def _templates(C, n_per, T, S, noise, g):
+    t = torch.randn(C, T, 3, S, S, generator=g)
+    t = torch.nn.functional.avg_pool2d(t.view(-1, 1, S, S), 9, 1, 4).view(C, T, 3, S, S) * 6          # smooth patterns
+    x = t.repeat_interleave(n_per, 0) + noise * torch.randn(C * n_per, T, 3, S, S, generator=g)
+    return x, torch.arange(C).repeat_interleave(n_per)
+
+
+def test_dm_distillation_then_evaluation_matches_the_oracle_loop():
+    from video_distillation_amd import distill, networks, plan, utils
+    C, T, S, n_pool, B, steps, epochs, lr_img, lr_net = 4, 8, 64, 12, 8, 12, 20, 2.0, 0.01
+    g = torch.Generator().manual_seed(2024)
+    train_x, _ = _templates(C, n_pool, T, S, 2.0, g)
+    test_x, test_y = _templates(C, 10, T, S, 2.0, g)
+    syn0 = train_x[::n_pool].clone()
+    counts, offsets = [n_pool] * C, [c * n_pool for c in range(C)]
+
+    # ---- the same DMTrainer logic on the two backends ----
+    be_hip = _SeededNets(distill.HipBackend(plan.NetGeometry(T, S, S), "cuda:0"), lambda p: p.cuda())
+    tr_hip = distill.DMTrainer(be_hip, distill.RealPool(train_x.cuda(), counts, offsets), C, 1, B, lr_img=lr_img, momentum=0.5,
+                               image_syn=syn0.clone().cuda())
+    be_cpu = _SeededNets(OracleBackend(), lambda p: p)
+    tr_cpu = distill.DMTrainer(be_cpu, distill.RealPool(train_x, counts, offsets), C, 1, B, lr_img=lr_img, momentum=0.5,
+                               image_syn=syn0.clone())
+    loss_hip, loss_cpu = [], []
+    for it in range(steps):
+        loss_hip.append(float(tr_hip.step(it)))
+        loss_cpu.append(float(tr_cpu.step(it)))
+    assert be_hip.inner._dither == 8 and be_hip.inner.real_last == "x3"
+    lerr = max(abs(a / b - 1) for a, b in zip(loss_hip, loss_cpu))
+    syn_hip, syn_cpu = tr_hip.image_syn.cpu(), tr_cpu.image_syn
+    moved = float((syn_cpu - syn0).norm() / syn0.norm())
+    serr = float((syn_hip - syn_cpu).norm() / (syn_cpu - syn0).norm())
+    print("DM %d steps: loss %.4f -> %.4f, max loss rel err %.2e; synthetic clips moved %.3f |x|, HIP vs oracle %.2e of the movement" % (
+        steps, loss_cpu[0], loss_cpu[-1], lerr, moved, serr))
+    assert loss_cpu[-1] < 0.9 * loss_cpu[0] and moved > 1e-3        # the distillation does something
+    assert lerr < 1e-3                                              # north_star: matching loss within 1e-3 at every iteration
+    assert serr < 5e-3                                              # synthetic tensors: accumulated over 12 momentum steps
+
+    # ---- evaluate_synset on each side's own synthetic clips, dropout off (its masks are drawn from different generators) ----
+    labels = torch.arange(C)
+    loader = torch.utils.data.DataLoader(utils.TensorDataset(test_x, test_y), batch_size=16, shuffle=False)
+    torch.manual_seed(77)
+    net = networks.ConvNet3D(3, C, 128, 3, 'relu', 'none', 'maxpooling', T, (S, S))
+    net.dropout.p = 0.0
+    eargs = types.SimpleNamespace(device="cuda", lr_net=lr_net, epoch_eval_train=epochs, batch_train=256, model="ConvNet3D", eval_mode="SS")
+    _, acc_train_hip, acc_test_hip, _ = utils.evaluate_synset(0, net, syn_hip.cuda(), labels.cuda(), loader, eargs, mode="none")
+    out = R.train_epochs(R.init_params(77, 3, C), syn_cpu, labels, lr_net, epochs, [list(range(C))] * (epochs + 1))
+    correct = 0
+    with torch.no_grad():
+        for xb, yb in loader:
+            correct += int((R.convnet3d_logits(R.standardise_batch(xb.float()), out["params"]).argmax(1) == yb).sum())
+    acc_test_cpu, acc_train_cpu = correct / len(test_y), out["acc"][-1]
+    print("evaluate_synset (%d epochs): train acc HIP %.3f oracle %.3f; test top-1 HIP %.3f oracle %.3f (chance %.2f)" % (
+        epochs + 1, acc_train_hip, acc_train_cpu, acc_test_hip, acc_test_cpu, 1.0 / C))
+    assert acc_test_cpu > 1.5 / C                                   # informative: well above chance
+    assert abs(acc_train_hip - acc_train_cpu) < 1e-9
+    assert abs(acc_test_hip - acc_test_cpu) <= 1.0 / len(test_y) + 1e-9     # at most one borderline test clip apart

@@ -12,10 +12,11 @@ Gradient criterion (flip tolerant): a max-pool window whose two largest entries 
 elsewhere depending on summation order -- the fp32 oracle differs from the fp64 one for exactly that reason (`oracle32_vs_64`
 below), and in this regime it happens in roughly one step out of five.  So every (step, class) entry is classified by the
 pooling decisions the HIP forward of that synthetic clip RECORDED (its arg-max bytes) against the fp64 oracle's max_pool3d
-decisions (tests/argmax_tools.py): an entry with no differing window in levels 1 / 2 is CLEAN and must meet the bar; an entry
-above the bar must show a differing window, every differing window must be a near-tie of the fp64 oracle itself (margin below
-2e-5 of the level's rms), and the error stays below the 5e-2 a last-level flip can cause.  The median over ALL entries meets
-the bar as well.
+decisions (tests/argmax_tools.py): an entry with no differing window at any level is CLEAN and must meet the bar at that very
+step; an entry above the bar must show a differing window, every differing window must be a near-tie of the fp64 oracle
+itself (margin below 2e-5 of the level's rms), and the error stays below the 5e-2 a last-level flip can cause (a first-level
+window carrying a large gradient moves up to 1e-2).  The median over ALL entries meets the bar as well.  (At 112x112x16 a clip
+has 800 k first-level windows and nearly every step has one or two such ties: there the median is what binds.)
 
 Measured values go to gpurun_out/r03_parity.json (copied to profiles/)."""
 import json
@@ -96,7 +97,7 @@ def late_regime_run(geom, C, NP, B, steps, lr, seed, modes=("shipped",), backend
     lead.be.embed_syn = spy_embed_syn
     rec = {m: {"loss_vs_fp32": [], "loss_vs_fp64": [], "grad_vs_fp32": [], "grad_vs_fp64": [], "grad_vs_fp64_per_class": [],
                "flipped_frac": []} for m in modes}
-    rec["decisions"] = {"mismatch_upper_levels_per_class": [], "not_near_tie_per_class": [], "mismatch_level0": []}
+    rec["decisions"] = {"mismatch_per_class": [], "not_near_tie_per_class": [], "mismatch_per_level": []}
     rec.update({"oracle32_vs_64": {"loss": [], "grad": [], "grad_per_class": []}, "feature_gap_over_norm": [], "oracle_seconds": []})
     for it in range(steps):
         state = (lead.image_syn.clone(), lead.buf.clone(), lead.steps_done)
@@ -134,12 +135,11 @@ def late_regime_run(geom, C, NP, B, steps, lr, seed, modes=("shipped",), backend
             r["flipped_frac"].append(float((d > 1e-2 * g64.abs().max()).double().mean()))
             if tr is lead:
                 dec = argmax_tools.compare_decisions(syn, weights, captured["am"])
-                rec["decisions"]["mismatch_upper_levels_per_class"].append(
-                    [a + b for a, b in zip(dec[1]["mismatch_per_clip"], dec[2]["mismatch_per_clip"])])
+                rec["decisions"]["mismatch_per_class"].append([sum(v) for v in zip(*[d_["mismatch_per_clip"] for d_ in dec])])
                 rec["decisions"]["not_near_tie_per_class"].append(
                     [sum(v) for v in zip(*[d_["not_near_tie_per_clip"] for d_ in dec])])
-                rec["decisions"]["mismatch_level0"].append(dec[0]["mismatch"])
-    flipped = np.asarray(rec["decisions"]["mismatch_upper_levels_per_class"]).reshape(-1) > 0
+                rec["decisions"]["mismatch_per_level"].append([d_["mismatch"] for d_ in dec])
+    flipped = np.asarray(rec["decisions"]["mismatch_per_class"]).reshape(-1) > 0
     for m in modes:
         per = np.asarray(rec[m]["grad_vs_fp64_per_class"]).reshape(-1)
         rec[m]["summary_clean"] = {"entries": int((~flipped).sum()), "of": int(flipped.size),
@@ -166,10 +166,10 @@ def _report(name, rec, modes):
     print("  fp32 oracle vs fp64 oracle:", rec["oracle32_vs_64"]["summary"])
     for m in modes:
         print("  %-8s vs oracle:" % m, rec[m]["summary"])
-        print("  %-8s clean entries (no differing pooling decision in levels 1 / 2):" % m, rec[m]["summary_clean"])
-    up = np.asarray(rec["decisions"]["mismatch_upper_levels_per_class"])
-    print("  (step, class) entries with a differing near-tie window in levels 1 / 2: %d of %d; level-0 mismatches per step: %s" % (
-        int((up > 0).sum()), up.size, rec["decisions"]["mismatch_level0"]))
+        print("  %-8s clean entries (pooling decisions equal to the fp64 oracle's at every level):" % m, rec[m]["summary_clean"])
+    up = np.asarray(rec["decisions"]["mismatch_per_class"])
+    print("  (step, class) entries with a differing near-tie window: %d of %d; mismatches per step and level: %s" % (
+        int((up > 0).sum()), up.size, rec["decisions"]["mismatch_per_level"]))
     print("  oracle seconds per step (fp32, fp64): %.1f %.1f" % tuple(np.mean(rec["oracle_seconds"], axis=0)))
 
 
@@ -183,32 +183,33 @@ def _assert_shipped(rec):
     assert s["loss_vs_fp32_max"] < 1e-3 and s["loss_vs_fp64_max"] < 1e-3
     assert s["grad_vs_fp64_median"] < GRAD_BAR, s
     per = np.asarray(rec["shipped"]["grad_vs_fp64_per_class"])
-    upper = np.asarray(rec["decisions"]["mismatch_upper_levels_per_class"])
+    upper = np.asarray(rec["decisions"]["mismatch_per_class"])
     far = np.asarray(rec["decisions"]["not_near_tie_per_class"])
     assert int(far.sum()) == 0, "a pooling decision differs from the fp64 oracle's in a window that is no near-tie: %s" % far.tolist()
     for it in range(per.shape[0]):
         for c in range(per.shape[1]):
-            if upper[it, c] == 0:          # same routing as the fp64 oracle in levels 1 and 2: the bar holds at this very step
+            if upper[it, c] == 0:          # same routing as the fp64 oracle at every level: the bar holds at this very step
                 assert per[it, c] < GRAD_BAR, (it, c, per[it, c])
             else:                          # a near-tie routed the other way (the fp32 oracle does the same, oracle32_vs_64)
                 assert per[it, c] < 5e-2, (it, c, per[it, c], int(upper[it, c]))
 
 
 def test_late_regime_shipped_mode_vs_oracle_64():
-    """The G12 configuration (2 classes x 64 real clips 64x64x8, 24 steps at lr 50)."""
+    """The G12 configuration (2 classes x 64 real clips 64x64x8, lr 50), 16 steps."""
     modes = ("shipped", "x3")
-    steps = int(os.environ.get("VD_PARITY_STEPS", "24"))
+    steps = int(os.environ.get("VD_PARITY_STEPS", "16"))
     rec = late_regime_run((8, 64, 64), C=2, NP=80, B=64, steps=steps, lr=50.0, seed=1201, modes=modes)
     _report("late regime 64x64x8", rec, modes)
     _record("late_64x64x8", rec)
     _assert_shipped(rec)
+    assert rec["shipped"]["summary_clean"]["entries"] >= rec["shipped"]["summary_clean"]["of"] // 2     # the per-step bar is not vacuous
     assert rec["x3"]["summary"]["grad_vs_fp64_median"] < 1e-4
 
 
 def test_late_regime_shipped_mode_vs_oracle_full_size():
-    """The benchmark's clip size: 3 classes x 64 real clips 112x112x16, 6 steps."""
+    """The benchmark's clip size: 2 classes x 64 real clips 112x112x16, 4 steps (the fp64 oracle takes 8 s per class term)."""
     modes = ("shipped",)
-    rec = late_regime_run((16, 112, 112), C=3, NP=72, B=64, steps=6, lr=20.0, seed=12, modes=modes)
+    rec = late_regime_run((16, 112, 112), C=2, NP=72, B=64, steps=4, lr=20.0, seed=12, modes=modes)
     _report("late regime 112x112x16", rec, modes)
     _record("late_112x112x16", rec)
     _assert_shipped(rec)

@@ -165,6 +165,13 @@ class HipBackend:
             self.s_real = torch.cuda.Stream(device=self.device, priority=pr)
             self.s_syn = torch.cuda.Stream(device=self.device, priority=ps)
         self._ev_real = None
+        # The first conv level of the real clips is the program that suffers most from sharing the GPU with the synthetic-clip
+        # stream's small launches (its two 64 KB workgroups fill a CU's LDS, so every CU a small kernel takes is lost to it for a
+        # whole box walk): VD_SYN_AFTER_L0=1 holds the synthetic-clip forward of a step back until the real side's first level
+        # has been launched and finished (an event behind it), so that it runs under levels 1 / 2 instead.
+        self.syn_after_l0 = self.two_streams and os.environ.get("VD_SYN_AFTER_L0", "0") == "1"
+        if self.syn_after_l0:
+            self.eng_real.ev_after_l0 = torch.cuda.Event()
         # Mixed mode (single-pass real side + hi/lo synthetic side of the same 16-bit format).  The real side
         # multiplies by rn16(W): a SYSTEMATIC perturbation of mean f_real (~2e-4 |f|, it does not average out over
         # the 64 clips of a batch) that the exact-weight synthetic side does not share, so it lands undiminished in
@@ -343,10 +350,17 @@ class RealPool:
         self.clips, self.counts, self.offsets = clips, list(counts), list(offsets)
 
     @staticmethod
-    def synthetic(num_classes: int, classes: Sequence[int], per_class: int, geo: P.NetGeometry, device, seed: int = 1234):
-        """randn clips standardised per channel, generated on the device.  Every class is drawn from its
-        own generator (seeded by ``seed`` and the class id) and standardised on its own, so a class's clips do not
-        depend on which rank holds it: every sharding of a benchmark run works on the same data."""
+    def synthetic(num_classes: int, classes: Sequence[int], per_class: int, geo: P.NetGeometry, device, seed: int = 1234,
+                  kind: str = "randn", noise: float = 2.0):
+        """Synthetic stand-in for the real training clips (no dataset ships), generated on the device.  Every class is drawn
+        from its own generator (seeded by ``seed`` and the class id) and standardised on its own, so a class's clips do not
+        depend on which rank holds it: every sharding of a benchmark run works on the same data.
+
+        ``kind='randn'``: independent N(0,1) pixels -- classes are indistinguishable, so any accuracy measured
+        on it is chance.  ``kind='templates'``: clip = a smooth random spatio-temporal template of its class (9x9 box-filtered
+        noise, amplitude 6) + ``noise`` x N(0,1): a LEARNABLE problem with the same value statistics after standardisation,
+        on which ``evaluate_synset``'s top-1 says something about the distilled clips."""
+        assert kind in ("randn", "templates")
         n = len(classes) * per_class
         clips = torch.empty((n, geo.frames, 3, geo.height, geo.width), dtype=torch.float32, device=device)
         counts = [per_class] * num_classes
@@ -356,6 +370,10 @@ class RealPool:
             gen.manual_seed(int(seed) * 1000003 + int(c))
             blk = clips[k * per_class:(k + 1) * per_class]
             blk.normal_(generator=gen)
+            if kind == "templates":
+                t = torch.randn((geo.frames * 3, 1, geo.height, geo.width), dtype=torch.float32, device=device, generator=gen)
+                t = torch.nn.functional.avg_pool2d(t, 9, 1, 4).view(1, geo.frames, 3, geo.height, geo.width) * 6.0
+                blk.mul_(float(noise)).add_(t)
             mean = blk.mean(dim=(0, 1, 3, 4), keepdim=True)
             std = blk.std(dim=(0, 1, 3, 4), keepdim=True)
             blk.sub_(mean).div_(std)
@@ -459,6 +477,8 @@ class DMTrainer:
                 be.set_real_weights(weights, self._per_class())
                 f_real = self._real_features(idx_t)
             with on_syn():
+                if getattr(be, "syn_after_l0", False):
+                    be.s_syn.wait_event(be.eng_real.ev_after_l0)
                 f_syn, handle = be.embed_syn(self.image_syn, weights)
                 be.real_to_syn(f_real)
                 f_real = self._exchange(f_real)      # (batch sharding) on the synthetic-clip stream: the real-clip stream is

@@ -211,6 +211,7 @@ class EmbedEngine:
         self._bwd_packed = False
         self._ws: Dict[str, torch.Tensor] = {}
         self.profile = None   # list -> (layer, clips, start_event, end_event) per forward launch
+        self.ev_after_l0 = None   # an event to record behind the first-level launch of forward_sets() / forward() (stream choreography)
 
     # ------------------------------------------------------------------------------------
     def _buf(self, name: str, shape, dtype) -> torch.Tensor:
@@ -314,6 +315,8 @@ class EmbedEngine:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if prof is not None else None
             if ev: ev[0].record()
             self.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, am0, nb, clip_index=cidx, group=group)
+            if self.ev_after_l0 is not None and c0 + nb >= B:
+                self.ev_after_l0.record()
             if ev: ev[1].record()
             self.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, am1, nb, group=group, emit_lo=hilo)
             if ev: ev[2].record()
@@ -369,6 +372,8 @@ class EmbedEngine:
                 else:
                     per0 = g.frames * 3 * g.height * (rowp // 8)
                     self.fwd[0].run(slots0[:, s * per * per0:], n_slots0, w[1], act1.data_ptr() + s * per * per1 * 16, n1, None, per, group=s)
+        if self.ev_after_l0 is not None:
+            self.ev_after_l0.record()
         for li, (src, n_src, per_src, dst_ptr, n_dst, per_dst_bytes) in enumerate((
                 (act1, n1, per1, act2.data_ptr(), n2, per2 * 16), (act2, n2, per2, feats.data_ptr(), 0, self.num_feat * 4)), start=1):
             if li == 2 and hilo:                        # hi+lo weights: one set

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvd_hip.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("conv_mfma.hip", "aux_kernels.hip", "program.hip", "planner.cpp")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("conv_mfma.hip", "aux_kernels.hip", "program.hip", "planner.cpp", "comm.cpp")]
 
 PREC = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
 EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv0_persistent", "vd_conv0_breg", "vd_pack_weights", "vd_round_operand", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_absmax_scale", "vd_dm_loss",
@@ -23,7 +23,9 @@ EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv0_persistent", "vd_conv0_br
            "vd_program_run", "vd_program_info", "vd_program_free",
            "vd_sgd_momentum_wd", "vd_frames_normalize", "vd_replica_sum", "vd_pack_weights_dither", "vd_unpool_relu_bwd_packed", "vd_mfma_peak", "vd_program_build", "vd_program_build_dgrad", "vd_program_build_wgrad", "vd_program_run_wgrad", "vd_train_create", "vd_train_workspace_bytes", "vd_train_step", "vd_train_free", "vd_blob_free", "vd_embed_create", "vd_embed_create_ex", "vd_embed_argmax_bytes", "vd_embed_backward_workspace_bytes",
            "vd_embed_forward_keep", "vd_embed_backward", "vd_program_run_scaled", "vd_embed_num_features",
-           "vd_embed_workspace_bytes", "vd_embed_set_weights", "vd_embed_forward", "vd_embed_free")
+           "vd_embed_workspace_bytes", "vd_embed_set_weights", "vd_embed_forward", "vd_embed_free",
+           "vd_comm_unique_id", "vd_comm_create", "vd_comm_size", "vd_comm_rank", "vd_comm_allreduce_f32", "vd_comm_allgather_f32",
+           "vd_comm_free")
 
 
 class VdConvParams(ctypes.Structure):
@@ -66,7 +68,7 @@ def build(force: bool = False, verbose: bool = False, debug_hooks: bool = False)
         if os.path.getmtime(out) >= newest:
             return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + (["-DVD_DBG_HOOKS=1"] if debug_hooks else []) + SOURCES
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + (["-DVD_DBG_HOOKS=1"] if debug_hooks else []) + SOURCES + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -92,7 +94,7 @@ def lib() -> ctypes.CDLL:
                 if "VD_LIB_PATH" in os.environ:      # an older build loaded on purpose for an A/B measurement
                     continue
                 raise RuntimeError("libvd_hip.so does not export %s" % name)
-            getattr(L, name).restype = {"vd_program_info": ctypes.c_int64, "vd_program_free": None, "vd_blob_free": None, "vd_embed_free": None, "vd_train_free": None, "vd_train_workspace_bytes": ctypes.c_int64,
+            getattr(L, name).restype = {"vd_program_info": ctypes.c_int64, "vd_program_free": None, "vd_blob_free": None, "vd_embed_free": None, "vd_train_free": None, "vd_comm_free": None, "vd_train_workspace_bytes": ctypes.c_int64,
                                         "vd_embed_num_features": ctypes.c_int64, "vd_embed_workspace_bytes": ctypes.c_int64,
                                         "vd_embed_argmax_bytes": ctypes.c_int64, "vd_embed_backward_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
         if L.vd_abi_version() != 3:
