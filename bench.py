@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--pool-kind", default="templates", choices=["templates", "randn"],
                     help="synthetic real pool: class template + noise (learnable: eval top-1 is informative) or plain randn clips "
                          "(SURVEY 8(d); top-1 is chance by construction).  Same value statistics, same timings.")
+    ap.add_argument("--pool-noise", type=float, default=1.0, help="--pool-kind templates: noise amplitude next to the template (rms 0.67)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="dm: skip the two short extra timed legs (parity_mode = all hi+lo pairs, fast_mode = round 2's single-pass mode)")
     ap.add_argument("--eval-epochs", type=int, default=10,
@@ -733,13 +734,13 @@ def main():
         raise SystemExit("--shard hybrid is a decomposition of --method dm")
     if shard == "batch":   # every rank holds the whole pool (11 GB) and embeds its slice of each class batch
         pool = distill.RealPool.synthetic(args.classes, list(range(args.classes)), args.pool_per_class, geo, device, seed=1234,
-                                          kind=args.pool_kind)
+                                          kind=args.pool_kind, noise=args.pool_noise)
     elif shard == "hybrid":   # the rank's block of whole classes + every split class
         block, split, _ = distill.hybrid_partition(args.classes, rank, world)
-        pool = distill.RealPool.synthetic(args.classes, block + split, args.pool_per_class, geo, device, seed=1234, kind=args.pool_kind)
+        pool = distill.RealPool.synthetic(args.classes, block + split, args.pool_per_class, geo, device, seed=1234, kind=args.pool_kind, noise=args.pool_noise)
     else:
         pool = distill.RealPool.synthetic(args.classes, list(range(c_lo, c_hi)), args.pool_per_class, geo, device, seed=1234,
-                                          kind=args.pool_kind)
+                                          kind=args.pool_kind, noise=args.pool_noise)
     if args.method == "dc":
         return bench_dc(args, h, distill, geo, pool)
     nsyn = (c_hi - c_lo) * (args.ipc if args.method == "dm" else 1)

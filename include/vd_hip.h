@@ -68,7 +68,8 @@ typedef struct VdConvParams {
     int32_t NTW;                  /* N tiles per wave (0/1: one; 2: an A fragment feeds two MFMAs; wave columns = NT / NTW) */
     const int64_t* clip_index;    /* first-layer programs (ncl = 1): source clip of batch clip b is src + clip_index[b]*clip stride (NULL: b) */
     int32_t mt_valid;             /* NTW = 2: M tiles per box that carry rows (< MW*MTW: the last wave row skips its padding tile); 0 = all */
-    int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups */
+    int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups;
+                                     vd_conv0_breg: bit 16 selects the variant that requests the next patch before the epilogue */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
     int32_t w_set_clips;          /* single-pass forward programs: > 0 = the B operand holds several sets, w_plane_stride elements apart; the box's
                                      first clip / w_set_clips picks the set (dithered real-side weights); 0 = one set */

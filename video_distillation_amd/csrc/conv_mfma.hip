@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <stdint.h>
+#include <utility>
 
 #include "../../include/vd_hip.h"
 
@@ -952,6 +953,218 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
     }
 }
 
+
+// LDS accesses of the overlapped epilogue below go through inline assembly: with an LDS-DMA in flight the compiler's wait
+// insertion puts s_waitcnt vmcnt(0) in front of every LDS access it can see (it cannot tell the staging tile from the DMA's
+// destination), which would serialise the epilogue behind the landing of the next patch.
+template <int I> struct VdIC { static constexpr int v = I; };
+template <class F, int... Is>
+__device__ __forceinline__ void vd_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(VdIC<Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void vd_static_for(F&& f) { vd_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int OFS>
+__device__ __forceinline__ void vd_lds_write_b16(uint32_t addr, uint32_t v) {       // (constant offsets ride in the instruction:
+    asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFS) : "memory");   //  one address register for all)
+}
+template <int OFS>
+__device__ __forceinline__ uint4 vd_lds_read_b128_wait(uint32_t addr) {
+    uint4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr), "n"(OFS) : "memory");
+    return r;
+}
+
+// conv0_breg_kernel with the phases of consecutive boxes overlapped (same tile program, same arithmetic, bitwise the same
+// results): the patch of box b+1 is requested right after the K loop of box b -- one barrier says every wave is done reading
+// the patch -- and lands while the epilogue of box b runs.  The epilogue needs no workgroup barrier any more: a wave stages
+// ITS 32 pooled positions x 32 channels in a private 2 KB tile (the 8 channels of a 16-byte output slot all belong to one wave)
+// and stores its own slots.  Per box: K loop | barrier | DMA issue, epilogue under the landing | barrier.
+template <int PREC>
+__global__ __launch_bounds__(256, 2) void conv0_breg2_kernel(const VdConvParams p, const int boxes_per_wg) {
+    constexpr int MTW = 4, S = 32, LU = 14;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int half = lane >> 5;
+    const int32_t* a_tab = p.tables + p.tab_ofs[0];
+    const int32_t* o_tab = p.tables + p.tab_ofs[1];
+    const int32_t* t_tab = p.tables + p.tab_ofs[2];
+    const int plane_bytes = p.lds_plane_bytes;
+    const int ngroups = (int)(p.gather_stride >> 6);
+    const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);
+    int* lds_tap = reinterpret_cast<int*>(smem + plane_bytes);
+    int* park = reinterpret_cast<int*>(smem + plane_bytes + 512) + wave * (LU * 64);
+    // byte address (LDS address space) of this wave's staging tile: [32 pooled positions][32 channels] 16-bit
+    const uint32_t stg = (uint32_t)(plane_bytes + 512 + 4 * LU * 64 * (int)sizeof(int) + wave * 2048);
+    const uint32_t stg_w = stg + (uint32_t)(half * 128 + (lane & 31) * 2);     // this lane's column in the rows it writes
+    const uint32_t stg_r = stg + (uint32_t)(lane * 16);                          // the first of the two slots it reads back
+    for (int k = tid; k < 2 * S; k += 256) lds_tap[k] = t_tab[k];
+    int a_off[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
+    // output origins of the two slots this lane stores per box (box independent: one box type)
+    int o_reg[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) o_reg[k] = o_tab[wm * 16 + (((lane + 64 * k) >> 2) >> 1)];
+    uint4 breg[S];
+    auto load_breg = [&](int set) {
+        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)set * (p.w_plane_stride >> 3) + (int64_t)wn * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) breg[s] = wp[(int64_t)s * 128];
+    };
+    int cur_set = 0;
+    const int n = wn * 32 + (lane & 31);
+    const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
+    const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
+    const int total = p.nclips * p.nbox;            // ncl == 1
+    int wgid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int b_lo = wgid * boxes_per_wg;
+    const int b_hi = (b_lo + boxes_per_wg < total) ? b_lo + boxes_per_wg : total;
+    if (b_lo >= b_hi) return;
+    auto park_next = [&](int b) {      // this wave's LU x 64 gather entries of box b -> its park region (asynchronous)
+        const int32_t* gtab = p.gather + (int64_t)(b % p.nbox) * p.gather_stride + lane;
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int gi = wave + u * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gtab + ((gi < ngroups) ? gi : ngroups - 1) * 64),
+                                             (__attribute__((address_space(3))) void*)(park + u * 64), 4, 0, 0);
+        }
+    };
+    auto issue_patch = [&](int b) {    // gather entries from the park (landed one barrier ago), then the patch DMA of box b
+        const int clip0 = b / p.nbox;
+        const uint32_t* csrc = src + (p.clip_index != nullptr ? p.clip_index[clip0] : (int64_t)clip0) * p.src_clip_stride4;
+        uint32_t off[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int e = park[u * 64 + lane];
+            off[u] = (e >= 0) ? (uint32_t)(e & 0xFFFFFF) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u) asm volatile("" : "+v"(off[u]));
+        int gi = wave;
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            asm volatile("" : "+s"(gi));
+            if (gi < ngroups) {
+                const uint32_t* gp = (off[u] != 0xFFFFFFFFu) ? csrc + off[u] : zslot;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)(smem + gi * 1024), 16, 0, 0);
+            }
+            gi += 4;
+        }
+    };
+    park_next(b_lo);
+    if (p.w_set_clips > 0) cur_set = (b_lo / p.nbox) / p.w_set_clips;
+    load_breg(cur_set);
+    __syncthreads();                     // tables published, first entries landed (vmcnt(0) + barrier)
+    issue_patch(b_lo);
+    if (b_lo + 1 < b_hi) park_next(b_lo + 1);
+    __syncthreads();                     // first patch landed
+    for (int b = b_lo; b < b_hi; ++b) {
+        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
+        if (p.w_set_clips > 0) {
+            const int set = clip0 / p.w_set_clips;
+            if (set != cur_set) { cur_set = set; load_breg(set); }
+        }
+        const int out_rel = p.boxes[bi * 8 + 3];
+        // ---- K loop: A two steps ahead (refill order of conv0_breg_kernel), B from registers ----
+        f32x16 acc[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+        {
+            uint4 A[2][MTW];
+            const int tp0 = lds_tap[half], tp1 = lds_tap[2 + half];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) A[0][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp0);
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) A[1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp1);
+            int tp2 = lds_tap[4 + half];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int tp3 = lds_tap[2 * ((s + 3 < S) ? s + 3 : S - 1) + half];
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) {
+                    acc[i] = mfma16<PREC>(A[s & 1][i], breg[s], acc[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 2 < S) A[s & 1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                tp2 = tp3;
+            }
+        }
+        VD_LDS_BARRIER();                // every wave is done reading the patch (and the park entries of box b+1 landed a barrier ago)
+        // ---- epilogue, first half: bias + ReLU + (1,2,2) max-pool -> this wave's private staging tile (frees the accumulators:
+        //      the DMA issue below needs their registers) ----
+        vd_static_for<MTW * 2>([&](auto ic) {
+            constexpr int i = decltype(ic)::v >> 1, qh = decltype(ic)::v & 1, r0 = 8 * qh;
+            float m0 = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 2], acc[i][r0 + 3]));
+            float m1 = fmaxf(fmaxf(acc[i][r0 + 4], acc[i][r0 + 5]), fmaxf(acc[i][r0 + 6], acc[i][r0 + 7]));
+            m0 = fmaxf(m0 + bias, 0.f); m1 = fmaxf(m1 + bias, 0.f);
+            // pooled position within this wave's 32: ql = (i * 4 + half + 2 * qh) * 2 (+ 1 for the second frame); rows of 64 bytes
+            uint16_t hi, lo;
+            split16<PREC>(m0, hi, lo);
+            vd_lds_write_b16<(i * 4 + 2 * qh) * 128>(stg_w, hi);
+            split16<PREC>(m1, hi, lo);
+            vd_lds_write_b16<(i * 4 + 2 * qh) * 128 + 64>(stg_w, hi);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + 1 < b_hi) {
+            issue_patch(b + 1);          // lands under the second half of the epilogue
+            if (b + 2 < b_hi) park_next(b + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue, second half: the wave's own 16-byte slots, staging tile -> HBM ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's staging writes (LDS operations of a wave complete in order)
+        {
+            const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
+            const int64_t lim64 = out_total - out_base;
+            const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
+            uint4* dslots = reinterpret_cast<uint4*>(p.dst) + out_base;
+            vd_static_for<2>([&](auto kc) {
+                constexpr int k = decltype(kc)::v;
+                const int item = lane + 64 * k;
+                const int ql = item >> 2, ch = item & 3;
+                const uint4 v = vd_lds_read_b128_wait<k * 1024>(stg_r);
+                const int o = o_reg[k];
+                const int base = o + (ql & 1) * p.out_t_stride;
+                if (o >= 0 && base < lim)
+                    dslots[(uint32_t)base + (uint32_t)(wn * 4 + ch) * (uint32_t)p.out_chunk_stride] = v;
+            });
+        }
+        // next patch (and the park entries of box b+2) landed: vmcnt(0) of every wave, then the barrier
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+template <int PREC>
+static int launch_conv0_breg2(const VdConvParams& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.nclips * p.nbox;
+    if (total <= 0) return 0;
+    auto kern = conv0_breg2_kernel<PREC>;
+    static VdDevCache cache;
+    int ncu = 0;
+    if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
+    const size_t lds = (size_t)p.lds_plane_bytes + 512 + 4 * 14 * 64 * sizeof(int) + 4 * 2048;
+    if (lds > 80 * 1024) return -3;
+    const int64_t slots = (int64_t)ncu * 2;
+    const int gens = p.persist > 0 ? p.persist : 4;
+    int per = (int)((total + slots * gens - 1) / (slots * gens));
+    if (per < 1) per = 1;
+    const int64_t grid = (total + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p, per);
+    return (int)hipGetLastError();
+}
+
 template <int PREC>
 static int launch_conv0_breg(const VdConvParams& p, hipStream_t st) {
     const int64_t total = (int64_t)p.nclips * p.nbox;
@@ -979,6 +1192,14 @@ extern "C" int vd_conv0_breg(const VdConvParams* pp, void* stream) {
         (p.gather_stride >> 6) > 4 * 14 || 8 * 1024 > p.lds_plane_bytes)
         return -2;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // persist bit 16: the variant with the next patch requested before the epilogue (conv0_breg2_kernel)
+    if (p.persist & 0x10000) {
+        VdConvParams q = p;
+        q.persist = p.persist & 0xFFFF;
+        if (p.prec == VD_PREC_F16) return launch_conv0_breg2<VD_PREC_F16>(q, st);
+        if (p.prec == VD_PREC_BF16) return launch_conv0_breg2<VD_PREC_BF16>(q, st);
+        return -2;
+    }
     if (p.prec == VD_PREC_F16) return launch_conv0_breg<VD_PREC_F16>(p, st);
     if (p.prec == VD_PREC_BF16) return launch_conv0_breg<VD_PREC_BF16>(p, st);
     return -2;

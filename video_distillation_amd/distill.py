@@ -165,13 +165,6 @@ class HipBackend:
             self.s_real = torch.cuda.Stream(device=self.device, priority=pr)
             self.s_syn = torch.cuda.Stream(device=self.device, priority=ps)
         self._ev_real = None
-        # The first conv level of the real clips is the program that suffers most from sharing the GPU with the synthetic-clip
-        # stream's small launches (its two 64 KB workgroups fill a CU's LDS, so every CU a small kernel takes is lost to it for a
-        # whole box walk): VD_SYN_AFTER_L0=1 holds the synthetic-clip forward of a step back until the real side's first level
-        # has been launched and finished (an event behind it), so that it runs under levels 1 / 2 instead.
-        self.syn_after_l0 = self.two_streams and os.environ.get("VD_SYN_AFTER_L0", "0") == "1"
-        if self.syn_after_l0:
-            self.eng_real.ev_after_l0 = torch.cuda.Event()
         # Mixed mode (single-pass real side + hi/lo synthetic side of the same 16-bit format).  The real side
         # multiplies by rn16(W): a SYSTEMATIC perturbation of mean f_real (~2e-4 |f|, it does not average out over
         # the 64 clips of a batch) that the exact-weight synthetic side does not share, so it lands undiminished in
@@ -477,8 +470,6 @@ class DMTrainer:
                 be.set_real_weights(weights, self._per_class())
                 f_real = self._real_features(idx_t)
             with on_syn():
-                if getattr(be, "syn_after_l0", False):
-                    be.s_syn.wait_event(be.eng_real.ev_after_l0)
                 f_syn, handle = be.embed_syn(self.image_syn, weights)
                 be.real_to_syn(f_real)
                 f_real = self._exchange(f_real)      # (batch sharding) on the synthetic-clip stream: the real-clip stream is

@@ -73,7 +73,10 @@ class _DevPlan:
                               and 2 * p.lds_plane_bytes + 8 * plan.S + 16 <= 160 * 1024)
 
         # first layer, x1 formats, 2x2-wave layout: kernel with the layer's B fragments resident in registers
-        self.breg_ok = (os.environ.get("VD_L0_BREG", "1") == "1" and not hip.is_x3(prec)
+        # VD_L0_BREG: 2 (default) = that kernel with the next patch requested before the epilogue (conv0_breg2_kernel), 1 = the
+        # round-2 phase order, 0 = the generic tile-program kernel
+        self.breg_variant = int(os.environ.get("VD_L0_BREG", "2"))
+        self.breg_ok = (self.breg_variant in (1, 2) and not hip.is_x3(prec)
                         and plan.epi == P.EPI_POOL_CL and plan.pool_t == 1 and plan.CC == 1 and plan.ncl == 1 and plan.NTW == 1
                         and (plan.NT, plan.MW, plan.MTW, plan.S) == (2, 2, 4, 32) and len(plan.types) == 1
                         and int(gt.shape[1]) // 64 <= 56 and plan.relu)
@@ -121,7 +124,13 @@ class _DevPlan:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if self.breg_ok and argmax is None and (not p.dbg or os.environ.get("VD_BREG_DBG") == "1"):
-            hip.check(hip.lib().vd_conv0_breg(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv0_breg(%s)" % self.plan.name)
+            persist = p.persist
+            if self.breg_variant == 2:
+                p.persist = persist | 0x10000          # (VdConvParams.persist bit 16 selects the overlapped variant)
+            try:
+                hip.check(hip.lib().vd_conv0_breg(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv0_breg(%s)" % self.plan.name)
+            finally:
+                p.persist = persist
         elif self.persistent_ok and argmax is None and not p.dbg:
             hip.check(hip.lib().vd_conv0_persistent(ctypes.byref(p), hip.stream_ptr(src.device)),
                       "vd_conv0_persistent(%s)" % self.plan.name)
@@ -189,7 +198,7 @@ class EmbedEngine:
         self.ntw = int(os.environ.get("VD_NTW", "2"))
         if ntw0 is None:
             # (x1 formats: the register-resident-B kernel runs the 2x2-wave one-N-tile layout)
-            breg = os.environ.get("VD_L0_BREG", "1") == "1"
+            breg = os.environ.get("VD_L0_BREG", "2") in ("1", "2")
             ntw0 = int(os.environ.get("VD_NTW0", "1" if (hip.is_x3(self.prec) or self.ntw != 2 or breg) else "2"))
         bal = (self.ntw == 2 and not hip.is_x3(self.prec) and os.environ.get("VD_BALANCED", "1") == "1")
         self.batch_hint = batch_hint      # typical clips per launch: small batches get latency-oriented programs
@@ -211,7 +220,6 @@ class EmbedEngine:
         self._bwd_packed = False
         self._ws: Dict[str, torch.Tensor] = {}
         self.profile = None   # list -> (layer, clips, start_event, end_event) per forward launch
-        self.ev_after_l0 = None   # an event to record behind the first-level launch of forward_sets() / forward() (stream choreography)
 
     # ------------------------------------------------------------------------------------
     def _buf(self, name: str, shape, dtype) -> torch.Tensor:
@@ -315,8 +323,6 @@ class EmbedEngine:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if prof is not None else None
             if ev: ev[0].record()
             self.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, am0, nb, clip_index=cidx, group=group)
-            if self.ev_after_l0 is not None and c0 + nb >= B:
-                self.ev_after_l0.record()
             if ev: ev[1].record()
             self.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, am1, nb, group=group, emit_lo=hilo)
             if ev: ev[2].record()
@@ -372,8 +378,6 @@ class EmbedEngine:
                 else:
                     per0 = g.frames * 3 * g.height * (rowp // 8)
                     self.fwd[0].run(slots0[:, s * per * per0:], n_slots0, w[1], act1.data_ptr() + s * per * per1 * 16, n1, None, per, group=s)
-        if self.ev_after_l0 is not None:
-            self.ev_after_l0.record()
         for li, (src, n_src, per_src, dst_ptr, n_dst, per_dst_bytes) in enumerate((
                 (act1, n1, per1, act2.data_ptr(), n2, per2 * 16), (act2, n2, per2, feats.data_ptr(), 0, self.num_feat * 4)), start=1):
             if li == 2 and hilo:                        # hi+lo weights: one set
