@@ -69,7 +69,8 @@ typedef struct VdConvParams {
     const int64_t* clip_index;    /* first-layer programs (ncl = 1): source clip of batch clip b is src + clip_index[b]*clip stride (NULL: b) */
     int32_t mt_valid;             /* NTW = 2: M tiles per box that carry rows (< MW*MTW: the last wave row skips its padding tile); 0 = all */
     int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups;
-                                     vd_conv0_breg: bit 16 selects the variant that requests the next patch before the epilogue */
+                                     vd_conv0_breg: bit 16 selects the variant that requests the next patch before the epilogue, bit 17 the one
+                                     that builds the patch from aligned register loads */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
     int32_t w_set_clips;          /* single-pass forward programs: > 0 = the B operand holds several sets, w_plane_stride elements apart; the box's
                                      first clip / w_set_clips picks the set (dithered real-side weights); 0 = one set */
@@ -78,6 +79,9 @@ typedef struct VdConvParams {
     int32_t emit_lo;              /* single-pass programs with the staged POOL_CL epilogue (argmax NULL): != 0 also writes the LOW plane
                                      rn16(v - rn16(v)) of every pooled output, dst_plane_stride slots behind the high one -- the next level
                                      can then run in the hi+lo format of the same 16-bit type (real side: level 2 in f16x3) */
+    int32_t src_planes, src_rows; /* first-level programs over pixel rows (vd_pix2rows): planes (frames x 3) and rows per plane of a clip; the
+                                     kernel that builds its patch from aligned loads (vd_conv0_breg, persist bit 17) derives row addresses
+                                     and the zero fill from them instead of a gather table; 0 elsewhere */
 } VdConvParams;
 
 int vd_abi_version(void);

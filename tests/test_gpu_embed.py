@@ -190,8 +190,9 @@ def test_experimental_persistent_first_layer_matches_generic():
 @pytest.mark.parametrize("geom,n", [((16, 112, 112), 5), ((8, 64, 64), 37)])
 def test_first_layer_kernel_variants_are_bitwise_equal(monkeypatch, geom, n):
     """The three first-layer kernels of the single-pass formats -- generic tile program (VD_L0_BREG=0), register-resident B
-    (1), register-resident B with the next patch requested before the epilogue and barrier-free per-wave output staging (2,
-    default) -- run the same tile program with the same K order per output: bitwise equal features, also through the index
+    (1), register-resident B with the next patch requested before the epilogue and barrier-free per-wave output staging (2),
+    the same with the patch built from aligned row loads in registers instead of LDS-DMA (3), and one eight-wave workgroup per CU
+    whose two groups alternate K loop / everything else (4, default) -- run the same tile program with the same K order per output: bitwise equal features, also through the index
     gather and with dithered operand sets switching inside a workgroup's box walk."""
     from video_distillation_amd import distill, engine, plan
     geo = plan.NetGeometry(*geom)
@@ -200,16 +201,17 @@ def test_first_layer_kernel_variants_are_bitwise_equal(monkeypatch, geom, n):
     idx = torch.randperm(n + 3, generator=torch.Generator().manual_seed(3))[:n - n % 8 if n >= 8 else n].cuda()
     w = distill.fresh_network_weights(9, "cuda:0")
     outs = {}
-    for variant in ("0", "1", "2"):
+    for variant in ("0", "1", "2", "3", "4"):
         monkeypatch.setenv("VD_L0_BREG", variant)
         eng = engine.EmbedEngine(geo, prec="f16", chunk=4096, ntw0=1)
         assert eng.fwd[0].breg_ok == (variant != "0") and eng.fwd[0].breg_variant == int(variant)
+        assert eng.fwd[0].breg3_ok == (variant != "0")
         G = 8 if idx.numel() % 8 == 0 and idx.numel() >= 8 else 0
         eng.set_weights(w, dither=G)
         rows = eng.pool_rows(pool)
         outs[variant] = (eng.forward(pool), eng.forward(pool, index=idx, rows=rows),
                          eng.forward_sets(pool, idx, rows=rows) if G else None)
-    for variant in ("1", "2"):
+    for variant in ("1", "2", "3", "4"):
         for a, b in zip(outs["0"], outs[variant]):
             assert (a is None and b is None) or torch.equal(a, b), variant
 

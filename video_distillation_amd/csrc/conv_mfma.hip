@@ -1068,6 +1068,18 @@ __global__ __launch_bounds__(256, 2) void conv0_breg2_kernel(const VdConvParams 
     issue_patch(b_lo);
     if (b_lo + 1 < b_hi) park_next(b_lo + 1);
     __syncthreads();                     // first patch landed
+    // dbg bit 3 (library built with -DVD_DBG_HOOKS=1, tools/stamps_breg2.py): cycles this workgroup's first wave spends in each
+    // phase, summed over its boxes -> stamps[block][0..5], boxes -> [6], whole walk -> [7]
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0, t_first = 0;
+    auto tick = [&](int k) {
+        if (VD_DBG(p) & 8) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            if (k >= 0) ph[k] += t - t_prev; else if (t_first == 0) t_first = t;
+            t_prev = t;
+        }
+    };
+    tick(-1);
     for (int b = b_lo; b < b_hi; ++b) {
         const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
         if (p.w_set_clips > 0) {
@@ -1102,7 +1114,9 @@ __global__ __launch_bounds__(256, 2) void conv0_breg2_kernel(const VdConvParams 
                 tp2 = tp3;
             }
         }
+        tick(0);
         VD_LDS_BARRIER();                // every wave is done reading the patch (and the park entries of box b+1 landed a barrier ago)
+        tick(1);
         // ---- epilogue, first half: bias + ReLU + (1,2,2) max-pool -> this wave's private staging tile (frees the accumulators:
         //      the DMA issue below needs their registers) ----
         vd_static_for<MTW * 2>([&](auto ic) {
@@ -1118,11 +1132,13 @@ __global__ __launch_bounds__(256, 2) void conv0_breg2_kernel(const VdConvParams 
             vd_lds_write_b16<(i * 4 + 2 * qh) * 128 + 64>(stg_w, hi);
         });
         __builtin_amdgcn_sched_barrier(0);
+        tick(2);
         if (b + 1 < b_hi) {
             issue_patch(b + 1);          // lands under the second half of the epilogue
             if (b + 2 < b_hi) park_next(b + 2);
         }
         __builtin_amdgcn_sched_barrier(0);
+        tick(3);
         // ---- epilogue, second half: the wave's own 16-byte slots, staging tile -> HBM ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's staging writes (LDS operations of a wave complete in order)
         {
@@ -1141,9 +1157,460 @@ __global__ __launch_bounds__(256, 2) void conv0_breg2_kernel(const VdConvParams 
                     dslots[(uint32_t)base + (uint32_t)(wn * 4 + ch) * (uint32_t)p.out_chunk_stride] = v;
             });
         }
+        tick(4);
         // next patch (and the park entries of box b+2) landed: vmcnt(0) of every wave, then the barrier
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        tick(5);
     }
+    if ((VD_DBG(p) & 8) && tid == 0 && p.stamps != nullptr) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)blockIdx.x * 8;
+        for (int k = 0; k < 6; ++k) o[k] = ph[k];
+        o[6] = (unsigned long long)(b_hi - b_lo);
+        o[7] = t_prev - t_first;
+    }
+}
+
+
+// Third form of the first-level kernel (phase stamps of conv0_breg2_kernel, tools/stamps_breg2.py: of 11.7 k cycles per box the
+// ISSUE of the patch's LDS-DMA takes 3.5 k -- the 16-byte windows of neighbouring output columns start 4 bytes apart, and the
+// texture-address unit serves such dword-aligned 16-byte lanes at ~16 bytes per clock, a quarter of its aligned rate; the
+// landing after it is short).  Here the patch is built from ALIGNED loads instead: a patch row (plane, h) needs 11 consecutive
+// dwords of one pixel row, starting at a 32-byte boundary; a lane loads two aligned 16-byte chunks of it into registers and
+// writes the four overlapping kw-slots d[j..j+3] they contain with ds_write_b128 -- every source byte is fetched once (the DMA
+// fetched it three times), no gather table, no LDS-DMA.  The loads of box b+1 are issued right after the K loop of box b and
+// return under its epilogue.  Same tile program, same K order: bitwise the results of the other two kernels.
+template <int PREC>
+__global__ __launch_bounds__(256, 2) void conv0_breg3_kernel(const VdConvParams p, const int boxes_per_wg) {
+    constexpr int MTW = 4, S = 32, NI = 3;          // NI: patch-row halves per lane (256 lanes x 3 >= 2 * pf * ph)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int half = lane >> 5;
+    const int32_t* a_tab = p.tables + p.tab_ofs[0];
+    const int32_t* o_tab = p.tables + p.tab_ofs[1];
+    const int32_t* t_tab = p.tables + p.tab_ofs[2];
+    const int plane_bytes = p.lds_plane_bytes;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);
+    int* lds_tap = reinterpret_cast<int*>(smem + plane_bytes);
+    uint16_t* stg16 = reinterpret_cast<uint16_t*>(smem + plane_bytes + 512 + wave * 2048);   // this wave's [32 positions][32 channels]
+    for (int k = tid; k < 2 * S; k += 256) lds_tap[k] = t_tab[k];
+    int a_off[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
+    int o_reg[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) o_reg[k] = o_tab[wm * 16 + (((lane + 64 * k) >> 2) >> 1)];
+    // a lane's patch-row halves (box independent): item it = tid + 256 k -> row r = it >> 1 = plane * ph + h, half hf = tid & 1.
+    // (plane, h) are recomputed where needed (r / ph by a 16-bit reciprocal, exact for r < 512: checked by the host) -- the K loop
+    // leaves no registers to keep them in
+    const int ph = p.type_desc[1], pitch_h = p.type_desc[3], pitch_f = p.type_desc[4], nitems = 2 * p.type_desc[0] * ph;
+    const int ph_magic = (65536 + ph - 1) / ph;
+    const int row4 = (int)(p.src_chunk_stride4 / ((int64_t)p.src_planes * p.src_rows));     // dwords per pixel row
+    uint4 breg[S];
+    auto load_breg = [&](int set) {
+        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)set * (p.w_plane_stride >> 3) + (int64_t)wn * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) breg[s] = wp[(int64_t)s * 128];
+    };
+    int cur_set = 0;
+    const int n = wn * 32 + (lane & 31);
+    const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
+    const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
+    const int total = p.nclips * p.nbox;            // ncl == 1
+    int wgid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int b_lo = wgid * boxes_per_wg;
+    const int b_hi = (b_lo + boxes_per_wg < total) ? b_lo + boxes_per_wg : total;
+    if (b_lo >= b_hi) return;
+    uint4 raw[NI][2];
+    auto load_raw = [&](int b) {       // the aligned chunks of box b's patch rows -> registers (zeros outside the clip); branch free:
+        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;      // rows outside the clip load a valid row of the box and are zeroed
+        const int32_t* box = p.boxes + bi * 8;
+        const int f0 = box[6] >> 16, h0 = (int)(int16_t)(box[6] & 0xFFFF), w0 = box[7];      // plane / row / dword of the patch origin
+        int tv = tid;
+        asm volatile("" : "+v"(tv));       // (opaque per call: otherwise the row coordinates below are hoisted out of the box loop into
+                                           //  registers the K loop does not have)
+        const char* base = reinterpret_cast<const char*>(
+            src + (p.clip_index != nullptr ? p.clip_index[clip0] : (int64_t)clip0) * p.src_clip_stride4 + ((int64_t)f0 * p.src_rows + h0) * row4 + w0);
+        const uint32_t off_valid = (uint32_t)((((f0 < 0 ? -f0 : 0) * p.src_rows + (h0 < 0 ? -h0 : 0)) * row4) * 4);   // first row of the box inside the clip
+        const uint32_t hf16 = (uint32_t)(tv & 1) * 16u;
+        const bool in_row = (w0 + 4 * (tv & 1) + 8 <= row4);                         // the second chunk stays inside the pixel row
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int it = tv + 256 * k, r = it >> 1;
+            const int pl = (r * ph_magic) >> 16, h = r - pl * ph;
+            const bool ok = it < nitems && (unsigned)(f0 + pl) < (unsigned)p.src_planes && (unsigned)(h0 + h) < (unsigned)p.src_rows;
+            const uint32_t o1 = (ok ? (uint32_t)((pl * p.src_rows + h) * row4 * 4) : off_valid) + hf16;
+            const uint32_t o2 = (ok && in_row) ? o1 + 16u : o1;
+            const uint4 v0 = *reinterpret_cast<const uint4*>(base + o1);
+            const uint4 v1 = *reinterpret_cast<const uint4*>(base + o2);
+            raw[k][0] = ok ? v0 : make_uint4(0, 0, 0, 0);
+            raw[k][1] = (ok && in_row) ? v1 : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto expand = [&]() {              // registers -> the four overlapping kw-slots of every loaded row half
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int it = tv + 256 * k, r = it >> 1;
+            if (it >= nitems) continue;
+            const int pl = (r * ph_magic) >> 16, h = r - pl * ph;
+            const uint4 a = raw[k][0], c = raw[k][1];
+            uint4* dst = reinterpret_cast<uint4*>(smem + (pl * pitch_f + h * pitch_h + 4 * (tv & 1)) * 16);
+            dst[0] = a;
+            dst[1] = make_uint4(a.y, a.z, a.w, c.x);
+            dst[2] = make_uint4(a.z, a.w, c.x, c.y);
+            dst[3] = make_uint4(a.w, c.x, c.y, c.z);
+        }
+    };
+    if (p.w_set_clips > 0) cur_set = (b_lo / p.nbox) / p.w_set_clips;
+    load_raw(b_lo);
+    load_breg(cur_set);
+    expand();
+    __syncthreads();                     // tables and the first patch published
+    // dbg bit 3 (library built with -DVD_DBG_HOOKS=1, tools/stamps_breg2.py): cycles per phase summed over the box walk
+    unsigned long long phs[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0, t_first = 0;
+    auto tick = [&](int k) {
+        if (VD_DBG(p) & 8) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            if (k >= 0) phs[k] += t - t_prev; else if (t_first == 0) t_first = t;
+            t_prev = t;
+        }
+    };
+    tick(-1);
+    for (int b = b_lo; b < b_hi; ++b) {
+        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
+        if (p.w_set_clips > 0) {
+            const int set = clip0 / p.w_set_clips;
+            if (set != cur_set) { cur_set = set; load_breg(set); }
+        }
+        const int out_rel = p.boxes[bi * 8 + 3];
+        f32x16 acc[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+        {
+            uint4 A[2][MTW];
+            const int tp0 = lds_tap[half], tp1 = lds_tap[2 + half];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) A[0][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp0);
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) A[1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp1);
+            int tp2 = lds_tap[4 + half];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int tp3 = lds_tap[2 * ((s + 3 < S) ? s + 3 : S - 1) + half];
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) {
+                    acc[i] = mfma16<PREC>(A[s & 1][i], breg[s], acc[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 2 < S) A[s & 1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                tp2 = tp3;
+            }
+        }
+        tick(0);
+        // the rows of the next box: return under the epilogue (the A registers are free now).  Unconditional -- the last box
+        // reloads itself -- so that `raw` is defined in every iteration and does not stay live across the K loop
+        load_raw(b + 1 < b_hi ? b + 1 : b);
+        __builtin_amdgcn_sched_barrier(0);
+        tick(1);
+        // ---- epilogue: bias + ReLU + (1,2,2) max-pool -> this wave's private staging tile -> its own 16-byte slots ----
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                const int r0 = 8 * qh;
+                float m0 = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 2], acc[i][r0 + 3]));
+                float m1 = fmaxf(fmaxf(acc[i][r0 + 4], acc[i][r0 + 5]), fmaxf(acc[i][r0 + 6], acc[i][r0 + 7]));
+                m0 = fmaxf(m0 + bias, 0.f); m1 = fmaxf(m1 + bias, 0.f);
+                const int ql = (i * 4 + half + 2 * qh) * 2;           // pooled position within this wave's 32
+                uint16_t hi, lo;
+                split16<PREC>(m0, hi, lo);
+                stg16[ql * 32 + (lane & 31)] = hi;
+                split16<PREC>(m1, hi, lo);
+                stg16[(ql + 1) * 32 + (lane & 31)] = hi;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        tick(2);
+        {
+            const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
+            const int64_t lim64 = out_total - out_base;
+            const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
+            uint4* dslots = reinterpret_cast<uint4*>(p.dst) + out_base;
+            const uint4* stg4 = reinterpret_cast<const uint4*>(stg16);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int item = lane + 64 * k;
+                const int ql = item >> 2, ch = item & 3;
+                const uint4 v = stg4[item];
+                const int o = o_reg[k];
+                const int base = o + (ql & 1) * p.out_t_stride;
+                if (o >= 0 && base < lim)
+                    dslots[(uint32_t)base + (uint32_t)(wn * 4 + ch) * (uint32_t)p.out_chunk_stride] = v;
+            }
+        }
+        tick(3);
+        VD_LDS_BARRIER();                // every wave is done reading the patch of box b ...
+        tick(4);
+        if (b + 1 < b_hi) expand();      // ... so the kw-slots of box b+1 may replace it
+        VD_LDS_BARRIER();
+        tick(5);
+    }
+    if ((VD_DBG(p) & 8) && tid == 0 && p.stamps != nullptr) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)blockIdx.x * 8;
+        for (int k = 0; k < 6; ++k) o[k] = phs[k];
+        o[6] = (unsigned long long)(b_hi - b_lo);
+        o[7] = t_prev - t_first;
+    }
+}
+
+template <int PREC>
+static int launch_conv0_breg3(const VdConvParams& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.nclips * p.nbox;
+    if (total <= 0) return 0;
+    auto kern = conv0_breg3_kernel<PREC>;
+    static VdDevCache cache;
+    int ncu = 0;
+    if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
+    size_t lds = (size_t)p.lds_plane_bytes + 512 + 4 * 2048;
+    if (lds > 80 * 1024) return -3;
+    if (p.dbg & 0x100) lds = 100 * 1024;          // diagnostic (tools/stamps_breg2.py --alone): one workgroup per CU, phases without a partner
+    const int64_t slots = (int64_t)ncu * 2;
+    const int gens = p.persist > 0 ? p.persist : 4;
+    int per = (int)((total + slots * gens - 1) / (slots * gens));
+    if (per < 1) per = 1;
+    const int64_t grid = (total + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p, per);
+    return (int)hipGetLastError();
+}
+
+
+// Fourth form: ONE workgroup of eight waves per CU, two groups of four that alternate roles box by box -- while group 0 runs
+// the K loop of its box (matrix pipes), group 1 finishes its previous box and prepares its next one (pool, stage, output slots,
+// row loads, kw-slot expansion: vector memory + LDS), then they swap; one s_barrier per phase, none inside a phase.  The phases
+// of conv0_breg3_kernel measured without a partner (tools/stamps_breg2.py --alone): K loop 4.8 k cycles, everything else 4.2 k;
+// two independent workgroups per CU drift into lockstep (both in their K loops, then both out of them: 3.5 k cycles per box
+// with idle matrix pipes), which this arrangement rules out by construction.  A wave of group 0 and one of group 1 share each
+// SIMD.  Same tile program, same K order per output: bitwise the results of the other first-level kernels.
+template <int PREC>
+__global__ __launch_bounds__(512, 1) void conv0_breg4_kernel(const VdConvParams p, const int boxes_per_wg) {
+    constexpr int MTW = 4, S = 32, NI = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, tg = tid & 255;          // role group, thread index within the group
+    const int wn = wave & 1, wm = (wave >> 1) & 1;
+    const int half = lane >> 5;
+    const int32_t* a_tab = p.tables + p.tab_ofs[0];
+    const int32_t* o_tab = p.tables + p.tab_ofs[1];
+    const int32_t* t_tab = p.tables + p.tab_ofs[2];
+    const int plane_bytes = p.lds_plane_bytes;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);
+    char* patch = smem + grp * plane_bytes;              // this group's patch
+    int* lds_tap = reinterpret_cast<int*>(smem + 2 * plane_bytes);
+    uint16_t* stg16 = reinterpret_cast<uint16_t*>(smem + 2 * plane_bytes + 512 + wave * 2048);
+    for (int k = tid; k < 2 * S; k += 512) lds_tap[k] = t_tab[k];
+    int a_off[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
+    int o_reg[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) o_reg[k] = o_tab[wm * 16 + (((lane + 64 * k) >> 2) >> 1)];
+    const int ph = p.type_desc[1], pitch_h = p.type_desc[3], pitch_f = p.type_desc[4], nitems = 2 * p.type_desc[0] * ph;
+    const int ph_magic = (65536 + ph - 1) / ph;
+    const int row4 = (int)(p.src_chunk_stride4 / ((int64_t)p.src_planes * p.src_rows));
+    uint4 breg[S];
+    auto load_breg = [&](int set) {
+        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)set * (p.w_plane_stride >> 3) + (int64_t)wn * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) breg[s] = wp[(int64_t)s * 128];
+    };
+    int cur_set = -1;
+    const int n = wn * 32 + (lane & 31);
+    const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
+    const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
+    const int total = p.nclips * p.nbox;            // ncl == 1
+    int wgid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int b_lo = wgid * boxes_per_wg;
+    const int b_hi = (b_lo + boxes_per_wg < total) ? b_lo + boxes_per_wg : total;
+    if (b_lo >= b_hi) return;
+    const int nmine = (b_hi - b_lo + 1 - grp) >> 1;      // boxes b_lo + grp, b_lo + grp + 2, ... of this group
+    uint4 raw[NI][2];
+    auto load_raw = [&](int b) {       // the aligned chunks of box b's patch rows -> registers (zeros outside the clip); branch free:
+        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;      // rows outside the clip load a valid row of the box and are zeroed
+        const int32_t* box = p.boxes + bi * 8;
+        const int f0 = box[6] >> 16, h0 = (int)(int16_t)(box[6] & 0xFFFF), w0 = box[7];      // plane / row / dword of the patch origin
+        int tv = tg;
+        asm volatile("" : "+v"(tv));       // (opaque per call: otherwise the row coordinates below are hoisted out of the box loop into
+                                           //  registers the K loop does not have)
+        const char* base = reinterpret_cast<const char*>(
+            src + (p.clip_index != nullptr ? p.clip_index[clip0] : (int64_t)clip0) * p.src_clip_stride4 + ((int64_t)f0 * p.src_rows + h0) * row4 + w0);
+        const uint32_t off_valid = (uint32_t)((((f0 < 0 ? -f0 : 0) * p.src_rows + (h0 < 0 ? -h0 : 0)) * row4) * 4);   // first row of the box inside the clip
+        const uint32_t hf16 = (uint32_t)(tv & 1) * 16u;
+        const bool in_row = (w0 + 4 * (tv & 1) + 8 <= row4);                         // the second chunk stays inside the pixel row
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int it = tv + 256 * k, r = it >> 1;
+            const int pl = (r * ph_magic) >> 16, h = r - pl * ph;
+            const bool ok = it < nitems && (unsigned)(f0 + pl) < (unsigned)p.src_planes && (unsigned)(h0 + h) < (unsigned)p.src_rows;
+            const uint32_t o1 = (ok ? (uint32_t)((pl * p.src_rows + h) * row4 * 4) : off_valid) + hf16;
+            const uint32_t o2 = (ok && in_row) ? o1 + 16u : o1;
+            const uint4 v0 = *reinterpret_cast<const uint4*>(base + o1);
+            const uint4 v1 = *reinterpret_cast<const uint4*>(base + o2);
+            raw[k][0] = ok ? v0 : make_uint4(0, 0, 0, 0);
+            raw[k][1] = (ok && in_row) ? v1 : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto expand = [&]() {
+        int tv = tg;
+        asm volatile("" : "+v"(tv));
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int it = tv + 256 * k, r = it >> 1;
+            if (it >= nitems) continue;
+            const int pl = (r * ph_magic) >> 16, h = r - pl * ph;
+            const uint4 a = raw[k][0], c = raw[k][1];
+            uint4* dst = reinterpret_cast<uint4*>(patch + (pl * pitch_f + h * pitch_h + 4 * (tv & 1)) * 16);
+            dst[0] = a;
+            dst[1] = make_uint4(a.y, a.z, a.w, c.x);
+            dst[2] = make_uint4(a.z, a.w, c.x, c.y);
+            dst[3] = make_uint4(a.w, c.x, c.y, c.z);
+        }
+    };
+    f32x16 acc[MTW];
+    // group 0 prepares its first box before the first phase; group 1 does so in phase 0, under group 0's first K loop
+    if (grp == 0) { load_raw(b_lo); expand(); }
+    {
+        const int first = b_lo + grp;
+        const int set = (p.w_set_clips > 0 && first < b_hi) ? (first / p.nbox) / p.w_set_clips : 0;
+        cur_set = set; load_breg(set);
+    }
+    __syncthreads();                     // tables published, group 0's first patch in place
+    // phases 0 .. 2 * n0: in phase q group g runs a K loop when (q + g) is even, the other half of its work when odd
+    const int n0 = (b_hi - b_lo + 1) >> 1;
+    for (int q = 0; q <= 2 * n0; ++q) {
+        const int j = (q - grp) >> 1;                    // index into this group's boxes (K loop: box j; other phase: finish j-1... see below)
+        if (((q + grp) & 1) == 0) {
+            // ---- K loop of this group's box j ----
+            if (j >= 0 && j < nmine) {
+                const int b = b_lo + grp + 2 * j;
+                if (p.w_set_clips > 0) {
+                    const int set = (b / p.nbox) / p.w_set_clips;
+                    if (set != cur_set) { cur_set = set; load_breg(set); }
+                }
+#pragma unroll
+                for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+                uint4 A[2][MTW];
+                const int tp0 = lds_tap[half], tp1 = lds_tap[2 + half];
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) A[0][i] = *reinterpret_cast<const uint4*>(patch + a_off[i] + tp0);
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) A[1][i] = *reinterpret_cast<const uint4*>(patch + a_off[i] + tp1);
+                int tp2 = lds_tap[4 + half];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int tp3 = lds_tap[2 * ((s + 3 < S) ? s + 3 : S - 1) + half];
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) {
+                        acc[i] = mfma16<PREC>(A[s & 1][i], breg[s], acc[i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s + 2 < S) A[s & 1][i] = *reinterpret_cast<const uint4*>(patch + a_off[i] + tp2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    tp2 = tp3;
+                }
+            }
+        } else {
+            // ---- the other half: request the rows of box jn = (q + 1 - grp) / 2, finish box jn - 1 (its accumulators are in this
+            //      wave's registers since the previous phase), build the kw-slots of box jn ----
+            const int jn = (q + 1 - grp) >> 1;
+            const bool have_next = jn >= 0 && jn < nmine, have_prev = jn - 1 >= 0 && jn - 1 < nmine;
+            {
+                const int bn = b_lo + grp + 2 * (have_next ? jn : (have_prev ? jn - 1 : 0));
+                load_raw(bn < b_hi ? bn : b_hi - 1);         // (unconditional: keeps `raw` out of the K loop's live ranges)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (have_prev) {
+                const int b = b_lo + grp + 2 * (jn - 1);
+                const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
+                const int out_rel = p.boxes[bi * 8 + 3];
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+                    for (int qh = 0; qh < 2; ++qh) {
+                        const int r0 = 8 * qh;
+                        float m0 = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 2], acc[i][r0 + 3]));
+                        float m1 = fmaxf(fmaxf(acc[i][r0 + 4], acc[i][r0 + 5]), fmaxf(acc[i][r0 + 6], acc[i][r0 + 7]));
+                        m0 = fmaxf(m0 + bias, 0.f); m1 = fmaxf(m1 + bias, 0.f);
+                        const int ql = (i * 4 + half + 2 * qh) * 2;
+                        uint16_t hi, lo;
+                        split16<PREC>(m0, hi, lo);
+                        stg16[ql * 32 + (lane & 31)] = hi;
+                        split16<PREC>(m1, hi, lo);
+                        stg16[(ql + 1) * 32 + (lane & 31)] = hi;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
+                const int64_t lim64 = out_total - out_base;
+                const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
+                uint4* dslots = reinterpret_cast<uint4*>(p.dst) + out_base;
+                const uint4* stg4 = reinterpret_cast<const uint4*>(stg16);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int item = lane + 64 * k;
+                    const int ql = item >> 2, ch = item & 3;
+                    const uint4 v = stg4[item];
+                    const int o = o_reg[k];
+                    const int base = o + (ql & 1) * p.out_t_stride;
+                    if (o >= 0 && base < lim)
+                        dslots[(uint32_t)base + (uint32_t)(wn * 4 + ch) * (uint32_t)p.out_chunk_stride] = v;
+                }
+            }
+            if (have_next) expand();         // this group's patch is free: its K loop ended a phase ago
+        }
+        VD_LDS_BARRIER();                    // the one barrier of a phase (all eight waves)
+    }
+}
+
+template <int PREC>
+static int launch_conv0_breg4(const VdConvParams& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.nclips * p.nbox;
+    if (total <= 0) return 0;
+    auto kern = conv0_breg4_kernel<PREC>;
+    static VdDevCache cache;
+    int ncu = 0;
+    if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
+    const size_t lds = (size_t)2 * p.lds_plane_bytes + 512 + 8 * 2048;
+    if (lds > 160 * 1024) return -3;
+    const int64_t slots = (int64_t)ncu;
+    const int gens = p.persist > 0 ? p.persist : 4;
+    int per = (int)((total + slots * gens - 1) / (slots * gens));
+    if (per < 2) per = 2;
+    per += per & 1;                          // an even number of boxes per workgroup: both role groups get the same share
+    const int64_t grid = (total + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, p, per);
+    return (int)hipGetLastError();
 }
 
 template <int PREC>
@@ -1192,6 +1659,26 @@ extern "C" int vd_conv0_breg(const VdConvParams* pp, void* stream) {
         (p.gather_stride >> 6) > 4 * 14 || 8 * 1024 > p.lds_plane_bytes)
         return -2;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // persist bit 18: one eight-wave workgroup per CU, two groups alternating K loop / everything else (conv0_breg4_kernel); same
+    // requirements as bit 17
+    if (p.persist & 0x40000) {
+        if (p.src_planes <= 0 || p.src_rows <= 0 || p.type_desc == nullptr) return -2;
+        VdConvParams q = p;
+        q.persist = p.persist & 0xFFFF;
+        if (p.prec == VD_PREC_F16) return launch_conv0_breg4<VD_PREC_F16>(q, st);
+        if (p.prec == VD_PREC_BF16) return launch_conv0_breg4<VD_PREC_BF16>(q, st);
+        return -2;
+    }
+    // persist bit 17: the patch built from aligned register loads (conv0_breg3_kernel); needs the pixel-row geometry in src_planes /
+    // src_rows, box origins in words 6 / 7 of the box rows, 8 output columns per box starting at a multiple of 4 dwords
+    if (p.persist & 0x20000) {
+        if (p.src_planes <= 0 || p.src_rows <= 0 || p.type_desc == nullptr) return -2;
+        VdConvParams q = p;
+        q.persist = p.persist & 0xFFFF;
+        if (p.prec == VD_PREC_F16) return launch_conv0_breg3<VD_PREC_F16>(q, st);
+        if (p.prec == VD_PREC_BF16) return launch_conv0_breg3<VD_PREC_BF16>(q, st);
+        return -2;
+    }
     // persist bit 16: the variant with the next patch requested before the epilogue (conv0_breg2_kernel)
     if (p.persist & 0x10000) {
         VdConvParams q = p;

@@ -766,6 +766,10 @@ std::vector<uint8_t> export_program(const Plan& pl, int persist) {
         boxes[(size_t)bi * 8 + 3] = (int32_t)pl.boxes[bi][4];
         boxes[(size_t)bi * 8 + 4] = ty;
         boxes[(size_t)bi * 8 + 5] = (int32_t)pl.boxes[bi][5];      // copy of the accumulation target (weight-gradient programs)
+        // patch origin in source slot coordinates: (f0 << 16) | (h0 & 0xffff), w0 -- read by the first-level kernel that builds
+        // its patch from aligned row loads (conv0_breg3_kernel)
+        boxes[(size_t)bi * 8 + 6] = (int32_t)(((uint32_t)(int32_t)pl.boxes[bi][1] << 16) | ((uint32_t)(int32_t)pl.boxes[bi][2] & 0xFFFFu));
+        boxes[(size_t)bi * 8 + 7] = (int32_t)pl.boxes[bi][3];
     }
     // gather table: for every LDS slot of a box's patch the source slot it is filled from (dword offset inside the
     // (clip, chunk) block, box-local clip index in bits 24..30); -1 = zero fill

@@ -73,13 +73,24 @@ class _DevPlan:
                               and 2 * p.lds_plane_bytes + 8 * plan.S + 16 <= 160 * 1024)
 
         # first layer, x1 formats, 2x2-wave layout: kernel with the layer's B fragments resident in registers
-        # VD_L0_BREG: 2 (default) = that kernel with the next patch requested before the epilogue (conv0_breg2_kernel), 1 = the
-        # round-2 phase order, 0 = the generic tile-program kernel
-        self.breg_variant = int(os.environ.get("VD_L0_BREG", "2"))
-        self.breg_ok = (self.breg_variant in (1, 2) and not hip.is_x3(prec)
+        # VD_L0_BREG: 4 (default) = one eight-wave workgroup per CU whose two groups alternate K loop / everything else
+        # (conv0_breg4_kernel), 3 = two workgroups per CU with the patch built from aligned row loads in registers (conv0_breg3_kernel),
+        # 2 = LDS-DMA patch requested before the epilogue (conv0_breg2_kernel), 1 = the round-2 phase order, 0 = the generic
+        # tile-program kernel.  All bitwise equal (tests/test_gpu_embed.py::test_first_layer_kernel_variants_are_bitwise_equal).
+        self.breg_variant = int(os.environ.get("VD_L0_BREG", "4"))
+        self.breg_ok = (self.breg_variant in (1, 2, 3, 4) and not hip.is_x3(prec)
                         and plan.epi == P.EPI_POOL_CL and plan.pool_t == 1 and plan.CC == 1 and plan.ncl == 1 and plan.NTW == 1
                         and (plan.NT, plan.MW, plan.MTW, plan.S) == (2, 2, 4, 32) and len(plan.types) == 1
                         and int(gt.shape[1]) // 64 <= 56 and plan.relu)
+
+        # the aligned-load variant: pixel-row source (w_step4 == 1), 8 output columns per box starting at a multiple of 4 dwords,
+        # every patch row's 12 dwords inside its 16-byte-aligned pixel row, three row halves per lane
+        t0 = plan.types[0]
+        self.breg3_ok = bool(self.breg_ok and plan.w_step4 == 1 and t0.pw == 8 and plan.row_pitch4 % 4 == 0
+                             and all(int(b[3]) % 4 == 0 and int(b[3]) >= 0 for b in plan.boxes) and 2 * t0.pf * t0.ph <= 768
+                             and abs(int(plan.boxes[:, 1].min())) < 32768 and abs(int(plan.boxes[:, 2].min())) < 32768)
+        if self.breg3_ok:
+            p.src_planes, p.src_rows = plan.F, plan.H
 
     def pack(self, w: torch.Tensor) -> None:
         assert w.dtype == torch.float32 and w.is_contiguous()
@@ -125,8 +136,12 @@ class _DevPlan:
             e0.record()
         if self.breg_ok and argmax is None and (not p.dbg or os.environ.get("VD_BREG_DBG") == "1"):
             persist = p.persist
-            if self.breg_variant == 2:
-                p.persist = persist | 0x10000          # (VdConvParams.persist bit 16 selects the overlapped variant)
+            if self.breg_variant == 4 and self.breg3_ok:
+                p.persist = persist | 0x40000          # (VdConvParams.persist bit 18: eight-wave workgroup, two alternating role groups)
+            elif self.breg_variant >= 3 and self.breg3_ok:
+                p.persist = persist | 0x20000          # (bit 17: patch from aligned row loads)
+            elif self.breg_variant >= 2:
+                p.persist = persist | 0x10000          # (bit 16: LDS-DMA patch requested before the epilogue)
             try:
                 hip.check(hip.lib().vd_conv0_breg(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv0_breg(%s)" % self.plan.name)
             finally:
@@ -198,7 +213,7 @@ class EmbedEngine:
         self.ntw = int(os.environ.get("VD_NTW", "2"))
         if ntw0 is None:
             # (x1 formats: the register-resident-B kernel runs the 2x2-wave one-N-tile layout)
-            breg = os.environ.get("VD_L0_BREG", "2") in ("1", "2")
+            breg = os.environ.get("VD_L0_BREG", "4") in ("1", "2", "3", "4")
             ntw0 = int(os.environ.get("VD_NTW0", "1" if (hip.is_x3(self.prec) or self.ntw != 2 or breg) else "2"))
         bal = (self.ntw == 2 and not hip.is_x3(self.prec) and os.environ.get("VD_BALANCED", "1") == "1")
         self.batch_hint = batch_hint      # typical clips per launch: small batches get latency-oriented programs

@@ -144,6 +144,10 @@ class ConvPlan:
             ty = int(box[0])
             out[bi, :5] = (descs[ty][7], descs[ty][8], descs[ty][9], int(box[4]), ty)
             out[bi, 5] = int(box[5])              # replica of the accumulation target (weight-gradient programs), else 0
+            # patch origin in source slot coordinates, (f0 << 16) | (h0 & 0xffff) and w0: read by the first-level kernel that
+            # builds its patch from aligned row loads (conv0_breg3_kernel)
+            out[bi, 6] = np.array((int(box[1]) << 16) | (int(box[2]) & 0xFFFF), dtype=np.int64).astype(np.int32)
+            out[bi, 7] = int(box[3])
         return out
 
     def flat_tables(self):
