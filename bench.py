@@ -97,7 +97,7 @@ def pmc_traffic(name, clips_per_launch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE passes, corrected as
     MI355X_MICROARCH.md prescribes), rescaled to this run's clips per launch.  A STATIC figure from profiles/, not a
     measurement of this run -> (bytes or None, source label)."""
-    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
         if os.path.exists(path):
             rec = json.load(open(path)).get(name)

@@ -25,7 +25,8 @@ def per_kernel(path, counter):
 res = {}
 # run_l1.py launches, in dispatch order: pix2rows, then the forward programs of layers 0, 1, 2
 keys = [k for k in order if k[0].startswith("pix2rows_kernel")][:1] + [k for k in order if k[0].startswith("void conv")][:3]
-labels = ["pix2rows_f16", "conv0_fwd_f16", "conv1_fwd_f16", "conv2_fwd_f16"]
+import os
+labels = ["pix2rows_f16", "conv0_fwd_f16", "conv1_fwd_f16", "conv2_fwd_f16x3_real" if os.environ.get("VD_RUN_L1_HILO") == "1" else "conv2_fwd_f16"]
 for key, label in zip(keys, labels):
     fv = sum(f[key]) / len(f[key])
     wv = sum(w[key]) / len(w[key]) if key in w else 0.0
