@@ -76,11 +76,12 @@ def parse():
     ap.add_argument("--pool-kind", default="templates", choices=["templates", "randn"],
                     help="synthetic real pool: class template + noise (learnable: eval top-1 is informative) or plain randn clips "
                          "(SURVEY 8(d); top-1 is chance by construction).  Same value statistics, same timings.")
-    ap.add_argument("--pool-noise", type=float, default=1.0, help="--pool-kind templates: noise amplitude next to the template (rms 0.67)")
+    ap.add_argument("--pool-noise", type=float, default=1.5, help="--pool-kind templates: noise amplitude next to the template (rms 0.67)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="dm: skip the two short extra timed legs (parity_mode = all hi+lo pairs, fast_mode = round 2's single-pass mode)")
-    ap.add_argument("--eval-epochs", type=int, default=10,
-                    help="dm: after the timed steps run evaluate_synset on the synthetic clips for this many epochs (0 = skip)")
+    ap.add_argument("--eval-epochs", type=int, default=500,
+                    help="dm: after the timed steps run evaluate_synset on the synthetic clips for this many epochs (0 = skip); 500 "
+                         "epochs take ~4 s on the HIP train step (the reference's default is 1000) and fit the 50 clips")
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="length of the sustained leg (0 = skip)")
     ap.add_argument("--dis-metric", default="ours", choices=["ours", "mse", "cos"], help="match_loss metric of --method dc")
     return ap.parse_args()

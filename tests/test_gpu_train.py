@@ -457,6 +457,59 @@ def test_atomic_accumulation_run_to_run_spread_is_bounded():
     assert spread < 2e-6 and hspread < 2e-6 and mspread < 2e-6
 
 
+def test_train_step_is_undisturbed_by_a_laned_gm_step(monkeypatch):
+    """State that could leak between users of the cached engines: a GMTrainer step on three class lanes --
+    slot engines, workspaces created on lane streams, the global precision table -- then ``hip_train_step`` on the default
+    stream with the SAME geometry / class count / batch bucket (hence the same cached TrainEngine as lane 0): its loss, logits
+    and all eight updated parameter tensors must equal those of the same step taken BEFORE the laned step to the fp32 atomics'
+    run-to-run noise (2e-6; a stale workspace or an unjoined lane stream would show as 1e-3 or worse), and its recorded
+    pooling decisions bitwise."""
+    from video_distillation_amd import distill, networks, plan, train
+    C, B = 3, 4
+    g = torch.Generator().manual_seed(4242)
+    x = torch.randn(B, 8, 3, 64, 64, generator=g).cuda()
+    y = (torch.arange(B) % C).cuda()
+    p0 = R.init_params(31, 3, C)
+    captured = []
+    orig_fw = train.TrainEngine._forward
+
+    def spy(self, xx, params):
+        out = orig_fw(self, xx, params)
+        captured.append([a.clone() for a in out[2]])
+        return out
+
+    def one_step():
+        net = networks.ConvNet3D(3, C, 128, 3, 'relu', 'none', 'maxpooling', 8, (64, 64)).cuda().train()
+        with torch.no_grad():
+            for p, q in zip(net.parameters(), p0):
+                p.copy_(q)
+        net.dropout.p = 0.0
+        opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        assert net.hip_trainable(x, opt, torch.nn.CrossEntropyLoss().cuda())
+        train.TrainEngine._forward = spy
+        try:
+            logits, loss = net.hip_train_step(x, y, opt)
+        finally:
+            train.TrainEngine._forward = orig_fw
+        torch.cuda.synchronize()
+        return float(loss), logits.clone(), [p.detach().clone() for p in net.parameters()]
+    before = one_step()
+    # the laned gradient-matching step in between: same geometry and class count, three lanes
+    monkeypatch.setenv("VD_GM_LANES", "3")
+    clips = torch.randn(C * 4, 8, 3, 64, 64, generator=g).to("cuda:0")
+    pool = distill.RealPool(clips, [4] * C, [4 * c for c in range(C)])
+    tr = distill.GMTrainer(distill.HipGMOps("cuda:0", "ours"), pool, plan.NetGeometry(8, 64, 64), C, 1, batch_real=4, lr_img=1e-3,
+                           outer_loop=1, dropout_p=0.0, net_init=lambda it: R.init_params(900 + it, 3, C))
+    float(tr.step(0))                      # (no explicit synchronize: the next step must order itself behind the lanes)
+    after = one_step()
+    assert all(torch.equal(a, b) for a, b in zip(captured[0], captured[-1])), "pooling decisions changed"
+    assert abs(after[0] / before[0] - 1) < 2e-6 and _rel(after[1], before[1].cpu().double()) < 2e-6
+    upd = [_rel(a - q.cuda(), (b - q.cuda()).cpu().double()) for a, b, q in zip(after[2], before[2], p0)]
+    print("train step before / after a laned GM step: loss %.7f / %.7f, per-tensor update difference %s" % (
+        before[0], after[0], ["%.1e" % v for v in upd]))
+    assert max(upd) < 2e-5
+
+
 def test_expert_trajectories_match_the_oracle_loop(tmp_path):
     """checkpoint.train_expert_trajectories (the buffer.py:64-95 producer on the HIP train step) against the same loop
     written out on the oracle: fresh net, SGD(momentum, weight decay) over shuffled mini-batches, parameters recorded
