@@ -6,6 +6,9 @@ import torch, numpy as np
 from video_distillation_amd import engine, plan
 nclips = 512
 li = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+alone = "--alone" in sys.argv        # one workgroup per CU: a workgroup's phases without a partner on its SIMDs
+if li == 0:
+    os.environ["VD_L0_BREG"] = "0"   # (the generic tile-program kernel carries these stamps; the breg kernels: tools/stamps_breg2.py)
 geo = plan.NetGeometry(16, 112, 112)
 x = torch.randn(nclips, 16, 3, 112, 112, device="cuda")
 params = [torch.randn(s, device="cuda") * 0.02 for s in [(64,3,3,7,7),(64,),(128,64,3,7,7),(128,),(128,128,3,7,7),(128,)]]
@@ -15,7 +18,7 @@ eng.forward(x); torch.cuda.synchronize()
 dp = eng.fwd[li]
 grid = dp.plan.grid(nclips)
 buf = torch.zeros(grid * 8, dtype=torch.int64, device="cuda")
-dp.params.dbg = 8; dp.params.stamps = buf.data_ptr()
+dp.params.dbg = 8 | (0x100 if alone else 0); dp.params.stamps = buf.data_ptr()
 eng.forward(x); torch.cuda.synchronize()
 dp.params.dbg = 0
 t = buf.cpu().numpy().reshape(grid, 8).astype(np.float64)

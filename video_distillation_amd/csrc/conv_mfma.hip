@@ -1726,8 +1726,9 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     const int groups = (p.nclips + p.ncl - 1) / p.ncl;
     const int64_t total = (int64_t)groups * p.nbox;
     if (total <= 0) return 0;
-    const size_t lds = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + (p.MW * MTW + BAL) * 4) * sizeof(int) + 16;
+    size_t lds = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + (p.MW * MTW + BAL) * 4) * sizeof(int) + 16;
     if (lds > 160 * 1024) return -3;
+    if ((p.dbg & 0x100) && lds < 100 * 1024) lds = 100 * 1024;   // diagnostic (tools/stamps.py --alone): one workgroup per CU
     auto kern = conv_mfma_kernel<PREC, MTW, SO, NTW, BAL>;
     if (p.NT % NTW != 0) return -2;
     const int ncols = p.NT / NTW;
