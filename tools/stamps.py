@@ -12,7 +12,12 @@ if li == 0:
 geo = plan.NetGeometry(16, 112, 112)
 x = torch.randn(nclips, 16, 3, 112, 112, device="cuda")
 params = [torch.randn(s, device="cuda") * 0.02 for s in [(64,3,3,7,7),(64,),(128,64,3,7,7),(128,),(128,128,3,7,7),(128,)]]
-eng = engine.EmbedEngine(geo, prec="f16", chunk=nclips)
+prec = [a for a in sys.argv[2:] if not a.startswith("--")]
+prec = prec[0] if prec else "f16"
+if prec != "f16":
+    nclips = 64
+    x = x[:nclips]
+eng = engine.EmbedEngine(geo, prec=prec, chunk=nclips)
 eng.set_weights(params)
 eng.forward(x); torch.cuda.synchronize()
 dp = eng.fwd[li]
