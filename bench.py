@@ -725,12 +725,14 @@ def main():
     c_lo, c_hi = distill.class_range(args.classes, rank, world)
     shard = args.shard
     if shard == "auto":
-        # Whole-class blocks (50 -> 7,7,6,...) need no data-path collective but leave ranks idle (ceiling 50/7 = 7.14x at 8);
-        # the balanced batch split (+ one 410 KB all-reduce) pays a rank's fixed per-launch costs on 50 small class slices
-        # (single-GPU proxy of a rank's step, tools/rank_proxy.py: 17.0 / 8.9 / 5.0 ms vs 17.1 / 8.7 / 5.3 ms at N = 2 / 4 / 8).
-        # The hybrid keeps whole classes and splits only the left-over ones: 400 real clips on every rank at N = 8.
-        uneven = world > 1 and args.classes % world != 0 and args.batch_real % world == 0
-        shard = "hybrid" if (uneven and args.method == "dm") else "class"
+        # Whole-class blocks (50 -> 7,7,6,...) need no data-path collective but leave ranks idle (ceiling 50/7 = 7.14x at 8); the hybrid
+        # keeps whole classes and splits only the left-over ones (400 real clips on every rank at N = 8, one 16 KB all-reduce).
+        # Single-GPU proxy of one rank's step in the shipped mode (tools/rank_proxy.py, profiles/r03_rank_proxy.txt; exchange not
+        # included): N = 2: class 18.1 / batch 18.6 ms; N = 4: class 9.8 / batch 10.4 / hybrid 10.6; N = 8: class 6.5 / batch 5.4 /
+        # hybrid 5.5 (5.5x / 6.6x / 6.5x of one GPU) -- so the hybrid is chosen where the class blocks are more than 8 % uneven
+        # (N = 8), whole-class blocks otherwise.
+        blocks_uneven = world > 1 and (-(-args.classes // world)) * world > 1.08 * args.classes
+        shard = "hybrid" if (blocks_uneven and args.batch_real % world == 0 and args.method == "dm") else "class"
     if shard == "hybrid" and args.method != "dm":
         raise SystemExit("--shard hybrid is a decomposition of --method dm")
     if shard == "batch":   # every rank holds the whole pool (11 GB) and embeds its slice of each class batch
