@@ -706,13 +706,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # VD_BENCH_ONE_DEVICE=1 (tests/test_gpu_collectives.py): all ranks share device 0 and exchange over gloo (RCCL refuses two ranks
+    # on one device) -- the N-rank data path of the trainers with the HIP kernels underneath, on a one-GPU box; not a timing mode
+    one_device = os.environ.get("VD_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1 or os.environ.get("VD_BENCH_FORCE_DIST") == "1":      # (the env: exercise the RCCL calls on a one-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+        if one_device:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
     if args.pool_per_class is None:
         args.pool_per_class = 1 if args.method == "mtt" else 93
 

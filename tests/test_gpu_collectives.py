@@ -63,6 +63,42 @@ def test_s2d_dc_mtt_issue_their_collectives_and_keep_the_loss():
     assert abs(b["grand_loss_last"] / a["grand_loss_last"] - 1) < 5e-2      # (dropout masks and atomics differ from run to run)
 
 
+def test_two_ranks_share_the_gpu_over_gloo_and_match_one_rank():
+    """The N = 2 data path with the HIP kernels underneath, on a one-GPU box: ``bench.py --gpus 2`` launched as the driver does
+    (torch.distributed.run, one process per rank) with ``VD_BENCH_ONE_DEVICE=1`` -- both ranks on device 0, exchange over gloo
+    (RCCL refuses two ranks on one device; the RCCL calls themselves run in the tests above).  Class blocks (4 + 3 classes),
+    batch split (every class's real batch halved, feature sums all-reduced) and the hybrid (3 + 3 whole classes, the seventh
+    class's batch split) must reproduce the one-rank loss; s2d all-reduces its hallucinator gradients."""
+    def two(extra, port):
+        e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VD_BENCH_ONE_DEVICE="1")
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                              "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2"] + COMMON + extra,
+                             cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    small = ["--classes", "7", "--pool-per-class", "70", "--eval-epochs", "1"]
+    one = _bench(small + ["--shard", "class"])
+    for k, (shard, per_step) in enumerate((("class", 1), ("batch", 2), ("hybrid", 2))):
+        got = two(small + ["--shard", shard], 29551 + k)
+        c = got["collectives"]
+        assert got["n_gpus"] == 2 and c["backend"] == "gloo" and not c["forced_on_one_rank"]
+        assert c["all_reduce"] == 3 * per_step and c["all_gather"] == 1, (shard, c)
+        assert abs(got["loss_last"] / one["loss_last"] - 1) < 1e-4, (shard, got["loss_last"], one["loss_last"])
+        assert "top1" in got["eval"]                                          # rank 0 trained a net on the GATHERED synthetic clips
+    s2d = ["--method", "s2d", "--classes", "4", "--pool-per-class", "70", "--eval-epochs", "0"]
+    a, b = _bench(s2d), two(s2d, 29555)
+    assert b["collectives"]["all_reduce"] == 3 * 2 and abs(b["loss_last"] / a["loss_last"] - 1) < 1e-4
+    # gradient matching: classes 2 + 1, every rank's loss all-reduced per step; trajectory matching: the student batch of 8 split
+    # 4 + 4, flat gradient and Hessian-vector product all-reduced per student step (tolerances: see the one-rank test above)
+    dc = ["--method", "dc", "--classes", "3", "--ipc", "1", "--frames", "8", "--size", "64", "--batch-real", "8", "--pool-per-class", "12"]
+    a, b = _bench(dc), two(dc, 29556)
+    assert b["n_gpus"] == 2 and b["collectives"]["all_reduce"] == 3 + 1 and abs(b["loss_last"] / a["loss_last"] - 1) < 5e-2
+    mtt = ["--method", "mtt", "--classes", "8", "--frames", "8", "--size", "64", "--syn-steps", "2", "--batch-syn", "8"]
+    a, b = _bench(mtt), two(mtt, 29557)
+    assert b["n_gpus"] == 2 and b["collectives"]["all_reduce"] == 4 * (2 * 2 + 2), b["collectives"]
+    assert abs(b["grand_loss_last"] / a["grand_loss_last"] - 1) < 5e-2
+
+
 def test_vd_comm_c_abi_one_rank_roundtrip():
     """vd_comm_* (include/vd_hip.h): a one-rank RCCL communicator created through the C ABI; all-reduce (in place and out of
     place) and all-gather on a side stream return the data unchanged, sizes / ranks / argument errors are reported."""

@@ -16,6 +16,8 @@ base = None
 for arg in (sys.argv[1:] or ["1", "2", "4", "8"]):
     N = int(arg)
     for shard in (("class",) if N == 1 else ("batch", "class") + (("hybrid",) if C % N else ())):
+        if os.environ.get("VD_PROXY_SHARDS") and shard not in os.environ["VD_PROXY_SHARDS"].split(","):
+            continue
         rank = 0
         lo, hi = distill.class_range(C, rank, N)
         nown = (C // N + 1) if shard == "hybrid" else hi - lo
@@ -30,6 +32,6 @@ for arg in (sys.argv[1:] or ["1", "2", "4", "8"]):
             tr.step(it, overlap=True)
         tr.sync(); torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
-        if N == 1:
+        if N == 1 or base is None:
             base = ms
         print("N=%d %-5s rank 0: %6.2f ms/step  -> %5.1f steps/s, %.2fx of N=1" % (N, shard, ms, 1e3 / ms, base / ms))
