@@ -91,6 +91,11 @@ int vd_abi_version(void);
  * ConvNet3D.features (networks.py:757, 768-770, 799) and their autograd backward w.r.t. the
  * input (distill_baseline.py:354, parameters frozen :336-337). */
 int vd_conv_mfma(const VdConvParams* params, void* stream);
+/* n <= 4 tile programs of the same shape class (prec, MTW, NT, MW; one N tile per wave; all plain or all accumulating / second-order)
+ * in ONE launch -- the four parity classes of an input-gradient pass (the backward of the same nn.Conv3d, distill_baseline.py:354),
+ * each of which alone starts too few workgroups to fill the chip at small batches.  Bitwise the results of n vd_conv_mfma calls.
+ * -2: the programs do not share an instantiation (the caller then launches them one by one). */
+int vd_conv_mfma_multi(const VdConvParams* const* params, int n, void* stream);
 
 /* The same tile program for the FIRST layer's forward over clips without gradient (x1 precisions,
  * one box type, NT=2 MW=2 MTW=4 S=32, pooled channels-last output, no arg-max): a persistent

@@ -216,6 +216,44 @@ def test_first_layer_kernel_variants_are_bitwise_equal(monkeypatch, geom, n):
             assert (a is None and b is None) or torch.equal(a, b), variant
 
 
+@pytest.mark.parametrize("geom,n,prec", [((8, 64, 64), 40, "f16x3"), ((8, 64, 64), 40, "f16"), ((16, 112, 112), 5, "f16x3"),
+                                         ((12, 96, 80), 9, "bf16x3"), ((8, 64, 64), 24, "bf16x3")])
+def test_parity_classes_in_one_launch_are_bitwise_equal(monkeypatch, geom, n, prec):
+    """The four parity-class programs of an input-gradient pass as ONE launch (engine.run_together -> vd_conv_mfma_multi;
+    programs of different tile shapes fall into separate launches) against four vd_conv_mfma launches: the same tile programs,
+    the same K order per output -- bitwise equal pixel gradients; likewise the accumulating second launches of the
+    second-order down sweep (train.GradMatchEngine.vjp: one atomic add per output on top of a plain store)."""
+    from video_distillation_amd import distill, engine, plan, train
+    geo = plan.NetGeometry(*geom)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(n, geom[0], 3, geom[1], geom[2], device="cuda", generator=g)
+    w = distill.fresh_network_weights(4, "cuda:0")
+    eng = engine.EmbedEngine(geo, prec=prec, chunk=4096, prec_bwd=prec)
+    eng.set_weights(w)
+    gf = torch.randn(n, eng.num_feat, device="cuda", generator=g)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VD_MULTI_LAUNCH", mode)
+        f, sv = eng.forward(x, keep=True)
+        outs[mode] = eng.backward(sv, gf).clone()
+    assert torch.equal(outs["0"], outs["1"])
+    assert float(outs["1"].abs().max()) > 0
+    if prec != "bf16x3" or geom[1] != 64:
+        return
+    K = 5
+    full = distill.fresh_full_network(4, K, "cuda:0")
+    labels = torch.arange(n, device="cuda") % K
+    gm = train.GradMatchEngine(geo, K, (2, 2, 2) if geom[1] > 64 else (2, 1, 1), "cuda:0")
+    v = [torch.randn(p.shape, device="cuda", generator=g) * 0.1 for p in full]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VD_MULTI_LAUNCH", mode)
+        _, _, _, state = gm.param_grads(x, labels, full)
+        res[mode] = gm.vjp(state, v, full).clone()
+    assert float(res["1"].abs().max()) > 0
+    assert float((res["0"] - res["1"]).norm() / res["1"].norm()) < 1e-6          # (weight-gradient atomics do not feed dx: expected 0)
+
+
 def test_odd_geometry_on_device():
     """12 x 96 x 80 clips on the GPU: odd conv extents (floor pooling), multi-type box plans, 7 clips per
     workgroup in the last layer's input-gradient passes."""

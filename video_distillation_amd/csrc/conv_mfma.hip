@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <stdint.h>
+#include <string.h>
 #include <utility>
 
 #include "../../include/vd_hip.h"
@@ -119,8 +120,10 @@ __device__ __forceinline__ void split16(float v, uint16_t& hi, uint16_t& lo) {
 // which halves the LDS read traffic per MFMA (the co-critical resource of the NTW = 1 layout).
 // BAL = 1 (with NTW = 2, MTW = 3): boxes of 7 M tiles on 2 x 2 waves -- every wave owns 3 M tiles x 2 N
 // tiles plus ONE N tile of the seventh M tile: 7 MFMAs per K step for 4 A-fragment reads (instead of 7).
+// (the kernel body is a device function so that two entry points share it: one program per launch -- p by value in the kernel
+//  arguments -- and up to VD_MULTI_MAX programs of the same instantiation in ONE launch, conv_mfma_multi_kernel below)
 template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0>
-__global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_kernel(const VdConvParams p, const int boxes_per_wg, const int total_boxes) {
+__device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int boxes_per_wg, const int total_boxes, const int block_id, const int nblocks) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     constexpr bool EXT = SO || MTW == 5;
     constexpr int TILES = MTW * NTW + BAL;              // accumulator tiles per wave
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
     // in that XCD's private L2 instead of being fetched once per XCD.  Bijective for any grid.
     int wgid;
     {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int nwg = nblocks, q = nwg >> 3, r = nwg & 7;
+        const int xcd = block_id & 7, k = block_id >> 3;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
     // Each workgroup walks `boxes_per_wg` consecutive boxes (launching one workgroup per box is
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
     auto finish = [&]() {
         if ((VD_DBG(p) & 8) && tid == 0 && p.stamps != nullptr) {
             stamp(7);
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)blockIdx.x * 8;
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)block_id * 8;
             for (int k = 0; k < 8; ++k) o[k] = t_stamp[k];
         }
     };
@@ -641,6 +644,30 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_ke
     }
     finish();
   }   // box loop
+}
+
+template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0>
+__global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_kernel(const VdConvParams p, const int boxes_per_wg, const int total_boxes) {
+    conv_mfma_body<PREC, MTW, SO, NTW, BAL>(p, boxes_per_wg, total_boxes, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several tile programs of ONE instantiation in one launch: the parity classes of an input-gradient pass (4 programs per level,
+// each too small to fill the chip at small batches: 64 workgroups for a 256-clip batch of 64x64x8 clips at the last level) go out
+// together; workgroup b runs box b - first[k] of program k.  The parameter blocks travel in the kernel arguments (scalar loads
+// with a wave-uniform index), results are bitwise those of the separate launches.
+#define VD_MULTI_MAX 4
+struct VdConvMulti {
+    VdConvParams p[VD_MULTI_MAX];
+    int first[VD_MULTI_MAX + 1];       // first[k] .. first[k+1]: the workgroups of program k
+    int total[VD_MULTI_MAX];           // boxes of program k
+};
+template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0>
+__global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_multi_kernel(const VdConvMulti m) {
+    const int b = (int)blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < VD_MULTI_MAX; ++i) k += (b >= m.first[i]) ? 1 : 0;
+    conv_mfma_body<PREC, MTW, SO, NTW, BAL>(m.p[k], 1, m.total[k], b - m.first[k], m.first[k + 1] - m.first[k]);
 }
 
 template <int PREC>
@@ -1813,4 +1840,82 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
         default: return -2;
     }
 #undef VD_DISPATCH
+}
+
+// ---- several programs of one instantiation in one launch ------------------------------------------------------------------
+template <int PREC, int MTW, bool SO = false>
+static int launch_multi(const VdConvParams* const* pp, int n, hipStream_t st) {
+    constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
+    VdConvMulti m;
+    ::memset(&m, 0, sizeof(m));
+    size_t lds = 0;
+    int64_t grid = 0;
+    int used = 0;
+    const int threads = 64 * pp[0]->NT * pp[0]->MW;
+    for (int k = 0; k < n; ++k) {
+        const VdConvParams& p = *pp[k];
+        const int groups = (p.nclips + p.ncl - 1) / p.ncl;
+        const int64_t total = (int64_t)groups * p.nbox;
+        if (total <= 0) continue;
+        if (total > 0x3fffffff) return -2;
+        const size_t l = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + p.MW * MTW * 4) * sizeof(int) + 16;
+        if (l > lds) lds = l;
+        m.p[used] = p;
+        m.first[used] = (int)grid;
+        m.total[used] = (int)total;
+        grid += (total + 7) & ~(int64_t)7;          // every program starts at a multiple of 8 workgroups: the XCD-contiguous box order
+        ++used;                                     // of the body reads the XCD off the low bits of its block index
+    }
+    if (used == 0) return 0;
+    if (lds > 160 * 1024 || grid > 0x7fffffff) return -3;
+    for (int k = used; k <= VD_MULTI_MAX; ++k) m.first[k] = (int)grid;
+    auto kern = conv_mfma_multi_kernel<PREC, MTW, SO>;
+    static VdDevCache cache;
+    int ncu = 0;
+    if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, m);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vd_conv_mfma_multi(const VdConvParams* const* pp, int n, void* stream) {
+    if (pp == nullptr || n < 1 || n > VD_MULTI_MAX) return -1;
+    for (int k = 0; k < n; ++k)
+        if (pp[k] == nullptr) return -1;
+    if (n == 1) return vd_conv_mfma(pp[0], stream);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const VdConvParams& a = *pp[0];
+    bool so = false;
+    for (int k = 0; k < n; ++k) {
+        const VdConvParams& p = *pp[k];
+        // one instantiation, one block shape; the plain layouts only (one N tile per wave, no first-level index, no low-plane output)
+        if (p.prec != a.prec || p.MTW != a.MTW || p.NT != a.NT || p.MW != a.MW || (p.NTW != 0 && p.NTW != 1)) return -2;
+        const int wgw = p.NT * p.MW;
+        if (wgw < 1 || wgw > 4 || p.lds_plane_bytes % 16 != 0 || p.ncl * 65536 <= 0 || p.S <= 0 || p.CC <= 0) return -2;
+        if (p.MTW < 8 && (p.gather_stride >> 6) > (int64_t)wgw * (p.MTW <= 4 ? 14 : 17)) return -2;
+        if (p.clip_index != nullptr || p.emit_lo != 0 || p.w_box_stride != 0 || p.MTW == 5) return -2;
+        so = so || p.atomic || p.select || p.src_split_cc > 0;
+    }
+    if (so) {       // accumulating / second-order programs: bf16 pairs only, as in vd_conv_mfma
+        if (a.prec != VD_PREC_BF16X3) return -2;
+        if (a.MTW == 2) return launch_multi<VD_PREC_BF16X3, 2, true>(pp, n, st);
+        if (a.MTW == 4) return launch_multi<VD_PREC_BF16X3, 4, true>(pp, n, st);
+        if (a.MTW == 7) return launch_multi<VD_PREC_BF16X3, 7, true>(pp, n, st);
+        if (a.MTW == 8) return launch_multi<VD_PREC_BF16X3, 8, true>(pp, n, st);
+        return -2;
+    }
+#define VD_DISPATCH_MULTI(PR)                                                \
+    case PR:                                                                 \
+        if (a.MTW == 2) return launch_multi<PR, 2>(pp, n, st);               \
+        if (a.MTW == 4) return launch_multi<PR, 4>(pp, n, st);               \
+        if (a.MTW == 7) return launch_multi<PR, 7>(pp, n, st);               \
+        if (a.MTW == 8) return launch_multi<PR, 8>(pp, n, st);               \
+        return -2;
+    switch (a.prec) {
+        VD_DISPATCH_MULTI(VD_PREC_BF16)
+        VD_DISPATCH_MULTI(VD_PREC_F16)
+        VD_DISPATCH_MULTI(VD_PREC_BF16X3)
+        VD_DISPATCH_MULTI(VD_PREC_F16X3)
+        default: return -2;
+    }
+#undef VD_DISPATCH_MULTI
 }

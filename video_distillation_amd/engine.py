@@ -110,7 +110,8 @@ class _DevPlan:
     def run(self, src: torch.Tensor, src_plane_slots: int, bias: Optional[torch.Tensor], dst_ptr: int,
             dst_plane_stride: int, argmax: Optional[torch.Tensor], nclips: int, out_scale: Optional[torch.Tensor] = None,
             wpk: Optional[torch.Tensor] = None, w_plane_elems: int = 0, clip_index: Optional[torch.Tensor] = None,
-            group: Optional[int] = None, set_clips: int = 0, emit_lo: bool = False) -> None:
+            group: Optional[int] = None, set_clips: int = 0, emit_lo: bool = False, launch: bool = True) -> None:
+        """``launch=False`` only fills the parameter block (``run_together`` then sends several programs out as one launch)."""
         p = self.params
         p.emit_lo = int(emit_lo)        # single-pass program, staged pooled epilogue: also write the low plane (dst_plane_stride behind)
         p.clip_index = 0 if clip_index is None else clip_index.data_ptr()
@@ -130,6 +131,8 @@ class _DevPlan:
         p.dst = dst_ptr; p.dst_plane_stride = dst_plane_stride
         p.argmax = 0 if argmax is None else argmax.data_ptr()
         p.nclips = nclips
+        if not launch:
+            return
         prof = LAUNCH_PROFILE
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -154,6 +157,47 @@ class _DevPlan:
         if prof is not None:
             e1.record()
             prof.append((self.plan.name, self.prec, 2.0 * self.plan.meta.get("macs_per_unit", 0) * nclips, e0, e1))
+
+
+def run_together(plans: Sequence["_DevPlan"], *args, **kwargs) -> None:
+    """``dp.run(*args, **kwargs)`` for every plan of ``plans`` (the parity classes of one input-gradient pass: same source,
+    same destination tensor, disjoint output positions), programs of the same instantiation in ONE launch (vd_conv_mfma_multi) --
+    a parity class alone starts too few workgroups to fill the chip at small batches.  Bitwise the separate launches' results
+    (tests/test_gpu_embed.py::test_parity_classes_in_one_launch_are_bitwise_equal); ``VD_MULTI_LAUNCH=0`` launches one by one."""
+    plans = list(plans)
+    if len(plans) < 2 or os.environ.get("VD_MULTI_LAUNCH", "1") != "1":
+        for dp in plans:
+            dp.run(*args, **kwargs)
+        return
+    groups: Dict[tuple, list] = {}
+    for dp in plans:
+        pl, p = dp.plan, dp.params
+        so = bool(p.atomic or p.select or p.src_split_cc > 0)
+        plain = pl.NTW in (0, 1) and pl.MTW in (2, 4, 7, 8) and not p.w_box_stride and not p.dbg and (not so or dp.prec == hip.PREC["bf16x3"])
+        key = (dp.prec, pl.MTW, pl.NT, pl.MW, so) if plain else ("single", id(dp))
+        groups.setdefault(key, []).append(dp)
+    for key, grp in groups.items():
+        for i in range(0, len(grp), 4):
+            part = grp[i:i + 4]
+            if len(part) == 1 or key[0] == "single":
+                for dp in part:
+                    dp.run(*args, **kwargs)
+                continue
+            for dp in part:
+                dp.run(*args, launch=False, **kwargs)
+            arr = (ctypes.POINTER(hip.VdConvParams) * len(part))(*[ctypes.pointer(dp.params) for dp in part])
+            prof = LAUNCH_PROFILE
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            dev = part[0].tables.device
+            hip.check(hip.lib().vd_conv_mfma_multi(arr, len(part), hip.stream_ptr(dev)),
+                      "vd_conv_mfma_multi(%s)" % ",".join(dp.plan.name for dp in part))
+            if prof is not None:
+                e1.record()
+                nclips = int(part[0].params.nclips)
+                name = os.path.commonprefix([dp.plan.name for dp in part]).rstrip("_") + "_x%d" % len(part)
+                prof.append((name, part[0].prec, sum(2.0 * dp.plan.meta.get("macs_per_unit", 0) * nclips for dp in part), e0, e1))
 
 
 def dither_groups(n: int, prec: str) -> int:
@@ -438,8 +482,7 @@ class EmbedEngine:
                     out = dx[c0:c0 + nb]
                 else:
                     out = self._buf("dx%d" % li, (nb, t, h, w, cin), torch.float32)
-                for dp in self.bwd[li]:
-                    dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb, out_scale=inv)
+                run_together(self.bwd[li], dy, nslots, None, out.data_ptr(), 0, None, nb, out_scale=inv)
                 grad = out
                 layout = 1
         return dx

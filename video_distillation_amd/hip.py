@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libvd_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("conv_mfma.hip", "aux_kernels.hip", "program.hip", "planner.cpp", "comm.cpp")]
 
 PREC = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
-EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv0_persistent", "vd_conv0_breg", "vd_pack_weights", "vd_round_operand", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_absmax_scale", "vd_dm_loss",
+EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv_mfma_multi", "vd_conv0_persistent", "vd_conv0_breg", "vd_pack_weights", "vd_round_operand", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_absmax_scale", "vd_dm_loss",
            "vd_group_sum", "vd_sgd_momentum", "vd_hallucinator_fwd", "vd_hallucinator_bwd", "vd_match_rows_fwd", "vd_match_rows_bwd", "vd_match_rows_fwd_multi", "vd_match_rows_bwd_multi", "vd_head_fwd", "vd_clip_minor_cl", "vd_clip_minor_pix", "vd_pack_dy", "vd_bias_grad", "vd_bias_grad_pooled", "vd_standardize", "vd_head_train_fwd", "vd_ce_loss", "vd_head_train_bwd", "vd_head_second_order", "vd_resplit_slots", "vd_program_load", "vd_program_pack_weights",
            "vd_program_run", "vd_program_info", "vd_program_free",
            "vd_sgd_momentum_wd", "vd_frames_normalize", "vd_replica_sum", "vd_pack_weights_dither", "vd_unpool_relu_bwd_packed", "vd_mfma_peak", "vd_program_build", "vd_program_build_dgrad", "vd_program_build_wgrad", "vd_program_run_wgrad", "vd_train_create", "vd_train_workspace_bytes", "vd_train_step", "vd_train_free", "vd_blob_free", "vd_embed_create", "vd_embed_create_ex", "vd_embed_argmax_bytes", "vd_embed_backward_workspace_bytes",

@@ -20,7 +20,7 @@ import torch
 
 from . import hip
 from . import plan as P
-from .engine import EmbedEngine, WgradOp, _DevPlan
+from .engine import EmbedEngine, WgradOp, _DevPlan, run_together
 
 
 def standardize(x: torch.Tensor) -> torch.Tensor:
@@ -162,8 +162,7 @@ class TrainEngine:
                     op.run_pooled(acts[li], False, act_plane[li], grad, am[li], layout, (To, Ho, Wo, pt), sc, g[2 * li], out_scale=inv)
             if li > 0 or dx is not None:
                 out = dx if li == 0 else eng._buf("dx%d" % li, (nb, t, h, w, cin), torch.float32)
-                for dp in eng.bwd[li]:
-                    dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb, out_scale=inv)
+                run_together(eng.bwd[li], dy, nslots, None, out.data_ptr(), 0, None, nb, out_scale=inv)
                 grad, layout = out, 1
 
     def loss_and_grads(self, x: torch.Tensor, labels: torch.Tensor, params: Sequence[torch.Tensor],
@@ -351,10 +350,8 @@ class GradMatchEngine(TrainEngine):
                                            OW, layout, hip.ptr(zb[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(None), st),
                       "vd_unpool_relu_bwd")
             out = dx if li == 0 else eng._buf("ax%d" % li, (nb, t, h, w, cin), torch.float32)
-            for dp in eng.bwd[li]:
-                dp.run(zb, nslots, None, out.data_ptr(), 0, None, nb)
-            for dp in self.bwdV[li]:
-                dp.run(dy, nslots, None, out.data_ptr(), 0, None, nb)
+            run_together(eng.bwd[li], zb, nslots, None, out.data_ptr(), 0, None, nb)
+            run_together(self.bwdV[li], dy, nslots, None, out.data_ptr(), 0, None, nb)       # (accumulates on top of the stores above)
             if hv:
                 # parameter side: z_l = conv(a_l, W_l) + b_l carries zbar_l, and g_{a_l} = convT(dz_l, W_l) carries gbar_l
                 op = self._wgrad(li, nb)
