@@ -323,8 +323,9 @@ def test_gm_trainer_class_lanes_match_serial(monkeypatch):
     syn0 = clips[[i for c in range(C) for i in (4 * c, 4 * c + 1)]].clone()
     init = lambda it: R.init_params(900 + it, 3, C)       # noqa: E731
 
-    def run(lanes):
+    def run(lanes, group=1):
         monkeypatch.setenv("VD_GM_LANES", str(lanes))
+        monkeypatch.setenv("VD_GM_GROUP", str(group))
         pool = distill.RealPool(clips, [4] * C, [4 * c for c in range(C)])
         tr = distill.GMTrainer(distill.HipGMOps("cuda:0", "ours"), pool, geo, C, ipc, batch_real=3, lr_img=1e-3, image_syn=syn0.clone(),
                                outer_loop=1, dropout_p=0.0, net_init=init)
@@ -334,7 +335,7 @@ def test_gm_trainer_class_lanes_match_serial(monkeypatch):
             loss = float(tr.step(0))
             out.append((loss, (tr.image_syn - syn0).cpu().double()))
         return out
-    serial, laned = run(1), run(3)
+    serial, laned = run(1), run(3) + run(3, group=4)      # (group 4: classes 0-3 and 4-5 share one real-batch forward per lane)
     noise = max(_rel(u, serial[0][1]) for _, u in serial[1:])
     err = max(_rel(u, serial[0][1]) for _, u in laned)
     print("GM lanes: loss serial %s lanes %s; update rel-l2 lanes-vs-serial %.2e (serial run-to-run %.2e)"
@@ -342,6 +343,33 @@ def test_gm_trainer_class_lanes_match_serial(monkeypatch):
     for l, _ in laned:
         assert abs(l - serial[0][0]) / serial[0][0] < 1e-4
     assert err < max(1e-3, 5 * noise)
+
+
+@pytest.mark.parametrize("prec_bwd", ["f16", "f16x3"])
+def test_grouped_real_batches_equal_separate_calls(prec_bwd):
+    """TrainEngine.loss_and_grads_grouped (one forward over the real batches of several classes, one backward per class on its slice
+    of the kept activations and arg-max bytes) against one loss_and_grads call per sub-batch: same losses, same eight gradients up
+    to the summation order of the weight-gradient atomics (2e-7 run to run)."""
+    from video_distillation_amd import plan, train
+    T, H, W, K, groups, per = 8, 64, 64, 6, 3, 5
+    g = torch.Generator().manual_seed(31)
+    x = R.standardise_batch(torch.randn(groups * per, T, 3, H, W, generator=g)).cuda()
+    labels = torch.arange(groups).repeat_interleave(per).cuda()
+    params = [p.cuda() for p in R.init_params(55, 3, K)]
+    te = train.TrainEngine(plan.NetGeometry(T, H, W), K, (2, 1, 1), "cuda:0", prec="f16x3", prec_bwd=prec_bwd)
+    mask = ((torch.rand(groups * per, te.C, te.Tp, generator=g) < 0.5).float() * 2.0).cuda()
+    losses, logits, gs = te.loss_and_grads_grouped(x, labels, params, groups, mask)
+    assert len(gs) == groups and tuple(logits.shape) == (groups * per, K)
+    for k in range(groups):
+        sl = slice(k * per, (k + 1) * per)
+        loss, lg, want = te.loss_and_grads(x[sl], labels[sl], params, mask[sl])
+        want = [t.clone() for t in want]
+        assert abs(float(losses[k]) - float(loss)) <= 1e-6 * abs(float(loss))
+        assert torch.equal(lg, logits[sl])
+        for a, b in zip(gs[k], want):
+            assert float((a - b).norm()) <= 2e-6 * float(b.norm()) + 1e-12, (k, tuple(a.shape))
+    with pytest.raises(ValueError):
+        te.loss_and_grads_grouped(x, labels, params, 4, mask)
 
 
 @pytest.mark.parametrize("B,K,use_mask", [(1, 4, False), (3, 5, True)])

@@ -745,6 +745,11 @@ class HipGMOps:
     def param_grads(self, net, x, labels, create_graph: bool, slot: int = 0):
         return net.param_grads(x, labels, create_graph=create_graph, slot=slot)[1]
 
+    def param_grads_grouped(self, net, x, labels, groups: int, slot: int = 0):
+        """Detached first-order parameter gradients of ``groups`` equal consecutive sub-batches (real batches of several classes):
+        one forward over all clips, one backward per sub-batch."""
+        return [[t.detach() for t in g] for _, g in net.param_grads_grouped(x, labels, groups, slot=slot)]
+
     def lane_streams(self, n: int):
         """Streams of the class lanes (GMTrainer): class terms are independent chains of ~150 small launches each, so several
         run concurrently, each on its own stream with its own engine slot."""
@@ -849,12 +854,28 @@ class GMTrainer:
                 totals = [torch.zeros((), device=dev) for _ in lanes]
                 for st in lanes:
                     st.wait_stream(main)
+                # VD_GM_GROUP = g > 1: the real batches of g consecutive classes of a lane share ONE forward (256 clips fill every
+                # level's launch; 64 leave the last level at a quarter of the chip), their backward passes run per class on slices
+                # of it.  Off by default: measured null (272.8 / 267.3 / 274.1 / 275.2 ms per step for g = 1 / 2 / 4 / 8 -- the
+                # other lanes already fill what a 64-clip launch leaves idle)
+                gsz = max(1, int(os.environ.get("VD_GM_GROUP", "1"))) if hasattr(ops, "param_grads_grouped") else 1
+                ncls = len(self.classes)
+                grouped = {}
                 for k, c in enumerate(self.classes):
-                    lane = k % nlanes
+                    lane = (k // gsz) % nlanes
                     with torch.cuda.stream(lanes[lane]):
-                        real = self.pool.clips[idx_t[k]]
-                        lab_r = torch.full((real.shape[0],), c, dtype=torch.int64, device=dev)
-                        gw_real = [t.detach() for t in ops.param_grads(net, real, lab_r, False, slot=lane)]
+                        if gsz > 1 and k % gsz == 0:
+                            k1 = min(k + gsz, ncls)
+                            real_all = self.pool.clips[idx_t[k:k1].reshape(-1)]
+                            # (labels built ON the device: an upload here would be a blocking copy on a busy lane stream)
+                            lab_all = torch.cat([torch.full((idx_t.shape[1],), cc, dtype=torch.int64, device=dev) for cc in self.classes[k:k1]])
+                            grouped = dict(zip(range(k, k1), ops.param_grads_grouped(net, real_all, lab_all, k1 - k, slot=lane)))
+                        if gsz > 1:
+                            gw_real = grouped.pop(k)
+                        else:
+                            real = self.pool.clips[idx_t[k]]
+                            lab_r = torch.full((real.shape[0],), c, dtype=torch.int64, device=dev)
+                            gw_real = [t.detach() for t in ops.param_grads(net, real, lab_r, False, slot=lane)]
                         lab_s = torch.full((self.ipc,), c, dtype=torch.int64, device=dev)
                         syn = self.image_syn[k * self.ipc:(k + 1) * self.ipc].detach().clone().requires_grad_(True)
                         gw_syn = ops.param_grads(net, syn, lab_s, True, slot=lane)

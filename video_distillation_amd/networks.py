@@ -497,6 +497,18 @@ class ConvNet3D(nn.Module):
         loss, _, g = te.loss_and_grads(x, labels, list(self.parameters()), mask)
         return loss, [t.clone() for t in g]
 
+    def param_grads_grouped(self, x, labels, groups: int, mask=None, slot: int = 0):
+        """``param_grads(create_graph=False)`` of ``groups`` equal consecutive sub-batches of x (the real batches of several classes
+        of one gradient-matching step) with one forward over all of them (train.TrainEngine.loss_and_grads_grouped).
+        Returns [(loss, [8 gradients])] per sub-batch."""
+        if not (self._hip_ok and x.is_cuda):
+            raise RuntimeError("ConvNet3D.param_grads_grouped: HIP tensors and the ConvNet3D of get_network only (no CPU path)")
+        te = self._train_engine(x, slot, _PRECISION["match_real_bwd"])
+        if mask is None:
+            mask = self._dropout_mask(x, te)
+        losses, _, gs = te.loss_and_grads_grouped(x, labels, list(self.parameters()), int(groups), mask)
+        return [(losses[k], gs[k]) for k in range(int(groups))]
+
     def hip_train_step(self, x, labels, optimizer):
         """forward + CrossEntropyLoss + backward + ``optimizer.step()`` for one batch, on the HIP
         path.  ``x`` is the (already standardised) batch (B,T,3,H,W).  Momentum buffers live in

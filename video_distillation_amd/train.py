@@ -119,7 +119,7 @@ class TrainEngine:
         return g_feat
 
     def feat_backward(self, x: torch.Tensor, nb: int, am, g_feat: torch.Tensor, g: Optional[Sequence[torch.Tensor]],
-                      dx: Optional[torch.Tensor] = None, keep_dense: bool = False) -> None:
+                      dx: Optional[torch.Tensor] = None, keep_dense: bool = False, acts_override=None) -> None:
         """Backward of the three conv levels for the feature gradient ``g_feat`` (nb, num_feat): per layer, last to
         first, un-pool + ReLU backward, bias gradient, weight gradient (accumulated into g[0..5], zeroed by the caller;
         skipped when ``g`` is None) and the input-gradient passes (down to the pixels, into ``dx``, when given).  The
@@ -127,7 +127,8 @@ class TrainEngine:
         ``keep_dense``: a second-order sweep will read the first layer's dense gradient slots (workspace ``dy0``); without
         it and without ``dx`` they are never materialised (``WgradOp.run_pooled``)."""
         eng, L, st = self.eng, hip.lib(), hip.stream_ptr(self.device)
-        acts, act_plane = self._acts(nb)
+        # (``acts_override`` = (activation views, plane strides): the clips are a slice of a larger forward, loss_and_grads_grouped)
+        acts, act_plane = acts_override if acts_override is not None else self._acts(nb)
         grad, layout = g_feat, 0
         scaled = eng.prec_bwd in (hip.PREC["f16"], hip.PREC["f16x3"])
         for li in (2, 1, 0):
@@ -194,6 +195,48 @@ class TrainEngine:
             state.update(nb=nb, am=am, dropped=hs["dropped"], logits=logits, dlog=dlog, amt=hs["amt"], mask=hs["mask"],
                          wl=hs["wl"], act_plane=act_plane, x=x)
         return loss_c.mean(), logits, g
+
+    def loss_and_grads_grouped(self, x: torch.Tensor, labels: torch.Tensor, params: Sequence[torch.Tensor], groups: int,
+                               mask: Optional[torch.Tensor] = None):
+        """``loss_and_grads`` of ``groups`` equal consecutive sub-batches of x (the real batches of several classes of a
+        gradient-matching step: same network, independent mean-CE losses) with ONE forward over all clips -- a 64-clip launch
+        leaves a quarter of the chip idle in the last level and a tail in the others -- and one backward per sub-batch on its slice
+        of the kept activations / arg-max bytes.  Returns (losses (groups,), logits, [8 gradients] per sub-batch); equal to
+        per-sub-batch calls (tests/test_gpu_train.py::test_grouped_real_batches_equal_separate_calls)."""
+        eng, L, st = self.eng, hip.lib(), hip.stream_ptr(self.device)
+        B = int(x.shape[0])
+        if groups < 1 or B % groups != 0:
+            raise ValueError("loss_and_grads_grouped: %d clips do not split into %d equal sub-batches" % (B, groups))
+        per = B // groups
+        x = x.detach().to(torch.float32).contiguous()
+        labels = labels.to(self.device, torch.int64).contiguous()
+        eng.set_weights(params[:6])
+        for li in (1, 2):
+            for dp in eng.bwd[li]:
+                dp.pack(eng._weights[2 * li])
+        feats, nb, am = self._forward(x, params)
+        hs = self.head_forward(feats, mask, params[6], params[7])
+        logits = hs["logits"]
+        loss_c = torch.empty(B, dtype=torch.float32, device=self.device)
+        dlog = torch.empty((B, self.K), dtype=torch.float32, device=self.device)
+        hip.check(L.vd_ce_loss(hip.ptr(logits), hip.ptr(labels), B, self.K, hip.ptr(loss_c), hip.ptr(dlog), st), "vd_ce_loss")
+        if groups > 1:
+            dlog.mul_(float(groups))            # vd_ce_loss scales by 1 / B: every sub-batch's loss is a mean over ITS clips
+        acts, act_plane = self._acts(nb)
+        per1, per2, nf = act_plane[1] // nb, act_plane[2] // nb, eng.num_feat
+        outs = []
+        for k in range(groups):
+            sl = slice(k * per, (k + 1) * per)
+            self.gflat.zero_()
+            g = self.grads()
+            hs_k = dict(hs, amt=hs["amt"][sl], dropped=hs["dropped"][sl], mask=None if hs["mask"] is None else hs["mask"][sl])
+            g_feat = self.head_backward(hs_k, dlog[sl], g[6], g[7])
+            am_k = (am[0][k * per * per1 * 8:(k + 1) * per * per1 * 8], am[1][k * per * per2 * 8:(k + 1) * per * per2 * 8],
+                    am[2][k * per * nf:(k + 1) * per * nf])
+            acts_k = [None, acts[1][:, k * per * per1:(k + 1) * per * per1], acts[2][:, k * per * per2:(k + 1) * per * per2]]
+            self.feat_backward(x[sl], per, am_k, g_feat, g, acts_override=(acts_k, act_plane))
+            outs.append([t.clone() for t in g])
+        return loss_c.view(groups, per).mean(1), logits, outs
 
     # ------------------------------------------------------------------------------------
     def sgd_step(self, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], bufs: Sequence[Optional[torch.Tensor]],
