@@ -123,10 +123,17 @@ def test_second_order_matches_fused_engine_and_fp64():
     want = torch.autograd.grad(sum((a * b.double()).sum() for a, b in zip(gw64, v)), [x64] + p64)
     errs = [_rel(a, b) for a, b in zip(got, want)]
     print("second-order errs (x, 8 params)", ["%.1e" % e for e in errs])
-    assert max(errs) < 5e-3 and sorted(errs)[4] < 2e-4
-    # fused engine
+    # fused engine (the same forward: its recorded arg-max bytes say whether a pooling decision differs from the fp64 oracle's)
     te = net._gm_engine(x.cuda())
     _, _, _, state = te.param_grads(x.cuda(), y.cuda(), [p.detach() for p in params], None)
+    from tests.argmax_tools import compare_decisions
+    dec = compare_decisions(x, [p.detach() for p in params], state["am"])
+    flips = sum(d["mismatch"] for d in dec)
+    print("pooling decisions differing from the fp64 oracle:", [d["mismatch"] for d in dec], "worst margin", max(d["worst_margin"] for d in dec))
+    assert all(d["not_near_tie"] == 0 for d in dec)      # only near-ties of the oracle itself may resolve differently
+    # no differing decision: 8e-6 measured; one flipped window of two 64x64x8 clips moves every adjoint by up to 1.3e-2 (seen when a
+    # change of the fp32 summation order in the first-level kernel resolved a 1e-7 near-tie the other way)
+    assert max(errs) < (2e-4 if flips == 0 else 5e-2)
     dx, hv = te.vjp(state, [t.cuda() for t in v], [p.detach() for p in params], param_adjoint=True)
     assert _rel(got[0], dx) < 1e-4
     assert max(_rel(a, b) for a, b in zip(got[1:], hv)) < 1e-4

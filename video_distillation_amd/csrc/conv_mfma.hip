@@ -25,7 +25,9 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <utility>
 
 #include "../../include/vd_hip.h"
@@ -114,25 +116,41 @@ __device__ __forceinline__ void split16(float v, uint16_t& hi, uint16_t& lo) {
 #ifndef VD_OCC_SMALL
 #define VD_OCC_SMALL 2
 #endif
+// SQ (hi+lo formats): PLANE-SEQUENTIAL K loop -- only ONE operand plane of a channel chunk's patch is resident at a time: the chunk
+// runs as two passes, (A_hi x B_lo + A_hi x B_hi) over the high plane, then A_lo x B_hi over the low plane staged into the same
+// LDS, so the program needs the LDS of a single-pass one and TWO workgroups share a CU where one did.  Same products; the
+// low-plane products of a chunk are added after its high-plane ones instead of interleaved with them (fp32 summation order).
+// It pays where a box has ONE chunk and a patch that is expensive to stage -- the first level (2 x 55 KB of dword-aligned kw-slots
+// per box: 5.44 -> 4.81 ms per 512 clips, same box) -- and costs where the chunks are many and short (16 chunks of the last
+// level: twice the chunk boundaries, 0.66 -> 0.77 ms; level 1: 8.29 -> 8.40), so only the first-level programs are dispatched to it.
 #define VD_OCC(PREC, MTW, NTW, BAL) \
     ((((MTW) * (NTW) + (BAL)) <= 4 && ((PREC) == VD_PREC_BF16 || (PREC) == VD_PREC_F16)) ? VD_OCC_SMALL : 2)
 // NTW = N tiles (of 32 output channels) per wave: with 2, an A fragment read from LDS feeds two MFMAs,
 // which halves the LDS read traffic per MFMA (the co-critical resource of the NTW = 1 layout).
 // BAL = 1 (with NTW = 2, MTW = 3): boxes of 7 M tiles on 2 x 2 waves -- every wave owns 3 M tiles x 2 N
 // tiles plus ONE N tile of the seventh M tile: 7 MFMAs per K step for 4 A-fragment reads (instead of 7).
+template <int I> struct VdIC { static constexpr int v = I; };
+template <class F, int... Is>
+__device__ __forceinline__ void vd_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(VdIC<Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void vd_static_for(F&& f) { vd_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // (the kernel body is a device function so that two entry points share it: one program per launch -- p by value in the kernel
 //  arguments -- and up to VD_MULTI_MAX programs of the same instantiation in ONE launch, conv_mfma_multi_kernel below)
-template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0>
+template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0, bool SQ = false>
 __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int boxes_per_wg, const int total_boxes, const int block_id, const int nblocks) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     constexpr bool EXT = SO || MTW == 5;
+    constexpr bool SEQ = X3 && SQ;                      // hi+lo formats: one operand plane resident at a time (see SQ above)
+    constexpr int LPL = (X3 && !SEQ) ? 2 : 1;           // patch planes resident in LDS
     constexpr int TILES = MTW * NTW + BAL;              // accumulator tiles per wave
     constexpr int MA = MTW + BAL;                       // M tiles (A fragments per K step) a wave touches
     static_assert(BAL == 0 || (NTW == 2 && !X3 && !SO), "balanced layout: single-pass formats, two N tiles per wave");
     constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
     constexpr int H1 = MTW - H0;
     constexpr int AD = 1;                               // x1: A-fragment prefetch distance (K-steps)
-    constexpr int DB = X3 ? (TILES <= 2 ? 5 : 2) : VD_DB_X1;   // B-fragment prefetch distance (K steps); x1: (DB+1) % (AD+1) == 0
+    constexpr int DB = X3 ? (TILES <= 2 ? 5 : ((SEQ && NTW == 1) ? 3 : 2)) : VD_DB_X1;   // B-fragment prefetch distance (K steps); x1: (DB+1) % (AD+1) == 0
+    //   (plane-sequential: the low-plane pass has one MFMA per tile and step instead of three, so its steps are short)
     static_assert(X3 || (DB + 1) % (AD + 1) == 0, "ring sizes must divide the unroll factor");
     constexpr int LU = (TILES <= 4) ? 14 : 17;   // DMA groups per wave (4 waves x LU x 64 slots >= the plan's patch)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -173,7 +191,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
     const int ngroups = (int)(p.gather_stride >> 6);   // 64-slot DMA groups per patch
     const int nwaves = nthreads >> 6;
     const int plane_bytes = p.lds_plane_bytes;
-    int* lds_tap = reinterpret_cast<int*>(smem + (X3 ? 2 : 1) * plane_bytes);
+    int* lds_tap = reinterpret_cast<int*>(smem + LPL * plane_bytes);
     int* lds_otab = lds_tap + 2 * p.S;
     const bool one_type = (p.ntypes == 1);
     const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
@@ -255,6 +273,10 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
         for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
 
     for (int cc = 0; cc < p.CC; ++cc) {
+      // (plane-sequential hi+lo: the chunk body runs twice, ph = 0 with the high plane of the patch resident, ph = 1 with the low
+      //  plane; ph is a compile-time constant of each copy)
+      vd_static_for<SEQ ? 2 : 1>([&](auto PHC) __attribute__((always_inline)) {
+        constexpr int ph = decltype(PHC)::v;
         __syncthreads();  // previous chunk's fragment reads are done
         // ---- stage the patch of this channel chunk: LU independent 16-byte loads in flight ----
         // first B fragments of this chunk: issued before the patch DMA so both latencies overlap
@@ -269,7 +291,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 bh[j] = wp[(int64_t)sc * wstep + j * 64];
-                if constexpr (X3) bl[j] = wp[(int64_t)sc * wstep + j * 64 + w_lo];
+                if constexpr (X3 && (!SEQ || ph == 0)) bl[j] = wp[(int64_t)sc * wstep + j * 64 + w_lo];
             }
         };
         uint4 bqh[DB + 1][NTW], bql[DB + 1][NTW];
@@ -292,7 +314,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 csrc = src + (int64_t)clip0 * p.src_clip_stride4 + p.src_split_off4 +
                        (int64_t)(cc - p.src_split_cc) * p.src_chunk_stride4;
         }
-        if (cc == 0) stamp(1);
+        if (cc == 0 && ph == 0) stamp(1);
         // LDS-DMA: each wave-instruction moves 64 slots (1 KiB) straight into LDS; the per-lane
         // SOURCE address comes from the gather table, the destination is lane-linear.  Zero fill
         // (conv padding, pitch padding, clips beyond the batch) reads a 16-byte zero slot.
@@ -305,11 +327,11 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 asm volatile("" : "+s"(gi));   // keep the per-group scalars (bound test, LDS address) out of SGPR-hungry hoisting
                 if (gi < ngroups) {     // wave-uniform
                     const bool ok = goff[HOIST ? u : 0] != 0xFFFFFFFFu;
-                    const uint32_t* gp = ok ? csrc + goff[HOIST ? u : 0] : zslot;
+                    const uint32_t* gp = ok ? csrc + goff[HOIST ? u : 0] + (ph ? p.src_plane_stride4 : (int64_t)0) : zslot;
                     char* dst = smem + gi * 1024;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                    if constexpr (X3) {
+                    if constexpr (X3 && !SEQ) {
                         const uint32_t* gl = ok ? csrc + goff[HOIST ? u : 0] + p.src_plane_stride4 : zslot;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gl,
                                                          (__attribute__((address_space(3))) void*)(dst + plane_bytes), 16, 0, 0);
@@ -338,11 +360,11 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                     asm volatile("" : "+s"(gi));
                     if (gi < ngroups) {
                         const bool ok = off[u] != 0xFFFFFFFFu;
-                        const uint32_t* gp = ok ? csrc + off[u] : zslot;
+                        const uint32_t* gp = ok ? csrc + off[u] + (ph ? p.src_plane_stride4 : (int64_t)0) : zslot;
                         char* dst = smem + gi * 1024;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                        if constexpr (X3) {
+                        if constexpr (X3 && !SEQ) {
                             const uint32_t* gl = ok ? csrc + off[u] + p.src_plane_stride4 : zslot;
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gl,
                                                              (__attribute__((address_space(3))) void*)(dst + plane_bytes), 16, 0, 0);
@@ -352,11 +374,11 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 }
             }
         }
-        if (cc == 0) stamp(2);
+        if (cc == 0 && ph == 0) stamp(2);
         __syncthreads();
-        if (cc == 0) stamp(3);
+        if (cc == 0 && ph == 0) stamp(3);
         // ---- K loop over tap pairs ---------------------------------------------------------
-        if (VD_DBG(p) & 2) continue;
+        if (VD_DBG(p) & 2) return;
         // B fragments are fetched DB steps ahead (counted vmcnt), A fragments one full step ahead
         // (x1: two register sets) or half a step ahead (x3: registers are short).
         if constexpr (!X3) {
@@ -417,6 +439,49 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                     k_step(u, s + u);
                 }
             }
+        } else if constexpr (SEQ) {
+            // hi+lo formats, one plane resident: the fragment a tile's MFMAs have just consumed is refilled at once with the
+            // next K step's (same idea as below).  Pass 0: A_hi x B_lo and A_hi x B_hi, pass 1: A_lo x B_hi.
+            {
+                constexpr int PH = ph;
+                int tap_next = lds_tap[2 * ((1 < S) ? 1 : 0) + half];
+                uint4 Ax[MTW];
+                {
+                    const int tap0 = lds_tap[half];
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) Ax[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap0);
+                }
+                for (int s = 0; s < S; s += DB + 1) {
+#pragma unroll
+                    for (int u = 0; u <= DB; ++u) {
+                        if (s + u >= S) break;
+                        load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
+                        uint4 bh[NTW], bl[NTW];
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j) { bh[j] = bqh[u][j]; bl[j] = bql[u][j]; }
+                        const int sn2 = (s + u + 2 < S) ? s + u + 2 : S - 1;
+                        const int tap_next2 = lds_tap[2 * sn2 + half];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < MTW; ++i) {
+                            if (NTW == 2 && BAL == 0 && i == MTW - 1 && short_row) continue;
+#pragma unroll
+                            for (int j = 0; j < NTW; ++j) {
+                                if constexpr (PH == 0) {
+                                    acc[j * MTW + i] = mfma16<PREC>(Ax[i], bl[j], acc[j * MTW + i]);
+                                    acc[j * MTW + i] = mfma16<PREC>(Ax[i], bh[j], acc[j * MTW + i]);
+                                } else {
+                                    acc[j * MTW + i] = mfma16<PREC>(Ax[i], bh[j], acc[j * MTW + i]);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            Ax[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        tap_next = tap_next2;
+                    }
+                }
+            }
         } else {
             // hi+lo formats: one register set of A fragments (hi and lo plane); the pair a tile's three MFMAs have just
             // consumed is refilled at once with the next K step's, so a read has the other tiles' MFMAs (almost a whole step)
@@ -460,6 +525,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 }
             }
         }
+      });
     }
 
     // ---- epilogue ---------------------------------------------------------------------
@@ -646,9 +712,9 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
   }   // box loop
 }
 
-template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0>
+template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0, bool SQ = false>
 __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_kernel(const VdConvParams p, const int boxes_per_wg, const int total_boxes) {
-    conv_mfma_body<PREC, MTW, SO, NTW, BAL>(p, boxes_per_wg, total_boxes, (int)blockIdx.x, (int)gridDim.x);
+    conv_mfma_body<PREC, MTW, SO, NTW, BAL, SQ>(p, boxes_per_wg, total_boxes, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Several tile programs of ONE instantiation in one launch: the parity classes of an input-gradient pass (4 programs per level,
@@ -984,11 +1050,6 @@ __global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p
 // LDS accesses of the overlapped epilogue below go through inline assembly: with an LDS-DMA in flight the compiler's wait
 // insertion puts s_waitcnt vmcnt(0) in front of every LDS access it can see (it cannot tell the staging tile from the DMA's
 // destination), which would serialise the epilogue behind the landing of the next patch.
-template <int I> struct VdIC { static constexpr int v = I; };
-template <class F, int... Is>
-__device__ __forceinline__ void vd_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(VdIC<Is>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void vd_static_for(F&& f) { vd_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int OFS>
 __device__ __forceinline__ void vd_lds_write_b16(uint32_t addr, uint32_t v) {       // (constant offsets ride in the instruction:
@@ -1747,16 +1808,16 @@ extern "C" int vd_conv0_persistent(const VdConvParams* pp, void* stream) {
     return -2;
 }
 
-template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0>
+template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0, bool SQ = false>
 static int launch(const VdConvParams& p, hipStream_t st) {
     constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
     const int groups = (p.nclips + p.ncl - 1) / p.ncl;
     const int64_t total = (int64_t)groups * p.nbox;
     if (total <= 0) return 0;
-    size_t lds = (size_t)(X3 ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + (p.MW * MTW + BAL) * 4) * sizeof(int) + 16;
+    size_t lds = (size_t)((X3 && !SQ) ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + (p.MW * MTW + BAL) * 4) * sizeof(int) + 16;
     if (lds > 160 * 1024) return -3;
     if ((p.dbg & 0x100) && lds < 100 * 1024) lds = 100 * 1024;   // diagnostic (tools/stamps.py --alone): one workgroup per CU
-    auto kern = conv_mfma_kernel<PREC, MTW, SO, NTW, BAL>;
+    auto kern = conv_mfma_kernel<PREC, MTW, SO, NTW, BAL, SQ>;
     if (p.NT % NTW != 0) return -2;
     const int ncols = p.NT / NTW;
     static VdDevCache cache;
@@ -1777,6 +1838,11 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     const int64_t grid = (total + per - 1) / per;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * ncols * p.MW), lds, st, p, per, (int)total);
     return (int)hipGetLastError();
+}
+
+static bool os_env_seq() {       // VD_X3_SEQ=0: both planes resident everywhere (A/B measurements)
+    static const bool on = [] { const char* e = getenv("VD_X3_SEQ"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
@@ -1823,6 +1889,11 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
         if (p.MTW == 7) return launch<VD_PREC_BF16X3, 7, true>(p, st);
         if (p.MTW == 8) return launch<VD_PREC_BF16X3, 8, true>(p, st);
         return -2;
+    }
+    // first-level hi+lo programs (one channel chunk per box, 4 M tiles per wave): the plane-sequential K loop (SQ above)
+    if (p.MTW == 4 && p.CC == 1 && p.ncl == 1 && os_env_seq()) {
+        if (p.prec == VD_PREC_BF16X3) return launch<VD_PREC_BF16X3, 4, false, 1, 0, true>(p, st);
+        if (p.prec == VD_PREC_F16X3) return launch<VD_PREC_F16X3, 4, false, 1, 0, true>(p, st);
     }
 #define VD_DISPATCH(PR)                                                   \
     case PR:                                                              \

@@ -219,9 +219,10 @@ class TrainEngine:
         logits = hs["logits"]
         loss_c = torch.empty(B, dtype=torch.float32, device=self.device)
         dlog = torch.empty((B, self.K), dtype=torch.float32, device=self.device)
-        hip.check(L.vd_ce_loss(hip.ptr(logits), hip.ptr(labels), B, self.K, hip.ptr(loss_c), hip.ptr(dlog), st), "vd_ce_loss")
-        if groups > 1:
-            dlog.mul_(float(groups))            # vd_ce_loss scales by 1 / B: every sub-batch's loss is a mean over ITS clips
+        for k in range(groups):                 # (per sub-batch: vd_ce_loss scales the logit gradient by 1 / its batch size -- exactly what a
+            sl = slice(k * per, (k + 1) * per)  #  separate call does; rescaling a 1 / B gradient would differ in the last bit, which the
+            hip.check(L.vd_ce_loss(hip.ptr(logits[sl]), hip.ptr(labels[sl]), per, self.K, hip.ptr(loss_c[sl]),   # f16 passes' power-of-two
+                                   hip.ptr(dlog[sl]), st), "vd_ce_loss")                                         #  scaling can amplify)
         acts, act_plane = self._acts(nb)
         per1, per2, nf = act_plane[1] // nb, act_plane[2] // nb, eng.num_feat
         outs = []
