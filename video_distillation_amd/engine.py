@@ -269,7 +269,20 @@ class EmbedEngine:
             if hip.is_x3(self.prec):
                 raise ValueError("last_hilo is an option of the single-pass formats (%s already carries hi+lo planes)" % prec)
             import dataclasses
-            self.fwd2x = _DevPlan(dataclasses.replace(net["fwd"][2], name="fwd2_hilo"), self.device, hip.PREC[prec + "x3"])
+            pl2 = net["fwd"][2]
+            if os.environ.get("VD_L2X_PLAN", "small") == "small" and pl2.NTW == 2 and pl2.MTW == 4 and pl2.ncl % 2 == 0:
+                # The hi+lo program keeps two operand planes of its patch in LDS: with the single-pass program's boxes (two clips, 4 M
+                # tiles x 2 N tiles per wave, 2 x 58 KB) only one workgroup fits a CU.  One clip per box (4 M tiles x 1 N tile per
+                # wave, 2 x 29 KB) lets two share it: 0.74 -> 0.68 ms per 512 clips, 4.53 -> 4.27 ms per launch in the bench (same
+                # box); same K order per output, bitwise the same features.
+                d2 = self.dims[2]
+                try:
+                    alt = P.plan_forward_cl("fwd2", d2[0], d2[1], d2[2], d2[3], d2[4], d2[11], feat_out=True, ntw=1, mtw_options=(4,))
+                    if alt.rows_total <= pl2.rows_total and 2 * alt.gather_table().shape[1] * 16 <= 72 * 1024:
+                        pl2 = alt
+                except ValueError:
+                    pass
+            self.fwd2x = _DevPlan(dataclasses.replace(pl2, name="fwd2_hilo"), self.device, hip.PREC[prec + "x3"])
         # operand precision of the input-gradient passes (default: same as the forward)
         self.prec_bwd = hip.PREC[prec_bwd] if prec_bwd else self.prec
         self.planes_bwd = 2 if hip.is_x3(self.prec_bwd) else 1
