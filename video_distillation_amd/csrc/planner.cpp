@@ -801,6 +801,15 @@ std::vector<uint8_t> export_program(const Plan& pl, int persist) {
     const int64_t sizes[7] = {(int64_t)desc.size(), (int64_t)tables.size(), (int64_t)boxes.size(), (int64_t)gt.size(),
                               (int64_t)pl.widx.size(), (int64_t)pl.col_off.size(), persist};
     memcpy(&h[28], sizes, sizeof(sizes));
+    {   // words 35, 36: planes / rows per plane of the source clip when the patch can be built from aligned 16-byte row loads
+        // (plan.ConvPlan.row_source: first-level programs over pixel rows, 2 x 2 waves of 4 M tiles, 8 output columns per box)
+        bool ok = pl.w_step4 == 1 && pl.CC == 1 && pl.ncl == 1 && pl.NTW <= 1 && pl.types.size() == 1 && pl.NT == 2 && pl.MW == 2 &&
+                  pl.MTW == 4 && pl.S == 32 && pl.types[0].pw == 8 && pl.row_pitch4 % 4 == 0 && 2 * pl.types[0].pf * pl.types[0].ph <= 768;
+        for (int bi = 0; ok && bi < nbox; ++bi)
+            ok = pl.boxes[bi][3] % 4 == 0 && pl.boxes[bi][3] >= 0 && std::llabs(pl.boxes[bi][1]) < 32768 && std::llabs(pl.boxes[bi][2]) < 32768;
+        h[35] = ok ? pl.F : 0;
+        h[36] = ok ? pl.H : 0;
+    }
     std::vector<uint8_t> blob(sizeof(h));
     memcpy(blob.data(), h, sizeof(h));
     auto append = [&](const std::vector<int32_t>& v) {

@@ -85,12 +85,9 @@ class _DevPlan:
 
         # the aligned-load variant: pixel-row source (w_step4 == 1), 8 output columns per box starting at a multiple of 4 dwords,
         # every patch row's 12 dwords inside its 16-byte-aligned pixel row, three row halves per lane
-        t0 = plan.types[0]
-        self.breg3_ok = bool(self.breg_ok and plan.w_step4 == 1 and t0.pw == 8 and plan.row_pitch4 % 4 == 0
-                             and all(int(b[3]) % 4 == 0 and int(b[3]) >= 0 for b in plan.boxes) and 2 * t0.pf * t0.ph <= 768
-                             and abs(int(plan.boxes[:, 1].min())) < 32768 and abs(int(plan.boxes[:, 2].min())) < 32768)
+        self.breg3_ok = bool(self.breg_ok and plan.row_source()[1] > 0)
         if self.breg3_ok:
-            p.src_planes, p.src_rows = plan.F, plan.H
+            p.src_planes, p.src_rows = plan.row_source()
 
     def pack(self, w: torch.Tensor) -> None:
         assert w.dtype == torch.float32 and w.is_contiguous()

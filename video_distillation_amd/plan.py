@@ -135,6 +135,18 @@ class ConvPlan:
             out[bi, :idx.size] = np.where(ok, rel | (ci << 24), -1)
         return out.astype(np.int32)
 
+    def row_source(self) -> Tuple[int, int]:
+        """(planes, rows per plane) of the source clip when this is a first-level program over 16-bit pixel rows whose patch
+        can be built from ALIGNED 16-byte row loads (csrc/conv_mfma.hip: conv0_breg3 / conv0_breg4): 2 x 2 waves of 4 M tiles,
+        32 K steps, one box type of 8 output columns starting at a multiple of 4 dwords, at most 768 patch-row halves,
+        box origins that fit 16 bits.  (0, 0) otherwise.  Exported in the program header (words 35, 36)."""
+        t0 = self.types[0]
+        ok = (self.w_step4 == 1 and self.CC == 1 and self.ncl == 1 and self.NTW in (0, 1) and len(self.types) == 1
+              and (self.NT, self.MW, self.MTW, self.S) == (2, 2, 4, 32) and t0.pw == 8 and self.row_pitch4 % 4 == 0
+              and all(int(b[3]) % 4 == 0 and int(b[3]) >= 0 for b in self.boxes) and 2 * t0.pf * t0.ph <= 768
+              and all(abs(int(b[1])) < 32768 and abs(int(b[2])) < 32768 for b in self.boxes))
+        return (int(self.F), int(self.H)) if ok else (0, 0)
+
     def device_boxes(self) -> np.ndarray:
         """int32 [nbox, 8] rows the kernel reads with one scalar load: offsets of the box type's
         a_off / out / tap tables inside flat_tables()[1], the output origin, the type id."""
@@ -185,6 +197,7 @@ def export_program(plan: "ConvPlan", persist: int = 4) -> bytes:
                plan.ncl, plan.nbox, int(gt.shape[1]), plan.clip_stride4, plan.chunk_stride4,
                mt_max if (plan.NTW == 2 and mt_max < plan.MW * plan.MTW) else 0]
     h[28:35] = [desc.size, tables.size, boxes.size, gt.size, widx.size, col.size, persist]
+    h[35:37] = plan.row_source()
     arrays = [desc.reshape(-1), tables, boxes, gt.reshape(-1), widx, col]
     return h.tobytes() + b"".join(np.ascontiguousarray(a, dtype=np.int32).tobytes() for a in arrays)
 
