@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--pool-noise", type=float, default=1.5, help="--pool-kind templates: noise amplitude next to the template (rms 0.67)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="dm: skip the two short extra timed legs (parity_mode = all hi+lo pairs, fast_mode = round 2's single-pass mode)")
+    ap.add_argument("--eval-seeds", type=int, default=3, help="dm: networks (fixed seeds) the eval leg trains; top1 is their mean")
     ap.add_argument("--eval-epochs", type=int, default=500,
                     help="dm: after the timed steps run evaluate_synset on the synthetic clips for this many epochs (0 = skip); 500 "
                          "epochs take ~4 s on the HIP train step (the reference's default is 1000) and fit the 50 clips")
@@ -121,6 +122,39 @@ def mfma_peak(device):
         torch.cuda.synchronize()
         best = max(best, blocks * 4 * iters * 8 * 32768.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
     return best
+
+
+def real_side_alone(trainer, backend, args, macs, it):
+    """The real side's three launches with NOTHING else on the chip (same run, after the timed region; 3 repetitions): inside a
+    step the synthetic-clip stream's kernels share the CUs with whichever real-side launch is running -- which one they land on is
+    a matter of LDS fit and dispatch order, the step time is what counts -- so `roofline.achieved` (in-step, the contract) moves by
+    +-10 % between builds with the kernel unchanged.  This is the kernel by itself."""
+    from video_distillation_amd import distill, engine
+    dev = trainer.image_syn.device
+    idx = distill.sample_real_indices(it, trainer.pool.counts, trainer.pool.offsets, args.batch_real, trainer.classes)
+    idx_t = torch.as_tensor(idx, device=dev)
+    trainer.sync(); torch.cuda.synchronize()
+    backend.set_real_weights(backend.new_network(seed=it), trainer._per_class())
+    trainer._real_features(idx_t); torch.cuda.synchronize()
+    engine.LAUNCH_PROFILE = []
+    try:
+        for _ in range(3):
+            trainer._real_features(idx_t)
+        torch.cuda.synchronize()
+        prof = engine.LAUNCH_PROFILE
+    finally:
+        engine.LAUNCH_PROFILE = None
+    ms = {}
+    for name, prec, flop, e0, e1 in prof:
+        ms.setdefault(name, []).append(e0.elapsed_time(e1))
+    out = {k + "_ms": sum(v) / len(v) for k, v in ms.items()}
+    if "fwd1" in ms:
+        clips = len(trainer.classes) * args.batch_real
+        t = out["fwd1_ms"] * 1e-3
+        out["achieved"] = 2.0 * macs[1] * clips / t / 1e12
+        out["frac"] = out["achieved"] / 2500.0
+        out["note"] = "level-1 forward launched with no other stream active (TFLOP/s, fraction of the 2.5 PFLOP/s spec peak)"
+    return out
 
 
 def best_threads(fn):
@@ -369,16 +403,23 @@ def run_eval(args, trainer, pool, device, rank):
     loader = torch.utils.data.DataLoader(test, batch_size=64, shuffle=False)
     eargs = types.SimpleNamespace(device=device, lr_net=0.01, epoch_eval_train=args.eval_epochs, batch_train=256,
                                   model="ConvNet3D", eval_mode="SS")
-    net = utils.get_network("ConvNet3D", 3, C, (args.size, args.size), frames=args.frames, dist=False).to(device)
+    # The outcome of 500 SGD epochs on 50 clips depends strongly on the network's initial weights and dropout masks (0.55 .. 0.97
+    # top-1 between unseeded runs of one build, an occasional collapsed run at chance): --eval-seeds networks are trained from fixed
+    # seeds and the MEAN top-1 is reported next to the per-seed values.
+    import contextlib
+    tops, trains = [], []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    import contextlib
-    with contextlib.redirect_stdout(sys.stderr):        # evaluate_synset prints its own progress line, like the reference
-        _, acc_train, acc_test, _ = utils.evaluate_synset(0, net, syn, labels, loader, eargs, mode="none")
+    for sd in range(max(1, args.eval_seeds)):
+        torch.manual_seed(1000 + sd)
+        net = utils.get_network("ConvNet3D", 3, C, (args.size, args.size), frames=args.frames, dist=False).to(device)
+        with contextlib.redirect_stdout(sys.stderr):        # evaluate_synset prints its own progress line, like the reference
+            _, acc_train, acc_test, _ = utils.evaluate_synset(sd, net, syn, labels, loader, eargs, mode="none")
+        tops.append(float(acc_test)); trains.append(float(acc_train))
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"top1": float(acc_test), "acc_train": float(acc_train), "epochs": args.eval_epochs + 1, "seconds": dt,
-            "ms_per_epoch": dt / (args.eval_epochs + 1) * 1e3, "test_clips": int(idx.numel()),
+    dt = (time.perf_counter() - t0) / len(tops)
+    return {"top1": sum(tops) / len(tops), "acc_train": sum(trains) / len(trains), "top1_per_seed": tops, "epochs": args.eval_epochs + 1,
+            "seconds": dt, "ms_per_epoch": dt / (args.eval_epochs + 1) * 1e3, "test_clips": int(idx.numel()),
             "note": ("class template + noise pool: chance is %.3f" % (1.0 / C)) if args.pool_kind == "templates" else
                     ("synthetic noise pool: top-1 is chance (%.3f) by construction" % (1.0 / C))}
 
@@ -474,6 +515,8 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
             roof["traffic"], roof["traffic_source"] = pmc_traffic("conv1_fwd_f16", clips) if clips else (None, None)
             roof["peak_measured"] = mfma_peak(device)
             roof["frac_of_measured"] = roof["achieved"] / roof["peak_measured"]
+            if not s2d and world == 1:
+                roof["alone"] = real_side_alone(trainer, backend, args, macs, args.warmup + args.steps + 8)
             for p in roof["programs"]:
                 if p["program"] in ("fwd0", "fwd2") and p["operands"] == args.prec_real:
                     roof[p["program"] + "_tflops"] = p["tflops"]
