@@ -79,7 +79,9 @@ def parse():
     ap.add_argument("--pool-noise", type=float, default=1.5, help="--pool-kind templates: noise amplitude next to the template (rms 0.67)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="dm: skip the two short extra timed legs (parity_mode = all hi+lo pairs, fast_mode = round 2's single-pass mode)")
-    ap.add_argument("--eval-seeds", type=int, default=3, help="dm: networks (fixed seeds) the eval leg trains; top1 is their mean")
+    ap.add_argument("--no-alone", action="store_true", help="dm: skip the stand-alone launches of the real side after the timed region "
+                    "(roofline.alone); profiling runs use it so that the kernel statistics hold in-step launches only")
+    ap.add_argument("--eval-seeds", type=int, default=5, help="dm: networks (fixed seeds) the eval leg trains; top1 is their mean")
     ap.add_argument("--eval-epochs", type=int, default=500,
                     help="dm: after the timed steps run evaluate_synset on the synthetic clips for this many epochs (0 = skip); 500 "
                          "epochs take ~4 s on the HIP train step (the reference's default is 1000) and fit the 50 clips")
@@ -515,7 +517,7 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
             roof["traffic"], roof["traffic_source"] = pmc_traffic("conv1_fwd_f16", clips) if clips else (None, None)
             roof["peak_measured"] = mfma_peak(device)
             roof["frac_of_measured"] = roof["achieved"] / roof["peak_measured"]
-            if not s2d and world == 1:
+            if not s2d and world == 1 and not args.no_alone:
                 roof["alone"] = real_side_alone(trainer, backend, args, macs, args.warmup + args.steps + 8)
             for p in roof["programs"]:
                 if p["program"] in ("fwd0", "fwd2") and p["operands"] == args.prec_real:

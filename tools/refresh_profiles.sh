@@ -23,7 +23,7 @@ prof() {  # name, then the program and its arguments
   timeout -k 5 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- "$@" > $OUT/$name.log 2>&1
   cp $(ls $OUT/$name/*/*kernel_stats.csv | head -1) $OUT/${name}_kernel_stats.csv
 }
-prof bench python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --eval-epochs 0 --sustain-seconds 0 --no-extra-legs
+prof bench python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --eval-epochs 0 --sustain-seconds 0 --no-extra-legs --no-alone
 grep '"metric"' $OUT/bench.log | tail -1 > $OUT/bench_1gpu_under_rocprof.json
 prof s2d python3 $ROOT/bench.py --method s2d --steps 8 --warmup 2 --no-cpu-baseline --sustain-seconds 0
 prof dc python3 $ROOT/bench.py --method dc --classes 8 --ipc 5 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0
