@@ -31,6 +31,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.vd_abi_version() == 3
 
 
+def test_argument_errors_are_reported_before_any_device_call():
+    """Entry points validate their arguments first (codes -1 / -2, include/vd_hip.h) -- callable without a GPU."""
+    from video_distillation_amd import hip
+    if not os.path.exists(hip.LIB_PATH):
+        hip.build()
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    assert lib.vd_conv_mfma(None, None) == -1
+    assert lib.vd_conv_mfma_multi(None, 2, None) == -1
+    a, b = hip.VdConvParams(), hip.VdConvParams()
+    for p, mtw in ((a, 4), (b, 2)):        # two programs of different tile shapes do not share an instantiation
+        p.prec, p.NT, p.MW, p.MTW, p.S, p.CC, p.ncl, p.lds_plane_bytes = 3, 1, 4, mtw, 8, 1, 1, 1024
+    arr = (ctypes.POINTER(hip.VdConvParams) * 2)(ctypes.pointer(a), ctypes.pointer(b))
+    assert lib.vd_conv_mfma_multi(arr, 0, None) == -1 and lib.vd_conv_mfma_multi(arr, 5, None) == -1
+    assert lib.vd_conv_mfma_multi(arr, 2, None) == -2
+
+
 def test_params_struct_layout_matches_header():
     """ctypes mirror of VdConvParams: same field order as the C struct (names must appear in the
     header in the same sequence) and the size hipcc computes for it."""
