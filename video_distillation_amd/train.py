@@ -12,7 +12,9 @@ is the module-level entry ``utils.epoch`` dispatches to.  No CPU path.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -56,6 +58,7 @@ class TrainEngine:
                        (self.K, self.C, 1, 1, 1), (self.K,)]
         self.sizes = [int(np.prod(s)) for s in self.shapes]
         self.gflat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=self.device)
+        self.side_wgrad = False        # set by ConvNet3D.hip_train_step (see feat_backward)
 
     def _wgrad(self, li: int, nb: int) -> WgradOp:
         op = self._wg.get((li, nb))
@@ -131,6 +134,11 @@ class TrainEngine:
         acts, act_plane = acts_override if acts_override is not None else self._acts(nb)
         grad, layout = g_feat, 0
         scaled = eng.prec_bwd in (hip.PREC["f16"], hip.PREC["f16x3"])
+        # ``side_wgrad``: the parameter side of a level (bias + weight gradient: staging, packing, one tile program, replica sum)
+        # depends only on the level's incoming gradient, and nothing downstream depends on it -- it runs on a side stream under
+        # the input-gradient passes of the same and the following levels; joined before returning
+        main = torch.cuda.current_stream(self.device)
+        side = self._side_stream() if (self.side_wgrad and g is not None) else None
         for li in (2, 1, 0):
             cin, cout, t, h, w, T, OH, OW, To, Ho, Wo, pt = eng.dims[li]
             nslots = nb * (cout // 8) * T * OH * OW
@@ -150,21 +158,31 @@ class TrainEngine:
                                                layout, hip.ptr(dy[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(sc), st),
                           "vd_unpool_relu_bwd")
             if g is not None:
-                # bias gradient from the pooled gradient (the dense dy has one non-zero per live pool window)
-                hip.check(L.vd_bias_grad_pooled(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout,
-                                                ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(g[2 * li + 1]), st),
-                          "vd_bias_grad_pooled")
-                op = self._wgrad(li, nb)
-                # pooled gradient -> packed B operand of the weight-gradient program in one pass (4-8x fewer bytes than
-                # re-reading the dense slots, which for the first layer are not even written when nobody else needs them)
-                if li == 0:
-                    op.run_pooled(x, True, 0, grad, am[0], layout, (To, Ho, Wo, pt), sc, g[0], out_scale=inv)
-                else:
-                    op.run_pooled(acts[li], False, act_plane[li], grad, am[li], layout, (To, Ho, Wo, pt), sc, g[2 * li], out_scale=inv)
+                if side is not None:
+                    side.wait_stream(main)          # the level's gradient and its scale are queued on the main stream
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    # bias gradient from the pooled gradient (the dense dy has one non-zero per live pool window)
+                    hip.check(L.vd_bias_grad_pooled(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout,
+                                                    ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(g[2 * li + 1]),
+                                                    hip.stream_ptr(self.device)), "vd_bias_grad_pooled")
+                    op = self._wgrad(li, nb)
+                    # pooled gradient -> packed B operand of the weight-gradient program in one pass (4-8x fewer bytes than
+                    # re-reading the dense slots, which for the first layer are not even written when nobody else needs them)
+                    if li == 0:
+                        op.run_pooled(x, True, 0, grad, am[0], layout, (To, Ho, Wo, pt), sc, g[0], out_scale=inv)
+                    else:
+                        op.run_pooled(acts[li], False, act_plane[li], grad, am[li], layout, (To, Ho, Wo, pt), sc, g[2 * li], out_scale=inv)
             if li > 0 or dx is not None:
                 out = dx if li == 0 else eng._buf("dx%d" % li, (nb, t, h, w, cin), torch.float32)
                 run_together(eng.bwd[li], dy, nslots, None, out.data_ptr(), 0, None, nb, out_scale=inv)
                 grad, layout = out, 1
+        if side is not None:
+            main.wait_stream(side)
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def loss_and_grads(self, x: torch.Tensor, labels: torch.Tensor, params: Sequence[torch.Tensor],
                        mask: Optional[torch.Tensor] = None, state: Optional[dict] = None):
