@@ -742,6 +742,8 @@ bool plan_wgrad(int cin, int cout, int t_in, int h_in, int w_in, int nclips, int
 }
 
 // plan.export_program: 40 int64 header words + int32 arrays type_desc | tables | boxes | gather | widx | col_off
+// (box walks of the first-level kernels: the grid is this many generations of resident workgroups -- see plan.export_program)
+#define VD_BOX_WALK_GENERATIONS 8
 std::vector<uint8_t> export_program(const Plan& pl, int persist) {
     std::vector<int32_t> desc, tables;
     int64_t pos = 0;
@@ -828,7 +830,7 @@ extern "C" int vd_program_build(int layer, int frames, int height, int width, in
     if (frames < 2 || height < 16 || width < 16) return -2;
     Plan pl;
     if (!plan_layer(layer, frames, height, width, prec, batch_hint, pl)) return -3;
-    const std::vector<uint8_t> b = export_program(pl, 4);
+    const std::vector<uint8_t> b = export_program(pl, VD_BOX_WALK_GENERATIONS);
     void* out = malloc(b.size());
     if (out == nullptr) return -5;
     memcpy(out, b.data(), b.size());
@@ -843,7 +845,7 @@ extern "C" int vd_program_build_dgrad(int layer, int parity_class, int frames, i
     if (frames < 2 || height < 16 || width < 16) return -2;
     Plan pl;
     if (!plan_dgrad_layer(layer, parity_class, frames, height, width, batch_hint, pl)) return -3;
-    const std::vector<uint8_t> b = export_program(pl, 4);
+    const std::vector<uint8_t> b = export_program(pl, VD_BOX_WALK_GENERATIONS);
     void* out = malloc(b.size());
     if (out == nullptr) return -5;
     memcpy(out, b.data(), b.size());
@@ -861,7 +863,7 @@ extern "C" int vd_program_build_wgrad(int layer, int frames, int height, int wid
     const int cout = layer == 0 ? 64 : 128;
     Plan pl;
     if (!plan_wgrad(cin, cout, t, h, w, nclips, planes, pl, block3, *replicas)) return -3;
-    const std::vector<uint8_t> b = export_program(pl, 4);
+    const std::vector<uint8_t> b = export_program(pl, VD_BOX_WALK_GENERATIONS);
     void* out = malloc(b.size());
     if (out == nullptr) return -5;
     memcpy(out, b.data(), b.size());

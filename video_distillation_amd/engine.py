@@ -55,7 +55,7 @@ class _DevPlan:
         p.out_chunk_stride, p.out_t_stride = plan.out_chunk_stride, plan.out_t_stride
         p.lds_plane_bytes = int(gt.shape[1]) * 16
         p.ntypes = len(plan.types)
-        p.persist = int(os.environ.get("VD_PERSIST", "4"))
+        p.persist = int(os.environ.get("VD_PERSIST", str(P.BOX_WALK_GENERATIONS)))
         p.tab_ofs[0], p.tab_ofs[1], p.tab_ofs[2] = int(desc[0][7]), int(desc[0][8]), int(desc[0][9])
         self.zero = torch.zeros(64, dtype=torch.uint8, device=device)
         p.zero_slot = self.zero.data_ptr()

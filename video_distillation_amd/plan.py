@@ -180,7 +180,13 @@ PROGRAM_MAGIC = b"VDPROG01"
 PROGRAM_HEADER_WORDS = 40
 
 
-def export_program(plan: "ConvPlan", persist: int = 4) -> bytes:
+BOX_WALK_GENERATIONS = 8     # first-level kernels walk boxes: grid = this many generations of resident workgroups.  4 -> 8 in round 3:
+#                              same stand-alone time (1.47 / 1.46 ms per 512 clips), but a workgroup of the eight-wave first-level
+#                              kernel holds its CU's LDS for half as long, so the synthetic-clip stream's kernels find CUs during
+#                              the first level instead of piling onto level 1 (step 35.66 / 35.63 ms, level-1 launch 21.6 -> 20.8 ms)
+
+
+def export_program(plan: "ConvPlan", persist: int = BOX_WALK_GENERATIONS) -> bytes:
     """Serialise a tile program for ``vd_program_load`` (include/vd_hip.h): 40 int64 header words
     followed by the int32 arrays type_desc | tables | boxes | gather | widx | col_off."""
     desc, tables = plan.flat_tables()
