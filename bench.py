@@ -780,8 +780,8 @@ def main():
         # Whole-class blocks (50 -> 7,7,6,...) need no data-path collective but leave ranks idle (ceiling 50/7 = 7.14x at 8); the hybrid
         # keeps whole classes and splits only the left-over ones (400 real clips on every rank at N = 8, one 16 KB all-reduce).
         # Single-GPU proxy of one rank's step in the shipped mode (tools/rank_proxy.py, profiles/r03_rank_proxy.txt; exchange not
-        # included): N = 2: class 18.1 / batch 18.6 ms; N = 4: class 9.8 / batch 10.4 / hybrid 10.6; N = 8: class 6.5 / batch 5.4 /
-        # hybrid 5.5 (5.5x / 6.6x / 6.5x of one GPU) -- so the hybrid is chosen where the class blocks are more than 8 % uneven
+        # included): N = 2: class 18.3 / batch 18.4 ms; N = 4: class 9.65 / batch 9.68 / hybrid 9.66; N = 8: class 5.7 / batch 4.9 /
+        # hybrid 4.9 (6.2x / 7.35x / 7.3x of one GPU) -- so the hybrid is chosen where the class blocks are more than 8 % uneven
         # (N = 8), whole-class blocks otherwise.
         blocks_uneven = world > 1 and (-(-args.classes // world)) * world > 1.08 * args.classes
         shard = "hybrid" if (blocks_uneven and args.batch_real % world == 0 and args.method == "dm") else "class"
