@@ -124,7 +124,10 @@ def test_odd_geometry_floor_pooling_and_multi_type_boxes():
     import torch.nn.functional as F
     geo = P.NetGeometry(12, 96, 80)
     net = P.plan_network(geo)
-    assert geo.num_feat == 384 and any(len(pl.types) > 1 for l in net["bwd"] for pl in l)
+    assert geo.num_feat == 384
+    d0 = net["dims"][0]
+    ragged = P.plan_dgrad_pix("bwd0_merged", d0[0], d0[1], d0[2], d0[3], d0[4])     # the 7 / 8-tile fallback decomposition of the
+    assert len(ragged.types) > 1                                                    # pixel-gradient program: several box types
     g = torch.Generator().manual_seed(7)
     x = torch.randn(2, 12, 3, 96, 80, generator=g).double()
     params = [p.double() for p in R.init_params(5)]
@@ -147,6 +150,13 @@ def test_odd_geometry_floor_pooling_and_multi_type_boxes():
         for pl in net['bwd'][li]: E.run_plan(pl,to_cl(dy.numpy()),params[2*li].numpy().ravel(),None,1,out)
         got = out.reshape(1,t_,cin,h,w).transpose(0,2,1,3,4) if li==0 else out.reshape(1,t_,h,w,cin).transpose(0,4,1,2,3)
         np.testing.assert_allclose(got,want.numpy(),rtol=1e-9,atol=1e-9)
+        if li == 0:      # ... the multi-type decomposition of the same program, and the small-box one of the training engines
+            small = P.plan_network(geo, bwd0_small=True)["bwd"][0][0]
+            assert small.MTW == 4 and small.nbox > ragged.nbox
+            for alt in (ragged, small):
+                out=np.zeros(cin*t_*h*w)
+                E.run_plan(alt,to_cl(dy.numpy()),params[0].numpy().ravel(),None,1,out)
+                np.testing.assert_allclose(out.reshape(1,t_,cin,h,w).transpose(0,2,1,3,4),want.numpy(),rtol=1e-9,atol=1e-9)
 
 
 def test_exported_program_blob_layout():

@@ -234,7 +234,7 @@ def round_weights(params: Sequence[torch.Tensor], prec: str) -> List[torch.Tenso
 class EmbedEngine:
     def __init__(self, geo: P.NetGeometry, prec: str = "bf16x3", device="cuda:0", chunk: int = 256,
                  prec_bwd: Optional[str] = None, ntw0: Optional[int] = None, batch_hint: Optional[int] = None,
-                 last_hilo: bool = False):
+                 last_hilo: bool = False, bwd0_small: bool = False):
         """``last_hilo`` (single-pass engines, forward without kept arg-max): the LAST conv level runs in the hi+lo format of the
         same 16-bit type -- level 1's program also writes the low plane of its pooled outputs (VdConvParams.emit_lo) and level 2
         multiplies hi+lo activations by hi+lo weights (3 MFMAs per product on 5.6 % of the network's FLOPs).  That removes two
@@ -258,7 +258,7 @@ class EmbedEngine:
             ntw0 = int(os.environ.get("VD_NTW0", "1" if (hip.is_x3(self.prec) or self.ntw != 2 or breg) else "2"))
         bal = (self.ntw == 2 and not hip.is_x3(self.prec) and os.environ.get("VD_BALANCED", "1") == "1")
         self.batch_hint = batch_hint      # typical clips per launch: small batches get latency-oriented programs
-        net = P.plan_network(geo, ntw=self.ntw, ntw0=ntw0, balanced=bal, batch_hint=batch_hint)
+        net = P.plan_network(geo, ntw=self.ntw, ntw0=ntw0, balanced=bal, batch_hint=batch_hint, bwd0_small=bwd0_small)
         self.dims = net["dims"]
         self.fwd = [_DevPlan(pl, self.device, self.prec) for pl in net["fwd"]]
         self.fwd2x = None

@@ -914,12 +914,12 @@ def latency_variant(pl: ConvPlan, batch_hint: Optional[int], make) -> ConvPlan:
 
 
 def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: int = 1, balanced: bool = False,
-                 batch_hint: Optional[int] = None) -> Dict[str, object]:
+                 batch_hint: Optional[int] = None, bwd0_small: bool = False) -> Dict[str, object]:
     """All tile programs of one ConvNet3D geometry: forward L0..L2 and the input-gradient
     passes (one per parity class per layer).  ``ntw`` / ``ntw0`` = N tiles per wave of the layer-1/2
     and of the first-layer forward programs; ``batch_hint`` = clips per launch the programs will typically see
     (small batches get latency-oriented decompositions, see ``latency_variant``)."""
-    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw, ntw0, balanced, batch_hint)
+    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw, ntw0, balanced, batch_hint, bwd0_small)
     if key in _PLAN_CACHE:
         return _PLAN_CACHE[key]
     dims = geo.layer_dims()
@@ -947,7 +947,18 @@ def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: i
     for li in range(3):
         cin, cout, t, h, w = dims[li][:5]
         if li == 0 and h % 2 == 0 and w % 2 == 0:
-            bwd.append([plan_dgrad_pix("bwd0_merged", cin, cout, t, h, w, lds_budget=lds_budget)])
+            # ``bwd0_small`` (the engines of the training / second-order passes): boxes of 4 M tiles per wave within 1800 LDS slots --
+            # a hi+lo program then holds 2 x 21 KB of patch and two or three workgroups share a CU (7-tile boxes: 2 x 53 KB, one
+            # workgroup, one wave per SIMD).  Embed backward of 256 clips 64x64x8 2.29 -> 2.00 ms, second-order pass 10.0 -> 9.2 ms,
+            # MTT+Ours 7.77 -> 8.23 it/s.  NOT for the synthetic-clip stream of DM, whose kernels run under the real side's: there the
+            # extra resident workgroups take more from the real stream than they save (step 35.6 -> 36.2 ms, N = 8 proxy 4.9 -> 5.4).
+            small = None
+            if bwd0_small:
+                try:
+                    small = plan_dgrad_pix("bwd0_merged", cin, cout, t, h, w, lds_budget=min(lds_budget, 1800), mtw_options=(4,))
+                except ValueError:
+                    small = None
+            bwd.append([small if small is not None else plan_dgrad_pix("bwd0_merged", cin, cout, t, h, w, lds_budget=lds_budget)])
             continue
         layer = []
         for ph, pw in dgrad_classes(h, w):

@@ -45,7 +45,8 @@ class TrainEngine:
         self.K = int(num_classes)
         self.pool_kernel = tuple(int(k) for k in pool_kernel)
         self.batch_hint = batch_hint
-        self.eng = EmbedEngine(geo, prec=prec, device=device, chunk=1 << 30, prec_bwd=prec_bwd, batch_hint=batch_hint)
+        self.eng = EmbedEngine(geo, prec=prec, device=device, chunk=1 << 30, prec_bwd=prec_bwd, batch_hint=batch_hint,
+                               bwd0_small=os.environ.get("VD_BWD0_SMALL", "1") == "1")
         if self.eng.planes_bwd > self.eng.planes or (prec[:2] != prec_bwd[:2]):
             raise ValueError("backward operands are read from the forward's activations: %s / %s do not combine"
                              % (prec, prec_bwd))
