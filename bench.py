@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--pool-noise", type=float, default=1.5, help="--pool-kind templates: noise amplitude next to the template (rms 0.67)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="dm: skip the two short extra timed legs (parity_mode = all hi+lo pairs, fast_mode = round 2's single-pass mode)")
+    ap.add_argument("--seed", type=int, default=0, help="seed of torch's global generators (dropout masks of DC / MTT, loader shuffles)")
     ap.add_argument("--no-alone", action="store_true", help="dm: skip the stand-alone launches of the real side after the timed region "
                     "(roofline.alone); profiling runs use it so that the kernel statistics hold in-step launches only")
     ap.add_argument("--eval-seeds", type=int, default=5, help="dm: networks (fixed seeds) the eval leg trains; top1 is their mean")
@@ -765,6 +766,7 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+    torch.manual_seed(args.seed)        # dropout masks of the DC / MTT class terms and the eval networks' shuffles: reproducible runs
     if args.pool_per_class is None:
         args.pool_per_class = 1 if args.method == "mtt" else 93
 

@@ -52,15 +52,15 @@ def test_s2d_dc_mtt_issue_their_collectives_and_keep_the_loss():
     dc = ["--method", "dc", "--classes", "3", "--ipc", "1", "--frames", "8", "--size", "64", "--batch-real", "8", "--pool-per-class", "12"]
     a, b = _bench(dc), _bench(dc, FORCE)
     assert b["collectives"]["all_reduce"] == 3 + 1            # every step's loss, incl. the extra profiling step of bench_dc
-    # (two runs of the laned DC step differ by the order of its fp32 atomics, which the 'ours' metric -- cosines of many near-zero
-    #  rows -- amplifies to a per cent or two: the collective is the identity here, the check is that it ran and the loss is sane)
-    assert abs(b["loss_last"] / a["loss_last"] - 1) < 5e-2 and b["roofline"]["launches"] > 0
+    # (bench.py seeds torch's generators, so both runs draw the same dropout masks: what is left is the order of the fp32 atomics
+    #  -- 1e-7 measured; unseeded runs spread +-2.5 %)
+    assert abs(b["loss_last"] / a["loss_last"] - 1) < 1e-4 and b["roofline"]["launches"] > 0
     mtt = ["--method", "mtt", "--classes", "8", "--frames", "8", "--size", "64", "--syn-steps", "2", "--batch-syn", "8"]
     a, b = _bench(mtt), _bench(mtt, FORCE)
     # per iteration: flat gradient + Hessian-vector product per student step (2 x 2), hallucinator + dynamic-memory gradients (2);
     # 3 timed / warm-up iterations + 1 profiling iteration
     assert b["collectives"]["all_reduce"] == 4 * (2 * 2 + 2), b["collectives"]
-    assert abs(b["grand_loss_last"] / a["grand_loss_last"] - 1) < 5e-2      # (dropout masks and atomics differ from run to run)
+    assert abs(b["grand_loss_last"] / a["grand_loss_last"] - 1) < 1e-4      # (same seed, same dropout masks: atomics' order only)
 
 
 def test_two_ranks_share_the_gpu_over_gloo_and_match_one_rank():
@@ -92,11 +92,13 @@ def test_two_ranks_share_the_gpu_over_gloo_and_match_one_rank():
     # 4 + 4, flat gradient and Hessian-vector product all-reduced per student step (tolerances: see the one-rank test above)
     dc = ["--method", "dc", "--classes", "3", "--ipc", "1", "--frames", "8", "--size", "64", "--batch-real", "8", "--pool-per-class", "12"]
     a, b = _bench(dc), two(dc, 29556)
-    assert b["n_gpus"] == 2 and b["collectives"]["all_reduce"] == 3 + 1 and abs(b["loss_last"] / a["loss_last"] - 1) < 5e-2
+    # (each rank draws its classes' dropout masks from the same seeded generator, i.e. other masks than the one-rank run's:
+    #  the losses agree to the dropout noise of this tiny configuration, +-2.5 %)
+    assert b["n_gpus"] == 2 and b["collectives"]["all_reduce"] == 3 + 1 and abs(b["loss_last"] / a["loss_last"] - 1) < 8e-2
     mtt = ["--method", "mtt", "--classes", "8", "--frames", "8", "--size", "64", "--syn-steps", "2", "--batch-syn", "8"]
     a, b = _bench(mtt), two(mtt, 29557)
     assert b["n_gpus"] == 2 and b["collectives"]["all_reduce"] == 4 * (2 * 2 + 2), b["collectives"]
-    assert abs(b["grand_loss_last"] / a["grand_loss_last"] - 1) < 5e-2
+    assert abs(b["grand_loss_last"] / a["grand_loss_last"] - 1) < 8e-2
 
 
 def test_vd_comm_c_abi_one_rank_roundtrip():
