@@ -79,6 +79,8 @@ def test_two_ranks_share_the_gpu_over_gloo_and_match_one_rank():
     small = ["--classes", "7", "--pool-per-class", "70", "--eval-epochs", "1"]
     one = _bench(small + ["--shard", "class"])
     for k, (shard, per_step) in enumerate((("class", 1), ("batch", 2), ("hybrid", 2))):
+        if shard == "hybrid" and os.environ.get("VD_TEST_ALL_SHARDS") != "1":
+            continue                      # (the eight-rank test below runs the hybrid decomposition)
         got = two(small + ["--shard", shard], 29551 + k)
         c = got["collectives"]
         assert got["n_gpus"] == 2 and c["backend"] == "gloo" and not c["forced_on_one_rank"]
@@ -99,6 +101,26 @@ def test_two_ranks_share_the_gpu_over_gloo_and_match_one_rank():
     a, b = _bench(mtt), two(mtt, 29557)
     assert b["n_gpus"] == 2 and b["collectives"]["all_reduce"] == 4 * (2 * 2 + 2), b["collectives"]
     assert abs(b["grand_loss_last"] / a["grand_loss_last"] - 1) < 8e-2
+
+
+def test_eight_ranks_share_the_gpu_with_the_default_decomposition():
+    """``bench.py --gpus 8`` exactly as the driver launches it (torch.distributed.run, eight processes, default --shard auto ->
+    the hybrid decomposition: 6 whole classes per rank + the real batches of classes 48 and 49 split eight ways), all ranks on
+    device 0 over gloo: the all-reduced DM loss equals the one-rank loss, rank 0 evaluates the gathered 50 synthetic clips."""
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VD_BENCH_ONE_DEVICE="1")
+    args = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--sustain-seconds", "0", "--no-extra-legs", "--eval-epochs", "1",
+            "--eval-seeds", "1"]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                          "127.0.0.1", "--master-port", "29581", "bench.py", "--gpus", "8"] + args,
+                         cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    one = _bench(args)
+    assert got["n_gpus"] == 8 and got["config"]["parallelism"].startswith("hybrid x8") and one["n_gpus"] == 1
+    c = got["collectives"]
+    assert c["backend"] == "gloo" and c["all_reduce"] == 3 * 2 and c["all_gather"] == 1, c      # per step: split-class feature sums + loss
+    assert abs(got["loss_last"] / one["loss_last"] - 1) < 1e-5, (got["loss_last"], one["loss_last"])
+    assert got["eval"]["test_clips"] > 0
 
 
 def test_vd_comm_c_abi_one_rank_roundtrip():
