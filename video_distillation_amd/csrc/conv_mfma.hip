@@ -1840,7 +1840,7 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-static bool os_env_seq() {       // VD_X3_SEQ=0: both planes resident everywhere (A/B measurements)
+static bool vd_first_level_seq_enabled() {       // VD_X3_SEQ=0: both planes resident everywhere (A/B measurements)
     static const bool on = [] { const char* e = getenv("VD_X3_SEQ"); return !(e && e[0] == '0'); }();
     return on;
 }
@@ -1891,7 +1891,7 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
         return -2;
     }
     // first-level hi+lo programs (one channel chunk per box, 4 M tiles per wave): the plane-sequential K loop (SQ above)
-    if (p.MTW == 4 && p.CC == 1 && p.ncl == 1 && os_env_seq()) {
+    if (p.MTW == 4 && p.CC == 1 && p.ncl == 1 && vd_first_level_seq_enabled()) {
         if (p.prec == VD_PREC_BF16X3) return launch<VD_PREC_BF16X3, 4, false, 1, 0, true>(p, st);
         if (p.prec == VD_PREC_F16X3) return launch<VD_PREC_F16X3, 4, false, 1, 0, true>(p, st);
     }
