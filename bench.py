@@ -68,6 +68,12 @@ def parse():
                          "class's real batch per rank (+ all-reduce of the per-class feature sums); hybrid = equal blocks of whole "
                          "classes + the left-over classes' batches split N ways (+ all-reduce of THEIR sums, 8 KB per class); "
                          "auto = hybrid when it balances better than class blocks, else class")
+    ap.add_argument("--exchange", default="owner", choices=["owner", "allreduce"],
+                    help="dm: what the timed steps do with the pixel gradients -- owner (default: a rank owns its classes' synthetic clips, "
+                         "nothing crosses xGMI) or allreduce (the task's literal 'all-reduce of the matching-loss gradient': the full "
+                         "C*ipc-clip gradient tensor, 120 MB at config 2, summed over the ranks through vd_comm_allreduce_f32 = RCCL).  "
+                         "With more than one rank the mode that is NOT timed runs as a short extra leg (exchange_allreduce / exchange_owner)")
+    ap.add_argument("--exchange-leg", action="store_true", help="dm: run the other exchange mode's short leg even with --no-extra-legs")
     ap.add_argument("--syn-steps", type=int, default=10, help="--method mtt: unrolled student steps (sh/s2d/s2d_MTT_ms_K400.sh)")
     ap.add_argument("--batch-syn", type=int, default=256, help="--method mtt: composed clips per student step")
     ap.add_argument("--mtt-raw", action="store_true", help="--method mtt: raw synthetic clips (distill_baseline.py MTT) instead of "
@@ -82,6 +88,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=0, help="seed of torch's global generators (dropout masks of DC / MTT, loader shuffles)")
     ap.add_argument("--no-alone", action="store_true", help="dm: skip the stand-alone launches of the real side after the timed region "
                     "(roofline.alone); profiling runs use it so that the kernel statistics hold in-step launches only")
+    ap.add_argument("--eval-atomic", action="store_true", help="dm: run the eval leg's training steps in the default (fp32-atomic) accumulation "
+                    "mode instead of the fixed-order one (then top1_per_seed moves in its last digits from run to run)")
     ap.add_argument("--eval-seeds", type=int, default=5, help="dm: networks (fixed seeds) the eval leg trains; top1 is their mean")
     ap.add_argument("--eval-epochs", type=int, default=500,
                     help="dm: after the timed steps run evaluate_synset on the synthetic clips for this many epochs (0 = skip); 500 "
@@ -180,6 +188,43 @@ def best_threads(fn):
 class Harness:
     def __init__(self, args, device, rank, world):
         self.args, self.device, self.rank, self.world = args, device, rank, world
+        self.comm = None
+
+    def open_comm(self):
+        """An RCCL communicator over the ranks behind the C ABI (hip.Comm -> vd_comm_*), when the process group runs on RCCL
+        (backend nccl: one device per rank); None otherwise (one process without a group, or the one-device gloo logic mode)."""
+        import torch.distributed as dist
+        if self.comm is None and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            from video_distillation_amd import hip
+            self.comm = hip.Comm(self.rank, self.world)
+        return self.comm
+
+    def topology(self, clips_per_step):
+        """Proof of the N-rank run for the JSON line (every rank calls): ``ranks_seen`` = an all-reduce of ones over the process
+        group; ``clips_per_step`` = every rank's real clips per step (all-gather); ``rccl`` = version and rank count as RCCL
+        itself reports them (ncclGetVersion / ncclCommCount of a communicator created over the ranks through vd_comm_*)."""
+        import torch.distributed as dist
+        rec = {"ranks_seen": 1, "clips_per_step": [int(clips_per_step)], "rccl": None,
+               "launched_by": "bench.py spawn_ranks" if os.environ.get("VD_BENCH_SPAWNED") == "1" else
+                              ("torch.distributed.run / external launcher" if "WORLD_SIZE" in os.environ else "single process")}
+        if dist.is_available() and dist.is_initialized():
+            ones = torch.ones(1, device=self.device)
+            dist.all_reduce(ones)
+            rec["ranks_seen"] = int(ones.item())
+            mine = torch.tensor([int(clips_per_step)], device=self.device, dtype=torch.int64)
+            parts = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine)
+            rec["clips_per_step"] = [int(p.item()) for p in parts]
+            rec["backend"] = dist.get_backend()
+            comm = self.open_comm()
+            if comm is not None:
+                from video_distillation_amd import hip
+                v = hip.Comm.version()
+                rec["rccl"] = {"version_code": v, "version": None if v is None else "%d.%d.%d" % (v // 10000, v // 100 % 100, v % 100),
+                               "nranks": comm.size(), "torch_nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version())}
+            else:
+                rec["rccl"] = {"note": "process group on gloo (all ranks share device 0: RCCL refuses two ranks on one device)"}
+        return rec
 
     def barrier(self):
         if self.world > 1:
@@ -393,15 +438,17 @@ def run_eval(args, trainer, pool, device, rank):
     initial synthetic clips; they may occur in real batches, as any pool clip).  On the default template pool the accuracy is
     informative; on --pool-kind randn it is chance level by construction."""
     import types
-    from video_distillation_amd import utils
+    from video_distillation_amd import networks, utils
     C = args.classes
     syn = trainer.gather_syn().detach().clone()            # (collective: every rank calls)
     if rank != 0:
         return None
     labels = torch.arange(C, device=device).repeat_interleave(args.ipc)
     resident = set(trainer.classes) | set(trainer.__dict__.get("split", []))       # classes whose real clips this rank holds
-    have = [c for c in range(C) if pool.counts[c] > 4 and (c in resident or trainer.__dict__.get("shard") == "batch")]
-    idx = torch.as_tensor([pool.offsets[c] + pool.counts[c] - 1 - k for c in have for k in range(4)], device=device)
+    call = getattr(pool, "counts_all", pool.counts)
+    held_out = all(call[c] - pool.counts[c] == 4 for c in range(C) if call[c] > 0)
+    have = [c for c in range(C) if call[c] > 4 and (c in resident or trainer.__dict__.get("shard") == "batch")]
+    idx = torch.as_tensor([pool.offsets[c] + call[c] - 1 - k for c in have for k in range(4)], device=device)
     test = utils.TensorDataset(pool.clips[idx], torch.as_tensor(have, device=device).repeat_interleave(4))
     loader = torch.utils.data.DataLoader(test, batch_size=64, shuffle=False)
     eargs = types.SimpleNamespace(device=device, lr_net=0.01, epoch_eval_train=args.eval_epochs, batch_train=256,
@@ -411,20 +458,46 @@ def run_eval(args, trainer, pool, device, rank):
     # seeds and the MEAN top-1 is reported next to the per-seed values.
     import contextlib
     tops, trains = [], []
+    from video_distillation_amd import hip
+    prev_det = hip.set_deterministic(not args.eval_atomic)     # fixed summation order: the same top-1 per seed in every run
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for sd in range(max(1, args.eval_seeds)):
+        # (NOT utils.get_network: like the reference's it reseeds torch's global generator from the wall clock on every call
+        #  -- SURVEY Q5 --, which is what made rounds 1-3's "fixed-seed" networks differ from run to run: initial weights,
+        #  dropout masks and shuffles all came from the clock.  The module is constructed directly, as get_network does inside.)
         torch.manual_seed(1000 + sd)
-        net = utils.get_network("ConvNet3D", 3, C, (args.size, args.size), frames=args.frames, dist=False).to(device)
+        net = networks.ConvNet3D(channel=3, num_classes=C, net_width=128, net_depth=3, net_act='relu', net_norm='none',
+                                 net_pooling='maxpooling', im_size=(args.size, args.size), frames=args.frames).to(device)
         with contextlib.redirect_stdout(sys.stderr):        # evaluate_synset prints its own progress line, like the reference
             _, acc_train, acc_test, _ = utils.evaluate_synset(sd, net, syn, labels, loader, eargs, mode="none")
         tops.append(float(acc_test)); trains.append(float(acc_train))
     torch.cuda.synchronize()
+    hip.set_deterministic(prev_det)
     dt = (time.perf_counter() - t0) / len(tops)
-    return {"top1": sum(tops) / len(tops), "acc_train": sum(trains) / len(trains), "top1_per_seed": tops, "epochs": args.eval_epochs + 1,
+    return {"deterministic": not args.eval_atomic, "test_split": "held out (never drawn as real or initial synthetic clips)" if held_out else
+            "last 4 clips of each class (drawable as real clips)",
+            "top1": sum(tops) / len(tops), "acc_train": sum(trains) / len(trains), "top1_per_seed": tops, "epochs": args.eval_epochs + 1,
             "seconds": dt, "ms_per_epoch": dt / (args.eval_epochs + 1) * 1e3, "test_clips": int(idx.numel()),
             "note": ("class template + noise pool: chance is %.3f" % (1.0 / C)) if args.pool_kind == "templates" else
                     ("synthetic noise pool: top-1 is chance (%.3f) by construction" % (1.0 / C))}
+
+
+def exchange_record(trainer, args, geo, h):
+    """What a DMTrainer's pixel-gradient exchange moved: nothing under owner-computes; for ``exchange='allreduce'`` the bytes of
+    the full gradient tensor per step and the mean time of the all-reduce call itself (HIP events around it on the
+    synthetic-clip stream: the collective plus whatever it waits for inside RCCL; this rank's view)."""
+    if trainer.exchange != "allreduce":
+        return {"pixel_gradient_bytes_per_step": 0, "note": "owner-computes: a rank updates the synthetic clips of its own classes"}
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    through = "vd_comm_allreduce_f32 (RCCL) on the synthetic-clip stream" if trainer.comm is not None else \
+        ("torch.distributed all_reduce (%s)" % dist.get_backend() if dist.is_initialized() else "no process group: identity")
+    ms = [e0.elapsed_time(e1) for e0, e1 in trainer.exchange_events]
+    nbytes = args.classes * args.ipc * args.frames * 3 * args.size * args.size * 4
+    return {"pixel_gradient_bytes_per_step": nbytes, "allreduce_calls": len(ms), "allreduce_ms_mean": (sum(ms) / len(ms)) if ms else None,
+            "allreduce_GBps_algorithmic": (nbytes / (sum(ms) / len(ms) * 1e-3) / 1e9) if ms and sum(ms) > 0 else None,
+            "through": through}
 
 
 def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
@@ -432,7 +505,8 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
     s2d = args.method == "s2d"
     if not s2d:
         trainer = distill.DMTrainer(backend, pool, args.classes, args.ipc, args.batch_real, lr_img=1.0, momentum=0.5,
-                                    rank=rank, world=world, shard=shard)
+                                    rank=rank, world=world, shard=shard, exchange=args.exchange,
+                                    comm=h.open_comm() if args.exchange == "allreduce" else None)
     else:   # sh/s2d/s2d_DM_ms.sh: vpc 1, spc 2, dpc 2, static frozen, SGD(.95) on dynamic memory + hallucinator
         gen = torch.Generator(device=device); gen.manual_seed(77)
         static_syn = torch.randn(args.classes * 2, 3, args.size, args.size, device=device, generator=gen)
@@ -483,6 +557,39 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
                           "loss_last": float(last) / args.classes}
             del tr2, be2
             torch.cuda.empty_cache()
+    # The exchange mode that is NOT the timed one, as a short leg of the same workload in the shipped precision mode: with
+    # --exchange owner (default) this is the literal pixel-gradient all-reduce, so that its cost stands next to owner-computes
+    # the first time more than one GPU is available.  Every rank runs it (it contains the collective).
+    if not s2d and (world > 1 or os.environ.get("VD_BENCH_EXCHANGE_LEG") == "1") and (args.exchange_leg or not args.no_extra_legs):
+        other = "allreduce" if args.exchange == "owner" else "owner"
+        tr3 = distill.DMTrainer(backend, pool, args.classes, args.ipc, args.batch_real, lr_img=1.0, momentum=0.5, rank=rank, world=world,
+                                shard=shard, exchange=other, comm=h.open_comm() if other == "allreduce" else None)
+        n_leg, warm = (5, 2)
+        for it in range(warm):
+            tr3.global_loss(tr3.step(it, overlap=True))
+        tr3.sync(); h.barrier()
+        tr3.exchange_events.clear()
+        t0 = time.perf_counter()
+        for it in range(warm, warm + n_leg):
+            last = tr3.global_loss(tr3.step(it, overlap=True))
+        tr3.sync(); h.barrier()
+        dt3 = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt3], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt3 = float(tmax)
+        ex = exchange_record(tr3, args, geo, h)
+        legs["exchange_" + other] = dict({"value": n_leg / dt3, "unit": "steps/s", "ms_per_step": dt3 / n_leg * 1e3, "steps": n_leg,
+                                          "warmup": warm, "loss_last": float(last) / args.classes}, **ex)
+        del tr3
+    if s2d or trainer.shard == "class":
+        clips = args.batch_real * len(trainer.classes)
+    elif trainer.shard == "hybrid":
+        clips = args.batch_real * len(trainer.block) + (args.batch_real // world) * len(trainer.split)
+    else:
+        clips = (args.batch_real // world) * args.classes
+    topo = h.topology(clips)
     out = None
     if rank == 0:
         macs = conv_layer_macs(geo)
@@ -533,6 +640,8 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
             out["eval"] = ev
         for name, leg in legs.items():
             out[name] = leg
+        out.update(topo)
+        out["exchange"] = dict({"mode": args.exchange}, **(exchange_record(trainer, args, geo, h) if not s2d else {}))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_dm(args, trainer, backend, args.warmup + args.steps, s2d if s2d else None)
     finish(h, out)
@@ -742,13 +851,57 @@ def bench_mtt(args, h, distill, geo):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` with no launcher in front: start the N ranks HERE -- N fresh child processes of this very
+    command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment (what torch.distributed.run would set) --
+    from a parent that has made no HIP call (``torch.cuda.device_count()`` does not start the runtime on this image), relay rank
+    0's JSON line (the children inherit this process's stdout; ranks other than 0 print nothing to it) and return non-zero if
+    any rank fails, ending the others by their exact PIDs.  The reference's counterpart is single-process nn.DataParallel over
+    the visible devices (reference utils.py:615-623)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    one_device = os.environ.get("VD_BENCH_ONE_DEVICE") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < n and not one_device:
+        raise SystemExit("--gpus %d but %d HIP device(s) visible (VD_BENCH_ONE_DEVICE=1 shares device 0 over gloo: a logic check, "
+                         "not a timing)" % (n, ndev))
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, VD_BENCH_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                print("bench.py: rank %d exited with code %d; stopping the other ranks" % (procs.index(p), code), file=sys.stderr)
+                for q in live:
+                    q.terminate()                       # exact PIDs of our own children
+    return rc if rc >= 0 else 1
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     quiet_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
@@ -766,6 +919,8 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+    if os.environ.get("VD_BENCH_FAIL_RANK") == str(rank) and world > 1:       # fault injection of tests/test_gpu_collectives.py
+        raise SystemExit(3)
     torch.manual_seed(args.seed)        # dropout masks of the DC / MTT class terms and the eval networks' shuffles: reproducible runs
     if args.pool_per_class is None:
         args.pool_per_class = 1 if args.method == "mtt" else 93
@@ -800,6 +955,11 @@ def main():
                                           kind=args.pool_kind, noise=args.pool_noise)
     if args.method == "dc":
         return bench_dc(args, h, distill, geo, pool)
+    # dm: the LAST 4 clips of every class are the evaluation's test split and are taken out of the range the real batches (and the
+    # initial synthetic clips) are drawn from -- held-out data (they used to be drawable as real clips)
+    pool.counts_all = list(pool.counts)
+    if args.method == "dm" and all(n == 0 or n - 4 >= args.batch_real for n in pool.counts):
+        pool.counts = [max(0, n - 4) for n in pool.counts]
     nsyn = (c_hi - c_lo) * (args.ipc if args.method == "dm" else 1)
     if shard == "hybrid":
         nsyn = (args.classes // world + 1) * args.ipc

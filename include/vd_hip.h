@@ -224,6 +224,11 @@ int vd_unpool_relu_bwd_packed(const float* g, const uint8_t* argmax, int64_t ncl
  * db[n] += sum of g over clips and pooled positions whose window was alive (bit 7 clear); accumulates (fp32 atomics). */
 int vd_bias_grad_pooled(const float* g, const uint8_t* argmax, int64_t nclips, int C, int64_t npos, int g_layout, float* db,
                         void* stream);
+/* The same with a FIXED summation order (bitwise reproducible): partial sums per (clip, block of 256 positions) into `scratch`
+ * (vd_bias_grad_pooled_scratch_floats(nclips, C, npos) floats, caller-owned), folded in index order, added to db. */
+int64_t vd_bias_grad_pooled_scratch_floats(int64_t nclips, int C, int64_t npos);
+int vd_bias_grad_pooled_ordered(const float* g, const uint8_t* argmax, int64_t nclips, int C, int64_t npos, int g_layout,
+                                float* scratch, float* db, void* stream);
 /* db[n] += sum over clips and positions of dy (hi + lo planes) -- Conv3d bias gradient. */
 int vd_bias_grad(const void* dy, int64_t dy_plane_slots, int planes, int64_t nclips, int N, int64_t npos, int prec,
                  const float* scale_inv, float* db, void* stream);
@@ -248,6 +253,22 @@ int vd_ce_loss(const float* logits, const int64_t* labels, int B, int K, float* 
 int vd_head_train_bwd(const float* dlogits, const int32_t* amax_t, const float* dropped, const float* mask, const float* w,
                       int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K, float* g_w, float* g_b,
                       float* g_feats, void* stream);
+/* Fixed-summation-order forms of the two calls above that accumulate with atomics (the deterministic training step, DESIGN
+ * 8b): vd_standardize_ordered -- per-block partial sums in `scratch` (4096 doubles, caller-owned), folded in one fixed order
+ * by every block; vd_head_train_bwd_ordered -- g_w / g_b as a gather over the clips in index order (no atomics).  Bitwise
+ * reproducible from run to run; results differ from the atomic forms only in the last bits (summation order). */
+int vd_standardize_ordered(const float* x, int64_t n, double* scratch, float* out, void* stream);
+int vd_head_train_bwd_ordered(const float* dlogits, const int32_t* amax_t, const float* dropped, const float* mask, const float* w,
+                              int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K, float* g_w, float* g_b,
+                              float* g_feats, void* stream);
+/* Process-wide accumulation-order switch (initial value: environment VD_DETERMINISTIC=1, else 0).  While it is on,
+ * weight-gradient programs PLANNED by the library (vd_program_build_wgrad, vd_train_create) give every box of positions its
+ * own accumulation copy -- an fp32 atomic add onto a zeroed word with one contributor is exact, vd_replica_sum then folds the
+ * copies in index order -- and vd_train_create'd handles use the *_ordered helpers: vd_train_step becomes bitwise
+ * reproducible (reference: utils.py:765-792 on a CPU is deterministic for a seed and thread count).  The mode is captured
+ * when a program / handle is created.  vd_set_deterministic returns the previous value. */
+int vd_set_deterministic(int on);
+int vd_get_deterministic(void);
 /* Re-split 16-bit operand elements between the hi/lo formats (f16 pairs <-> bf16 pairs); lo pointers optional. */
 int vd_resplit_slots(const void* src_hi, const void* src_lo, int64_t n_elems, int src_prec, void* dst_hi, void* dst_lo,
                      int dst_prec, void* stream);
@@ -402,7 +423,8 @@ typedef struct VdComm VdComm;
 typedef struct { char internal[128]; } VdCommId;
 int vd_comm_unique_id(VdCommId* id);
 int vd_comm_create(const VdCommId* id, int nranks, int rank, VdComm** out);
-int vd_comm_size(const VdComm* c);
+int vd_comm_size(const VdComm* c);                 /* ncclCommCount of the communicator */
+int vd_comm_version(int* version);                 /* ncclGetVersion (major * 10000 + minor * 100 + patch) */
 int vd_comm_rank(const VdComm* c);
 int vd_comm_allreduce_f32(VdComm* c, const float* send, float* recv, int64_t n, void* stream);
 int vd_comm_allgather_f32(VdComm* c, const float* send, float* recv, int64_t n_per_rank, void* stream);

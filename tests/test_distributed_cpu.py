@@ -31,7 +31,7 @@ class _Pool:
     pass
 
 
-def _g3_setup(rank, world, shard="class"):
+def _g3_setup(rank, world, shard="class", exchange="owner"):
     z = np.load(os.path.join(GOLDEN, "g3_dm_steps.npz"))
     (syn,) = randn(z["syn_seed"], (3, 8, 3, 64, 64))
     reals = [randn(z["real_seeds"][it], *[(4, 8, 3, 64, 64)] * 3) for it in range(2)]
@@ -42,12 +42,13 @@ def _g3_setup(rank, world, shard="class"):
         block, _, mine = distill.hybrid_partition(3, rank, world)
         own = block + mine
     tr = distill.DMTrainer(OracleBackend(net_seeds=z["net_seeds"]), pool, 3, 1, 4, lr_img=float(z["lr"]),
-                           momentum=float(z["momentum"]), rank=rank, world=world, image_syn=syn[own].clone(), shard=shard)
+                           momentum=float(z["momentum"]), rank=rank, world=world, image_syn=syn[own].clone(), shard=shard,
+                           exchange=exchange)
     return z, tr
 
 
-def _g3_run(rank, world, shard="class"):
-    z, tr = _g3_setup(rank, world, shard)
+def _g3_run(rank, world, shard="class", exchange="owner"):
+    z, tr = _g3_setup(rank, world, shard, exchange)
     orig = distill.sample_real_indices
     losses = []
     try:
@@ -92,6 +93,20 @@ def _worker_g3_hybrid(rank, world, port, q):
         z, losses, syn = _g3_run(rank, world, shard="hybrid")
         if rank == 0:
             q.put((losses, syn.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_g3_allreduce(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        before = dict(distill.COLLECTIVE_CALLS)
+        z, losses, syn = _g3_run(rank, world, shard="hybrid", exchange="allreduce")
+        calls = distill.COLLECTIVE_CALLS["all_reduce"] - before["all_reduce"]
+        if rank == 0:
+            q.put((losses, syn.numpy(), calls))
     finally:
         dist.destroy_process_group()
 
@@ -161,6 +176,18 @@ def test_dm_trainer_two_ranks_hybrid_matches_golden():
     z = np.load(os.path.join(GOLDEN, "g3_dm_steps.npz"))
     np.testing.assert_allclose(losses, z["losses"], rtol=1e-5)
     np.testing.assert_allclose(syn[:, ::2, :, ::4, ::4], z["syn2"], rtol=1e-4, atol=1e-5)
+
+
+def test_dm_trainer_two_ranks_pixel_gradient_allreduce_matches_golden():
+    """``exchange='allreduce'``: the literal "all-reduce of the matching-loss gradient" -- the full (C * ipc, ...) pixel-gradient
+    tensor, each rank's rows scattered into zeros, summed over the ranks, the owner updating from the reduced tensor (the
+    tensor distill_baseline.py:353-355 steps on) -- gives the same two steps as owner-computes (hybrid ownership: rank 0 owns
+    classes 0 and 2, rank 1 class 1, so the scatter rows are not contiguous)."""
+    losses, syn, calls = _spawn(_worker_g3_allreduce, 2)
+    z = np.load(os.path.join(GOLDEN, "g3_dm_steps.npz"))
+    np.testing.assert_allclose(losses, z["losses"], rtol=1e-5)
+    np.testing.assert_allclose(syn[:, ::2, :, ::4, ::4], z["syn2"], rtol=1e-4, atol=1e-5)
+    assert calls == 2 * 3          # per step: split-class feature sums, pixel gradients, loss
 
 
 def _g5_run(rank, world):

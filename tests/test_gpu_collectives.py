@@ -103,20 +103,65 @@ def test_two_ranks_share_the_gpu_over_gloo_and_match_one_rank():
     assert abs(b["grand_loss_last"] / a["grand_loss_last"] - 1) < 8e-2
 
 
+def test_a_failing_rank_fails_the_spawned_run():
+    """``bench.py --gpus 2`` (self-spawned): a rank that dies makes the parent stop the other rank and exit non-zero, with no JSON
+    line on stdout (VD_BENCH_FAIL_RANK is the test's fault injection)."""
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VD_BENCH_ONE_DEVICE="1", VD_BENCH_FAIL_RANK="1")
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + COMMON + ["--classes", "4", "--pool-per-class", "70", "--eval-epochs", "0"],
+                         cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "rank 1 exited" in out.stderr
+
+
+def test_pixel_gradient_allreduce_leg():
+    """The literal "all-reduce of the matching-loss gradient" as a counted mode (DMTrainer(exchange='allreduce')): (i) one rank,
+    RCCL: the full gradient tensor goes through vd_comm_allreduce_f32 on the synthetic-clip stream (a 1-rank all-reduce is the
+    identity, so the leg's loss is the owner-computes loss); (ii) two self-spawned ranks on device 0 over gloo: the reduced
+    tensor's rows give the same update as owner-computes.  The JSON line carries bytes and ms of the exchange."""
+    small = ["--classes", "6", "--pool-per-class", "70", "--eval-epochs", "0", "--exchange-leg"]
+    one = _bench(small, dict(FORCE, VD_BENCH_EXCHANGE_LEG="1", MASTER_PORT="29543"))
+    leg = one["exchange_allreduce"]
+    assert leg["through"].startswith("vd_comm_allreduce_f32") and leg["allreduce_calls"] == 5
+    assert leg["pixel_gradient_bytes_per_step"] == 6 * 16 * 3 * 112 * 112 * 4 and leg["allreduce_ms_mean"] > 0
+    assert one["rccl"]["nranks"] == 1 and one["rccl"]["version_code"] > 20000 and one["exchange"]["mode"] == "owner"
+    # the leg's trainer starts from the same initial clips and runs iterations 0..6; the main run's loss_last is iteration 2:
+    # compare the two modes at equal iterations instead -- a main run timed in allreduce mode whose leg is owner-computes
+    other = _bench(small + ["--exchange", "allreduce"], dict(FORCE, VD_BENCH_EXCHANGE_LEG="1", MASTER_PORT="29544"))
+    assert other["exchange"]["mode"] == "allreduce" and other["exchange"]["allreduce_calls"] >= 2
+    assert abs(other["loss_last"] / one["loss_last"] - 1) < 1e-5
+    assert abs(other["exchange_owner"]["loss_last"] / leg["loss_last"] - 1) < 1e-5
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VD_BENCH_ONE_DEVICE="1")
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + COMMON + small, cwd=ROOT, env=e, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    two = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["ranks_seen"] == 2 and two["clips_per_step"] == [192, 192] and two["rccl"].get("nranks") is None
+    assert two["exchange_allreduce"]["through"] == "torch.distributed all_reduce (gloo)"
+    assert abs(two["exchange_allreduce"]["loss_last"] / leg["loss_last"] - 1) < 1e-4
+    assert abs(two["loss_last"] / one["loss_last"] - 1) < 1e-4
+
+
 def test_eight_ranks_share_the_gpu_with_the_default_decomposition():
-    """``bench.py --gpus 8`` exactly as the driver launches it (torch.distributed.run, eight processes, default --shard auto ->
+    """``bench.py --gpus 8`` with NO launcher in front (the shape of the driver's one-GPU command; bench.py spawns the ranks;
+    the launcher form is exercised by the two-rank test above), eight processes, default --shard auto ->
     the hybrid decomposition: 6 whole classes per rank + the real batches of classes 48 and 49 split eight ways), all ranks on
     device 0 over gloo: the all-reduced DM loss equals the one-rank loss, rank 0 evaluates the gathered 50 synthetic clips."""
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VD_BENCH_ONE_DEVICE="1")
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None)
     args = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--sustain-seconds", "0", "--no-extra-legs", "--eval-epochs", "1",
             "--eval-seeds", "1"]
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
-                          "127.0.0.1", "--master-port", "29581", "bench.py", "--gpus", "8"] + args,
-                         cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    # NO launcher in front: bench.py starts its eight ranks itself (spawn_ranks) and relays rank 0's line
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "8"] + args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    got = json.loads(lines[-1])
     one = _bench(args)
     assert got["n_gpus"] == 8 and got["config"]["parallelism"].startswith("hybrid x8") and one["n_gpus"] == 1
+    assert got["ranks_seen"] == 8 and got["launched_by"] == "bench.py spawn_ranks" and one["ranks_seen"] == 1
+    assert got["clips_per_step"] == [400] * 8 and one["clips_per_step"] == [3200]          # 6 whole classes + 1/8 of two = 400 per rank
     c = got["collectives"]
     assert c["backend"] == "gloo" and c["all_reduce"] == 3 * 2 and c["all_gather"] == 1, c      # per step: split-class feature sums + loss
     assert abs(got["loss_last"] / one["loss_last"] - 1) < 1e-5, (got["loss_last"], one["loss_last"])

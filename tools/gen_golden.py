@@ -695,6 +695,52 @@ def g15():
     npz("g15_frame_datasets.npz", **out)
 
 
+def g16(networks, utils):
+    """The metric's accuracy half at the benchmark's scale: the REFERENCE's evaluate_synset (utils.py:848-886, imported) on the
+    learnable 50-class problem of tests/synth_problem.py -- C=50, IPC=1, 64x64x8, epoch_eval_train=100, five fixed network
+    seeds -- once with dropout off (the HIP run can follow it epoch by epoch: same initial weights, same data, the batch is
+    the whole set) and once with the reference's dropout 0.5 (masks come from the CPU generator here and from the device
+    generator on the HIP path: comparable only statistically).  Records every epoch's training loss / accuracy and the final
+    3-pass test accuracy per seed."""
+    sys.path.insert(0, os.path.dirname(OUT.rstrip("/")).rsplit("/tests", 1)[0])
+    from tests.synth_problem import template_problem, checksum
+    C, T, S, epochs, seeds = 50, 8, 64, 100, [1000, 1001, 1002, 1003, 1004]
+    noise_test = float(os.environ.get("VD_G16_NOISE_TEST", "7.0"))
+    train_x, train_y, test_x, test_y = template_problem(C, T, S, n_test=8, noise_train=1.0, noise_test=noise_test)
+    args = _Args()
+    args.device = 'cpu'; args.lr_net = 0.01; args.epoch_eval_train = epochs; args.batch_train = 256
+    args.model = 'ConvNet3D'; args.eval_mode = 'SS'
+    testloader = torch.utils.data.DataLoader(utils.TensorDataset(test_x, test_y), batch_size=64, shuffle=False)
+    out = {}
+    orig_epoch = utils.epoch
+    for tag, p_drop in (("p0", 0.0), ("p5", 0.5)):
+        curves, accs, tests, tlosses, ws = [], [], [], [], []
+        for sd in seeds:
+            net = make_net(networks, sd, C, S, T)
+            net.dropout.p = p_drop
+            torch.manual_seed(sd + 7); random.seed(sd + 7); np.random.seed(sd + 7)
+            rec = []
+
+            def spy(mode, loader, net_, opt, crit, a):
+                o = orig_epoch(mode, loader, net_, opt, crit, a)
+                rec.append((mode, o[0], o[1]))
+                return o
+            utils.epoch = spy
+            try:
+                net_out, acc_train, acc_test, _ = utils.evaluate_synset(0, net, train_x, train_y, testloader, args, mode='none')
+            finally:
+                utils.epoch = orig_epoch
+            tr = [(l, a) for m, l, a in rec if m == 'train']
+            te = [(l, a) for m, l, a in rec if m == 'test']
+            curves.append([t[0] for t in tr]); accs.append([t[1] for t in tr]); tests.append(acc_test); tlosses.append(te[-1][0])
+            ws.append(net_out.logit.weight.detach().reshape(C, -1)[:4, :8].numpy().copy())
+            print("g16 %s seed %d: loss %.4f -> %.4f, train acc %.2f, test top-1 %.3f" % (tag, sd, tr[0][0], tr[-1][0], acc_train, acc_test))
+        out.update({tag + "_train_loss": np.array(curves), tag + "_train_acc": np.array(accs), tag + "_test_acc": np.array(tests),
+                    tag + "_test_loss": np.array(tlosses), tag + "_logit_w": np.array(ws)})
+    npz("g16_eval_c50.npz", C=C, T=T, S=S, epochs=epochs, seeds=np.array(seeds), lr_net=0.01, n_test=8, noise_train=1.0,
+        noise_test=noise_test, problem_seed=1606, train_checksum=np.array(checksum(train_x)), test_checksum=np.array(checksum(test_x)), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -703,7 +749,8 @@ def main():
     for name, fn in (("g1", lambda: g1(networks)), ("g2", lambda: g2_g3(networks)), ("g4", lambda: g4_g5(networks, utils)),
                      ("g6", lambda: g6(networks, utils)), ("g7", lambda: g7(networks, utils)),
                      ("g9", lambda: g9(networks, utils)), ("g10", lambda: g10(networks, utils)),
-                     ("g11", lambda: g11(networks, utils)), ("g12", lambda: g12(networks)), ("g13", lambda: g13(networks, utils)), ("g14", lambda: g14(networks, utils)), ("g15", g15)):
+                     ("g11", lambda: g11(networks, utils)), ("g12", lambda: g12(networks)), ("g13", lambda: g13(networks, utils)), ("g14", lambda: g14(networks, utils)), ("g15", g15),
+                     ("g16", lambda: g16(networks, utils))):
         if not only or name in only:
             fn()
 

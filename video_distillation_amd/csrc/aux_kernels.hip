@@ -1270,7 +1270,7 @@ extern "C" int vd_bias_grad(const void* dy, int64_t dy_plane_slots, int planes, 
 // byte is clear.  Reads 4-8x fewer bytes than summing the dense dy slots (vd_bias_grad).
 __global__ __launch_bounds__(256) void bias_grad_pooled_kernel(const float* __restrict__ g, const uint8_t* __restrict__ amax,
                                                                 int C, int64_t npos, int g_layout, int pos_per_block,
-                                                                float* __restrict__ db) {
+                                                                float* __restrict__ db, int partial) {
     __shared__ float red[256];
     const int64_t clip = blockIdx.x;
     const int n = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C;
@@ -1288,8 +1288,20 @@ __global__ __launch_bounds__(256) void bias_grad_pooled_kernel(const float* __re
     __syncthreads();
     if (pl == 0) {
         for (int k = 1; k < npl; ++k) acc += red[k * C + n];
-        atomicAdd(&db[n], acc);
+        if (partial) db[((int64_t)clip * gridDim.y + blockIdx.y) * C + n] = acc;     // ordered mode: one slot per workgroup, folded below
+        else atomicAdd(&db[n], acc);
     }
+}
+
+// Ordered mode (vd_*_ordered, DESIGN 8b "deterministic training step"): the workgroups' partial sums, one row of C floats per
+// (clip, position block), are folded in index order by ONE thread per channel -- a fixed summation order, so the result is
+// bitwise reproducible where the atomic form's last bits depend on the order the workgroups retire in.
+__global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict__ part, int64_t nrows, int C, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= C) return;
+    float acc = 0.f;
+    for (int64_t r = 0; r < nrows; ++r) acc += part[r * C + n];
+    out[n] += acc;
 }
 
 extern "C" int vd_bias_grad_pooled(const float* g, const uint8_t* argmax, int64_t nclips, int C, int64_t npos, int g_layout,
@@ -1299,7 +1311,28 @@ extern "C" int vd_bias_grad_pooled(const float* g, const uint8_t* argmax, int64_
     const int ppb = 256;
     const unsigned gy = (unsigned)((npos + ppb - 1) / ppb);
     hipLaunchKernelGGL(bias_grad_pooled_kernel, dim3((unsigned)nclips, gy), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g,
-                       argmax, C, npos, g_layout, ppb, db);
+                       argmax, C, npos, g_layout, ppb, db, 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int64_t vd_bias_grad_pooled_scratch_floats(int64_t nclips, int C, int64_t npos) {
+    if (nclips <= 0 || npos <= 0 || C <= 0) return 0;
+    return nclips * ((npos + 255) / 256) * C;
+}
+
+// vd_bias_grad_pooled with a FIXED summation order: partial sums per (clip, block of 256 positions) into `scratch`
+// (vd_bias_grad_pooled_scratch_floats floats, caller-owned), then folded in index order and added to db.
+extern "C" int vd_bias_grad_pooled_ordered(const float* g, const uint8_t* argmax, int64_t nclips, int C, int64_t npos, int g_layout,
+                                           float* scratch, float* db, void* stream) {
+    if (C <= 0 || C > 256 || 256 % C != 0 || C % 8 != 0 || nclips > 0x7fffffff) return -2;
+    if (nclips <= 0 || npos <= 0) return 0;
+    if (scratch == nullptr || db == nullptr) return -1;
+    const int ppb = 256;
+    const unsigned gy = (unsigned)((npos + ppb - 1) / ppb);
+    hipLaunchKernelGGL(bias_grad_pooled_kernel, dim3((unsigned)nclips, gy), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g,
+                       argmax, C, npos, g_layout, ppb, scratch, 1);
+    hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), scratch,
+                       nclips * (int64_t)gy, C, db);
     return (int)hipGetLastError();
 }
 
@@ -1408,11 +1441,13 @@ __global__ __launch_bounds__(256) void head_train_bwd_kernel(const float* __rest
         if (mask != nullptr) a *= mask[((int64_t)clip * C + c) * Tp + t];
         dp[t * C + c] = a;
     }
-    for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
-        const int c = i % C, k = i / C;
-        atomicAdd(&g_w[i], dl[k] * dropped[((int64_t)clip * Tp + am[k]) * C + c]);
+    if (g_w != nullptr) {               // (NULL in the ordered mode: head_param_grad_ordered_kernel computes both)
+        for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+            const int c = i % C, k = i / C;
+            atomicAdd(&g_w[i], dl[k] * dropped[((int64_t)clip * Tp + am[k]) * C + c]);
+        }
+        for (int k = threadIdx.x; k < K; k += blockDim.x) atomicAdd(&g_b[k], dl[k]);
     }
-    for (int k = threadIdx.x; k < K; k += blockDim.x) atomicAdd(&g_b[k], dl[k]);
     __syncthreads();
     const float inv = 1.f / (float)(kt * kh * kw);
     float* gf = g_feats + (int64_t)clip * C * To * Ho * Wo;
@@ -1424,6 +1459,44 @@ __global__ __launch_bounds__(256) void head_train_bwd_kernel(const float* __rest
         (void)x; (void)y;
         gf[i] = a * inv;
     }
+}
+
+// Ordered mode of the logit conv's parameter gradients: a gather instead of a scatter -- one thread per (class k, channel c)
+// walks the clips in index order,  g_w[k][c] += sum_clip dl[clip][k] * dropped[clip][amax_t[clip][k]][c];  threads with c == C
+// do the bias,  g_b[k] += sum_clip dl[clip][k].  No atomics, fixed order: bitwise reproducible.
+__global__ __launch_bounds__(256) void head_param_grad_ordered_kernel(const float* __restrict__ dlogits, const int32_t* __restrict__ amax_t,
+                                                                       const float* __restrict__ dropped, int64_t nclips, int C, int Tp,
+                                                                       int K, float* __restrict__ g_w, float* __restrict__ g_b) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)K * (C + 1)) return;
+    const int k = (int)(i / (C + 1)), c = (int)(i % (C + 1));
+    float acc = 0.f;
+    if (c == C) {
+        for (int64_t clip = 0; clip < nclips; ++clip) acc += dlogits[clip * K + k];
+        g_b[k] += acc;
+    } else {
+        for (int64_t clip = 0; clip < nclips; ++clip)
+            acc += dlogits[clip * K + k] * dropped[(clip * Tp + amax_t[clip * K + k]) * C + c];
+        g_w[(int64_t)k * C + c] += acc;
+    }
+}
+
+// vd_head_train_bwd with the parameter gradients summed over the clips in a fixed order (no atomics); same arguments.
+extern "C" int vd_head_train_bwd_ordered(const float* dlogits, const int32_t* amax_t, const float* dropped, const float* mask,
+                                         const float* w, int64_t nclips, int C, int To, int Ho, int Wo, int kt, int kh, int kw, int K,
+                                         float* g_w, float* g_b, float* g_feats, void* stream) {
+    if (nclips <= 0) return 0;
+    if (Ho - kh + 1 != 1 || Wo - kw + 1 != 1 || To - kt + 1 < 1) return -2;
+    if (g_w == nullptr || g_b == nullptr) return -1;
+    const int Tp = To - kt + 1;
+    const size_t lds = (size_t)Tp * C * sizeof(float);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(head_train_bwd_kernel, dim3((unsigned)nclips), dim3(256), lds, st, dlogits, amax_t, dropped, mask, w, C, To, Ho,
+                       Wo, kt, kh, kw, K, (float*)nullptr, (float*)nullptr, g_feats);
+    const int64_t n = (int64_t)K * (C + 1);
+    hipLaunchKernelGGL(head_param_grad_ordered_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dlogits, amax_t, dropped,
+                       nclips, C, Tp, K, g_w, g_b);
+    return (int)hipGetLastError();
 }
 
 extern "C" int vd_head_train_bwd(const float* dlogits, const int32_t* amax_t, const float* dropped, const float* mask,
@@ -1614,6 +1687,49 @@ __global__ void standardize_kernel(const float* __restrict__ x, int64_t n, const
     const float m = (float)mean, inv = (float)(1.0 / sqrt(var));
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (x[i] - m) * inv;
+}
+
+// Ordered mode: every block writes its two partial sums to its own slot; every block of the second kernel folds the slots in
+// the same fixed order (lane-strided, then a fixed shuffle tree), so mean and std do not depend on the order blocks retire in.
+__global__ void sum_sumsq_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
+    __shared__ float red[16];
+    float s = 0.f, q = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        s += v; q += v * v;
+    }
+    const float ts = block_sum(s, red);
+    const float tq = block_sum(q, red);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = (double)ts; part[2 * blockIdx.x + 1] = (double)tq; }
+}
+
+__global__ void standardize_ordered_kernel(const float* __restrict__ x, int64_t n, const double* __restrict__ part, int nparts,
+                                           float* __restrict__ out) {
+    __shared__ double tot[2];
+    if (threadIdx.x < 64) {
+        double s = 0.0, q = 0.0;
+        for (int b = threadIdx.x; b < nparts; b += 64) { s += part[2 * b]; q += part[2 * b + 1]; }
+        for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+        if (threadIdx.x == 0) { tot[0] = s; tot[1] = q; }
+    }
+    __syncthreads();
+    const double mean = tot[0] / (double)n;
+    const double var = (tot[1] - (double)n * mean * mean) / (double)(n - 1);
+    const float m = (float)mean, inv = (float)(1.0 / sqrt(var));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (x[i] - m) * inv;
+}
+
+// vd_standardize with a fixed summation order; `scratch` holds VD_STANDARDIZE_ORDERED_SCRATCH (4096) doubles, caller-owned.
+extern "C" int vd_standardize_ordered(const float* x, int64_t n, double* scratch, float* out, void* stream) {
+    if (n < 2) return -2;
+    if (x == nullptr || scratch == nullptr || out == nullptr) return -1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sum_sumsq_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, scratch);
+    hipLaunchKernelGGL(standardize_ordered_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, scratch, (int)blocks, out);
+    return (int)hipGetLastError();
 }
 
 extern "C" int vd_standardize(const float* x, int64_t n, double* scratch2, float* out, void* stream) {

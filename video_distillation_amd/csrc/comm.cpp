@@ -28,6 +28,8 @@ struct Rccl {
     int (*CommDestroy)(void* comm) = nullptr;
     int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, void* stream) = nullptr;
     int (*AllGather)(const void* send, void* recv, size_t sendcount, int dtype, void* comm, void* stream) = nullptr;
+    int (*GetVersion)(int* version) = nullptr;        // optional
+    int (*CommCount)(void* comm, int* count) = nullptr;      // optional: the communicator's own idea of its size
     bool ok = false;
 };
 
@@ -47,6 +49,8 @@ void load_rccl() {
     *(void**)&g_rccl.CommDestroy = dlsym(g_rccl.lib, "ncclCommDestroy");
     *(void**)&g_rccl.AllReduce = dlsym(g_rccl.lib, "ncclAllReduce");
     *(void**)&g_rccl.AllGather = dlsym(g_rccl.lib, "ncclAllGather");
+    *(void**)&g_rccl.GetVersion = dlsym(g_rccl.lib, "ncclGetVersion");
+    *(void**)&g_rccl.CommCount = dlsym(g_rccl.lib, "ncclCommCount");
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.AllGather;
 }
 
@@ -85,7 +89,22 @@ extern "C" int vd_comm_create(const VdCommId* id, int nranks, int rank, VdComm**
     return 0;
 }
 
-extern "C" int vd_comm_size(const VdComm* c) { return c ? c->nranks : -1; }
+// Number of ranks as the RCCL communicator itself reports it (ncclCommCount), not the value passed to vd_comm_create.
+extern "C" int vd_comm_size(const VdComm* c) {
+    if (c == nullptr) return -1;
+    const Rccl* r = rccl();
+    int n = c->nranks;
+    if (r != nullptr && r->CommCount != nullptr && c->comm != nullptr && r->CommCount(c->comm, &n) != 0) return -11;
+    return n;
+}
+
+// RCCL's version code (ncclGetVersion: major * 10000 + minor * 100 + patch for 2.9+).
+extern "C" int vd_comm_version(int* version) {
+    if (version == nullptr) return -1;
+    const Rccl* r = rccl();
+    if (r == nullptr || r->GetVersion == nullptr) return -10;
+    return r->GetVersion(version) == 0 ? 0 : -11;
+}
 extern "C" int vd_comm_rank(const VdComm* c) { return c ? c->rank : -1; }
 
 // recv[i] = sum over ranks of send[i]; send == recv is allowed (in place).  Asynchronous on `stream`.

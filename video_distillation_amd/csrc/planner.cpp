@@ -10,6 +10,7 @@
 //     ds_read_b128 (MI355X LDS lane groups),
 //   * gather table of the patch (LDS-DMA source offsets), tap offsets, output offsets, weight gather index.
 // Geometry: Conv3d k(3,7,7) s(1,2,2) p(1,3,3) -> ReLU -> MaxPool3d (reference networks.py:792-814).
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -699,7 +700,9 @@ void plan_wgrad_block(int cin, int cout, int t_in, int h_in, int w_in, int nclip
     pl.types.push_back(best);
     for (int t0 = 0; t0 < T; t0 += nt) for (int oh0 = 0; oh0 < OH; oh0 += noh) for (int ow0 = 0; ow0 < OW; ow0 += now)
         pl.boxes.push_back({0, (int64_t)t0 - 1, (int64_t)2 * oh0 - 3, (int64_t)2 * ow0 - 3, 0, 0});
-    const int replicas = std::max(1, std::min(16, pl.nbox() / 28));
+    // (ordered mode, vd_set_deterministic: every box gets its OWN copy -- an atomic add onto a zeroed float with a single
+    //  contributor is exact, so the only summation left is vd_replica_sum's fixed-order fold over the copies)
+    const int replicas = vd_get_deterministic() ? pl.nbox() : std::max(1, std::min(16, pl.nbox() / 28));
     for (int bi = 0; bi < pl.nbox(); ++bi) pl.boxes[bi][5] = bi % replicas;
     pl.CC = CCb; pl.F = t_in; pl.H = h_in; pl.W = w_in; pl.row_pitch4 = w_in * 4; pl.w_step4 = 4;
     pl.chunk_stride4 = (int64_t)t_in * h_in * w_in * 4; pl.clip_stride4 = (int64_t)CCb * t_in * h_in * w_in * 4;
@@ -873,3 +876,22 @@ extern "C" int vd_program_build_wgrad(int layer, int frames, int height, int wid
 }
 
 extern "C" void vd_blob_free(void* blob) { free(blob); }
+
+// Process-wide switch of the accumulation order (include/vd_hip.h): initial value from the environment (VD_DETERMINISTIC=1).
+namespace {
+std::atomic<int> g_deterministic{-1};
+}
+extern "C" int vd_get_deterministic(void) {
+    int v = g_deterministic.load();
+    if (v < 0) {
+        const char* e = getenv("VD_DETERMINISTIC");
+        v = (e != nullptr && e[0] == '1') ? 1 : 0;
+        g_deterministic.store(v);
+    }
+    return v;
+}
+extern "C" int vd_set_deterministic(int on) {
+    const int prev = vd_get_deterministic();
+    g_deterministic.store(on ? 1 : 0);
+    return prev;
+}

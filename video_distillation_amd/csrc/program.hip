@@ -365,6 +365,7 @@ struct VdTrain {
     int block[3][3], replicas[3];
     int K, kt, kh, kw, Tp;
     int64_t nclips;
+    int ordered;          // vd_get_deterministic() when the handle was created: fixed-order accumulation everywhere
 };
 
 static int64_t a256(int64_t n) { return (n + 255) & ~(int64_t)255; }
@@ -386,6 +387,7 @@ extern "C" int vd_train_create(int frames, int height, int width, int num_classe
     int hint = 1;
     while (hint < nclips && hint < 512) hint *= 2;
     int rc = vd_embed_create_ex(frames, height, width, prec, prec_bwd, nclips > 512 ? 0 : hint, &t->e);
+    t->ordered = vd_get_deterministic();      // (vd_program_build_wgrad below reads the same switch: one copy per box)
     for (int l = 0; rc == 0 && l < 3; ++l) {
         void* blob = nullptr;
         int64_t n = 0;
@@ -401,7 +403,7 @@ extern "C" int vd_train_create(int frames, int height, int width, int num_classe
 }
 
 struct TrainLayout {      // byte offsets into the caller's workspace
-    int64_t fwd, argmax, bwd, xT, bp, copies, feats, g_feat, dropped, logits, amt, loss, dlog, grads, scale, total;
+    int64_t fwd, argmax, bwd, xT, bp, copies, feats, g_feat, dropped, logits, amt, loss, dlog, grads, scale, bias_part, total;
     int64_t gofs[8], gsz[8];
 };
 
@@ -433,6 +435,12 @@ static TrainLayout train_layout(const VdTrain* t) {
     L.grads = o;
     for (int i = 0; i < 8; ++i) { L.gsz[i] = sizes[i]; L.gofs[i] = take(sizes[i] * 4); }
     L.scale = take(16 * 4);
+    int64_t part = 0;       // ordered mode: the bias gradients' per-workgroup partial sums
+    for (int l = 0; t->ordered && l < 3; ++l) {
+        const int* d = e->dims[l];
+        part = std::max<int64_t>(part, vd_bias_grad_pooled_scratch_floats(B, d[1], (int64_t)d[8] * d[9] * d[10]) * 4);
+    }
+    L.bias_part = take(part);
     L.total = o + 256;    // room for rounding an arbitrary caller pointer up to the next 256-byte boundary
     return L;
 }
@@ -473,8 +481,8 @@ extern "C" int vd_train_step(VdTrain* t, float* const* params, float* const* mom
     if (rc == 0) rc = vd_ce_loss(logits, labels, (int)B, t->K, loss_c, dlog, stream);
     if (rc) return rc;
     if (hipMemsetAsync(ws + L.grads, 0, (size_t)(L.scale - L.grads), st) != hipSuccess) return -9;
-    rc = vd_head_train_bwd(dlog, amt, dropped, dropout_mask, params[6], B, d2[1], d2[8], d2[9], d2[10], t->kt, t->kh, t->kw, t->K,
-                           g[6], g[7], g_feat, stream);
+    rc = (t->ordered ? vd_head_train_bwd_ordered : vd_head_train_bwd)(dlog, amt, dropped, dropout_mask, params[6], B, d2[1], d2[8], d2[9],
+                                                                      d2[10], t->kt, t->kh, t->kw, t->K, g[6], g[7], g_feat, stream);
     if (rc) return rc;
     // kept activations and arg-max bytes: the layout of embed_forward_impl
     const int64_t n0 = B * e->slots0_per_clip, n1 = B * e->slots1_per_clip, n2 = B * e->slots2_per_clip;
@@ -518,7 +526,10 @@ extern "C" int vd_train_step(VdTrain* t, float* const* params, float* const* mom
                                     e->planes_bwd == 2 ? dy + nslots * 16 : nullptr, e->prec_bwd, sc, stream);
             if (rc) return rc;
         }
-        if ((rc = vd_bias_grad_pooled(grad, am[l], B, cout, (int64_t)d[8] * d[9] * d[10], layout, g[2 * l + 1], stream))) return rc;
+        if (t->ordered) rc = vd_bias_grad_pooled_ordered(grad, am[l], B, cout, (int64_t)d[8] * d[9] * d[10], layout,
+                                                         reinterpret_cast<float*>(ws + L.bias_part), g[2 * l + 1], stream);
+        else rc = vd_bias_grad_pooled(grad, am[l], B, cout, (int64_t)d[8] * d[9] * d[10], layout, g[2 * l + 1], stream);
+        if (rc) return rc;
         // weight gradient: x clip-minor, dy packed straight from the pooled gradient, boxes accumulate into copies
         const int64_t xT_plane = (int64_t)cin * CCb * npos_in;
         if (l == 0) rc = vd_clip_minor_pix(clips, B, d[2], d[3], d[4], xT, e->planes_bwd == 2 ? xT + xT_plane * 16 : nullptr, e->prec_bwd, stream);

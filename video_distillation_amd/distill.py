@@ -395,8 +395,17 @@ class DMTrainer:
 
     def __init__(self, backend, pool: RealPool, num_classes: int, ipc: int, batch_real: int, lr_img: float,
                  momentum: float = 0.5, rank: int = 0, world: int = 1, image_syn: Optional[torch.Tensor] = None,
-                 shard: str = "class"):
-        """``shard='class'``: a rank embeds the whole real batch of its own classes (no data-path
+                 shard: str = "class", exchange: str = "owner", comm=None):
+        """``exchange``: what happens to the pixel gradients of a step.  ``'owner'`` (default): a rank owns the synthetic clips
+        and momentum of its classes, so nothing is exchanged (owner-computes).  ``'allreduce'``: the literal form of the
+        task's "all-reduce of the matching-loss gradient" -- every rank scatters its rows into the FULL (C * ipc, T, 3, H, W)
+        gradient tensor (zeros elsewhere; 120 MB at C = 50, 112 x 112 x 16), the tensor is sum-all-reduced (``comm``: a
+        ``hip.Comm`` = RCCL through vd_comm_allreduce_f32 on the synthetic-clip stream; without one, torch.distributed's
+        group) and the rank updates its rows from the reduced tensor -- the same update (the other ranks contribute zeros to
+        a rank's rows), at the price of the exchange, which ``exchange_ms`` records per step (HIP events around the call).
+        That is the tensor distill_baseline.py:353-355 would step on after nn.DataParallel's gather.
+
+        ``shard='class'``: a rank embeds the whole real batch of its own classes (no data-path
         collective).  ``shard='batch'``: every rank embeds 1/world of EVERY class's real batch and
         the per-class feature sums (C x D fp32, 410 KB) are all-reduced; the synthetic clips stay
         class-owned.  The latter balances 50 classes over 8 ranks exactly (6.25 class-equivalents
@@ -426,6 +435,37 @@ class DMTrainer:
         self.image_syn = image_syn.contiguous()
         self.buf = torch.zeros_like(self.image_syn)
         self.steps_done = 0
+        assert exchange in ("owner", "allreduce")
+        self.exchange, self.comm = exchange, comm
+        self.exchange_events: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        self._g_full = None
+
+    def _allreduce_pixel_grad(self, grad: torch.Tensor) -> torch.Tensor:
+        """``exchange='allreduce'``: this rank's gradient rows through the all-reduced full tensor (see ``__init__``)."""
+        if self._g_full is None:
+            self._g_full = torch.empty((self.num_classes * self.ipc,) + tuple(grad.shape[1:]), dtype=grad.dtype, device=grad.device)
+            own = self.owned_classes()
+            self._g_rows = (torch.as_tensor(own, device=grad.device, dtype=torch.int64).view(-1, 1) * self.ipc
+                            + torch.arange(self.ipc, device=grad.device)).view(-1)
+        full = self._g_full
+        full.zero_()
+        full.index_copy_(0, self._g_rows, grad)
+        timed = full.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if self.comm is not None:
+            COLLECTIVE_CALLS["all_reduce"] += 1
+            COLLECTIVE_CALLS["bytes"] += full.numel() * full.element_size()
+            self.comm.all_reduce(full)
+        else:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                _all_reduce(full)
+        if timed:
+            e1.record()
+            self.exchange_events.append((e0, e1))
+        return full.index_select(0, self._g_rows)
 
     def owned_classes(self, rank: Optional[int] = None) -> List[int]:
         """Classes whose synthetic clips ``rank`` (default: this rank) owns, in the order of its ``image_syn`` rows."""
@@ -475,6 +515,8 @@ class DMTrainer:
                 f_real = self._exchange(f_real)      # (batch sharding) on the synthetic-clip stream: the real-clip stream is
                 loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)     # free to start the next iteration's forward meanwhile
                 grad = be.embed_backward(handle, g_syn)
+                if self.exchange == "allreduce":
+                    grad = self._allreduce_pixel_grad(grad)
                 be.sgd(self.image_syn, self.buf, grad, self.lr_img, self.momentum, first=(self.steps_done == 0))
                 loss = loss_c.sum()
             if not overlap:
@@ -489,6 +531,8 @@ class DMTrainer:
         f_syn, handle = be.embed_syn(self.image_syn, weights) if hasattr(be, "embed_syn") else be.embed_keep(self.image_syn)
         loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
         grad = be.embed_backward(handle, g_syn)
+        if self.exchange == "allreduce":
+            grad = self._allreduce_pixel_grad(grad)
         be.sgd(self.image_syn, self.buf, grad, self.lr_img, self.momentum, first=(self.steps_done == 0))
         self.steps_done += 1
         return loss_c.sum()

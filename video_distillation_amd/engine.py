@@ -503,14 +503,16 @@ class WgradOp:
     program of the MFMA kernel (plan.plan_wgrad): x is re-laid out clip-minor, dy is packed into
     per-box B fragments, boxes of positions accumulate into dW with fp32 atomics."""
 
-    def __init__(self, cin: int, cout: int, t: int, h: int, w: int, nclips: int, prec: str, device):
+    def __init__(self, cin: int, cout: int, t: int, h: int, w: int, nclips: int, prec: str, device, ordered: bool = False):
+        """``ordered``: one accumulation copy per box, folded in index order (plan.plan_wgrad; bitwise reproducible)."""
         self.cin, self.cout, self.t, self.h, self.w, self.nclips = cin, cout, t, h, w, nclips
+        self.ordered = bool(ordered)
         self.prec = hip.PREC[prec]
         self.planes = 2 if hip.is_x3(self.prec) else 1
         self.device = torch.device(device)
         blk = os.environ.get("VD_WG_BLOCK")
         self.plan = P.plan_wgrad("wgrad%dx%d" % (cin, cout), cin, cout, t, h, w, nclips, block=tuple(int(v) for v in blk.split(",")) if blk else None,
-                                 planes=self.planes)
+                                 planes=self.planes, ordered=self.ordered)
         self.dp = _DevPlan(self.plan, self.device, self.prec)
         self.T, self.OH, self.OW = self.plan.meta["grid"]
         self.CCb = self.plan.CC

@@ -24,8 +24,10 @@ EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv_mfma_multi", "vd_conv0_per
            "vd_sgd_momentum_wd", "vd_frames_normalize", "vd_replica_sum", "vd_pack_weights_dither", "vd_unpool_relu_bwd_packed", "vd_mfma_peak", "vd_program_build", "vd_program_build_dgrad", "vd_program_build_wgrad", "vd_program_run_wgrad", "vd_train_create", "vd_train_workspace_bytes", "vd_train_step", "vd_train_free", "vd_blob_free", "vd_embed_create", "vd_embed_create_ex", "vd_embed_argmax_bytes", "vd_embed_backward_workspace_bytes",
            "vd_embed_forward_keep", "vd_embed_backward", "vd_program_run_scaled", "vd_embed_num_features",
            "vd_embed_workspace_bytes", "vd_embed_set_weights", "vd_embed_forward", "vd_embed_free",
-           "vd_comm_unique_id", "vd_comm_create", "vd_comm_size", "vd_comm_rank", "vd_comm_allreduce_f32", "vd_comm_allgather_f32",
-           "vd_comm_free")
+           "vd_comm_unique_id", "vd_comm_create", "vd_comm_size", "vd_comm_version", "vd_comm_rank", "vd_comm_allreduce_f32", "vd_comm_allgather_f32",
+           "vd_comm_free",
+           "vd_bias_grad_pooled_scratch_floats", "vd_bias_grad_pooled_ordered", "vd_standardize_ordered", "vd_head_train_bwd_ordered",
+           "vd_set_deterministic", "vd_get_deterministic")
 
 
 class VdConvParams(ctypes.Structure):
@@ -68,7 +70,24 @@ def build(force: bool = False, verbose: bool = False, debug_hooks: bool = False)
         if os.path.getmtime(out) >= newest:
             return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + (["-DVD_DBG_HOOKS=1"] if debug_hooks else []) + SOURCES + ["-ldl"]
+    # one object per source (rebuilt only when that source or the header is newer), compiled concurrently, then one link
+    objdir = os.path.join(_HERE, "csrc", "build_dbg" if debug_hooks else "build")
+    os.makedirs(objdir, exist_ok=True)
+    header = os.path.join(_HERE, "..", "include", "vd_hip.h")
+    flags = ["-O3", "--offload-arch=gfx950", "-fPIC"] + (["-DVD_DBG_HOOKS=1"] if debug_hooks else [])
+    jobs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), os.path.getmtime(header)):
+            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -94,13 +113,24 @@ def lib() -> ctypes.CDLL:
                 if "VD_LIB_PATH" in os.environ:      # an older build loaded on purpose for an A/B measurement
                     continue
                 raise RuntimeError("libvd_hip.so does not export %s" % name)
-            getattr(L, name).restype = {"vd_program_info": ctypes.c_int64, "vd_program_free": None, "vd_blob_free": None, "vd_embed_free": None, "vd_train_free": None, "vd_comm_free": None, "vd_train_workspace_bytes": ctypes.c_int64,
+            getattr(L, name).restype = {"vd_program_info": ctypes.c_int64, "vd_program_free": None, "vd_blob_free": None, "vd_embed_free": None, "vd_train_free": None, "vd_comm_free": None, "vd_train_workspace_bytes": ctypes.c_int64, "vd_bias_grad_pooled_scratch_floats": ctypes.c_int64,
                                         "vd_embed_num_features": ctypes.c_int64, "vd_embed_workspace_bytes": ctypes.c_int64,
                                         "vd_embed_argmax_bytes": ctypes.c_int64, "vd_embed_backward_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
         if L.vd_abi_version() != 3:
             raise RuntimeError("libvd_hip.so ABI version mismatch")
         _lib = L
     return _lib
+
+
+def deterministic() -> bool:
+    """Whether accumulations run in a fixed order (bitwise reproducible training step): the library's process-wide
+    switch, initialised from VD_DETERMINISTIC."""
+    return bool(lib().vd_get_deterministic())
+
+
+def set_deterministic(on: bool) -> bool:
+    """Switch the fixed-order accumulation mode; engines / programs created afterwards follow it.  Returns the previous value."""
+    return bool(lib().vd_set_deterministic(int(bool(on))))
 
 
 def stream_ptr(device=None) -> ctypes.c_void_p:
@@ -118,3 +148,41 @@ def ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
 
 def is_x3(prec: int) -> bool:
     return prec >= 2
+
+
+class Comm:
+    """An RCCL communicator behind the C ABI (vd_comm_*, include/vd_hip.h): created over the ranks of the default torch.distributed
+    group (rank 0's 128-byte id travels through ``broadcast_object_list``), collectives issued on the caller's CURRENT HIP stream.
+    Used where the exchange goes through the library's own entry points instead of torch's process group (bench.py's
+    ``--exchange allreduce`` leg and the rccl block of its JSON line)."""
+
+    def __init__(self, rank: int, world: int):
+        import torch.distributed as dist
+        L = lib()
+        ident = (ctypes.c_char * 128)()
+        if rank == 0:
+            check(L.vd_comm_unique_id(ident), "vd_comm_unique_id")
+        if world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (ctypes.c_char * 128).from_buffer_copy(box[0])
+        self._c = ctypes.c_void_p()
+        check(L.vd_comm_create(ident, world, rank, ctypes.byref(self._c)), "vd_comm_create")
+        self.rank, self.world = rank, world
+
+    def size(self) -> int:
+        return int(lib().vd_comm_size(self._c))
+
+    @staticmethod
+    def version() -> Optional[int]:
+        v = ctypes.c_int(0)
+        return int(v.value) if lib().vd_comm_version(ctypes.byref(v)) == 0 else None
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        check(lib().vd_comm_allreduce_f32(self._c, ptr(t), ptr(t), ctypes.c_int64(t.numel()), stream_ptr(t.device)), "vd_comm_allreduce_f32")
+
+    def free(self) -> None:
+        if self._c:
+            lib().vd_comm_free(self._c)
+            self._c = ctypes.c_void_p()

@@ -726,7 +726,18 @@ WGRAD_BLOCKS = ((8, 4, 4), (4, 4, 14), (8, 2, 14), (4, 7, 7), (2, 7, 14), (4, 2,
 
 
 def plan_wgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, nclips: int,
-               lds_budget: int = 3700, block=None, planes: int = 1) -> ConvPlan:
+               lds_budget: int = 3700, block=None, planes: int = 1, ordered: bool = False) -> ConvPlan:
+    """``ordered``: every box of positions accumulates into its OWN copy (replicas = boxes) -- an fp32 atomic add onto a
+    zeroed word with a single contributor is exact, and vd_replica_sum folds the copies in index order: the weight gradient
+    becomes bitwise reproducible (the deterministic training step).  Same boxes, same tile program."""
+    if ordered:
+        import copy
+        base = plan_wgrad(name, cin, cout, t_in, h_in, w_in, nclips, lds_budget, block, planes)
+        pl = copy.copy(base)
+        pl.boxes = base.boxes.copy()
+        pl.boxes[:, 5] = np.arange(pl.boxes.shape[0])
+        pl.meta = dict(base.meta, replicas=int(pl.boxes.shape[0]))
+        return pl
     if block is None:
         # Among the blocks of positions whose patch fits the LDS budget and the DMA-group budget of the workgroup (cout/32
         # waves x 17 groups of 64 slots), the one with the smallest  (K steps incl. the padding of partial blocks) /

@@ -31,6 +31,11 @@ def standardize(x: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("standardize: HIP tensors only (no CPU path)")
     x = x.detach().to(torch.float32).contiguous()
     out = torch.empty_like(x)
+    if hip.deterministic():         # fixed summation order: per-block partial sums, folded identically by every block
+        scratch = torch.empty(4096, dtype=torch.float64, device=x.device)
+        hip.check(hip.lib().vd_standardize_ordered(hip.ptr(x), ctypes.c_int64(x.numel()), hip.ptr(scratch), hip.ptr(out),
+                                                   hip.stream_ptr(x.device)), "vd_standardize_ordered")
+        return out
     scratch = torch.empty(2, dtype=torch.float64, device=x.device)
     hip.check(hip.lib().vd_standardize(hip.ptr(x), ctypes.c_int64(x.numel()), hip.ptr(scratch), hip.ptr(out),
                                        hip.stream_ptr(x.device)), "vd_standardize")
@@ -62,11 +67,12 @@ class TrainEngine:
         self.side_wgrad = False        # set by ConvNet3D.hip_train_step (see feat_backward)
 
     def _wgrad(self, li: int, nb: int) -> WgradOp:
-        op = self._wg.get((li, nb))
+        det = hip.deterministic()
+        op = self._wg.get((li, nb, det))
         if op is None:
             cin, cout, t, h, w = self.eng.dims[li][:5]
-            op = WgradOp(cin, cout, t, h, w, nb, self.prec_bwd_name, self.device)
-            self._wg[(li, nb)] = op
+            op = WgradOp(cin, cout, t, h, w, nb, self.prec_bwd_name, self.device, ordered=det)
+            self._wg[(li, nb, det)] = op
         return op
 
     def grads(self) -> List[torch.Tensor]:
@@ -117,9 +123,10 @@ class TrainEngine:
         B = int(dlog.shape[0])
         kt, kh, kw = self.pool_kernel
         g_feat = torch.empty((B, self.eng.num_feat), dtype=torch.float32, device=self.device)
-        hip.check(L.vd_head_train_bwd(hip.ptr(dlog), hip.ptr(hs["amt"]), hip.ptr(hs["dropped"]), hip.ptr(hs["mask"]),
-                                      hip.ptr(hs["wl"]), ctypes.c_int64(B), self.C, self.To, self.Ho, self.Wo, kt, kh, kw,
-                                      self.K, hip.ptr(g_w), hip.ptr(g_b), hip.ptr(g_feat), st), "vd_head_train_bwd")
+        fn = L.vd_head_train_bwd_ordered if hip.deterministic() else L.vd_head_train_bwd
+        hip.check(fn(hip.ptr(dlog), hip.ptr(hs["amt"]), hip.ptr(hs["dropped"]), hip.ptr(hs["mask"]),
+                     hip.ptr(hs["wl"]), ctypes.c_int64(B), self.C, self.To, self.Ho, self.Wo, kt, kh, kw,
+                     self.K, hip.ptr(g_w), hip.ptr(g_b), hip.ptr(g_feat), st), "vd_head_train_bwd")
         return g_feat
 
     def feat_backward(self, x: torch.Tensor, nb: int, am, g_feat: torch.Tensor, g: Optional[Sequence[torch.Tensor]],
@@ -163,9 +170,16 @@ class TrainEngine:
                     side.wait_stream(main)          # the level's gradient and its scale are queued on the main stream
                 with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                     # bias gradient from the pooled gradient (the dense dy has one non-zero per live pool window)
-                    hip.check(L.vd_bias_grad_pooled(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout,
-                                                    ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(g[2 * li + 1]),
-                                                    hip.stream_ptr(self.device)), "vd_bias_grad_pooled")
+                    if hip.deterministic():
+                        nsc = int(L.vd_bias_grad_pooled_scratch_floats(ctypes.c_int64(nb), cout, ctypes.c_int64(To * Ho * Wo)))
+                        bsc = eng._buf("bias_part%d" % li, (nsc,), torch.float32)
+                        hip.check(L.vd_bias_grad_pooled_ordered(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout,
+                                                                ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(bsc), hip.ptr(g[2 * li + 1]),
+                                                                hip.stream_ptr(self.device)), "vd_bias_grad_pooled_ordered")
+                    else:
+                        hip.check(L.vd_bias_grad_pooled(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout,
+                                                        ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(g[2 * li + 1]),
+                                                        hip.stream_ptr(self.device)), "vd_bias_grad_pooled")
                     op = self._wgrad(li, nb)
                     # pooled gradient -> packed B operand of the weight-gradient program in one pass (4-8x fewer bytes than
                     # re-reading the dense slots, which for the first layer are not even written when nobody else needs them)
