@@ -522,10 +522,13 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
     def step(it):
         return gl(trainer.step(it, overlap=True))
     dt, per_step, prof, losses = h.run(step, trainer.sync, trainer.mark)
-    sustained = h.sustained(step, trainer.sync, args.warmup + args.steps)
+    # the evaluation runs on the synthetic clips as they are after EXACTLY warmup + steps iterations (before the sustained leg,
+    # whose step count is set by the clock): DM steps are free of atomics, the evaluation's training steps run in the fixed-order
+    # mode, so `eval.top1_per_seed` is the same in every run of the same command line
     ev = None
     if args.eval_epochs > 0 and not s2d:
         ev = run_eval(args, trainer, pool, device, rank)
+    sustained = h.sustained(step, trainer.sync, args.warmup + args.steps)
     # Two short extra legs of the same workload, on record next to the headline: the fp32-grade mode (every operand a hi+lo pair)
     # and round 2's fast mode (single pass on every real level and in the input gradient).  Every rank runs them.
     legs = {}

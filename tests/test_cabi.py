@@ -45,6 +45,16 @@ def test_argument_errors_are_reported_before_any_device_call():
     arr = (ctypes.POINTER(hip.VdConvParams) * 2)(ctypes.pointer(a), ctypes.pointer(b))
     assert lib.vd_conv_mfma_multi(arr, 0, None) == -1 and lib.vd_conv_mfma_multi(arr, 5, None) == -1
     assert lib.vd_conv_mfma_multi(arr, 2, None) == -2
+    # a plain and an accumulating (atomic / select) program of the SAME tile shape do not share a launch either: the plain one
+    # would run under the second-order instantiation (header: "all plain or all accumulating; -2 otherwise")
+    c, d = hip.VdConvParams(), hip.VdConvParams()
+    for p in (c, d):
+        p.prec, p.NT, p.MW, p.MTW, p.S, p.CC, p.ncl, p.lds_plane_bytes = 2, 1, 4, 4, 8, 1, 1, 1024
+    d.atomic = 1
+    arr2 = (ctypes.POINTER(hip.VdConvParams) * 2)(ctypes.pointer(c), ctypes.pointer(d))
+    assert lib.vd_conv_mfma_multi(arr2, 2, None) == -2
+    d.atomic, d.select = 0, 1
+    assert lib.vd_conv_mfma_multi(arr2, 2, None) == -2
 
 
 def test_params_struct_layout_matches_header():

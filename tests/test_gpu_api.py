@@ -399,12 +399,19 @@ def test_g12_late_regime_dm_run(golden_dir):
     # shipped; round 2's fast mode (dithered real-side weights only); the two older remedies: value pass, nothing
     ta, tb, tf = trainer("x3"), trainer("mixed"), trainer("fast")
     tv, tc = trainer("fast", dither=False), trainer("fast", dither=False, value_pass=False)
+    # the shipped mode when its real side CANNOT be dithered (fewer than four clips per class, or dithering off): value pass with
+    # the last level kept exact on both sides (the real side's last level runs on the exact hi+lo W2) -- and the round-3 form of
+    # it, which rounded W2 on the synthetic side only, reproduced by making embed_syn believe real_last = x1
+    tw, tw_old = trainer("mixed", dither=False), trainer("mixed", dither=False)
+    assert tw.be.inner.real_last == "x3" and tw.be.inner.eng_real.fwd2x is not None
+    tw_old.be.inner.real_last = "x1"
     assert tv.be.weight_format == "f16" and tc.be.weight_format is None and ta.be.weight_format is None
     assert tb.be.inner.real_last == "x3" and tf.be.inner.real_last == "x1"
     sub = lambda t: t.cpu()[:, ::2, :, ::4, ::4]       # noqa: E731
     orig = D.sample_real_indices
     rec = {"x3_vs_reference": {"loss": [], "grad": []}, "mixed_vs_x3": {"loss": [], "grad": []}, "fast_vs_x3": {"loss": [], "grad": []},
-           "mixed_valuepass_vs_x3": {"loss": [], "grad": []}, "mixed_plain_vs_x3": {"loss": [], "grad": []}}
+           "mixed_valuepass_vs_x3": {"loss": [], "grad": []}, "mixed_plain_vs_x3": {"loss": [], "grad": []},
+           "shipped_valuepass_vs_x3": {"loss": [], "grad": []}, "shipped_valuepass_all_levels_vs_x3": {"loss": [], "grad": []}}
     try:
         for it in range(steps):
             D.sample_real_indices = lambda it_, counts, offsets, b, classes, it=it: np.concatenate(
@@ -414,7 +421,8 @@ def test_g12_late_regime_dm_run(golden_dir):
             ga = ta.buf - mu * state[1] if it > 0 else ta.buf.clone()       # buf = mu*buf + g
             rec["x3_vs_reference"]["loss"].append(abs(la / float(z["losses"][it]) - 1))
             rec["x3_vs_reference"]["grad"].append(_rel(sub(ga), z["grads"][it]))
-            for tr, key in ((tb, "mixed_vs_x3"), (tf, "fast_vs_x3"), (tv, "mixed_valuepass_vs_x3"), (tc, "mixed_plain_vs_x3")):
+            for tr, key in ((tb, "mixed_vs_x3"), (tf, "fast_vs_x3"), (tv, "mixed_valuepass_vs_x3"), (tc, "mixed_plain_vs_x3"),
+                            (tw, "shipped_valuepass_vs_x3"), (tw_old, "shipped_valuepass_all_levels_vs_x3")):
                 tr.image_syn.copy_(state[0]); tr.buf.copy_(state[1]); tr.steps_done = state[2]
                 lt = float(tr.step(it))
                 gt = tr.buf - mu * state[1] if it > 0 else tr.buf.clone()
@@ -425,7 +433,9 @@ def test_g12_late_regime_dm_run(golden_dir):
     rec["feature_diff_over_norm"] = [float(v) for v in z["rel_diff"].mean(1)]
     _record("g12", rec)
     assert tb.be.inner._dither == 8 and tv.be.inner._dither == 0
-    for k in ("x3_vs_reference", "mixed_vs_x3", "fast_vs_x3", "mixed_valuepass_vs_x3", "mixed_plain_vs_x3"):
+    assert tw.be.inner._dither == 0 and tw.be.inner.weight_format == "f16"
+    for k in ("x3_vs_reference", "mixed_vs_x3", "fast_vs_x3", "mixed_valuepass_vs_x3", "mixed_plain_vs_x3", "shipped_valuepass_vs_x3",
+              "shipped_valuepass_all_levels_vs_x3"):
         print("G12 %s: max loss rel %.2e, grad rel-l2 max %.2e median %.2e" % (k, max(rec[k]["loss"]), max(rec[k]["grad"]),
                                                                               float(np.median(rec[k]["grad"]))))
     assert max(rec["x3_vs_reference"]["loss"]) < 1e-3
@@ -437,6 +447,10 @@ def test_g12_late_regime_dm_run(golden_dir):
     assert np.median(rec["fast_vs_x3"]["grad"]) > 1.2 * np.median(rec["mixed_vs_x3"]["grad"])
     assert np.median(rec["mixed_valuepass_vs_x3"]["grad"]) > 1.3 * np.median(rec["fast_vs_x3"]["grad"])
     assert np.median(rec["mixed_plain_vs_x3"]["grad"]) > 1.5 * np.median(rec["mixed_valuepass_vs_x3"]["grad"])
+    # value pass next to a hi+lo last level: rounding W2 on the synthetic side only puts rn16(W2)'s perturbation back into the
+    # difference of the means; keeping the last level exact on both sides must be the better of the two
+    assert np.median(rec["shipped_valuepass_vs_x3"]["grad"]) < 0.9 * np.median(rec["shipped_valuepass_all_levels_vs_x3"]["grad"])
+    assert np.median(rec["shipped_valuepass_vs_x3"]["grad"]) < np.median(rec["mixed_valuepass_vs_x3"]["grad"])
 
 
 def test_two_gpu_bench_matches_single_gpu_loss():

@@ -1891,7 +1891,11 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
         return -2;
     }
     // first-level hi+lo programs (one channel chunk per box, 4 M tiles per wave): the plane-sequential K loop (SQ above)
-    if (p.MTW == 4 && p.CC == 1 && p.ncl == 1 && vd_first_level_seq_enabled()) {
+    // (its LDS holds ONE patch plane; a staged channels-last epilogue stages hi+lo tiles -- 2 * MW * MTW * 4 * sets * NT * 32 * 2
+    //  bytes -- in that plane: a program whose plane is smaller than its staging falls through to the two-plane kernel)
+    const int64_t sq_stage = (p.epi == VD_EPI_POOL_CL && p.argmax == nullptr)
+        ? (int64_t)2 * p.MW * p.MTW * 4 * (p.pool_t == 2 ? 1 : 2) * p.NT * 32 * 2 : 0;
+    if (p.MTW == 4 && p.CC == 1 && p.ncl == 1 && sq_stage <= p.lds_plane_bytes && vd_first_level_seq_enabled()) {
         if (p.prec == VD_PREC_BF16X3) return launch<VD_PREC_BF16X3, 4, false, 1, 0, true>(p, st);
         if (p.prec == VD_PREC_F16X3) return launch<VD_PREC_F16X3, 4, false, 1, 0, true>(p, st);
     }
@@ -1956,8 +1960,11 @@ extern "C" int vd_conv_mfma_multi(const VdConvParams* const* pp, int n, void* st
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const VdConvParams& a = *pp[0];
     bool so = false;
+    const bool so0 = a.atomic || a.select || a.src_split_cc > 0;
     for (int k = 0; k < n; ++k) {
         const VdConvParams& p = *pp[k];
+        // all plain or all accumulating / second-order (include/vd_hip.h): a plain program must not run under the SO instantiation
+        if ((p.atomic || p.select || p.src_split_cc > 0) != so0) return -2;
         // one instantiation, one block shape; the plain layouts only (one N tile per wave, no first-level index, no low-plane output)
         if (p.prec != a.prec || p.MTW != a.MTW || p.NT != a.NT || p.MW != a.MW || (p.NTW != 0 && p.NTW != 1)) return -2;
         const int wgw = p.NT * p.MW;

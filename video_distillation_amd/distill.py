@@ -151,6 +151,8 @@ class HipBackend:
             real_last = os.environ.get("VD_REAL_LAST", "x3")
         assert real_last in ("x1", "x3")
         self.real_last = real_last if prec_real in ("f16", "bf16") else "x1"
+        if prec_syn == prec_real and not prec_bwd:
+            self.real_last = "x1"       # one engine for both sides (kept arg-max forwards): a last_hilo engine has no such forward
         self.eng_real = engine.EmbedEngine(geo, prec=prec_real, device=device, chunk=chunk, last_hilo=(self.real_last == "x3"))
         self.eng_syn = self.eng_real if (prec_syn == prec_real and not prec_bwd) else \
             engine.EmbedEngine(geo, prec=prec_syn, device=device, chunk=chunk, prec_bwd=prec_bwd, batch_hint=syn_batch_hint)
@@ -196,7 +198,9 @@ class HipBackend:
         eng.set_weights(weights)
         feats, handle = eng.forward(x, keep=True)
         if self.weight_format is not None and not self._dither:
-            eng.set_weights(weights, quantize=self.weight_format)
+            # value pass: the levels the (undithered) real side multiplies by plain rn16(W) -- with real_last = x3 its last level
+            # runs on the exact hi+lo W2, so W2 stays exact here as well
+            eng.set_weights(weights, quantize=self.weight_format, quantize_levels=(0, 1) if self.real_last == "x3" else (0, 1, 2))
             feats = eng.forward(x)
         return feats, handle
 

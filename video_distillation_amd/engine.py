@@ -211,7 +211,7 @@ def dither_groups(n: int, prec: str) -> int:
     return g if g >= 4 else 0
 
 
-def round_weights(params: Sequence[torch.Tensor], prec: str) -> List[torch.Tensor]:
+def round_weights(params: Sequence[torch.Tensor], prec: str, levels: Sequence[int] = (0, 1, 2)) -> List[torch.Tensor]:
     """[w0, b0, w1, b1, w2, b2, ...] with every conv WEIGHT replaced by (float) rn16(w) in the operand format
     ``prec`` (biases are added in fp32 and stay as they are).  A mixed-precision step -- real clips single-pass
     f16, synthetic clips hi+lo f16 pairs, f16 input gradient -- that is fed these weights multiplies by the SAME
@@ -220,7 +220,7 @@ def round_weights(params: Sequence[torch.Tensor], prec: str) -> List[torch.Tenso
     distillation converges and the difference of the means shrinks)."""
     out, L = [], hip.lib()
     for i, p in enumerate(params):
-        if i % 2 == 0 and p.dim() == 5 and i < 6:
+        if i % 2 == 0 and p.dim() == 5 and i < 6 and (i // 2) in levels:     # (``levels``: conv levels whose weights are rounded)
             p = p.detach().to(torch.float32).contiguous()
             q = torch.empty_like(p)
             hip.check(L.vd_round_operand(hip.ptr(p), ctypes.c_int64(p.numel()), hip.PREC[prec], hip.ptr(q),
@@ -299,13 +299,16 @@ class EmbedEngine:
             self._ws[name] = t
         return t[:n].view(*shape)
 
-    def set_weights(self, params: Sequence[torch.Tensor], quantize: Optional[str] = None, dither: int = 0) -> None:
+    def set_weights(self, params: Sequence[torch.Tensor], quantize: Optional[str] = None, dither: int = 0,
+                    quantize_levels: Sequence[int] = (0, 1, 2)) -> None:
         """params = [w0, b0, w1, b1, w2, b2] fp32 on the device (ConvNet3D.features order).  ``quantize`` ('f16' /
-        'bf16'): round the three weight tensors to that operand format first (``round_weights``).  ``dither`` = G >= 2
-        (single-pass engines): additionally pack G dithered operand sets, selected by ``forward(..., group=g)``."""
+        'bf16'): round the weight tensors of ``quantize_levels`` to that operand format first (``round_weights``; the value
+        pass rounds exactly the levels the real side multiplies by plain rn16 weights -- not the last one when that runs in
+        hi+lo pairs with exact weights).  ``dither`` = G >= 2 (single-pass engines): additionally pack G dithered operand
+        sets, selected by ``forward(..., group=g)``."""
         ws = [p.detach().to(self.device, torch.float32).contiguous() for p in params[:6]]
         if quantize is not None:
-            ws = round_weights(ws, quantize)
+            ws = round_weights(ws, quantize, quantize_levels)
         self._weights = ws
         for li in range(3):
             if li == 2 and self.fwd2x is not None:      # the last level multiplies by the exact hi+lo weights: nothing to dither

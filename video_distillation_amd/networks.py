@@ -134,7 +134,10 @@ class _EmbedFunction(torch.autograd.Function):
             mode = getattr(net, "real_dither", "auto")
             dithered = (getattr(net, "_real_dithered_key", None) == net._weights_key()) if mode == "auto" else bool(mode)
             if q is not None and not dithered:   # value pass (see distill.HipBackend.weight_format)
-                net._sync_engine(eng, quantize=q)
+                # (the undithered real side still runs its last level on the exact hi+lo weights when real_last = x3: the value
+                #  pass rounds only the levels that side multiplies by rn16(W))
+                real_hilo = _PRECISION["real_last"] == "x3" and _PRECISION["syn"] == _PRECISION["real"] + "x3"
+                net._sync_engine(eng, quantize=q, quantize_levels=(0, 1) if real_hilo else (0, 1, 2))
                 feats = eng.forward(x)
             ctx.saved = saved
             ctx.eng = eng
@@ -369,14 +372,14 @@ class ConvNet3D(nn.Module):
         bump; an in-place edit through ``.data`` (``p.data.mul_(2)``) does NOT bump it -- call this after such an edit."""
         self._pack_epoch = getattr(self, "_pack_epoch", 0) + 1
 
-    def _sync_engine(self, eng, quantize=None, dither: int = 0) -> None:
+    def _sync_engine(self, eng, quantize=None, dither: int = 0, quantize_levels=(0, 1, 2)) -> None:
         # the cached engines outlive nets: remember the owner by a weak reference, not by id() (a new net may be built
         # at a freed net's address, on storage the caching allocator hands out again)
         import weakref
-        key = (self._weights_key(), quantize, dither)
+        key = (self._weights_key(), quantize, dither, tuple(quantize_levels) if quantize else None)
         owner = getattr(eng, "_owner_ref", None)
         if owner is None or owner() is not self or getattr(eng, "_owner_key", None) != key:
-            eng.set_weights(self._feature_params(), quantize=quantize, dither=dither)
+            eng.set_weights(self._feature_params(), quantize=quantize, dither=dither, quantize_levels=quantize_levels)
             eng._owner_key = key
             eng._owner_ref = weakref.ref(self)
 
