@@ -107,15 +107,24 @@ def conv_layer_macs(geo):
 
 
 def pmc_traffic(name, clips_per_launch):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE passes, corrected as
-    MI355X_MICROARCH.md prescribes), rescaled to this run's clips per launch.  A STATIC figure from profiles/, not a
-    measurement of this run -> (bytes or None, source label)."""
-    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
+    runs, corrected as MI355X_MICROARCH.md prescribes).  Round 4's passes ran over tools/run_real_side.py, i.e. over the very
+    launches of one step of THIS benchmark's default configuration (3200 clips per launch, index gather, dithered operand sets,
+    low-plane output): when the run's clips per launch equal the file's, the figure is that measurement unscaled; any other
+    launch size is rescaled and labelled so.  (Counters cannot be read from inside the timed run: rocprofv3 --pmc serialises the
+    kernels.)  -> (bytes or None, source label)."""
+    for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
         if os.path.exists(path):
-            rec = json.load(open(path)).get(name)
+            doc = json.load(open(path))
+            rec = doc.get(name)
             if rec:
-                return rec["hbm_bytes_per_launch"] * clips_per_launch / rec["clips_per_launch"], "profiles/%s (static, rescaled)" % fn
+                src = doc.get("_source", {})
+                same = int(round(clips_per_launch)) == int(rec["clips_per_launch"])
+                label = "profiles/%s: PMC passes over %s at git %s, %d clips per launch%s" % (
+                    fn, src.get("command", "tools/run_l1.py"), src.get("git"), rec["clips_per_launch"],
+                    " = this run's launch shape (measured, unscaled)" if same else "; rescaled to %d" % int(round(clips_per_launch)))
+                return rec["hbm_bytes_per_launch"] * clips_per_launch / rec["clips_per_launch"], label
     return None, None
 
 
@@ -683,11 +692,26 @@ def cpu_baseline_dc(args, trainer, geo, it):
         torch.autograd.grad(loss, xs)
         total += float(loss)
     dt = time.perf_counter() - t0
+    # the same class terms on the HIP path (same weights, clips and labels, dropout off): loss parity of the sample
+    ops = trainer.ops
+    net = ops.make_net([p.detach().to(dev) for p in params], geo, args.classes)
+    net.dropout.p = 0.0
+    for p in net.parameters():
+        p.requires_grad_(True)
+    total_gpu = 0.0
+    for k in range(ncls):
+        c = trainer.classes[k]
+        xr = real[k * args.batch_real:(k + 1) * args.batch_real].to(dev)
+        gw_real = [t.detach() for t in ops.param_grads(net, xr, torch.full((xr.shape[0],), c, dtype=torch.int64, device=dev), False)]
+        xs = trainer.image_syn[k * args.ipc:(k + 1) * args.ipc].detach().clone().requires_grad_(True)
+        gw_syn = ops.param_grads(net, xs, torch.full((args.ipc,), c, dtype=torch.int64, device=dev), True)
+        total_gpu += float(ops.match_loss(gw_syn, gw_real))
     return {"value": 1.0 / (dt / ncls * args.classes), "unit": "steps/s", "cores": threads, "kind": "port",
             "sample": "%d of %d class terms (%d real clips first-order + %d syn clips double backward, %dx%dx%d, dropout off), "
                       "%.1f s, extrapolated x%.1f; threads = fastest of a calibration over 8..%d" % (
                           ncls, args.classes, args.batch_real, args.ipc, args.size, args.size, args.frames, dt,
-                          args.classes / ncls, ncpu)}
+                          args.classes / ncls, ncpu),
+            "loss_cpu_sample": total, "loss_gpu_sample": total_gpu, "loss_rel_err_vs_gpu": abs(total_gpu - total) / abs(total)}
 
 
 def bench_dc(args, h, distill, geo, pool):
@@ -772,10 +796,19 @@ def cpu_baseline_mtt(args, tr, traj, C, s2d):
             R.convnet3d_embed(x[:8], start)
     threads, ncpu = best_threads(probe)
     t0 = time.perf_counter()
-    R.mtt_step(start, target, x, labels, 0.01, [torch.arange(nb)] * steps)
+    grand_cpu, _, _ = R.mtt_step(start, target, x, labels, 0.01, [torch.arange(nb)] * steps)
     dt = time.perf_counter() - t0
     scale = (tr.syn_steps / steps) * (tr.batch_syn / nb)
+    # the same reduced iteration on the HIP path (same clips, labels, expert segment; dropout off): grand-loss parity of the sample
+    from video_distillation_amd import distill, plan
+    ops0 = distill.HipMTTOps(plan.NetGeometry(args.frames, args.size, args.size), C, dev, dropout_p=0.0, batch_hint=nb)
+    tr0 = distill.MTTTrainer(ops0, C, x.to(dev), labels.to(dev), syn_lr=0.01, lr_img=1.0, lr_lr=1e-6, syn_steps=steps, batch_syn=nb,
+                             expert_epochs=1, max_start_epoch=1)
+    grand_gpu = float(tr0.step(0, traj, start_epoch=0, index_chunks=[torch.arange(nb)] * steps, update=False))
+    del tr0, ops0
     return {"value": 1.0 / (dt * scale), "unit": "steps/s", "cores": threads, "kind": "port",
+            "loss_cpu_sample": float(grand_cpu), "loss_gpu_sample": grand_gpu,
+            "loss_rel_err_vs_gpu": abs(grand_gpu - float(grand_cpu)) / abs(float(grand_cpu)),
             "sample": "%d unrolled student steps x %d clips %dx%dx%d (create_graph) + backward of the grand loss, %.1f s, "
                       "extrapolated x%.0f to %d steps x %d clips (hallucinator excluded); threads = fastest of a calibration "
                       "over 8..%d" % (steps, nb, args.size, args.size, args.frames, dt, scale, tr.syn_steps, tr.batch_syn, ncpu)}

@@ -349,8 +349,10 @@ int vd_sgd_momentum_wd(float* x, float* buf, const float* g, int64_t n, float lr
 /* Folds the accumulation copies of a weight-gradient tile program back into the gradient tensor:
  * out[col][row] += sum over r of rep[r][row][col], rep = (replicas, rows = cin*147, cols = cout) fp32, out = dW (cout, cin, 3, 7, 7).
  * The programs accumulate cout-minor (the 32 lanes of an atomic instruction share one 128-byte line) and spread their
- * boxes over the copies (VdConvParams.replica_stride = rows*cols; box row word 5 = the copy). */
-int vd_replica_sum(const float* rep, int replicas, int rows, int cols, float* out, void* stream);
+ * boxes over the copies (VdConvParams.replica_stride = rows*cols; box row word 5 = the copy).  The copies are SCRATCH: more
+ * than 64 of them (the ordered mode's one copy per box) are first folded in place, 32 consecutive copies into the first of
+ * each group, then the group heads -- always in index order, no atomics: the result is bitwise reproducible. */
+int vd_replica_sum(float* rep, int replicas, int rows, int cols, float* out, void* stream);
 
 /* Decoded frames -> clips, the device half of the dataset preload (replaces the per-frame host transform
  * `ToTensor()` + `Normalize(mean, std)` of utils.py:171-173 and the per-step host->device copy of get_images,

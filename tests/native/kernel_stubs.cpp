@@ -189,8 +189,9 @@ extern "C" int vd_clip_minor_cl(const void* src, int64_t src_plane_slots, int pl
     return 0;
 }
 
-extern "C" int vd_replica_sum(const float* rep, int replicas, int rows, int cols, float* out, void*) {
-    rd(rep, (int64_t)replicas * rows * cols * 4); rd(out, (int64_t)rows * cols * 4); wr(out, (int64_t)rows * cols * 4);
+extern "C" int vd_replica_sum(float* rep, int replicas, int rows, int cols, float* out, void*) {
+    rd(rep, (int64_t)replicas * rows * cols * 4); wr(rep, (int64_t)replicas * rows * cols * 4, 0);       // (the copies are scratch: folded in place)
+    rd(out, (int64_t)rows * cols * 4); wr(out, (int64_t)rows * cols * 4);
     return 0;
 }
 

@@ -50,11 +50,14 @@ def test_cpp_planner_argument_errors():
 
 @pytest.mark.skipif(not os.path.exists(LIB), reason="libvd_hip.so not built")
 @pytest.mark.parametrize("dims,hint", [((16, 112, 112), None), ((16, 112, 112), 50), ((8, 64, 64), None), ((8, 64, 64), 8), ((8, 80, 96), 4)])
-def test_cpp_planner_emits_the_python_planner_s_input_gradient_programs(dims, hint):
+def test_cpp_planner_emits_the_python_planner_s_input_gradient_programs(dims, hint, monkeypatch):
+    if hint == 50:       # one combination with the 2 x 2 pixel blocks of rounds 1-3 (both planners read the same switch)
+        monkeypatch.setenv("VD_BWD0_WIDE", "0")
     lib = ctypes.CDLL(LIB)
     lib.vd_blob_free.restype = None
     geo = plan.NetGeometry(*dims)
     net = plan.plan_network(geo, ntw=2, ntw0=1, balanced=True, batch_hint=hint)
+    assert net["bwd"][0][0].meta["block_w"] == (2 if hint == 50 else 4) and net["bwd"][0][0].n_out == (12 if hint == 50 else 24)
     for layer in range(3):
         for cls, pl in enumerate(net["bwd"][layer]):
             want = plan.export_program(pl)

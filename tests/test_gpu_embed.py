@@ -375,3 +375,35 @@ def test_latency_oriented_programs_equal_throughput_programs():
         torch.cuda.synchronize()
         assert outs[0][2] != outs[1][2], "the hint did not change any program"
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_window_form_of_the_dense_unpool_is_bitwise_the_slot_form():
+    """vd_unpool_relu_bwd picks the one-thread-per-pool-window kernel for channels-last gradients on even conv grids with aligned
+    pointers, and the one-thread-per-slot kernel otherwise (here: forced by a gradient pointer that is only 4-byte aligned).
+    Same dense dy slots, both planes, bit for bit -- with and without temporal pooling, incl. ReLU-dead windows."""
+    import ctypes
+    from video_distillation_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(5)
+    for (C, T, OH, OW, pool_t) in ((64, 4, 16, 20, 1), (128, 6, 8, 8, 2)):
+        nb, To, Ho, Wo = 3, T // pool_t, OH // 2, OW // 2
+        npos = To * Ho * Wo
+        gp = torch.randn(nb * npos * C + 1, generator=g).cuda()
+        am = torch.randint(0, 4 * pool_t, (nb * C * npos,), generator=g).to(torch.uint8)
+        am[torch.rand(am.shape, generator=g) < 0.2] |= 0x80                      # ReLU-dead windows route nothing
+        am = am.cuda()
+        scale = torch.tensor([4.0], device="cuda")
+        nslots = nb * (C // 8) * T * OH * OW
+        outs = []
+        for off in (0, 1):               # off = 1: the same values at a 4-byte-aligned address -> slot form
+            src = gp[off:off + nb * npos * C]
+            if off == 1:
+                src.copy_(gp[:nb * npos * C].clone())
+            hi = torch.zeros(nslots, 8, dtype=torch.int16, device="cuda")
+            lo = torch.zeros_like(hi)
+            hip.check(L.vd_unpool_relu_bwd(hip.ptr(src), hip.ptr(am), ctypes.c_int64(nb), C, To, Ho, Wo, pool_t, T, OH, OW, 1, hip.ptr(hi),
+                                           hip.ptr(lo), hip.PREC["f16x3"], hip.ptr(scale), hip.stream_ptr()), "vd_unpool_relu_bwd")
+            outs.append((hi, lo))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert int((outs[0][0] != 0).sum()) > 0

@@ -77,12 +77,18 @@ def test_evaluate_synset_at_fifty_classes_follows_the_reference():
           "60-100 %.1e; first epoch above 1e-3: %d" % (rel[:, :10].max(), rel[:, 10:30].max(), rel[:, 30:60].max(), rel[:, 60:].max(), first))
     print("dropout off: test top-1 per seed HIP %s reference %s (mean %.4f vs %.4f, seed spread sigma %.3f)" % (
         np.round(hip_acc, 4).tolist(), np.round(ref_acc, 4).tolist(), hip_acc.mean(), ref_acc.mean(), ref_acc.std(ddof=1)))
+    # measured (round 4): epochs 0-9 1.3e-4, 10-29 2.7e-3, 30-59 5.8e-2, 60-100 4.9e-2; first epoch above 1e-3: 16
     assert rel[:, :10].max() < 1e-3                  # north_star's 1e-3 on the loss while the trajectories coincide
     assert rel[:, 10:30].max() < 2e-2                # the stated band for the next epochs (chaotic growth of the rounding differences)
+    assert rel[:, 30:].max() < 0.25                  # ... and to the end (losses of 0.007 - 0.035 by then)
     assert all(o[1] == 1.0 for o in out["p0"])       # training accuracy: 1.0 = the reference's
     sigma = float(ref_acc.std(ddof=1))
-    assert abs(hip_acc.mean() - ref_acc.mean()) < 2 * sigma / np.sqrt(len(ref_acc))     # mean top-1: within two standard errors
-    assert np.abs(hip_acc - ref_acc).max() < 2 * sigma                                   # every seed: within the seed spread
+    # the statistical criterion (mean within two standard errors of the reference's seed spread, every seed within 2 sigma) and
+    # the measured one: per seed 0.72 / 0.545 / 0.6175 / 0.7025 / 0.4825 against 0.71 / 0.5225 / 0.6125 / 0.715 / 0.495 --
+    # at most 9 of 400 test clips apart, mean 0.6135 against 0.6110 (0.4 % relative)
+    assert abs(hip_acc.mean() - ref_acc.mean()) < 2 * sigma / np.sqrt(len(ref_acc))
+    assert np.abs(hip_acc - ref_acc).max() < 2 * sigma
+    assert abs(hip_acc.mean() - ref_acc.mean()) < 0.015 and np.abs(hip_acc - ref_acc).max() < 0.05
 
     # ---- dropout 0.5 (the reference's setting): masks come from different generators, so only the statistics compare ----
     ref5, hip5 = z["p5_test_acc"], np.array([o[2] for o in out["p5"]])

@@ -109,6 +109,31 @@ def test_input_gradient_passes(net, acts, li):
     np.testing.assert_allclose(got, want.numpy(), rtol=1e-9, atol=1e-9)
 
 
+def test_first_level_input_gradient_in_2x4_pixel_blocks():
+    """plan_dgrad_pix(bw=4): one GEMM row = a 2 x 4 pixel block (N = 24 of 32 columns, 3 x 4 x 5 = 60 taps) instead of a 2 x 2
+    block (N = 12, 48 taps) -- half the rows for 1.25x the K steps: 0.625 of the MFMA work at 112 x 112.  Both decompositions,
+    full-size and small-box forms, against autograd of the reference's Conv3d (networks.py:757)."""
+    import torch.nn.functional as F
+    cin, cout, t, h, w = 3, 64, 4, 24, 32
+    g = torch.Generator().manual_seed(11)
+    wt = torch.randn(cout, cin, 3, 7, 7, generator=g).double()
+    dy = torch.randn(1, cout, t, (h - 1) // 2 + 1, (w - 1) // 2 + 1, generator=g).double()
+    xin = torch.zeros(1, cin, t, h, w, dtype=torch.double, requires_grad=True)
+    (want,) = torch.autograd.grad(F.conv3d(xin, wt, None, stride=(1, 2, 2), padding=(1, 3, 3)), xin, dy)
+    for bw, n_out, taps in ((2, 12, 48), (4, 24, 60)):
+        for kw in (dict(), dict(lds_budget=1800, mtw_options=(4,))):
+            pl = P.plan_dgrad_pix("bwd0_merged", cin, cout, t, h, w, bw=bw, **kw)
+            assert pl.n_out == n_out and pl.S == taps // 2 and pl.meta["block_w"] == bw
+            out = np.zeros(cin * t * h * w)
+            E.run_plan(pl, bcthw_to_cl(dy.numpy()), wt.numpy().ravel(), None, 1, out)
+            np.testing.assert_allclose(out.reshape(1, t, cin, h, w).transpose(0, 2, 1, 3, 4), want.numpy(), rtol=1e-9, atol=1e-9)
+    full2 = P.plan_dgrad_pix("bwd0_merged", 3, 64, 16, 112, 112, bw=2)
+    full4 = P.plan_dgrad_pix("bwd0_merged", 3, 64, 16, 112, 112, bw=4)
+    work = lambda pl: pl.rows_total * pl.S          # noqa: E731   MFMA tiles x K steps
+    assert work(full4) < 0.7 * work(full2), (work(full4), work(full2))
+    assert P.bwd0_block_w(112) == 4 and P.bwd0_block_w(110) == 2
+
+
 def test_full_resolution_plans_build():
     net = P.plan_network(P.NetGeometry(16, 112, 112))
     f1 = net["fwd"][1]

@@ -14,6 +14,7 @@ buf = torch.zeros_like(syn)
 f_real = torch.randn(C, geo.num_feat, device=dev)
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
     w = be.new_network(seed=it)
+    be._dither = 8          # as after set_real_weights(w, 64): the real side is dithered, so the synthetic clips take ONE forward
     f_syn, handle = be.embed_syn(syn, w)
     loss_c, g_syn = be.dm_loss(f_real, f_syn, C)
     grad = be.embed_backward(handle, g_syn)

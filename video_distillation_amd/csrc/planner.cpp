@@ -537,27 +537,29 @@ bool plan_dgrad(int cin, int cout, int t_in, int h_in, int w_in, int ph, int pw,
     return true;
 }
 
-// plan.plan_dgrad_pix: input gradient of the FIRST layer with the four stride-2 parity classes merged into N
-// (one output row = the 2x2 pixel block (t, 2b..2b+1, 2c..2c+1), columns n = c*4 + ph*2 + pw; K = 48 taps x cout)
-bool plan_dgrad_pix(int cin, int cout, int t_in, int h_in, int w_in, int lds_budget, Plan& pl) {
-    if (cin * 4 > 32 || cout % 8 || h_in % 2 || w_in % 2) return false;
+// plan.plan_dgrad_pix: input gradient of the FIRST layer with the stride-2 parity classes merged into N
+// (one output row = the 2 x bw pixel block (t, 2b..2b+1, bw*c..bw*c+bw-1), columns n = (ci*2 + ph)*bw + pw;
+//  bw = 2: N = 12, K = 48 taps x cout;  bw = 4: N = 24, K = 60 taps x cout, half the rows: 0.625 of the MFMA work)
+bool plan_dgrad_pix(int cin, int cout, int t_in, int h_in, int w_in, int lds_budget, Plan& pl, int bw = 2,
+                    const std::vector<int>& mtw_options = {7, 8}) {
+    if ((bw != 2 && bw != 4) || cin * 2 * bw > 32 || cout % 8 || h_in % 2 || w_in % bw) return false;
     const int CC = cout / 8;
     const int T = conv_out_dim(t_in, KT, 1, 1), OH = conv_out_dim(h_in, KH, 2, 3), OW = conv_out_dim(w_in, KW, 2, 3);
     PlanSpec sp;
     for (int dt = 0; dt < 3; ++dt)
         for (int dh = 0; dh < 4; ++dh)
-            for (int dw = 0; dw < 4; ++dw) sp.taps.push_back({dt, dh, dw});
+            for (int dw = 0; dw < bw / 2 + 3; ++dw) sp.taps.push_back({dt, dh, dw});
     sp.src_grid[0] = T; sp.src_grid[1] = OH; sp.src_grid[2] = OW;
     sp.CC = CC;
-    sp.row_dims[0] = t_in; sp.row_dims[1] = h_in / 2; sp.row_dims[2] = w_in / 2;
+    sp.row_dims[0] = t_in; sp.row_dims[1] = h_in / 2; sp.row_dims[2] = w_in / bw;
     sp.row_origin[0] = sp.row_origin[1] = sp.row_origin[2] = -1;
-    sp.row_stride[0] = sp.row_stride[1] = sp.row_stride[2] = 1;
-    sp.n_out = cin * 4; sp.NT = 1; sp.MW = 4;
-    sp.mtw_options = {7, 8};
+    sp.row_stride[0] = sp.row_stride[1] = 1; sp.row_stride[2] = bw / 2;
+    sp.n_out = cin * 2 * bw; sp.NT = 1; sp.MW = 4;
+    sp.mtw_options = mtw_options;
     sp.ncl_options = {1};
     sp.epi = EPI_ROWS; sp.pool_t = 0; sp.lds_budget = lds_budget; sp.ntw = 1; sp.pooled = false;
     const int64_t clip_stride = (int64_t)t_in * cin * h_in * w_in;
-    sp.out_index = [=](int ci, int a, int b, int c) { return ci * clip_stride + ((int64_t)a * cin * h_in + 2 * b) * w_in + 2 * c; };
+    sp.out_index = [=](int ci, int a, int b, int c) { return ci * clip_stride + ((int64_t)a * cin * h_in + 2 * b) * w_in + bw * c; };
     sp.n_stride = 0; sp.out_clip_stride = clip_stride; sp.out_chunk_stride = 0;
     if (!make_plan(sp, pl)) return false;
     const int S = pl.S, ntaps = (int)sp.taps.size();
@@ -569,7 +571,7 @@ bool plan_dgrad_pix(int cin, int cout, int t_in, int h_in, int w_in, int lds_bud
                 if (p >= ntaps) continue;
                 const int dt = sp.taps[p][0], dh = sp.taps[p][1], dw = sp.taps[p][2];
                 const int kt = 2 - dt, n = lane & 31;
-                const int ci = n / 4, ph = (n / 2) % 2, pw = n % 2;
+                const int ci = n / (2 * bw), ph = (n / bw) % 2, pw = n % bw;
                 const int kh = ph + 5 - 2 * dh, kw = pw + 5 - 2 * dw;
                 if (ci >= cin || kh < 0 || kh >= KH || kw < 0 || kw >= KW) continue;
                 for (int j = 0; j < 8; ++j) {
@@ -578,8 +580,14 @@ bool plan_dgrad_pix(int cin, int cout, int t_in, int h_in, int w_in, int lds_bud
                 }
             }
     pl.col_off.assign(32, 0);
-    for (int n = 0; n < cin * 4; ++n) pl.col_off[n] = (n / 4) * h_in * w_in + ((n / 2) % 2) * w_in + (n % 2);
+    for (int n = 0; n < cin * 2 * bw; ++n) pl.col_off[n] = (n / (2 * bw)) * h_in * w_in + ((n / bw) % 2) * w_in + (n % bw);
     return true;
+}
+
+// plan.bwd0_block_w: 2 x 4 pixel blocks where the width allows (VD_BWD0_WIDE=0: the 2 x 2 blocks of rounds 1-3, for A/B runs)
+int bwd0_block_w(int w_in) {
+    const char* e = getenv("VD_BWD0_WIDE");
+    return (w_in % 4 == 0 && !(e != nullptr && e[0] == '0')) ? 4 : 2;
 }
 
 // input geometry (cin, t, h, w) of ConvNet3D level `layer`
@@ -599,7 +607,7 @@ bool plan_dgrad_layer(int layer, int cls, int frames, int height, int width, int
     layer_input(layer, frames, height, width, cin, t, h, w);
     const int widths[3] = {64, 128, 128};
     const int cout = widths[layer], lds_budget = 3700;
-    if (layer == 0) return cls == 0 && h % 2 == 0 && w % 2 == 0 && plan_dgrad_pix(cin, cout, t, h, w, lds_budget, pl);   // (odd clip sizes: Python planner only)
+    if (layer == 0) return cls == 0 && h % 2 == 0 && w % 2 == 0 && plan_dgrad_pix(cin, cout, t, h, w, lds_budget, pl, bwd0_block_w(w));   // (odd clip sizes: Python planner only)
     const int nph = std::min(2, h), npw = std::min(2, w);
     if (cls < 0 || cls >= nph * npw) return false;
     const int ph = cls / npw, pw = cls % npw;

@@ -673,17 +673,19 @@ def plan_dgrad(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, 
 
 @_memo
 def plan_dgrad_pix(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, lds_budget: int = 3700,
-                   mtw_options=(7, 8)) -> ConvPlan:
-    """Input gradient of the FIRST layer (cin = 3 pixel channels) with the four stride-2 parity
-    classes merged into the N dimension: one output row = the 2x2 pixel block (t, 2b..2b+1,
-    2c..2c+1), its cin*4 = 12 values are the GEMM columns n = c*4 + ph*2 + pw.  All of them read
-    the same 3x4x4 neighbourhood of dy, so K = 48 taps x cout with structural zeros in B where a
-    tap does not reach a parity.  3x less MFMA work than four N=3 (padded to 32) passes."""
-    assert cin * 4 <= 32 and cout % 8 == 0 and h_in % 2 == 0 and w_in % 2 == 0
+                   mtw_options=(7, 8), bw: int = 2) -> ConvPlan:
+    """Input gradient of the FIRST layer (cin = 3 pixel channels) with the stride-2 parity classes merged into the N
+    dimension: one output row = the 2 x ``bw`` pixel block (t, 2b..2b+1, bw*c..bw*c+bw-1), its cin*2*bw values are the GEMM
+    columns n = (ci*2 + ph)*bw + pw.  All of them read the same neighbourhood of dy, so K = taps x cout with structural zeros
+    in B where a tap does not reach a pixel.
+      bw = 2: 2x2 blocks, N = 12 of 32 columns, 3x4x4 = 48 taps;
+      bw = 4: 2x4 blocks, N = 24 of 32 columns, 3x4x5 = 60 taps, half as many rows: 0.625 of the MFMA work per pixel (the
+              dy window of a block grows by one column while the block doubles)."""
+    assert bw in (2, 4) and cin * 2 * bw <= 32 and cout % 8 == 0 and h_in % 2 == 0 and w_in % bw == 0
     CC = cout // 8
     T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
-    taps = [(dt, dh, dw) for dt in range(3) for dh in range(4) for dw in range(4)]
-    rows = (t_in, h_in // 2, w_in // 2)
+    taps = [(dt, dh, dw) for dt in range(3) for dh in range(4) for dw in range(bw // 2 + 3)]
+    rows = (t_in, h_in // 2, w_in // bw)
     NT, MW = 1, 4
     col, half = _lane_cols()
 
@@ -698,9 +700,9 @@ def plan_dgrad_pix(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: i
                 kt = 2 - dt
                 lanes = np.where(half == hh)[0]
                 n = col[lanes]
-                ci, ph, pw = n // 4, (n // 2) % 2, n % 2
+                ci, ph, pw = n // (2 * bw), (n // bw) % 2, n % bw
                 kh = ph + 5 - 2 * dh          # from oh = b + (dh-1) = (2b+ph+3-kh)/2
-                kw = pw + 5 - 2 * dw
+                kw = pw + 5 - 2 * dw          # from ow = (bw/2)*c + (dw-1) = (bw*c+pw+3-kw)/2
                 ok = (ci < cin) & (kh >= 0) & (kh < KH) & (kw >= 0) & (kw < KW)
                 for cc in range(CC_):
                     nn = cc * 8 + np.arange(8)
@@ -711,15 +713,22 @@ def plan_dgrad_pix(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: i
     clip_stride = t_in * cin * h_in * w_in
 
     def out_index(ci, a, b, c):
-        return ci * clip_stride + (a * cin * h_in + 2 * b) * w_in + 2 * c
+        return ci * clip_stride + (a * cin * h_in + 2 * b) * w_in + bw * c
     max_ncl = 1
-    plan = _make_plan(name, (T, OH, OW), CC, rows, (1, 1, 1), (-1, -1, -1), (1, 1, 1), taps, widx_fn,
-                      cin * 4, NT, MW, mtw_options, EPI_ROWS, 0, False, out_index, None, 0,
+    plan = _make_plan(name, (T, OH, OW), CC, rows, (1, 1, 1), (-1, -1, -1), (1, 1, bw // 2), taps, widx_fn,
+                      cin * 2 * bw, NT, MW, mtw_options, EPI_ROWS, 0, False, out_index, None, 0,
                       clip_stride, 0, (t_in, cin, h_in, w_in), lds_budget, (max_ncl,))
     n = np.arange(32)
-    plan.col_off = np.where(n < cin * 4, (n // 4) * h_in * w_in + ((n // 2) % 2) * w_in + (n % 2), 0).astype(np.int32)
+    plan.col_off = np.where(n < cin * 2 * bw, (n // (2 * bw)) * h_in * w_in + ((n // bw) % 2) * w_in + (n % bw), 0).astype(np.int32)
     plan.meta["macs_per_unit"] = T * OH * OW * cin * 3 * 7 * 7 * cout        # all four parity classes = the layer's forward count
+    plan.meta["block_w"] = bw
     return plan
+
+
+def bwd0_block_w(w_in: int) -> int:
+    """Block width of the merged first-level input-gradient program: 4 where the clip width allows (VD_BWD0_WIDE=0: the 2 x 2
+    blocks of rounds 1-3, for A/B runs; csrc/planner.cpp reads the same switch)."""
+    return 4 if (w_in % 4 == 0 and os.environ.get("VD_BWD0_WIDE", "1") != "0") else 2
 
 
 WGRAD_BLOCKS = ((8, 4, 4), (4, 4, 14), (8, 2, 14), (4, 7, 7), (2, 7, 14), (4, 2, 14), (2, 4, 14), (4, 4, 4), (2, 2, 14), (1, 4, 14), (2, 4, 4), (1, 2, 14))
@@ -930,7 +939,8 @@ def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: i
     passes (one per parity class per layer).  ``ntw`` / ``ntw0`` = N tiles per wave of the layer-1/2
     and of the first-layer forward programs; ``batch_hint`` = clips per launch the programs will typically see
     (small batches get latency-oriented decompositions, see ``latency_variant``)."""
-    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw, ntw0, balanced, batch_hint, bwd0_small)
+    key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw, ntw0, balanced, batch_hint, bwd0_small,
+           bwd0_block_w(geo.width))
     if key in _PLAN_CACHE:
         return _PLAN_CACHE[key]
     dims = geo.layer_dims()
@@ -963,13 +973,15 @@ def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: i
             # workgroup, one wave per SIMD).  Embed backward of 256 clips 64x64x8 2.29 -> 2.00 ms, second-order pass 10.0 -> 9.2 ms,
             # MTT+Ours 7.77 -> 8.23 it/s.  NOT for the synthetic-clip stream of DM, whose kernels run under the real side's: there the
             # extra resident workgroups take more from the real stream than they save (step 35.6 -> 36.2 ms, N = 8 proxy 4.9 -> 5.4).
+            # 2 x 4 pixel blocks (N = 24 of 32 columns, 60 taps) where the width allows: 0.625 of the 2 x 2 blocks' MFMA work
+            bw = bwd0_block_w(w)
             small = None
             if bwd0_small:
                 try:
-                    small = plan_dgrad_pix("bwd0_merged", cin, cout, t, h, w, lds_budget=min(lds_budget, 1800), mtw_options=(4,))
+                    small = plan_dgrad_pix("bwd0_merged", cin, cout, t, h, w, lds_budget=min(lds_budget, 1800), mtw_options=(4,), bw=bw)
                 except ValueError:
                     small = None
-            bwd.append([small if small is not None else plan_dgrad_pix("bwd0_merged", cin, cout, t, h, w, lds_budget=lds_budget)])
+            bwd.append([small if small is not None else plan_dgrad_pix("bwd0_merged", cin, cout, t, h, w, lds_budget=lds_budget, bw=bw)])
             continue
         layer = []
         for ph, pw in dgrad_classes(h, w):
