@@ -274,7 +274,7 @@ def test_g11_evaluate_synset_multi_static_on_hip(golden_dir):
 # The SHIPPED precision mode = HipBackend's defaults = what bench.py times: real clips single-pass f16 with dithered weights and
 # the last conv level in hi+lo pairs, synthetic clips f16 hi+lo pairs, input gradient f16 hi+lo pairs.  "fast" is round 2's
 # mode (single pass on every real level and in the input gradient).  Against the ORACLE at every step of the late regime:
-# tests/test_gpu_parity_late.py.  Measured errors are appended to gpurun_out/r03_parity.json (copied to profiles/ by hand).
+# tests/test_gpu_parity_late.py.  Measured errors are appended to gpurun_out/r04_parity.json (copied to profiles/ by hand).
 # ------------------------------------------------------------------------------------------------
 MODES = {"mixed": dict(),
          "fast": dict(prec_real="f16", prec_syn="f16x3", prec_bwd="f16", real_last="x1"),
@@ -284,7 +284,7 @@ MODES = {"mixed": dict(),
 def _record(key, value):
     import json
     path = os.environ.get("VD_PARITY_LOG", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                        "gpurun_out", "r03_parity.json"))
+                                                        "gpurun_out", "r04_parity.json"))
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         data = json.load(open(path)) if os.path.exists(path) else {}

@@ -21,9 +21,18 @@ COMMON = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--sustain-secon
 FORCE = {"VD_BENCH_FORCE_DIST": "1", "VD_FORCE_COLLECTIVES": "1", "VD_FORCE_BATCH_SHARD": "1", "MASTER_PORT": "29541"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 def _bench(extra, env=None):
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     e.update(env or {})
+    if "MASTER_PORT" in e:          # a fresh rendezvous port per child: consecutive one-rank groups on one fixed port have collided
+        e["MASTER_PORT"] = _free_port()
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + COMMON + extra, cwd=ROOT, env=e, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]

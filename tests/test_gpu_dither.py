@@ -135,8 +135,12 @@ def test_module_embed_value_pass_follows_real_dither_and_the_weights():
     syn = torch.randn(1, 8, 3, 64, 64, generator=g).cuda()
     eng = engine.EmbedEngine(plan.NetGeometry(8, 64, 64), prec="f16x3")
 
+    # the value pass rounds the weights of the levels the undithered real side multiplies by plain rn16(W): all three with a
+    # single-pass last level, levels 0 / 1 when the real side's last level runs on exact hi+lo weights (real_last = x3, the default)
+    levels = (0, 1) if networks.get_precision()["real_last"] == "x3" else (0, 1, 2)
+
     def expect(quantize):
-        eng.set_weights(net._feature_params(), quantize=quantize)
+        eng.set_weights(net._feature_params(), quantize=quantize, quantize_levels=levels)
         return eng.forward(syn)
 
     def syn_feats():

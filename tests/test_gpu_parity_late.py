@@ -19,7 +19,7 @@ window carrying a large gradient moves up to 1e-2).  (At 112x112x16 a clip has 8
 one or two such ties; the bar binds on the entries that have none -- measured 0.74e-3 -- and the median over all entries is
 recorded, not asserted: 1.1e-3 there, 0.73e-3 at 64x64x8 where 27 of 32 entries are clean.)
 
-Measured values go to gpurun_out/r03_parity.json (copied to profiles/)."""
+Measured values go to gpurun_out/r04_parity.json (copied to profiles/)."""
 import json
 import os
 import time
@@ -39,7 +39,7 @@ MODES = {"shipped": dict(prec_real="f16", prec_syn="f16x3", prec_bwd=None),     
 
 def _record(key, value):
     path = os.environ.get("VD_PARITY_LOG", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                        "gpurun_out", "r03_parity.json"))
+                                                        "gpurun_out", "r04_parity.json"))
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         data = json.load(open(path)) if os.path.exists(path) else {}

@@ -1,22 +1,23 @@
 #!/bin/bash
 # Regenerate the evidence under profiles/ on a GPU box (run from the repo root through gpurun);
-# results land in gpurun_out/prof/ and are copied to profiles/r03_* afterwards (tools/copy_profiles.sh).
+# results land in gpurun_out/prof/ and are copied to profiles/r04_* afterwards (tools/copy_profiles.sh).
 # Every rocprofv3 run is bounded by `timeout` and writes csv (the rocpd default has hung a box for its whole limit).
+# PMC passes run alone (--kernel-trace only next to --pmc), one counter group per run.
 set -u
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_1gpu.json
+python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs --sustain-seconds 0 2>/dev/null | tail -1 > $OUT/bench_1gpu_again.json
 python3 bench.py --method s2d --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_s2d.json
 python3 bench.py --frames 8 --size 64 --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_config1_shape.json
 python3 bench.py --method dc --classes 51 --ipc 5 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_dc.json
 python3 bench.py --method mtt --classes 400 --frames 8 --size 64 --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_mtt.json
+VD_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 8 --steps 3 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --eval-epochs 1 --eval-seeds 1 --exchange-leg --no-extra-legs 2>/dev/null | tail -1 > $OUT/bench_8ranks_one_device.json
 python3 tools/mfma_peak.py > $OUT/mfma_peak.txt 2>/dev/null
-python3 tools/bench_aux.py > $OUT/aux_kernels_gbps.json 2>/dev/null
-VD_L0_BREG=3 python3 tools/stamps_breg2.py 512 > $OUT/l0_phase_stamps.txt 2>&1
-VD_L0_BREG=3 python3 tools/stamps_breg2.py 512 --alone >> $OUT/l0_phase_stamps.txt 2>&1
-VD_L0_BREG=2 python3 tools/stamps_breg2.py 512 >> $OUT/l0_phase_stamps.txt 2>&1
+python3 tools/bench_train.py 50 > $OUT/train_step.txt 2>/dev/null
+VD_DETERMINISTIC=1 python3 tools/bench_train.py 50 > $OUT/train_step_deterministic.txt 2>/dev/null
 cd /tmp
 prof() {  # name, then the program and its arguments
   local name=$1; shift
@@ -25,17 +26,22 @@ prof() {  # name, then the program and its arguments
 }
 prof bench python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --eval-epochs 0 --sustain-seconds 0 --no-extra-legs --no-alone
 grep '"metric"' $OUT/bench.log | tail -1 > $OUT/bench_1gpu_under_rocprof.json
+cp $(ls $OUT/bench/*/*kernel_trace.csv | head -1) $OUT/bench_kernel_trace.csv
 prof s2d python3 $ROOT/bench.py --method s2d --steps 8 --warmup 2 --no-cpu-baseline --sustain-seconds 0
 prof dc python3 $ROOT/bench.py --method dc --classes 8 --ipc 5 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0
 prof mtt python3 $ROOT/bench.py --method mtt --classes 400 --frames 8 --size 64 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0
-export VD_RUN_L1_HILO=1
+prof aux python3 $ROOT/tools/bench_aux.py
+prof syn_side python3 $ROOT/tools/syn_side_trace.py 20
+prof train_atomic python3 $ROOT/tools/train_trace.py 50
+VD_DETERMINISTIC=1 prof train_deterministic python3 $ROOT/tools/train_trace.py 50
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 280 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/tools/run_l1.py 512 f16 > $OUT/pmc_$c.log 2>&1
+  timeout -k 5 280 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/tools/run_real_side.py 4 > $OUT/pmc_$c.log 2>&1
   cp $(ls $OUT/pmc_$c/*/*counter_collection.csv | head -1) $OUT/pmc_${c}_counter_collection.csv
 done
 cd $ROOT
-python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE_counter_collection.csv $OUT/pmc_WRITE_SIZE_counter_collection.csv 512 $OUT/pmc_traffic.json > /dev/null
-rm -rf $OUT/bench $OUT/s2d $OUT/dc $OUT/mtt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+python3 tools/pmc_real_side.py $OUT/pmc_FETCH_SIZE_counter_collection.csv $OUT/pmc_WRITE_SIZE_counter_collection.csv 3200 $OUT/pmc_traffic.json > /dev/null
+python3 tools/aux_kernel_gbps.py $OUT/aux_kernel_stats.csv $OUT/aux_kernels.json > /dev/null
+rm -rf $OUT/bench $OUT/s2d $OUT/dc $OUT/mtt $OUT/aux $OUT/syn_side $OUT/train_atomic $OUT/train_deterministic $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 bash tools/pmc_sq.sh > $OUT/pmc_sq.log 2>&1
 python3 tools/pmc_sq_summary.py gpurun_out/pmc_sq $OUT/pmc_sq_summary.json > /dev/null 2>&1
 cp gpurun_out/pmc_sq/pass*.csv $OUT/ 2>/dev/null

@@ -453,6 +453,10 @@ class EmbedEngine:
         for li, (src, n_src, per_src, dst_ptr, n_dst, per_dst_bytes) in enumerate((
                 (act1, n1, per1, act2.data_ptr(), n2, per2 * 16), (act2, n2, per2, feats.data_ptr(), 0, self.num_feat * 4)), start=1):
             if li == 2 and hilo:                        # hi+lo weights: one set
+                if os.environ.get("VD_L2_X2_SIM") == "act":
+                    # measurement knob: the NUMERICS of a two-MFMA last level a_hi x (W_hi + W_lo) -- the low plane
+                    # of the activations dropped -- at the cost of the three-MFMA program (what the parity of such a mode would be)
+                    src[1].zero_()
                 self.fwd2x.run(src, n_src, w[5], dst_ptr, 0, None, B)
             elif per % self.fwd[li].plan.ncl == 0:       # a box never spans two sets: one launch
                 self.fwd[li].run(src, n_src, w[2 * li + 1], dst_ptr, n_dst, None, B, set_clips=per, emit_lo=(li == 1 and hilo))
