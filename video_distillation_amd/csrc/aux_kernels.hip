@@ -246,7 +246,7 @@ __global__ void unpool_relu_bwd_kernel(const float* __restrict__ g, const uint8_
 // The same scatter with one thread per 2 x 2 spatial pool WINDOW of one conv frame (even conv grids: every dense position
 // belongs to exactly one window): the window's 8 arg-max bytes and 8 gradient values are read ONCE instead of four times (the
 // channels-last layout holds both as one 8-byte / 32-byte run), and the four slots it writes are two 32-byte runs per plane,
-// contiguous across neighbouring threads.  Same values bit for bit; 0.31 -> 0.15 ms for the first level's 640 MB of 50 clips.
+// contiguous across neighbouring threads.  Same values bit for bit; 0.31 -> 0.22 ms for the first level's 640 MB of 50 clips.
 __global__ void unpool_relu_bwd_win_kernel(const float* __restrict__ g, const uint8_t* __restrict__ amax, int64_t nwin,
                                            int C, int To, int Ho, int Wo, int pool_t, int T, int OH, int OW,
                                            uint4* __restrict__ hi, uint4* __restrict__ lo, int prec, const float* __restrict__ scale) {
