@@ -600,6 +600,16 @@ void layer_input(int layer, int frames, int height, int width, int& cin, int& t,
     }
 }
 
+// plan.latency_variant's acceptance rule: more workgroups, and either (almost) no more padded rows than the base program or --
+// a TINY launch, fewer workgroups than a quarter of the chip's 512 slots -- fewer M tiles per wave whatever it pads
+bool latency_better(const Plan& alt, const Plan& best, const Plan& base, int batch_hint) {
+    if (alt.grid(batch_hint) <= best.grid(batch_hint)) return false;
+    const char* e = getenv("VD_TINY_GRID");
+    const int tiny_grid = e != nullptr ? atoi(e) : 128;
+    const bool tiny = best.grid(batch_hint) < tiny_grid && alt.MTW < best.MTW && alt.grid(batch_hint) <= 512;
+    return (double)alt.rows_total <= (double)base.rows_total * 1.05 || tiny;
+}
+
 // the input-gradient programs of `layer` as plan.plan_network builds them: layer 0 -> one merged program (even H, W);
 // layers 1, 2 -> one program per stride-2 parity class (index = ph * 2 + pw), latency-oriented variant for small batches
 bool plan_dgrad_layer(int layer, int cls, int frames, int height, int width, int batch_hint, Plan& pl) {
@@ -618,7 +628,7 @@ bool plan_dgrad_layer(int layer, int cls, int frames, int height, int width, int
         for (const auto& opts : tries) {
             Plan alt;
             if (!plan_dgrad(cin, cout, t, h, w, ph, pw, lds_budget, opts, alt)) continue;
-            if (alt.grid(batch_hint) > pl.grid(batch_hint) && (double)alt.rows_total <= (double)base.rows_total * 1.05) pl = alt;
+            if (latency_better(alt, pl, base, batch_hint)) pl = alt;
         }
     }
     return true;
@@ -654,7 +664,7 @@ bool plan_layer(int layer, int frames, int height, int width, int prec, int batc
         for (const auto& opts : tries) {
             Plan alt;
             if (!plan_forward_cl(cin, cout, t, h, w, pt, feat, lds_budget, opts, 1, alt)) continue;
-            if (alt.grid(batch_hint) > pl.grid(batch_hint) && (double)alt.rows_total <= (double)base.rows_total * 1.05) pl = alt;
+            if (latency_better(alt, pl, base, batch_hint)) pl = alt;
         }
     }
     return true;

@@ -913,6 +913,7 @@ _PLAN_CACHE: Dict[Tuple, Dict[str, object]] = {}
 
 
 SMALL_TILES_FIRST = (2, 4, 7, 8)
+TINY_GRID = int(os.environ.get("VD_TINY_GRID", "128"))      # latency_variant: launches below this many workgroups ignore padding (0: off)
 
 
 def latency_variant(pl: ConvPlan, batch_hint: Optional[int], make) -> ConvPlan:
@@ -928,7 +929,14 @@ def latency_variant(pl: ConvPlan, batch_hint: Optional[int], make) -> ConvPlan:
             alt = make(opts)
         except ValueError:
             continue
-        if alt.grid(batch_hint) > best.grid(batch_hint) and alt.rows_total <= pl.rows_total * slack:
+        if alt.grid(batch_hint) <= best.grid(batch_hint):
+            continue
+        # (round 4) a TINY launch -- fewer workgroups than a quarter of the chip's 512 slots -- is one workgroup's latency whatever
+        # it pads: fewer M tiles per wave win even where the rows do not fill them (the (1,1) parity class of the last level's
+        # input gradient: 72 rows per clip, 7 tiles x 3 clips per box = 17 workgroups of 172 us for 50 clips; 2-tile boxes: 100
+        # workgroups that also join the other classes' launch)
+        tiny = best.grid(batch_hint) < TINY_GRID and alt.MTW < best.MTW and alt.grid(batch_hint) <= 512
+        if alt.rows_total <= pl.rows_total * slack or tiny:
             best = alt
     return best
 
