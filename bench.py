@@ -359,6 +359,9 @@ def finish(h, out, extra_rank0=None):
     if out is not None:     # data-path collectives this rank's trainers issued over the whole run (warm-up, timed, sustained, eval)
         out["collectives"] = dict(distill.COLLECTIVE_CALLS, backend=(dist.get_backend() if dist.is_initialized() else None),
                                   forced_on_one_rank=(h.world == 1 and distill.collectives_on(1)))
+    if h.comm is not None:
+        h.comm.free()
+        h.comm = None
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -443,9 +446,11 @@ def cpu_baseline_dm(args, trainer, backend, it, s2d=None):
 
 def run_eval(args, trainer, pool, device, rank):
     """evaluate_synset (utils.py:848-886) on the current synthetic clips: a fresh ConvNet3D trained for --eval-epochs
-    epochs with the HIP train step, tested (3 passes, HIP inference) on 4 held-out pool clips per class (never drawn as
-    initial synthetic clips; they may occur in real batches, as any pool clip).  On the default template pool the accuracy is
-    informative; on --pool-kind randn it is chance level by construction."""
+    epochs with the HIP train step (ordered accumulation mode unless --eval-atomic), tested (3 passes, HIP inference) on the
+    LAST 4 pool clips of every class, which main() took out of the range real batches and initial synthetic clips are drawn
+    from.  Networks are built directly from fixed seeds (not through get_network, which reseeds from the wall clock), so the
+    per-seed accuracies repeat from run to run.  On the default template pool the accuracy is informative; on --pool-kind
+    randn it is chance level by construction."""
     import types
     from video_distillation_amd import networks, utils
     C = args.classes
@@ -744,6 +749,7 @@ def bench_dc(args, h, distill, geo, pool):
             del os.environ["VD_GM_LANES"]
         else:
             os.environ["VD_GM_LANES"] = lanes_env
+    topo = h.topology(args.batch_real * len(trainer.classes))
     out = None
     if rank == 0:
         macs = sum(conv_layer_macs(geo))
@@ -767,6 +773,7 @@ def bench_dc(args, h, distill, geo, pool):
             out["roofline"] = roof
         if sustained:
             out["sustained"] = sustained
+        out.update(topo)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_dc(args, trainer, geo, args.warmup + args.steps + 1)
     finish(h, out)
@@ -855,6 +862,7 @@ def bench_mtt(args, h, distill, geo):
     dt, per_step, _, losses = h.run(step, lambda: None, mark, profile=False)
     sustained = h.sustained(step, lambda: None, args.warmup + args.steps)
     prof = h.profile_steps(step, lambda: None, args.warmup + args.steps)
+    topo = h.topology(len(range(rank, tr.batch_syn, max(world, 1))) * tr.syn_steps)      # this rank's share of every student batch
     out = None
     if rank == 0:
         macs = sum(conv_layer_macs(geo))
@@ -881,6 +889,7 @@ def bench_mtt(args, h, distill, geo):
             out["roofline"] = roof
         if sustained:
             out["sustained"] = sustained
+        out.update(topo)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_mtt(args, tr, traj, C, s2d)
     finish(h, out)
