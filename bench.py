@@ -58,8 +58,9 @@ def parse():
     ap.add_argument("--prec-bwd", default=os.environ.get("VD_PREC_BWD", "f16x3"),
                     help="operand precision of the input-gradient passes (f16x3: hi+lo pairs; f16: single pass; both with per-layer "
                          "power-of-two scaling)")
-    ap.add_argument("--real-last", default=None, choices=["x1", "x3"],
-                    help="real side's last conv level: x3 = hi+lo operand pairs (default, VD_REAL_LAST), x1 = single pass like the others")
+    ap.add_argument("--real-last", default=None, choices=["x1", "x3", "c8"],
+                    help="real side's last conv level: x3 = hi+lo operand pairs (default, VD_REAL_LAST), c8 = hi+lo with the two correction "
+                         "products on the fp8 matrix instruction (two MFMA-equivalents per product), x1 = single pass like the others")
     ap.add_argument("--chunk", type=int, default=3200, help="real clips per launch (all of a single-GPU step by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-classes", type=int, default=10, help="dm/s2d: class terms timed for the CPU baseline")
@@ -647,7 +648,8 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
             for p in roof["programs"]:
                 if p["program"] in ("fwd0", "fwd2") and p["operands"] == args.prec_real:
                     roof[p["program"] + "_tflops"] = p["tflops"]
-                if p["program"] == "fwd2_hilo":      # the real side's last level in hi+lo pairs: 3 MFMAs per algorithmic product
+                if p["program"] in ("fwd2_hilo", "fwd2_c8"):      # the real side's last level in hi+lo pairs: 3 MFMAs per algorithmic product
+                    #                                                (fwd2_c8: the corrections on the fp8 instruction: 2 MFMA-equivalents)
                     roof["fwd2_tflops"] = p["tflops"]
                     roof["fwd2_ms_per_launch"] = p["ms_total"] / max(p["launches"], 1)
             out["roofline"] = roof

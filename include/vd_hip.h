@@ -24,6 +24,13 @@ extern "C" {
 #define VD_PREC_F16    1   /* fp16 operands, one MFMA per product                       */
 #define VD_PREC_BF16X3 2   /* hi/lo split bf16 operands, three MFMAs (fp32-class error) */
 #define VD_PREC_F16X3  3   /* hi/lo split fp16 operands, three MFMAs                    */
+#define VD_PREC_F16C8  4   /* fp16 operands + the two hi/lo CORRECTION products on the block-scaled fp8 matrix instruction
+                              (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3, 2.2x the fp16 rate): a_hi W_hi in fp16, a_lo W_hi + a_hi W_lo in
+                              fp8 once per four K steps -- two MFMA-equivalents per product instead of three, the corrections
+                              exact to 2^-4 of themselves (2^-16 of the product).  The real side's LAST level only (pooled
+                              features, 4 M tiles x 1 N tile per wave, K steps a multiple of 4): plane 1 of its source holds the
+                              low parts as fp8 bytes (VdConvParams.emit_lo = 2 of the producing program), plane 1 of its packed
+                              weights the fp8 fragments of vd_pack_weights_c8, out_scale points at that call's two E8M0 scales */
 
 #define VD_EPI_POOL_CL   0
 #define VD_EPI_POOL_FEAT 1
@@ -110,6 +117,13 @@ int vd_conv0_persistent(const VdConvParams* params, void* stream);
  * precisions) through the planner's gather table.  n = number of packed elements. */
 int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, void* out_hi, void* out_lo,
                     int prec, void* stream);
+/* Operand planes of a VD_PREC_F16C8 program: out_hi = the fp16 fragments (as vd_pack_weights with VD_PREC_F16), out_c8 = the
+ * same number of bytes holding, per four K steps, the fp8 (e4m3) fragments of W_hi x s and (W - W_hi) x s x 2^11 in the order the
+ * kernel consumes them; s = the power of two that brings max|w| into [128, 256).  widx = the program's weight gather table
+ * [CC][S][NT][64][8] (S a multiple of 4).  scales6 (6 floats of device scratch, caller-owned): words 0 and 1 receive, as int32, the
+ * E8M0 scale codes VdConvParams.out_scale must point at when the program runs. */
+int vd_pack_weights_c8(const float* w, int64_t w_elems, const int32_t* widx, int CC, int S, int NT, void* out_hi, void* out_c8,
+                       float* scales6, void* stream);
 /* Dithered single-pass weights for the real side of DM (f16 / bf16): out[g][i] = packed element i for launch group g of
  * `groups` (a power of two <= 64); every weight is rounded up in round(lam * groups) of the groups and down in the others, so
  * the mean over the groups equals the fp32 weight to 1/(2 groups) ulp and the weight-rounding perturbation of a class's mean

@@ -1,0 +1,104 @@
+"""The real side's last level with fp8 CORRECTIONS (VD_PREC_F16C8, ``EmbedEngine(last_hilo='c8')``): the main product a_hi W_hi in
+fp16, the two hi+lo correction products a_lo W_hi + a_hi W_lo on the block-scaled fp8 matrix instruction once per four K steps
+-- two MFMA-equivalents per product instead of three.  The corrections are 2^-12 of the product, so their fp8 rounding (2^-4
+of themselves) leaves 2^-16: this test pins that the mode keeps the hi+lo level's accuracy -- which a mistake in the operand
+order would NOT show as a failure elsewhere (garbled corrections look like a single-pass level, still inside every 1e-3 bar)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.mark.parametrize("geom,n", [((16, 112, 112), 16), ((8, 64, 64), 32)])
+def test_fp8_corrected_last_level_keeps_the_hi_lo_accuracy(geom, n):
+    from video_distillation_amd import engine, plan
+    geo = plan.NetGeometry(*geom)
+    T, H, W = geom
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(1, T, 3, H, W, generator=g) + 0.1 * torch.randn(n, T, 3, H, W, generator=g))
+    params = R.init_params(4321, 3, 5)
+    with torch.no_grad():
+        want = R.convnet3d_embed(x, params)
+    w = [p.cuda() for p in params[:6]]
+    e1 = engine.EmbedEngine(geo, prec="f16", chunk=4096); e1.set_weights(w)
+    e3 = engine.EmbedEngine(geo, prec="f16", chunk=4096, last_hilo=True); e3.set_weights(w)
+    try:
+        e8 = engine.EmbedEngine(geo, prec="f16", chunk=4096, last_hilo="c8")
+    except ValueError:
+        pytest.skip("no one-clip 4 x 1-tile last-level program at this geometry")
+    e8.set_weights(w)
+    assert e8.fwd2x.plan.S % 4 == 0 and e8.last_c8
+    xc = x.cuda()
+    f1, f3, f8 = e1.forward(xc), e3.forward(xc), e8.forward(xc)
+    torch.cuda.synchronize()
+    assert torch.isfinite(f8).all()
+    d83 = [_rel(f8[i], f3[i]) for i in range(n)]
+    d13 = [_rel(f1[i], f3[i]) for i in range(n)]
+    per = lambda f: float(np.median([_rel(f[i], want[i]) for i in range(n)]))      # noqa: E731
+    cm = lambda f: _rel(f.mean(0), want.mean(0))                                    # noqa: E731
+    print("%s: per-clip feature error vs fp32 oracle: single pass %.2e, hi+lo last level %.2e, fp8-corrected %.2e; class mean %.2e / %.2e / %.2e; "
+          "fp8-corrected vs hi+lo per clip: median %.2e max %.2e (single pass vs hi+lo: %.2e)" % (
+              geom, per(f1), per(f3), per(f8), cm(f1), cm(f3), cm(f8), float(np.median(d83)), max(d83), float(np.median(d13))))
+    # levels 0 and 1 are the same single-pass programs in all three engines, so f8 - f3 isolates the last level's arithmetic:
+    # hi+lo pairs are exact to 4e-7 there, a single-pass level is off by ~1.5e-4; the fp8 corrections must land at a tenth of that
+    assert max(d83) < 4e-5 and float(np.median(d83)) < 0.2 * float(np.median(d13))
+    assert per(f8) < 1.02 * per(f3) + 1e-6 and cm(f8) < 1.05 * cm(f3) + 2e-6
+    # same result whatever the launch is split into, and reproducible
+    e8c = engine.EmbedEngine(geo, prec="f16", chunk=5, last_hilo="c8"); e8c.set_weights(w)
+    assert torch.equal(e8c.forward(xc), f8) and torch.equal(e8.forward(xc), f8)
+
+
+def test_fp8_corrected_level_survives_large_and_tiny_weights():
+    """The weight fragments are scaled by a power of two taken from max|W| (vd_pack_weights_c8), so the mode does not depend
+    on PyTorch's default initialisation: weights 64x larger / smaller give the same relative accuracy; activations beyond
+    the fp8 image's range (1792) are clamped in the CORRECTION only (the fp16 main product is untouched)."""
+    from video_distillation_amd import engine, plan
+    geo = plan.NetGeometry(16, 112, 112)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 16, 3, 112, 112, generator=g).cuda()
+    base = [p.cuda() for p in R.init_params(77, 3, 5)[:6]]
+    for scale in (1.0, 64.0, 1.0 / 8.0):       # (much smaller weights leave fp16's normal range: every 16-bit format of this build degrades there)
+        w = [t.clone() for t in base]
+        w[4] = w[4] * scale
+        e3 = engine.EmbedEngine(geo, prec="f16", chunk=64, last_hilo=True); e3.set_weights(w)
+        e8 = engine.EmbedEngine(geo, prec="f16", chunk=64, last_hilo="c8"); e8.set_weights(w)
+        f3, f8 = e3.forward(x), e8.forward(x)
+        d = max(_rel(f8[i], f3[i]) for i in range(4))
+        print("last-level weights x %g: fp8-corrected vs hi+lo %.2e" % (scale, d))
+        assert torch.isfinite(f8).all() and d < 4e-5
+
+
+def test_deferred_backward_is_the_same_arithmetic():
+    """``DMTrainer.defer_backward`` (overlapped steps): step i's backward + SGD are issued at the start of step i + 1's synthetic
+    side, behind the first level of step i + 1's real side, instead of right behind step i's loss.  Same kernels, same order
+    per tensor -- SGD(i) still precedes the forward of step i + 1 --, so losses, synthetic clips and momentum after six
+    overlapped steps are bitwise those of the undeferred trainer; ``sync()`` issues the last pending backward."""
+    from video_distillation_amd import distill, plan
+    geo = plan.NetGeometry(8, 64, 64)
+    C, per = 4, 12
+    g = torch.Generator().manual_seed(21)
+    clips = torch.randn(C * per, 8, 3, 64, 64, generator=g).cuda()
+    pool = distill.RealPool(clips, [per] * C, [c * per for c in range(C)])
+
+    def run(defer):
+        be = distill.HipBackend(geo, "cuda:0")
+        tr = distill.DMTrainer(be, pool, C, 1, 8, lr_img=5.0, momentum=0.5)
+        tr.defer_backward = defer
+        losses = [tr.step(it, overlap=True) for it in range(6)]
+        if defer:
+            assert tr._pending is not None          # the sixth backward has not been issued yet
+        tr.sync()
+        assert tr._pending is None
+        torch.cuda.synchronize()
+        return [float(l) for l in losses], tr.image_syn.clone(), tr.buf.clone()
+    a, b = run(False), run(True)
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert float((a[1] - clips[::per]).abs().max()) > 0          # the clips did move

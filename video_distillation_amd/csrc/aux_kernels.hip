@@ -108,6 +108,65 @@ __global__ void pack_weights_dither_kernel(const float* __restrict__ w, const in
     }
 }
 
+// Operand planes of a VD_PREC_F16C8 program (include/vd_hip.h): plane 0 = the fp16 fragments vd_pack_weights writes; plane 1 = per
+// (chunk, group of four K steps, N tile, lane) 64 bytes -- the 16-byte pieces the kernel loads at steps 4g .. 4g+3 -- holding the
+// fp8 (e4m3) fragment of W_hi = rn16(W) scaled by s (pieces 0, 1: elements j = 0..31) and of W_lo = W - W_hi scaled by s * 2^11
+// (pieces 2, 3), element j = 8 q + e = (step 4g + q, this lane's tap half, channel e).  s = the power of two that brings max|W| into
+// [128, 256) (vd_absmax_scale); scales[0..1] receive the E8M0 codes 127 - log2(s) and 127 - log2(s) - 11 the kernel hands to the
+// matrix instruction, scales[2..5] are scratch of the max reduction.
+__global__ void pack_weights_c8_kernel(const float* __restrict__ w, const int32_t* __restrict__ widx, int CC, int S, int NT,
+                                       const float* __restrict__ sc, uint4* __restrict__ plane1, int* __restrict__ codes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte piece per thread
+    const int64_t npieces = (int64_t)CC * S * NT * 64;
+    const float s_hi = sc[0], s_lo = sc[0] * 2048.f;
+    if (i == 0) {
+        const int e = (int)(__float_as_uint(s_hi) >> 23) - 127;          // s_hi is a power of two
+        codes[0] = 127 - e; codes[1] = 127 - e - 11;
+    }
+    if (i >= npieces) return;
+    const int lane = (int)(i & 63);
+    int64_t r = i >> 6;
+    const int nt = (int)(r % NT); r /= NT;
+    const int st = (int)(r % S);
+    const int cc = (int)(r / S);
+    const int g = st >> 2, q = st & 3;
+    const bool lo = q >= 2;
+    uint32_t out[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        float v[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = 16 * (q & 1) + 4 * d + b;                      // element of the 32-byte fragment half this piece holds
+            const int qs = j >> 3, e = j & 7;
+            const int32_t wi = widx[((((int64_t)cc * S + 4 * g + qs) * NT + nt) * 64 + lane) * 8 + e];
+            const float x = wi >= 0 ? w[wi] : 0.f;
+            const float hi = (float)(_Float16)x;
+            float y = lo ? (x - hi) * s_lo : hi * s_hi;
+            v[b] = fminf(fmaxf(y, -448.f), 448.f);
+        }
+        int word = 0;
+        word = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], word, false);
+        word = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], word, true);
+        out[d] = (uint32_t)word;
+    }
+    plane1[i] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+extern "C" int vd_pack_weights_c8(const float* w, int64_t w_elems, const int32_t* widx, int CC, int S, int NT, void* out_hi, void* out_c8,
+                                  float* scales6, void* stream) {
+    if (w == nullptr || widx == nullptr || out_hi == nullptr || out_c8 == nullptr || scales6 == nullptr) return -1;
+    if (CC <= 0 || S <= 0 || NT <= 0 || S % 4 != 0 || w_elems <= 0) return -2;
+    const int64_t n = (int64_t)CC * S * NT * 64 * 8;
+    int rc = vd_pack_weights(w, widx, n, out_hi, nullptr, VD_PREC_F16, stream);
+    if (rc) return rc;
+    if ((rc = vd_absmax_scale(w, w_elems, 256.0f, scales6 + 2, stream))) return rc;       // scales6[2] = s, [3] = 1 / s, [4] = max bits
+    const int64_t npieces = n / 8;
+    hipLaunchKernelGGL(pack_weights_c8_kernel, dim3((unsigned)((npieces + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       w, widx, CC, S, NT, scales6 + 2, reinterpret_cast<uint4*>(out_c8), reinterpret_cast<int*>(scales6));
+    return (int)hipGetLastError();
+}
+
 extern "C" int vd_pack_weights_dither(const float* w, const int32_t* widx, int64_t n, int groups, void* out, int prec, void* stream) {
     if (groups < 1 || groups > 64 || (groups & (groups - 1)) != 0) return -2;
     if (prec != VD_PREC_F16 && prec != VD_PREC_BF16) return -2;          // single-pass formats: the hi+lo formats carry the weights exactly

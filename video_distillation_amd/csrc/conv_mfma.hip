@@ -50,6 +50,31 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+// VD_PREC_F16C8: power-of-two scalings of the fp8 operands of the correction products (E8M0 codes = 127 + log2 of what the stored
+// byte must be multiplied by): low parts of the activations are stored x 2^9 (a_lo <= 2^-11 a), the fp8 image of a high fragment
+// is a / 4 (v_cvt_scalef32_pk_fp8_f16 divides by its scale operand; beyond 464 it returns NaN, hence the clamp at 1792)
+#define VD_C8_ALO_SHIFT 9
+#define VD_C8_SA_LO (127 - VD_C8_ALO_SHIFT)
+#define VD_C8_SA_HI (127 + 2)
+__device__ __forceinline__ void vd_c8_hi_image(const uint4& a, int& w0, int& w1) {      // 8 f16 -> 8 e4m3 bytes of a / 4
+    // (four conversions, nothing else: the PRODUCER of the plane clamps its outputs to 1792 -- emit_lo = 2 -- so a / 4 stays inside
+    //  e4m3's finite range; the instruction returns NaN beyond 464)
+    i16x2 r0 = {0, 0}, r1 = {0, 0};
+    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, __builtin_bit_cast(f16x2, a.x), 4.0f, false);
+    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, __builtin_bit_cast(f16x2, a.y), 4.0f, true);
+    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, __builtin_bit_cast(f16x2, a.z), 4.0f, false);
+    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, __builtin_bit_cast(f16x2, a.w), 4.0f, true);
+    w0 = __builtin_bit_cast(int, r0); w1 = __builtin_bit_cast(int, r1);
+}
+__device__ __forceinline__ uint32_t vd_c8_lo_byte(float v) {            // e4m3 byte of (v - rn16(v)) * 2^9, clamped to the finite range
+    float r = (v - (float)(_Float16)v) * (float)(1 << VD_C8_ALO_SHIFT);
+    r = fminf(fmaxf(r, -448.f), 448.f);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(r, r, 0, false) & 0xffu;
+}
 
 // Per-kernel, per-DEVICE launch preparation (160 KB dynamic LDS attribute, CU count): hipFuncSetAttribute applies to the
 // current device only, and several host threads / devices may launch the same instantiation.
@@ -139,7 +164,9 @@ __device__ __forceinline__ void vd_static_for(F&& f) { vd_static_for_impl(f, std
 //  arguments -- and up to VD_MULTI_MAX programs of the same instantiation in ONE launch, conv_mfma_multi_kernel below)
 template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0, bool SQ = false>
 __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int boxes_per_wg, const int total_boxes, const int block_id, const int nblocks) {
-    constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
+    constexpr bool C8 = (PREC == VD_PREC_F16C8);        // fp16 main product + fp8 corrections (two operand planes, like the hi+lo formats)
+    constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3 || C8);
+    static_assert(!C8 || (MTW == 4 && NTW == 1 && BAL == 0 && !SO && !SQ), "VD_PREC_F16C8: the last level's 4 x 1-tile layout only");
     constexpr bool EXT = SO || MTW == 5;
     constexpr bool SEQ = X3 && SQ;                      // hi+lo formats: one operand plane resident at a time (see SQ above)
     constexpr int LPL = (X3 && !SEQ) ? 2 : 1;           // patch planes resident in LDS
@@ -149,7 +176,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
     constexpr int H0 = (MTW + 1) / 2;   // tiles whose A fragments are fetched one half-step ahead
     constexpr int H1 = MTW - H0;
     constexpr int AD = 1;                               // x1: A-fragment prefetch distance (K-steps)
-    constexpr int DB = X3 ? (TILES <= 2 ? 5 : ((SEQ && NTW == 1) ? 3 : 2)) : VD_DB_X1;   // B-fragment prefetch distance (K steps); x1: (DB+1) % (AD+1) == 0
+    constexpr int DB = C8 ? 3 : X3 ? (TILES <= 2 ? 5 : ((SEQ && NTW == 1) ? 3 : 2)) : VD_DB_X1;     // (C8: a ring of 4 = one correction group)   // B-fragment prefetch distance (K steps); x1: (DB+1) % (AD+1) == 0
     //   (plane-sequential: the low-plane pass has one MFMA per tile and step instead of three, so its steps are short)
     static_assert(X3 || (DB + 1) % (AD + 1) == 0, "ring sizes must divide the unroll factor");
     constexpr int LU = (TILES <= 4) ? 14 : 17;   // DMA groups per wave (4 waves x LU x 64 slots >= the plan's patch)
@@ -237,7 +264,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
     // (1) the gather entries of this wave's DMA groups: the longest dependent chain of the prologue,
     //     so they are requested first; they are the same for every channel chunk and stay in registers.
     const int32_t* gtab = p.gather + (int64_t)bi * p.gather_stride;
-    constexpr bool HOIST = (TILES < 8);   // MTW = 8 has no registers to spare: it re-reads the table per chunk
+    constexpr bool HOIST = (TILES < 8) && !C8;   // MTW = 8 (and the fp8-corrected program) have no registers to spare: they re-read the table per chunk
     uint32_t goff[HOIST ? LU : 1];
 #pragma unroll
     for (int u = 0; u < (HOIST ? LU : 1); ++u) {
@@ -291,7 +318,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 bh[j] = wp[(int64_t)sc * wstep + j * 64];
-                if constexpr (X3 && (!SEQ || ph == 0)) bl[j] = wp[(int64_t)sc * wstep + j * 64 + w_lo];
+                if constexpr (X3 && !C8 && (!SEQ || ph == 0)) bl[j] = wp[(int64_t)sc * wstep + j * 64 + w_lo];   // (C8: plane 1 holds fp8 pieces, loaded by the K loop itself)
             }
         };
         uint4 bqh[DB + 1][NTW], bql[DB + 1][NTW];
@@ -437,6 +464,93 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 for (int u = 0; u <= DB; ++u) {
                     if (s + u >= S) break;
                     k_step(u, s + u);
+                }
+            }
+        } else if constexpr (C8) {
+            // fp16 main product every K step; the two correction products once per FOUR steps on the fp8 instruction (K = 64 = 4 steps x
+            // 2 taps x 8 channels).  Element j = 8 q + e of a lane's 32-byte fp8 fragment is (step 4 g + q, this lane's tap half,
+            // channel e) in BOTH operands (vd_pack_weights_c8 packs B in that order; the instruction pairs element j of the A lane
+            // (row, half) with element j of the B lane (column, half): tools/micro/mfma_f8_probe.hip).  The low parts come from plane 1
+            // of the patch (8 bytes per slot), the fp8 image of the high fragment is converted from the registers the fp16 MFMA has
+            // just consumed -- no second LDS read for it.
+            const int* sc8 = reinterpret_cast<const int*>(p.out_scale);
+            const int sb_hi = sc8[0], sb_lo = sc8[1];
+            int tap_next = lds_tap[2 * ((1 < S) ? 1 : 0) + half];
+            uint4 Ah[MTW];
+            {
+                const int tap0 = lds_tap[half];
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap0);
+            }
+            // the four 16-byte pieces of a group's fp8 B fragments (plane 1 of the packed weights, stored at the group's four steps):
+            // pieces 0, 1 (W_hi image) are loaded at the END of the previous group, pieces 2, 3 (W_lo image) at steps 0 and 1 of the
+            // group itself -- four registers-quads in all, every load two or more K steps ahead of the correction products that use it
+            auto piece = [&](int st) { return wp[(int64_t)((st < S) ? st : S - 1) * wstep + w_lo]; };
+            uint4 b8_0 = piece(0), b8_1 = piece(1), b8_2, b8_3;
+            for (int s = 0; s < S; s += 4) {
+                i32x8 a8hi[MTW];
+                int tapq[4];                 // this lane half's tap offsets of the group's four steps (for the low-part reads)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tapq[u] = lds_tap[2 * (s + u) + half];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
+                    if (u == 0) b8_2 = piece(s + 2);
+                    if (u == 1) b8_3 = piece(s + 3);
+                    const int sn2 = (s + u + 2 < S) ? s + u + 2 : S - 1;
+                    const int tap_next2 = lds_tap[2 * sn2 + half];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u < 3) {
+#pragma unroll
+                        for (int i = 0; i < MTW; ++i) {
+                            acc[i] = mfma16<PREC>(Ah[i], bqh[u][0], acc[i]);
+                            int w0, w1;
+                            vd_c8_hi_image(Ah[i], w0, w1);
+                            a8hi[i][2 * u] = w0; a8hi[i][2 * u + 1] = w1;
+                            __builtin_amdgcn_sched_barrier(0);
+                            Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
+                        // last step of the group.  Behind tile i's main product its four low-part slots are read; the correction products
+                        // follow one (a_lo W_hi) and two (a_hi W_lo) tiles later, so that consecutive writes of one accumulator are always
+                        // separated by matrix instructions on other accumulators (a dependent MFMA waits for its predecessor's passes)
+                        const i32x8 B8hi = {(int)b8_0.x, (int)b8_0.y, (int)b8_0.z, (int)b8_0.w, (int)b8_1.x, (int)b8_1.y, (int)b8_1.z, (int)b8_1.w};
+                        const i32x8 B8lo = {(int)b8_2.x, (int)b8_2.y, (int)b8_2.z, (int)b8_2.w, (int)b8_3.x, (int)b8_3.y, (int)b8_3.z, (int)b8_3.w};
+                        i32x8 a8lo[2];
+                        auto corr_lo = [&](auto IC) __attribute__((always_inline)) {
+                            constexpr int i = decltype(IC)::v;
+                            acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8lo[i & 1], B8hi, acc[i], 0, 0, 0, VD_C8_SA_LO, 0, sb_hi);
+                        };
+                        auto corr_hi = [&](auto IC) __attribute__((always_inline)) {
+                            constexpr int i = decltype(IC)::v;
+                            acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8hi[i], B8lo, acc[i], 0, 0, 0, VD_C8_SA_HI, 0, sb_lo);
+                        };
+                        vd_static_for<MTW>([&](auto IC) __attribute__((always_inline)) {
+                            constexpr int i = decltype(IC)::v;
+                            acc[i] = mfma16<PREC>(Ah[i], bqh[3][0], acc[i]);
+                            int w0, w1;
+                            vd_c8_hi_image(Ah[i], w0, w1);
+                            a8hi[i][6] = w0; a8hi[i][7] = w1;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const uint2 lo = *reinterpret_cast<const uint2*>(smem + plane_bytes + a_off[i] + tapq[q]);
+                                a8lo[i & 1][2 * q] = (int)lo.x; a8lo[i & 1][2 * q + 1] = (int)lo.y;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (i >= 1) corr_lo(VdIC<i - 1>{});
+                            if constexpr (i >= 2) corr_hi(VdIC<i - 2>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                        corr_lo(VdIC<MTW - 1>{});
+                        corr_hi(VdIC<MTW - 2>{});
+                        corr_hi(VdIC<MTW - 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        b8_0 = piece(s + 4); b8_1 = piece(s + 5);          // the next group's W_hi image
+                    }
+                    tap_next = tap_next2;
                 }
             }
         } else if constexpr (SEQ) {
@@ -614,15 +728,24 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 if (p.pool_t == 2) m0 = fmaxf(m0, m1);
                 m0 += bias; m1 += bias;
                 if (p.relu) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
+                if (!X3 && !EXT && p.emit_lo == 2) {      // the fp8 image of these values (x 1/4) must stay finite for the consumer: clamp at 1792
+                    m0 = fminf(fmaxf(m0, -1792.f), 1792.f); m1 = fminf(fmaxf(m1, -1792.f), 1792.f);
+                }
                 const int q = (gi * 4 + half + 2 * qh) * nsets;
                 uint16_t hi, lo;
                 split16<PREC>(m0, hi, lo);
                 stg[q * NCH + n] = hi;
-                if (lo_out) stg[(Q + q) * NCH + n] = lo;
+                // (emit_lo = 2: plane 1 for a VD_PREC_F16C8 consumer -- per 16-byte slot the 8 low parts as e4m3 bytes, x 2^9, then 8 zero bytes)
+                const bool lo8 = !X3 && !EXT && p.emit_lo == 2;
+                uint8_t* stg8 = reinterpret_cast<uint8_t*>(stg);
+                const int b8 = (n >> 3) * 16 + (n & 7);
+                if (lo8) { stg8[(Q + q) * NCH * 2 + b8] = (uint8_t)vd_c8_lo_byte(m0); stg8[(Q + q) * NCH * 2 + b8 + 8] = 0; }
+                else if (lo_out) stg[(Q + q) * NCH + n] = lo;
                 if (p.pool_t != 2) {
                     split16<PREC>(m1, hi, lo);
                     stg[(q + 1) * NCH + n] = hi;
-                    if (lo_out) stg[(Q + q + 1) * NCH + n] = lo;
+                    if (lo8) { stg8[(Q + q + 1) * NCH * 2 + b8] = (uint8_t)vd_c8_lo_byte(m1); stg8[(Q + q + 1) * NCH * 2 + b8 + 8] = 0; }
+                    else if (lo_out) stg[(Q + q + 1) * NCH + n] = lo;
                 }
                 continue;
             }
@@ -1810,7 +1933,7 @@ extern "C" int vd_conv0_persistent(const VdConvParams* pp, void* stream) {
 
 template <int PREC, int MTW, bool SO = false, int NTW = 1, int BAL = 0, bool SQ = false>
 static int launch(const VdConvParams& p, hipStream_t st) {
-    constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3);
+    constexpr bool X3 = (PREC == VD_PREC_BF16X3 || PREC == VD_PREC_F16X3 || PREC == VD_PREC_F16C8);
     const int groups = (p.nclips + p.ncl - 1) / p.ncl;
     const int64_t total = (int64_t)groups * p.nbox;
     if (total <= 0) return 0;
@@ -1856,6 +1979,12 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     if (p.ncl * 65536 <= 0 || p.S <= 0 || p.CC <= 0) return -2;
     if (p.MTW * ntw < 8 && (p.gather_stride >> 6) > (int64_t)wgw * (p.MTW * ntw <= 4 ? 14 : 17)) return -2;   // patch larger than the DMA register budget
     if (p.clip_index != nullptr && (p.ncl != 1 || p.CC != 1 || p.MTW * ntw > 4)) return -2;
+    if (p.prec == VD_PREC_F16C8) {      // fp16 + fp8 corrections: the last level's forward only (see include/vd_hip.h)
+        if (ntw != 1 || p.MTW != 4 || p.S % 4 != 0 || p.epi != VD_EPI_POOL_FEAT || p.out_scale == nullptr || p.select || p.atomic ||
+            p.src_split_cc > 0 || p.w_box_stride != 0 || p.emit_lo != 0)
+            return -2;
+        return launch<VD_PREC_F16C8, 4>(p, st);
+    }
     if (p.emit_lo != 0) {   // low plane of a single-pass program's pooled outputs: staged channels-last epilogue only, and the staging tile
                             // (two planes of pooled rows) must fit the one patch plane it aliases
         const int mt_tot = p.MW * p.MTW + ((ntw == 2 && p.MTW == 3) ? 1 : 0);

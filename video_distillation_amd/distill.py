@@ -141,19 +141,31 @@ class HipBackend:
     def __init__(self, geo: P.NetGeometry, device, prec_real: str = "f16", prec_syn: str = "f16x3", chunk: int = 512,
                  prec_bwd: Optional[str] = "f16x3", syn_batch_hint: Optional[int] = None, real_last: Optional[str] = None):
         """``real_last``: operand format of the real side's LAST conv level when ``prec_real`` is single-pass -- "x3" (hi+lo
-        pairs: level 1 emits both planes of its output, level 2 runs three MFMAs per product on 5.6 % of the FLOPs) or "x1";
-        default from ``VD_REAL_LAST`` (see DESIGN section 2 for the measured error budget and cost of either)."""
+        pairs: level 1 emits both planes of its output, level 2 runs three MFMAs per product on 5.6 % of the FLOPs), "c8" (the
+        same hi+lo level with its two correction products on the block-scaled fp8 matrix instruction: two MFMA-equivalents per
+        product, class means equal to x3's to 3 digits; round 4's default where the geometry has the one-clip last-level program,
+        x3 elsewhere) or "x1"; default from ``VD_REAL_LAST`` (DESIGN sections 2 / 5.1c: error budget and cost of each)."""
         from . import engine, hip
         self.hip = hip
         self.device = torch.device(device)
         self.geo = geo
         if real_last is None:
-            real_last = os.environ.get("VD_REAL_LAST", "x3")
-        assert real_last in ("x1", "x3")
+            real_last = os.environ.get("VD_REAL_LAST", "c8")
+        assert real_last in ("x1", "x3", "c8")
         self.real_last = real_last if prec_real in ("f16", "bf16") else "x1"
         if prec_syn == prec_real and not prec_bwd:
             self.real_last = "x1"       # one engine for both sides (kept arg-max forwards): a last_hilo engine has no such forward
-        self.eng_real = engine.EmbedEngine(geo, prec=prec_real, device=device, chunk=chunk, last_hilo=(self.real_last == "x3"))
+        # "c8": the hi+lo last level with its two correction products on the fp8 matrix instruction (VD_PREC_F16C8: two
+        # MFMA-equivalents per product instead of three, same accuracy on the class means); f16 and the one-clip last-level program
+        # only -- other formats / geometries fall back to the three-MFMA form
+        self.eng_real = None
+        if self.real_last == "c8":
+            try:
+                self.eng_real = engine.EmbedEngine(geo, prec=prec_real, device=device, chunk=chunk, last_hilo="c8")
+            except ValueError:
+                self.real_last = "x3"
+        if self.eng_real is None:
+            self.eng_real = engine.EmbedEngine(geo, prec=prec_real, device=device, chunk=chunk, last_hilo=(self.real_last == "x3"))
         self.eng_syn = self.eng_real if (prec_syn == prec_real and not prec_bwd) else \
             engine.EmbedEngine(geo, prec=prec_syn, device=device, chunk=chunk, prec_bwd=prec_bwd, batch_hint=syn_batch_hint)
         self.num_feat = geo.num_feat
@@ -200,7 +212,7 @@ class HipBackend:
         if self.weight_format is not None and not self._dither:
             # value pass: the levels the (undithered) real side multiplies by plain rn16(W) -- with real_last = x3 its last level
             # runs on the exact hi+lo W2, so W2 stays exact here as well
-            eng.set_weights(weights, quantize=self.weight_format, quantize_levels=(0, 1) if self.real_last == "x3" else (0, 1, 2))
+            eng.set_weights(weights, quantize=self.weight_format, quantize_levels=(0, 1) if self.real_last in ("x3", "c8") else (0, 1, 2))
             feats = eng.forward(x)
         return feats, handle
 
@@ -443,6 +455,10 @@ class DMTrainer:
         self.exchange, self.comm = exchange, comm
         self.exchange_events: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
         self._g_full = None
+        self._pending = None
+        # (default: with the fp8-corrected last level, whose short launch no longer absorbs the synthetic side's kernels -- they then
+        #  land on the first level, where they cost most; measured -0.3 .. -0.5 ms per step together, nothing apart: DESIGN 5.1c)
+        self.defer_backward = os.environ.get("VD_DEFER_BWD", "1" if getattr(backend, "real_last", None) == "c8" else "0") == "1"
 
     def _allreduce_pixel_grad(self, grad: torch.Tensor) -> torch.Tensor:
         """``exchange='allreduce'``: this rank's gradient rows through the all-reduced full tensor (see ``__init__``)."""
@@ -510,18 +526,27 @@ class DMTrainer:
             for w in weights:
                 w.record_stream(be.s_real)
                 w.record_stream(be.s_syn)
+            defer = overlap and self.defer_backward
+            ev_l0 = None
             with on_real():
                 be.set_real_weights(weights, self._per_class())
-                f_real = self._real_features(idx_t)
+                if defer:       # an event behind the first level's launch of THIS step's real side (see ``_flush_backward``)
+                    ev_l0 = torch.cuda.Event()
+                    be.eng_real.after_first_level = lambda: ev_l0.record(be.s_real)
+                try:
+                    f_real = self._real_features(idx_t)
+                finally:
+                    be.eng_real.after_first_level = None
             with on_syn():
+                if defer:
+                    self._flush_backward(ev_l0)     # the PREVIOUS step's backward + SGD, held back until this step's first level is done
                 f_syn, handle = be.embed_syn(self.image_syn, weights)
                 be.real_to_syn(f_real)
                 f_real = self._exchange(f_real)      # (batch sharding) on the synthetic-clip stream: the real-clip stream is
                 loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)     # free to start the next iteration's forward meanwhile
-                grad = be.embed_backward(handle, g_syn)
-                if self.exchange == "allreduce":
-                    grad = self._allreduce_pixel_grad(grad)
-                be.sgd(self.image_syn, self.buf, grad, self.lr_img, self.momentum, first=(self.steps_done == 0))
+                self._pending = (handle, g_syn, self.steps_done == 0)
+                if not defer:
+                    self._flush_backward(None)
                 loss = loss_c.sum()
             if not overlap:
                 be.join(loss)
@@ -540,6 +565,25 @@ class DMTrainer:
         be.sgd(self.image_syn, self.buf, grad, self.lr_img, self.momentum, first=(self.steps_done == 0))
         self.steps_done += 1
         return loss_c.sum()
+
+    def _flush_backward(self, after: Optional["torch.cuda.Event"]) -> None:
+        """Backward to the pixels + SGD of the latest class terms (on the CURRENT = synthetic-clip stream).  With
+        ``defer_backward`` (overlapped steps only) step i's backward is issued at the START of step i + 1's synthetic side, behind an
+        event that follows the first level of step i + 1's real side: the first-level kernel runs ONE eight-wave workgroup per CU
+        (all 160 KB of LDS), so a synthetic-side workgroup that gets a CU keeps a whole first-level workgroup out for as long as
+        it lives, while under levels 1 / 2 (two workgroups per CU) it merely replaces one of two -- the same work costs less there.
+        Same arithmetic, same order per tensor: SGD(i) still precedes the forward of step i + 1."""
+        if self._pending is None:
+            return
+        handle, g_syn, first = self._pending
+        self._pending = None
+        be = self.be
+        if after is not None:
+            torch.cuda.current_stream(self.image_syn.device).wait_event(after)
+        grad = be.embed_backward(handle, g_syn)
+        if self.exchange == "allreduce":
+            grad = self._allreduce_pixel_grad(grad)
+        be.sgd(self.image_syn, self.buf, grad, self.lr_img, self.momentum, first=first)
 
     def _real_features(self, idx_t: torch.Tensor) -> torch.Tensor:
         """This rank's contribution to the real side: all clips' features of the owned classes (class sharding), or --
@@ -609,8 +653,11 @@ class DMTrainer:
         return local_loss
 
     def sync(self) -> None:
-        """Wait (on the caller's stream) for everything the trainer has in flight."""
+        """Wait (on the caller's stream) for everything the trainer has in flight (a deferred backward is issued first)."""
         if getattr(self.be, "two_streams", False):
+            if getattr(self, "_pending", None) is not None:
+                with self.be.on_syn():
+                    self._flush_backward(None)
             self.be.join()
 
     def mark(self):

@@ -96,6 +96,15 @@ class _DevPlan:
                                             hip.ptr(self.wpk[0]), hip.ptr(lo), self.prec, hip.stream_ptr(w.device)),
                   "vd_pack_weights")
 
+    def pack_c8(self, w: torch.Tensor, scales: torch.Tensor) -> None:
+        """Operand planes of a VD_PREC_F16C8 program (vd_pack_weights_c8): fp16 fragments + the fp8 fragments of W_hi and W_lo;
+        ``scales`` (>= 6 floats of device scratch) receives the two E8M0 codes ``run(..., out_scale=scales)`` hands to the kernel."""
+        assert w.dtype == torch.float32 and w.is_contiguous() and self.wpk.shape[0] == 2
+        pl = self.plan
+        hip.check(hip.lib().vd_pack_weights_c8(hip.ptr(w), ctypes.c_int64(w.numel()), hip.ptr(self.widx), pl.CC, pl.S, pl.NT,
+                                               hip.ptr(self.wpk[0]), hip.ptr(self.wpk[1]), hip.ptr(scales), hip.stream_ptr(w.device)),
+                  "vd_pack_weights_c8")
+
     def pack_dither(self, w: torch.Tensor, groups: int) -> None:
         """``groups`` dithered single-pass operand sets (vd_pack_weights_dither); ``run(..., group=g)`` multiplies by set g."""
         assert w.dtype == torch.float32 and w.is_contiguous() and self.wpk.shape[0] == 1
@@ -110,7 +119,8 @@ class _DevPlan:
             group: Optional[int] = None, set_clips: int = 0, emit_lo: bool = False, launch: bool = True) -> None:
         """``launch=False`` only fills the parameter block (``run_together`` then sends several programs out as one launch)."""
         p = self.params
-        p.emit_lo = int(emit_lo)        # single-pass program, staged pooled epilogue: also write the low plane (dst_plane_stride behind)
+        p.emit_lo = int(emit_lo)        # single-pass program, staged pooled epilogue: 1 = also write the fp16 low plane (dst_plane_stride
+        #                                 behind), 2 = write fp8 low parts there instead (for a VD_PREC_F16C8 consumer)
         p.clip_index = 0 if clip_index is None else clip_index.data_ptr()
         p.out_scale = 0 if out_scale is None else out_scale.data_ptr()
         p.w_set_clips = 0
@@ -262,6 +272,7 @@ class EmbedEngine:
         self.dims = net["dims"]
         self.fwd = [_DevPlan(pl, self.device, self.prec) for pl in net["fwd"]]
         self.fwd2x = None
+        self.last_c8 = False
         if last_hilo:
             if hip.is_x3(self.prec):
                 raise ValueError("last_hilo is an option of the single-pass formats (%s already carries hi+lo planes)" % prec)
@@ -274,12 +285,22 @@ class EmbedEngine:
                 # box); same K order per output, bitwise the same features.
                 d2 = self.dims[2]
                 try:
-                    alt = P.plan_forward_cl("fwd2", d2[0], d2[1], d2[2], d2[3], d2[4], d2[11], feat_out=True, ntw=1, mtw_options=(4,))
+                    alt = P.plan_forward_cl("fwd2", d2[0], d2[1], d2[2], d2[3], d2[4], d2[11], feat_out=True, ntw=1, mtw_options=(4,),
+                                            step_multiple=4 if last_hilo == "c8" else 1)
                     if alt.rows_total <= pl2.rows_total and 2 * alt.gather_table().shape[1] * 16 <= 72 * 1024:
                         pl2 = alt
                 except ValueError:
                     pass
-            self.fwd2x = _DevPlan(dataclasses.replace(pl2, name="fwd2_hilo"), self.device, hip.PREC[prec + "x3"])
+            # ``last_hilo == "c8"`` (f16 only): the last level as VD_PREC_F16C8 -- fp16 main product, the two hi+lo correction products
+            # on the block-scaled fp8 matrix instruction once per four K steps (two MFMA-equivalents per product instead of three);
+            # level 1 then emits fp8 low parts (emit_lo = 2) instead of the fp16 low plane.  Needs the one-clip 4 x 1-tile program.
+            self.last_c8 = (last_hilo == "c8")
+            if self.last_c8 and not (prec == "f16" and pl2.NTW == 1 and pl2.MTW == 4 and pl2.S % 4 == 0):
+                raise ValueError("last_hilo='c8' needs the f16 format and the one-clip 4 x 1-tile last-level program (geometry %s)" % (geo,))
+            self.fwd2x = _DevPlan(dataclasses.replace(pl2, name="fwd2_c8" if self.last_c8 else "fwd2_hilo"), self.device,
+                                  hip.PREC["f16c8"] if self.last_c8 else hip.PREC[prec + "x3"])
+            if self.last_c8:
+                self.c8_scales = torch.zeros(8, dtype=torch.float32, device=self.device)
         # operand precision of the input-gradient passes (default: same as the forward)
         self.prec_bwd = hip.PREC[prec_bwd] if prec_bwd else self.prec
         self.planes_bwd = 2 if hip.is_x3(self.prec_bwd) else 1
@@ -312,7 +333,10 @@ class EmbedEngine:
         self._weights = ws
         for li in range(3):
             if li == 2 and self.fwd2x is not None:      # the last level multiplies by the exact hi+lo weights: nothing to dither
-                self.fwd2x.pack(ws[4])
+                if self.last_c8:
+                    self.fwd2x.pack_c8(ws[4], self.c8_scales)
+                else:
+                    self.fwd2x.pack(ws[4])
                 continue
             self.fwd[li].pack(ws[2 * li])
             if dither >= 2:
@@ -396,10 +420,10 @@ class EmbedEngine:
             if ev: ev[0].record()
             self.fwd[0].run(slots0, n_slots0, w[1], act1.data_ptr(), n1, am0, nb, clip_index=cidx, group=group)
             if ev: ev[1].record()
-            self.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, am1, nb, group=group, emit_lo=hilo)
+            self.fwd[1].run(act1, n1, w[3], act2.data_ptr(), n2, am1, nb, group=group, emit_lo=(2 if self.last_c8 else 1) if hilo else 0)
             if ev: ev[2].record()
             if hilo:
-                self.fwd2x.run(act2, n2, w[5], feats[c0:].data_ptr(), 0, None, nb)
+                self.fwd2x.run(act2, n2, w[5], feats[c0:].data_ptr(), 0, None, nb, out_scale=self.c8_scales if self.last_c8 else None)
             else:
                 self.fwd[2].run(act2, n2, w[5], feats[c0:].data_ptr(), 0, am2, nb, group=group)
             if ev:
@@ -450,6 +474,8 @@ class EmbedEngine:
                 else:
                     per0 = g.frames * 3 * g.height * (rowp // 8)
                     self.fwd[0].run(slots0[:, s * per * per0:], n_slots0, w[1], act1.data_ptr() + s * per * per1 * 16, n1, None, per, group=s)
+        if getattr(self, "after_first_level", None) is not None:      # (distill.DMTrainer: an event behind the first level's launch)
+            self.after_first_level()
         for li, (src, n_src, per_src, dst_ptr, n_dst, per_dst_bytes) in enumerate((
                 (act1, n1, per1, act2.data_ptr(), n2, per2 * 16), (act2, n2, per2, feats.data_ptr(), 0, self.num_feat * 4)), start=1):
             if li == 2 and hilo:                        # hi+lo weights: one set
@@ -457,13 +483,14 @@ class EmbedEngine:
                     # measurement knob: the NUMERICS of a two-MFMA last level a_hi x (W_hi + W_lo) -- the low plane
                     # of the activations dropped -- at the cost of the three-MFMA program (what the parity of such a mode would be)
                     src[1].zero_()
-                self.fwd2x.run(src, n_src, w[5], dst_ptr, 0, None, B)
+                self.fwd2x.run(src, n_src, w[5], dst_ptr, 0, None, B, out_scale=self.c8_scales if self.last_c8 else None)
             elif per % self.fwd[li].plan.ncl == 0:       # a box never spans two sets: one launch
-                self.fwd[li].run(src, n_src, w[2 * li + 1], dst_ptr, n_dst, None, B, set_clips=per, emit_lo=(li == 1 and hilo))
+                self.fwd[li].run(src, n_src, w[2 * li + 1], dst_ptr, n_dst, None, B, set_clips=per,
+                                 emit_lo=(2 if self.last_c8 else 1) if (li == 1 and hilo) else 0)
             else:
                 for s in range(G):
                     self.fwd[li].run(src[:, s * per * per_src:], n_src, w[2 * li + 1], dst_ptr + s * per * per_dst_bytes, n_dst, None,
-                                     per, group=s, emit_lo=(li == 1 and hilo))
+                                     per, group=s, emit_lo=(2 if self.last_c8 else 1) if (li == 1 and hilo) else 0)
         return feats
 
     def backward(self, saved, g_feat: torch.Tensor) -> torch.Tensor:

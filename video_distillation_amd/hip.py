@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvd_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("conv_mfma.hip", "aux_kernels.hip", "program.hip", "planner.cpp", "comm.cpp")]
 
-PREC = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3}
+PREC = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3, "f16c8": 4}      # f16c8: fp16 + fp8 corrections (the real side's last level only)
 EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv_mfma_multi", "vd_conv0_persistent", "vd_conv0_breg", "vd_pack_weights", "vd_round_operand", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_absmax_scale", "vd_dm_loss",
            "vd_group_sum", "vd_sgd_momentum", "vd_hallucinator_fwd", "vd_hallucinator_bwd", "vd_match_rows_fwd", "vd_match_rows_bwd", "vd_match_rows_fwd_multi", "vd_match_rows_bwd_multi", "vd_head_fwd", "vd_clip_minor_cl", "vd_clip_minor_pix", "vd_pack_dy", "vd_bias_grad", "vd_bias_grad_pooled", "vd_standardize", "vd_head_train_fwd", "vd_ce_loss", "vd_head_train_bwd", "vd_head_second_order", "vd_resplit_slots", "vd_program_load", "vd_program_pack_weights",
            "vd_program_run", "vd_program_info", "vd_program_free",
@@ -27,7 +27,7 @@ EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv_mfma_multi", "vd_conv0_per
            "vd_comm_unique_id", "vd_comm_create", "vd_comm_size", "vd_comm_version", "vd_comm_rank", "vd_comm_allreduce_f32", "vd_comm_allgather_f32",
            "vd_comm_free",
            "vd_bias_grad_pooled_scratch_floats", "vd_bias_grad_pooled_ordered", "vd_standardize_ordered", "vd_head_train_bwd_ordered",
-           "vd_set_deterministic", "vd_get_deterministic")
+           "vd_set_deterministic", "vd_get_deterministic", "vd_pack_weights_c8")
 
 
 class VdConvParams(ctypes.Structure):

@@ -363,12 +363,13 @@ def _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, 
 
 def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps, widx_fn,
                n_out, NT, MW, mtw_options, epi, pool_t, relu, out_index, out_valid, n_stride,
-               out_clip_stride, out_chunk_stride, out_shape, lds_budget, ncl_options=(1,), force_box=None, ntw=1):
+               out_clip_stride, out_chunk_stride, out_shape, lds_budget, ncl_options=(1,), force_box=None, ntw=1, step_multiple=1):
     """Generic planner.  Row (a,b,c) has its tap-(0,0,0) origin at source slot coords
-    (row_stride[0]*a+row_origin[0], ...).  ``taps`` is a list of non-negative (df,dh,dw)."""
+    (row_stride[0]*a+row_origin[0], ...).  ``taps`` is a list of non-negative (df,dh,dw).  ``step_multiple``: pad the K steps
+    (tap pairs) to a multiple of it with zero-weight taps (VD_PREC_F16C8 programs correct four steps at a time)."""
     F, H, W = src_grid
     ntaps = len(taps)
-    S = (ntaps + 1) // 2
+    S = -(-((ntaps + 1) // 2) // step_multiple) * step_multiple
     taps_p = list(taps) + [(0, 0, 0)] * (2 * S - ntaps)
     mdf = max(t[0] for t in taps); mdh = max(t[1] for t in taps); mdw = max(t[2] for t in taps)
     sa, sb, sc = row_stride
@@ -479,7 +480,7 @@ def _memo(fn):
 
 @_memo
 def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, pool_t: int,
-                    feat_out: bool, lds_budget: int = 3700, mtw_options=(7, 8, 4, 2), ntw: int = 1) -> ConvPlan:
+                    feat_out: bool, lds_budget: int = 3700, mtw_options=(7, 8, 4, 2), ntw: int = 1, step_multiple: int = 1) -> ConvPlan:
     """Forward Conv3d(cin->cout) + ReLU + MaxPool(pool_t,2,2) over a channels-last chunked
     source [clip][cin/8][t][h][w] (slots of 8 channels).  ``ntw`` = N tiles per wave: with 2 the
     workgroup is 2 wave columns x 2 wave rows of 4 M tiles x 2 N tiles, and every A fragment read
@@ -536,7 +537,7 @@ def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: 
     ncl_options = sorted({1, max_ncl} | {n for n in (2, 4, 8) if n <= max_ncl})
     plan = _make_plan(name, (t_in, h_in, w_in), CC, rows, (2, 2, 2), (-1, -3, -3), (1, 2, 2), taps,
                       widx_fn, cout, NT, MW, mtw_options, epi, pool_t, True, out_index, None, n_stride,
-                      clip_stride, chunk_stride, out_shape, lds_budget, ncl_options, ntw=ntw)
+                      clip_stride, chunk_stride, out_shape, lds_budget, ncl_options, ntw=ntw, step_multiple=step_multiple)
     plan.NTW = ntw
     return plan
 
