@@ -8,11 +8,11 @@ from collections import defaultdict
 
 fetch_csv, write_csv, clips, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 KERNELS = (("conv0_fwd_f16", "void conv0_breg"), ("conv1_fwd_f16", "void conv_mfma_kernel<1, 3, false, 2, 1"),
-           ("conv2_fwd_f16x3_real", "void conv_mfma_kernel<3, 4, false, 1, 0"))
+           ("conv2_fwd_f16x3_real", "void conv_mfma_kernel<3, 4, false, 1, 0"), ("conv2_fwd_f16c8_real", "void conv_mfma_kernel<4, 4, false, 1, 0"))
 # algorithmic bytes per clip: level 0 reads 16-bit pixel rows once and writes pooled f16 slots (+ nothing else);
 # level 1 reads them and writes both planes of its pooled output; level 2 reads both planes and writes fp32 features
 ALGO = {"conv0_fwd_f16": 16 * 3 * 112 * 120 * 2 + 64 * 16 * 28 * 28 * 2, "conv1_fwd_f16": 64 * 16 * 28 * 28 * 2 + 2 * 128 * 8 * 7 * 7 * 2,
-        "conv2_fwd_f16x3_real": 2 * 128 * 8 * 7 * 7 * 2 + 2048 * 4}
+        "conv2_fwd_f16x3_real": 2 * 128 * 8 * 7 * 7 * 2 + 2048 * 4, "conv2_fwd_f16c8_real": 2 * 128 * 8 * 7 * 7 * 2 + 2048 * 4}
 
 
 def per_kernel(path, counter):
