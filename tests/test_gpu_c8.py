@@ -102,3 +102,39 @@ def test_deferred_backward_is_the_same_arithmetic():
     a, b = run(False), run(True)
     assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert float((a[1] - clips[::per]).abs().max()) > 0          # the clips did move
+
+
+def test_deferred_backward_of_the_s2d_trainer_is_the_same_arithmetic():
+    """The same for ``S2DTrainer`` (config 3): backward through the embedding AND the hallucinator + the SGD steps on dynamic
+    memory and hallucinator, deferred behind the next step's first level: dynamic memories, hallucinator and losses bitwise
+    equal after five overlapped steps (the hallucinator's parameter gradients use atomics: compared to their noise)."""
+    from video_distillation_amd import distill, plan
+    geo = plan.NetGeometry(8, 64, 64)
+    C, per = 3, 10
+    g = torch.Generator().manual_seed(22)
+    clips = torch.randn(C * per, 8, 3, 64, 64, generator=g).cuda()
+    pool = distill.RealPool(clips, [per] * C, [c * per for c in range(C)])
+    static = torch.randn(C * 2, 3, 64, 64, generator=g).cuda()
+    dynamic = torch.randn(C, 2, 8, 1, 64, 64, generator=g).cuda()
+    hal_w = torch.empty(3, 4, 3, 3, 3).uniform_(-0.096, 0.096, generator=g).cuda()
+    hal_b = torch.empty(3).uniform_(-0.096, 0.096, generator=g).cuda()
+
+    def run(defer):
+        be = distill.HipBackend(geo, "cuda:0")
+        tr = distill.S2DTrainer(be, pool, C, 1, 2, 2, 8, static, dynamic, hal_w, hal_b, lr_dynamic=0.01, lr_hal=1e-6)
+        tr.defer_backward = defer
+        losses = [tr.step(it, overlap=True) for it in range(5)]
+        tr.sync()
+        assert tr._pending is None and tr.last_grads is not None
+        torch.cuda.synchronize()
+        return [float(l) for l in losses], tr.dynamic.clone(), tr.hal_w.clone()
+    a, a2, b = run(False), run(False), run(True)
+    # (the hallucinator's gradients accumulate with fp32 atomics and these five steps amplify their last bits: the yardstick is
+    #  what two UNDEFERRED runs differ by)
+    noise_l = max(abs(x / y - 1) for x, y in zip(a[0], a2[0]))
+    noise_d = _rel(a2[1], a[1])
+    got_l = max(abs(x / y - 1) for x, y in zip(a[0], b[0]))
+    got_d = _rel(b[1], a[1])
+    print("s2d deferred vs undeferred: losses %.1e (two undeferred runs: %.1e), dynamic memories %.1e (%.1e)" % (got_l, noise_l, got_d, noise_d))
+    assert got_l <= 10 * noise_l + 1e-6 and got_d <= 10 * noise_d + 1e-7
+    assert float((a[1] - dynamic.reshape(a[1].shape)).abs().max()) > 0

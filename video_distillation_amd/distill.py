@@ -717,6 +717,9 @@ class S2DTrainer:
         self.buf_w, self.buf_b = torch.zeros_like(self.hal_w), torch.zeros_like(self.hal_b)
         self.buf_s = torch.zeros_like(self.static) if train_static else None
         self.steps_done = 0
+        self._pending = None
+        self.last_grads = None
+        self.defer_backward = os.environ.get("VD_DEFER_BWD", "1" if getattr(backend, "real_last", None) == "c8" else "0") == "1"
 
     def indices(self, it: int, draws: Optional[Tuple[np.ndarray, np.ndarray]] = None):
         """distill_s2d_ms.py:402-406 for the owned classes; the two randint(2) draws are seeded per
@@ -754,44 +757,72 @@ class S2DTrainer:
             for w in weights:
                 w.record_stream(be.s_real)
                 w.record_stream(be.s_syn)
+            defer = overlap and self.defer_backward      # (as DMTrainer.defer_backward: the previous step's backward behind THIS step's first level)
+            ev_l0 = None
             with on_real():
                 be.set_real_weights(weights, self.batch_real)
-                f_real = be.embed_pool(self.pool.clips, idx_t, self.batch_real)
+                if defer:
+                    ev_l0 = torch.cuda.Event()
+                    be.eng_real.after_first_level = lambda: ev_l0.record(be.s_real)
+                try:
+                    f_real = be.embed_pool(self.pool.clips, idx_t, self.batch_real)
+                finally:
+                    if defer:
+                        be.eng_real.after_first_level = None
         elif hasattr(be, "set_real_weights"):
+            defer = False
             be.set_weights(weights, self.batch_real)
             f_real = be.embed_pool(self.pool.clips, idx_t, self.batch_real)
         else:
+            defer = False
             be.set_weights(weights)
             f_real = be.embed_pool(self.pool.clips, idx_t)
         with on_syn():
+            if defer:
+                self._flush_backward(ev_l0)
             image_syn = be.hallucinate(self.static, self.dynamic, sidx, didx, self.hal_w, self.hal_b)
             f_syn, handle = be.embed_syn(image_syn, weights) if hasattr(be, "embed_syn") else be.embed_keep(image_syn)
             if two:
                 be.real_to_syn(f_real)
             loss_c, g_syn = be.dm_loss(f_real, f_syn, ncls)
-            g_img = be.embed_backward(handle, g_syn)
-            g_dyn, g_stat, g_w, g_b = be.hallucinate_backward(g_img, self.static, self.dynamic, sidx, didx, self.hal_w,
-                                                              self.train_static)
-            if collectives_on(self.world):   # the hallucinator is shared by all classes: one 1.3 KB all-reduce
-                import torch.distributed as dist
-                flat = torch.cat([g_w.reshape(-1), g_b.reshape(-1)])
-                _all_reduce(flat)
-                g_w, g_b = flat[:324].view_as(g_w), flat[324:]
-            first = self.steps_done == 0
-            be.sgd(self.dynamic, self.buf_d, g_dyn, self.lr_dynamic, self.momentum, first)
-            be.sgd(self.hal_w, self.buf_w, g_w.contiguous(), self.lr_hal, self.momentum, first)
-            be.sgd(self.hal_b, self.buf_b, g_b.contiguous(), self.lr_hal, self.momentum, first)
-            if self.train_static:
-                be.sgd(self.static, self.buf_s, g_stat, self.lr_static, self.momentum, first)
+            self._pending = (handle, g_syn, sidx, didx, self.steps_done == 0)
+            if not defer:
+                self._flush_backward(None)
             loss = loss_c.sum()
         if two and not overlap:
-            be.join(loss, g_dyn, g_w, g_b)
+            be.join(loss, *self.last_grads)
         self.steps_done += 1
-        self.last_grads = (g_dyn, g_w, g_b)
         return loss
+
+    def _flush_backward(self, after) -> None:
+        """Backward through the embedding and the hallucinator + the SGD steps of the latest class terms, on the current
+        (synthetic-clip) stream; see ``DMTrainer._flush_backward`` for the deferred form."""
+        if self._pending is None:
+            return
+        handle, g_syn, sidx, didx, first = self._pending
+        self._pending = None
+        be = self.be
+        if after is not None:
+            torch.cuda.current_stream(self.dynamic.device).wait_event(after)
+        g_img = be.embed_backward(handle, g_syn)
+        g_dyn, g_stat, g_w, g_b = be.hallucinate_backward(g_img, self.static, self.dynamic, sidx, didx, self.hal_w,
+                                                          self.train_static)
+        if collectives_on(self.world):   # the hallucinator is shared by all classes: one 1.3 KB all-reduce
+            flat = torch.cat([g_w.reshape(-1), g_b.reshape(-1)])
+            _all_reduce(flat)
+            g_w, g_b = flat[:324].view_as(g_w), flat[324:]
+        be.sgd(self.dynamic, self.buf_d, g_dyn, self.lr_dynamic, self.momentum, first)
+        be.sgd(self.hal_w, self.buf_w, g_w.contiguous(), self.lr_hal, self.momentum, first)
+        be.sgd(self.hal_b, self.buf_b, g_b.contiguous(), self.lr_hal, self.momentum, first)
+        if self.train_static:
+            be.sgd(self.static, self.buf_s, g_stat, self.lr_static, self.momentum, first)
+        self.last_grads = (g_dyn, g_w, g_b)
 
     def sync(self) -> None:
         if getattr(self.be, "two_streams", False):
+            if self._pending is not None:
+                with self.be.on_syn():
+                    self._flush_backward(None)
             self.be.join()
 
     global_loss = DMTrainer.global_loss
