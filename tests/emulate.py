@@ -35,6 +35,8 @@ def run_plan(plan, src, w_flat, bias, nclips, out):
             pf, ph, pw, pitch_h, pitch_f, pitch_c, mt, a_ofs, o_ofs, t_ofs = [int(v) for v in descs[ty][:10]]
             a_off = tables[a_ofs:a_ofs + mt * 32] // 16
             tap_off = tables[t_ofs:t_ofs + 2 * plan.S] // 16
+            pos = plan.epi == P.EPI_POS_FEAT        # position tiles: skip masks behind the taps, B operands per box, pool across tiles
+            skip = tables[t_ofs + 2 * plan.S:t_ofs + 2 * plan.S + plan.S // 4] if pos else None
             nout = mt * 4 if plan.epi != P.EPI_ROWS else mt * 32
             out_tab = tables[o_ofs:o_ofs + nout]
             acc = np.zeros((mt * 32, plan.NT * 32))
@@ -53,8 +55,17 @@ def run_plan(plan, src, w_flat, bias, nclips, out):
                 # A[row, s, half, j]
                 for s in range(plan.S):
                     for hh in range(2):
-                        a = patch[a_off + tap_off[2 * s + hh]]            # [rows, 8]
                         lanes = np.where(half == hh)[0]
+                        if pos:
+                            for i in range(mt):
+                                if (int(skip[s // 4]) >> i) & 1:
+                                    continue
+                                sl = a_off[i * 32:(i + 1) * 32] + tap_off[2 * s + hh]
+                                assert sl.min() >= 0 and sl.max() < plan.ncl * pitch_c, "position tile reads outside its patch"
+                                for nt in range(plan.NT):
+                                    acc[i * 32:(i + 1) * 32, nt * 32:(nt + 1) * 32] += patch[sl] @ wp[bi * plan.CC + cc, s, nt, lanes, :].T
+                            continue
+                        a = patch[a_off + tap_off[2 * s + hh]]            # [rows, 8]
                         for nt in range(plan.NT):
                             bmat = wp[cc, s, nt, lanes, :]                 # [32 cols, 8]
                             acc[:, nt * 32:(nt + 1) * 32] += a @ bmat.T
@@ -64,7 +75,14 @@ def run_plan(plan, src, w_flat, bias, nclips, out):
                 acc = acc + np.where(nvalid, np.pad(bias, (0, max(0, plan.NT * 32 - bias.size)))[:plan.NT * 32], 0.0)[None, :]
             if plan.relu:
                 acc = np.maximum(acc, 0.0)
-            if plan.epi == P.EPI_ROWS:
+            if pos:
+                for e in range(16):
+                    o = int(out_tab[e])
+                    if o < 0 or clip0 + o // plan.out_clip_stride >= nclips:
+                        continue
+                    rows = [i * 32 + 2 * e + d for i in range(mt) for d in range(2)]
+                    out[clip0 * plan.out_clip_stride + out_rel + o + n * plan.n_stride] = acc[rows].max(axis=0)
+            elif plan.epi == P.EPI_ROWS:
                 for r in range(mt * 32):
                     o = int(out_tab[r])
                     if o < 0:

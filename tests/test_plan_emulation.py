@@ -88,6 +88,35 @@ def test_forward_layer2_features_and_ragged_clip_group(net, acts):
     np.testing.assert_array_equal(got, am)
 
 
+@pytest.mark.parametrize("n", [3, 9])
+def test_forward_layer2_in_position_tiles(net, acts, n):
+    """plan_forward_pos: rows = (clip, frame) pairs of one output position, taps skipped per tile, pool across the four tiles;
+    ragged clip groups (n % ncl != 0).  Every tap the program multiplies reads inside the un-padded patch (asserted by the emulator)."""
+    params, x, col = acts
+    dims = net["dims"][2]
+    pl = P.plan_forward_pos("fwd2_pos", dims[0], dims[1], dims[2], dims[3], dims[4], dims[11])
+    assert pl.epi == P.EPI_POS_FEAT and pl.ncl * dims[5] == 32 and pl.w_box_stride == pl.CC * pl.S * pl.NT * 512
+    assert all(t.tap_off.size == 2 * pl.S + pl.S // 4 for t in pl.types)
+    g = torch.Generator().manual_seed(5)
+    a1 = torch.relu(torch.randn(n, dims[0], dims[2], dims[3], dims[4], generator=g).double())
+    y = F.conv3d(a1, params[4], params[5], stride=(1, 2, 2), padding=(1, 3, 3))
+    want = F.max_pool3d(torch.relu(y), (2, 2, 2)).reshape(n, -1).numpy()
+    out = np.zeros(n * GEO.num_feat)
+    E.run_plan(pl, bcthw_to_cl(a1.numpy()), params[4].numpy().ravel(), params[5].numpy(), n, out)
+    np.testing.assert_allclose(out.reshape(n, -1), want, rtol=1e-9, atol=1e-9)
+
+
+def test_position_tiles_at_the_benchmark_geometry_halve_the_matrix_work():
+    dims = P.NetGeometry(16, 112, 112).layer_dims()[2]
+    pl = P.plan_forward_pos("fwd2_pos", dims[0], dims[1], dims[2], dims[3], dims[4], dims[11])
+    old = P.plan_forward_cl("fwd2", dims[0], dims[1], dims[2], dims[3], dims[4], dims[11], feat_out=True, mtw_options=(4,), step_multiple=4)
+    assert (pl.S, pl.ncl, pl.nbox) == (56, 4, 4) and pl.meta["mfma_per_chunk"] == [152] * 4
+    per_clip_new = sum(pl.meta["mfma_per_chunk"]) / pl.ncl
+    per_clip_old = old.S * old.MW * old.MTW * old.nbox / old.ncl
+    assert per_clip_new / per_clip_old == 0.5
+    assert all(t.conflict_cycles == 4.0 for t in pl.types)
+
+
 @pytest.mark.parametrize("li", [0, 1, 2])
 def test_input_gradient_passes(net, acts, li):
     params, x, col = acts

@@ -221,12 +221,46 @@ class HipBackend:
         if self.eng_syn is not self.eng_real:
             self.eng_syn.set_weights(weights)
 
-    def set_real_weights(self, weights, per_class: int = 0) -> None:
+    def set_real_weights(self, weights, per_class: int = 0, slot: Optional[int] = None) -> None:
         """Weights of the real-clip engine for a step whose real batches hold ``per_class`` clips per class on this rank
-        (0: unknown -> no dithering): packs the dithered operand sets when there are enough clips to deal them to."""
+        (0: unknown -> no dithering): packs the dithered operand sets when there are enough clips to deal them to.  ``slot``:
+        which of the engine's packed-operand buffer sets to fill and launch from (``prepare_real_weights``)."""
         from . import engine
         self._dither = engine.dither_groups(int(per_class), self.prec_real) if (self.dither_enabled and self.eng_syn is not self.eng_real) else 0
-        self.eng_real.set_weights(weights, dither=self._dither)
+        self.eng_real.set_weights(weights, dither=self._dither, slot=slot)
+
+    def prepare_real_weights(self, weights, per_class: int, step: int) -> None:
+        """``set_real_weights`` on a PREPARATION stream, into the buffer set ``step % 2``: the operand packing of a step (0.2 - 0.3 ms
+        of small launches: fp16 fragments, eight dithered sets for two levels, the fp8 fragments and their scale) used to sit on
+        the real-clip stream between the last level of step i and the first level of step i + 1; with two buffer sets it runs
+        under step i's launches -- it waits only for the launches of step i - 1, the previous readers of its buffers -- and
+        the real-clip stream waits for an event that has long fired.  Called with the real-clip stream current."""
+        if not self.two_streams or os.environ.get("VD_PREP_STREAM", "1") != "1":
+            return self.set_real_weights(weights, per_class)
+        if getattr(self, "s_prep", None) is None:
+            self.s_prep = torch.cuda.Stream(device=self.device, priority=-1)
+            self._real_done = {}
+        k = step % 2
+        cur = torch.cuda.current_stream(self.device)                   # = the real-clip stream
+        self.s_prep.wait_stream(torch.cuda.default_stream(self.device))          # the freshly drawn fp32 weights
+        prev = self._real_done.get(k)
+        if prev is not None:
+            self.s_prep.wait_event(prev)                               # the launches that last read buffer set k
+        for w in weights:
+            w.record_stream(self.s_prep)
+        with torch.cuda.stream(self.s_prep):
+            self.set_real_weights(weights, per_class, slot=k)
+            ev = torch.cuda.Event()
+            ev.record(self.s_prep)
+        cur.wait_event(ev)
+        self._prep_slot = k
+
+    def real_launches_done(self) -> None:
+        """Record (on the current = real-clip stream) that the launches reading the current buffer set have been issued."""
+        if getattr(self, "s_prep", None) is not None and getattr(self, "_prep_slot", None) is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._real_done[self._prep_slot] = ev
 
     # -- stream plumbing (no-ops for single-stream / CPU test backends) ----------------------
     def fork(self):
@@ -529,7 +563,10 @@ class DMTrainer:
             defer = overlap and self.defer_backward
             ev_l0 = None
             with on_real():
-                be.set_real_weights(weights, self._per_class())
+                if hasattr(be, "prepare_real_weights"):
+                    be.prepare_real_weights(weights, self._per_class(), self.steps_done)
+                else:
+                    be.set_real_weights(weights, self._per_class())
                 if defer:       # an event behind the first level's launch of THIS step's real side (see ``_flush_backward``)
                     ev_l0 = torch.cuda.Event()
                     be.eng_real.after_first_level = lambda: ev_l0.record(be.s_real)
@@ -537,6 +574,8 @@ class DMTrainer:
                     f_real = self._real_features(idx_t)
                 finally:
                     be.eng_real.after_first_level = None
+                if hasattr(be, "real_launches_done"):
+                    be.real_launches_done()
             with on_syn():
                 if defer:
                     self._flush_backward(ev_l0)     # the PREVIOUS step's backward + SGD, held back until this step's first level is done

@@ -89,6 +89,18 @@ class _DevPlan:
         if self.breg3_ok:
             p.src_planes, p.src_rows = plan.row_source()
 
+    def use_slot(self, k: int) -> None:
+        """Switch to the k-th set of packed-operand buffers (``wpk`` and the dithered sets ``wpk_d``), allocated on first use.  Two
+        sets let the operands of step i + 1 be packed on a side stream while the launches of step i still read theirs
+        (EmbedEngine.set_weights(slot=), distill.DMTrainer)."""
+        slots = self.__dict__.setdefault("_slots", {0: (self.wpk, getattr(self, "wpk_d", None))})
+        cur = self.__dict__.get("_slot", 0)
+        slots[cur] = (self.wpk, getattr(self, "wpk_d", None))
+        if k not in slots:
+            slots[k] = (torch.empty_like(self.wpk), None)
+        self.wpk, self.wpk_d = slots[k]
+        self._slot = k
+
     def pack(self, w: torch.Tensor) -> None:
         assert w.dtype == torch.float32 and w.is_contiguous()
         lo = self.wpk[1] if self.wpk.shape[0] == 2 else None
@@ -321,7 +333,7 @@ class EmbedEngine:
         return t[:n].view(*shape)
 
     def set_weights(self, params: Sequence[torch.Tensor], quantize: Optional[str] = None, dither: int = 0,
-                    quantize_levels: Sequence[int] = (0, 1, 2)) -> None:
+                    quantize_levels: Sequence[int] = (0, 1, 2), slot: Optional[int] = None) -> None:
         """params = [w0, b0, w1, b1, w2, b2] fp32 on the device (ConvNet3D.features order).  ``quantize`` ('f16' /
         'bf16'): round the weight tensors of ``quantize_levels`` to that operand format first (``round_weights``; the value
         pass rounds exactly the levels the real side multiplies by plain rn16 weights -- not the last one when that runs in
@@ -331,6 +343,12 @@ class EmbedEngine:
         if quantize is not None:
             ws = round_weights(ws, quantize, quantize_levels)
         self._weights = ws
+        if slot is not None:      # (forward operands only: the packed buffers of slot ``slot``; the launches that follow read them)
+            for dp in self.fwd + ([self.fwd2x] if self.fwd2x is not None else []):
+                dp.use_slot(slot)
+            if self.last_c8:
+                sc = self.__dict__.setdefault("_c8_scale_slots", {})
+                self.c8_scales = sc.setdefault(slot, torch.zeros(8, dtype=torch.float32, device=self.device))
         for li in range(3):
             if li == 2 and self.fwd2x is not None:      # the last level multiplies by the exact hi+lo weights: nothing to dither
                 if self.last_c8:
@@ -349,6 +367,10 @@ class EmbedEngine:
             for li in range(3):
                 for dp in self.bwd[li]:
                     dp.pack(self._weights[2 * li])
+                    if os.environ.get("VD_BWD_X2_SIM") == "w" and dp.wpk.shape[0] == 2:
+                        # measurement knob: the NUMERICS of a two-MFMA input gradient (g_hi + g_lo) x W_hi -- the low
+                        # plane of the weights dropped -- at the cost of the three-MFMA program
+                        dp.wpk[1].zero_()
             self._bwd_packed = True
 
     # ------------------------------------------------------------------------------------
@@ -522,6 +544,8 @@ class EmbedEngine:
                 hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am), ctypes.c_int64(nb), cout, To, Ho, Wo, pt,
                                                T, OH, OW, layout, hip.ptr(dy[0]), hip.ptr(lo), self.prec_bwd, hip.ptr(sc), st),
                           "vd_unpool_relu_bwd")
+                if lo is not None and os.environ.get("VD_BWD_X2_SIM") == "g":
+                    lo.zero_()      # measurement knob: the numerics of g_hi x (W_hi + W_lo)
                 if li == 0:
                     out = dx[c0:c0 + nb]
                 else:

@@ -542,6 +542,140 @@ def plan_forward_cl(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: 
     return plan
 
 
+EPI_POS_FEAT = 3     # position tiles (plan_forward_pos): the four M tiles of a wave are the four positions of ONE pool window, pooled
+#                      across the tiles; fp32 features out
+
+
+def with_skip_table(plan: ConvPlan) -> ConvPlan:
+    """A VD_PREC_F16C8 program carries, behind the 2 S tap offsets of every box type, S / 4 words of TILE SKIP MASKS (bit i of word g:
+    M tile i of a wave takes no part in K steps 4 g .. 4 g + 3).  Programs that skip nothing get zeros."""
+    assert plan.S % 4 == 0
+    for t in plan.types:
+        if t.tap_off.size == 2 * plan.S:
+            t.tap_off = np.concatenate([t.tap_off, np.zeros(plan.S // 4, dtype=np.int32)]).astype(np.int32)
+    return plan
+
+
+@_memo
+def plan_forward_pos(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in: int, pool_t: int) -> ConvPlan:
+    """The LAST level's forward (features out) in POSITION TILES, for the fp8-corrected program (VD_PREC_F16C8).
+
+    With a 7 x 7 input grid, stride 2 and a 7 x 7 kernel only 51 % of a position's spatial taps fall inside the grid, and a tile of
+    32 consecutive positions cannot skip any of them: some row always needs the tap.  Here a tile's 32 rows are (clip, frame) pairs
+    of ONE output position (32 / T clips per box), the four tiles of a wave are the four positions of one 2 x 2 pool window, a
+    workgroup is one window x all output channels, and a box type per window lists ITS taps -- the union over the window's
+    positions, grouped by which of the four tiles they are valid for (skip masks, ``with_skip_table``; groups padded to four K
+    steps with zero-weight taps).  MFMAs per product: 152 instead of 304 per channel chunk at 7 x 7.  The patch holds only the
+    window's real pixels (no conv padding in h / w; one zero frame at either end), the B operands are packed once per window
+    (``w_box_stride``), and the pool runs ACROSS the four accumulator tiles (and over the frame pair inside a lane)."""
+    assert cin % 8 == 0 and cout == 128 and pool_t == 2
+    CC, NT = cin // 8, cout // 32
+    T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
+    To, Ho, Wo = T // 2, OH // 2, OW // 2
+    if T % 2 or 32 % T or T > 32 or Ho < 1 or Wo < 1:
+        raise ValueError("%s: position tiles need an even frame count that divides 32" % name)
+    ncl = 32 // T
+    npos = To * Ho * Wo
+    feat_stride = cout * npos
+    col, half = _lane_cols()
+    pf = T + 2
+    win = []
+    for a in range(Ho):
+        for b in range(Wo):
+            pos = [(2 * a + (i >> 1), 2 * b + (i & 1)) for i in range(4)]
+            ok_h = [[0 <= 2 * oh + kh - 3 < h_in for kh in range(KH)] for oh, _ in pos]
+            ok_w = [[0 <= 2 * ow + kw - 3 < w_in for kw in range(KW)] for _, ow in pos]
+            hs = [2 * oh + kh - 3 for i, (oh, _) in enumerate(pos) for kh in range(KH) if ok_h[i][kh]]
+            ws = [2 * ow + kw - 3 for i, (_, ow) in enumerate(pos) for kw in range(KW) if ok_w[i][kw]]
+            h0, w0, ph, pw = min(hs), min(ws), max(hs) - min(hs) + 1, max(ws) - min(ws) + 1
+            groups: Dict[int, list] = {}
+            for kh in range(KH):
+                for kw in range(KW):
+                    skip = sum(1 << i for i in range(4) if not (ok_h[i][kh] and ok_w[i][kw]))
+                    if skip != 15:
+                        groups.setdefault(skip, []).extend((kt, kh, kw) for kt in range(KT))
+            win.append(dict(a=a, b=b, pos=pos, h0=h0, w0=w0, ph=ph, pw=pw, groups=groups))
+    # K steps: per window, mask groups in the order of falling tile count, each padded to a multiple of 8 taps (4 steps)
+    for wd in win:
+        taps, masks = [], []
+        for skip in sorted(wd["groups"], key=lambda m: (bin(m).count("1"), m)):
+            g = wd["groups"][skip]
+            npad = -len(g) % 8
+            taps += g + [None] * npad
+            masks += [skip] * ((len(g) + npad) // 8)
+        wd["taps"], wd["masks"] = taps, masks
+    S = max(len(wd["taps"]) for wd in win) // 2
+    ph_max, pw_max = max(wd["ph"] for wd in win), max(wd["pw"] for wd in win)
+    # LDS pitches: a tile's rows are (clip, frame) -> slots ci * pitch_c + t * pitch_f: search the paddings for conflict-free b128 reads
+    best = None
+    for dpf in range(0, 16):
+        pitch_f = ph_max * pw_max + dpf
+        for dpc in range(0, 16):
+            pitch_c = pf * pitch_f + dpc
+            rows = np.array([ci * pitch_c + t * pitch_f for ci in range(ncl) for t in range(T)], dtype=np.int64)
+            key = (_conflict_cycles(rows), pitch_c)
+            if best is None or key < best[0]:
+                best = (key, pitch_f, pitch_c)
+    (cyc, _), pitch_f, pitch_c = best
+    pitch_h = pw_max
+    types, boxes, widx_all = [], [], []
+    for wi, wd in enumerate(win):
+        a_off = np.zeros(4 * 32, dtype=np.int64)
+        for i, (oh, ow) in enumerate(wd["pos"]):
+            for ci in range(ncl):
+                for t in range(T):
+                    r = ci * T + t          # row r of the tile: frames 2 tau, 2 tau + 1 are registers k, k + 1 of one lane
+                    a_off[i * 32 + r] = ci * pitch_c + t * pitch_f + (2 * oh - 3 - wd["h0"]) * pitch_h + (2 * ow - 3 - wd["w0"])
+        taps = wd["taps"] + [None] * (2 * S - len(wd["taps"]))
+        masks = wd["masks"] + [15] * (S // 4 - len(wd["masks"]))
+        tap_off = np.zeros(2 * S, dtype=np.int64)
+        last = (0, 0, 0)
+        for k, tp in enumerate(taps):       # a zero-weight tap reads where a tap of its group reads (any in-range slot would do)
+            if tp is None:
+                grp = [x for x in taps[(k // 8) * 8:(k // 8) * 8 + 8] if x is not None]
+                tp_r = grp[0] if grp else None
+            else:
+                tp_r = tp
+            if tp_r is None:
+                tap_off[k] = 0
+                continue
+            kt, kh, kw = tp_r
+            tap_off[k] = kt * pitch_f + kh * pitch_h + kw
+        # groups nothing takes part in must still read inside the patch if a prefetch touches them: they are skipped by all tiles
+        out = -np.ones(16, dtype=np.int64)          # entry e: rows 2 e, 2 e + 1 of every tile = (clip e // (T / 2), frame pair e % (T / 2))
+        for ci in range(ncl):
+            for tau in range(To):
+                out[(ci * T + 2 * tau) // 2] = ci * feat_stride + tau * Ho * Wo
+        tap_tab = np.concatenate([tap_off * SLOT_BYTES, np.array(masks, dtype=np.int64)])
+        types.append(BoxType(pf, ph_max, pw_max, pitch_h, pitch_f, pitch_c, 4, (a_off * SLOT_BYTES).astype(np.int32),
+                             out.astype(np.int32), tap_tab.astype(np.int32), float(cyc)))
+        boxes.append([wi, -1, wd["h0"], wd["w0"], wd["a"] * Wo + wd["b"], 0])
+        idx = -np.ones((CC, S, NT, 64, 8), dtype=np.int64)
+        for s in range(S):
+            for hh in range(2):
+                tp = taps[2 * s + hh]
+                if tp is None:
+                    continue
+                kt, kh, kw = tp
+                lanes = np.where(half == hh)[0]
+                for nt in range(NT):
+                    n = nt * 32 + col[lanes]
+                    for cc in range(CC):
+                        c = cc * 8 + np.arange(8)
+                        idx[cc, s, nt, lanes, :] = (((n[:, None] * cin + c[None, :]) * KT + kt) * KH + kh) * KW + kw
+        widx_all.append(idx)
+    widx = np.stack(widx_all).reshape(len(win) * CC, S, NT, 64, 8).astype(np.int32)
+    ntaps_used = sum(len([t for t in wd["taps"] if t is not None]) for wd in win)
+    plan = ConvPlan(name=name, CC=CC, F=t_in, H=h_in, W=w_in, row_pitch4=w_in * 4, chunk_stride4=t_in * h_in * w_in * 4,
+                    clip_stride4=CC * t_in * h_in * w_in * 4, NT=NT, MW=1, MTW=4, S=S, ncl=ncl,
+                    boxes=np.asarray(boxes, dtype=np.int32), types=types, widx=widx, epi=EPI_POS_FEAT, pool_t=2, relu=True,
+                    n_out=cout, n_stride=npos, out_clip_stride=feat_stride, out_chunk_stride=0, out_shape=(cout, To, Ho, Wo),
+                    w_box_stride=CC * S * NT * 64 * 8, rows_total=len(win) * 4 * 32 // ncl, rows_useful=T * 4 * Ho * Wo,
+                    meta={"box": (T, 2, 2), "macs_per_unit": int(T * 4 * Ho * Wo) * KT * KH * KW * cin * cout, "pos_tiles": 1,
+                          "mfma_per_chunk": [int(sum(4 * (4 - bin(m).count("1")) for m in wd["masks"])) for wd in win]})
+    return plan
+
+
 def pix_row_pitch(w: int) -> int:
     """Elements per 16-bit pixel row written by vd_pix2rows: 3 leading zeros + W pixels + zero
     tail, rounded up to a multiple of 8 (16 bytes)."""
