@@ -35,6 +35,12 @@ extern "C" {
 #define VD_EPI_POOL_CL   0
 #define VD_EPI_POOL_FEAT 1
 #define VD_EPI_ROWS      2
+#define VD_EPI_POS_FEAT  3   /* VD_PREC_F16C8 programs in POSITION TILES (plan.plan_forward_pos): a tile's 32 rows are (clip, frame)
+                                pairs of ONE output position, the four M tiles of a wave the four positions of one 2 x 2 pool
+                                window; fp32 features out, pooled ACROSS the tiles (out table: 16 entries, one per row pair).  One
+                                box type and one packed B operand set (w_box_stride apart) per window.  Behind the 2 S tap offsets
+                                of every box type of a VD_PREC_F16C8 program follow S / 4 TILE SKIP MASKS: bit i of word g = M tile i
+                                takes no part in K steps 4 g .. 4 g + 3 (its taps lie outside the input grid) */
 
 /* One tile program (see video_distillation_amd/plan.py).  All pointers are device
  * pointers; strides are in the units given. */

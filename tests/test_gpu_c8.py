@@ -3,6 +3,8 @@ fp16, the two hi+lo correction products a_lo W_hi + a_hi W_lo on the block-scale
 -- two MFMA-equivalents per product instead of three.  The corrections are 2^-12 of the product, so their fp8 rounding (2^-4
 of themselves) leaves 2^-16: this test pins that the mode keeps the hi+lo level's accuracy -- which a mistake in the operand
 order would NOT show as a failure elsewhere (garbled corrections look like a single-pass level, still inside every 1e-3 bar)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -54,6 +56,22 @@ def test_fp8_corrected_last_level_keeps_the_hi_lo_accuracy(geom, n):
     # same result whatever the launch is split into, and reproducible
     e8c = engine.EmbedEngine(geo, prec="f16", chunk=5, last_hilo="c8"); e8c.set_weights(w)
     assert torch.equal(e8c.forward(xc), f8) and torch.equal(e8.forward(xc), f8)
+    # position tiles (the default where 32 % frames == 0) against the row-major program: the same products, another order of the taps
+    assert (e8.fwd2x.plan.epi == plan.EPI_POS_FEAT) == (os.environ.get("VD_C8_POS", "1") == "1")
+    old = os.environ.get("VD_C8_POS")
+    os.environ["VD_C8_POS"] = "0"
+    try:
+        e8r = engine.EmbedEngine(geo, prec="f16", chunk=4096, last_hilo="c8"); e8r.set_weights(w)
+    finally:
+        if old is None:
+            del os.environ["VD_C8_POS"]
+        else:
+            os.environ["VD_C8_POS"] = old
+    assert e8r.fwd2x.plan.epi == plan.EPI_POOL_FEAT
+    f8r = e8r.forward(xc)
+    d88 = max(_rel(f8[i], f8r[i]) for i in range(n))
+    print("position tiles vs row-major fp8-corrected program: %.2e" % d88)
+    assert d88 < 2e-6
 
 
 def test_fp8_corrected_level_survives_large_and_tiny_weights():

@@ -60,14 +60,14 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 #define VD_C8_ALO_SHIFT 9
 #define VD_C8_SA_LO (127 - VD_C8_ALO_SHIFT)
 #define VD_C8_SA_HI (127 + 2)
-__device__ __forceinline__ void vd_c8_hi_image(const uint4& a, int& w0, int& w1) {      // 8 f16 -> 8 e4m3 bytes of a / 4
+__device__ __forceinline__ void vd_c8_hi_image(const uint4& a, int& w0, int& w1, const float div = 4.0f) {      // 8 f16 -> 8 e4m3 bytes of a / div
     // (four conversions, nothing else: the PRODUCER of the plane clamps its outputs to 1792 -- emit_lo = 2 -- so a / 4 stays inside
     //  e4m3's finite range; the instruction returns NaN beyond 464)
     i16x2 r0 = {0, 0}, r1 = {0, 0};
-    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, __builtin_bit_cast(f16x2, a.x), 4.0f, false);
-    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, __builtin_bit_cast(f16x2, a.y), 4.0f, true);
-    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, __builtin_bit_cast(f16x2, a.z), 4.0f, false);
-    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, __builtin_bit_cast(f16x2, a.w), 4.0f, true);
+    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, __builtin_bit_cast(f16x2, a.x), div, false);
+    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, __builtin_bit_cast(f16x2, a.y), div, true);
+    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, __builtin_bit_cast(f16x2, a.z), div, false);
+    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, __builtin_bit_cast(f16x2, a.w), div, true);
     w0 = __builtin_bit_cast(int, r0); w1 = __builtin_bit_cast(int, r1);
 }
 __device__ __forceinline__ uint32_t vd_c8_lo_byte(float v) {            // e4m3 byte of (v - rn16(v)) * 2^9, clamped to the finite range
@@ -220,6 +220,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
     const int plane_bytes = p.lds_plane_bytes;
     int* lds_tap = reinterpret_cast<int*>(smem + LPL * plane_bytes);
     int* lds_otab = lds_tap + 2 * p.S;
+    int* lds_skip = lds_otab + (p.MW * MTW + BAL) * 4;      // VD_PREC_F16C8: S / 4 tile skip masks behind the type's tap offsets
     const bool one_type = (p.ntypes == 1);
     const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);   // dword addressing: a slot may start at any dword
@@ -235,6 +236,8 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
         const int32_t* o_tab0 = p.tables + p.tab_ofs[1];
         const int32_t* t_tab0 = p.tables + p.tab_ofs[2];
         for (int k = tid; k < 2 * p.S; k += nthreads) lds_tap[k] = t_tab0[k];
+        if constexpr (C8)
+            for (int k = tid; k < (p.S >> 2); k += nthreads) lds_skip[k] = t_tab0[2 * p.S + k];
         if (p.epi != VD_EPI_ROWS)
             for (int k = tid; k < mt_tot * 4; k += nthreads) lds_otab[k] = o_tab0[k];
 #pragma unroll
@@ -254,6 +257,15 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
         // groups (= input channels).  Box-major order makes the workgroups resident on an XCD stream the
         // SAME B concurrently, so it is fetched into that L2 once instead of once per channel.
         if (p.w_box_stride != 0) {
+            const int ngrp = total_boxes / p.nbox;
+            bi = bid / ngrp;
+            grp = bid - bi * ngrp;
+        }
+    }
+    if constexpr (C8) {
+        // position-tile programs, persist bit 19: WINDOW-major box order -- with the XCD-contiguous ranges above an XCD then works on
+        // one pool window, i.e. streams ONE of the program's packed B operand sets through its L2 instead of all of them
+        if (p.persist & 0x80000) {
             const int ngrp = total_boxes / p.nbox;
             bi = bid / ngrp;
             grp = bid - bi * ngrp;
@@ -285,6 +297,8 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
         const int32_t* t_tab = p.tables + box[2];
         __syncthreads();   // the previous box's epilogue is done with the LDS tables
         for (int k = tid; k < 2 * p.S; k += nthreads) lds_tap[k] = t_tab[k];
+        if constexpr (C8)
+            for (int k = tid; k < (p.S >> 2); k += nthreads) lds_skip[k] = t_tab[2 * p.S + k];
         if (p.epi != VD_EPI_ROWS)
             for (int k = tid; k < mt_tot * 4; k += nthreads) lds_otab[k] = o_tab[k];
 #pragma unroll
@@ -312,7 +326,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
         // (single-pass programs: w_set_clips > 0 selects one of several operand sets, w_plane_stride apart, by the box's first
         //  clip -- the dithered weights of the real side, distill.HipBackend.embed_pool)
         const int64_t wset = (!X3 && !EXT && p.w_set_clips > 0) ? (int64_t)(clip0 / p.w_set_clips) * w_lo : (int64_t)0;
-        const uint4* wp = wbase + wset + (EXT ? (((int64_t)bi * p.w_box_stride) >> 3) : (int64_t)0) + ((int64_t)cc * S * p.NT + wn * NTW) * 64 + lane;
+        const uint4* wp = wbase + wset + ((EXT || C8) ? (((int64_t)bi * p.w_box_stride) >> 3) : (int64_t)0) + ((int64_t)cc * S * p.NT + wn * NTW) * 64 + lane;
         auto load_b = [&](int s, uint4* bh, uint4* bl) {
             const int sc = (VD_DBG(p) & 16) ? 0 : ((s < S) ? s : S - 1);   // dbg 16: always the same (cached) B fragment
 #pragma unroll
@@ -473,21 +487,35 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
             // (row, half) with element j of the B lane (column, half): tools/micro/mfma_f8_probe.hip).  The low parts come from plane 1
             // of the patch (8 bytes per slot), the fp8 image of the high fragment is converted from the registers the fp16 MFMA has
             // just consumed -- no second LDS read for it.
+            // TILE SKIP MASKS (position-tile programs, plan_forward_pos): bit i of a group's word = M tile i of this wave takes no part
+            // in the group's four K steps -- none of its rows has those taps inside the input grid -- so its fragment reads, its
+            // conversions and its matrix instructions are skipped (wave-uniform scalar branches).  Zero for every other program.
             const int* sc8 = reinterpret_cast<const int*>(p.out_scale);
             const int sb_hi = sc8[0], sb_lo = sc8[1];
+            auto skip_of = [&](int st) { return __builtin_amdgcn_readfirstlane(lds_skip[((st < S) ? st : S - 4) >> 2]); };
+            int skip = skip_of(0);
             int tap_next = lds_tap[2 * ((1 < S) ? 1 : 0) + half];
             uint4 Ah[MTW];
             {
                 const int tap0 = lds_tap[half];
 #pragma unroll
-                for (int i = 0; i < MTW; ++i) Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap0);
+                for (int i = 0; i < MTW; ++i) {
+                    Ah[i] = make_uint4(0, 0, 0, 0);
+                    if (!((skip >> i) & 1)) Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap0);
+                }
             }
             // the four 16-byte pieces of a group's fp8 B fragments (plane 1 of the packed weights, stored at the group's four steps):
             // pieces 0, 1 (W_hi image) are loaded at the END of the previous group, pieces 2, 3 (W_lo image) at steps 0 and 1 of the
             // group itself -- four registers-quads in all, every load two or more K steps ahead of the correction products that use it
-            auto piece = [&](int st) { return wp[(int64_t)((st < S) ? st : S - 1) * wstep + w_lo]; };
-            uint4 b8_0 = piece(0), b8_1 = piece(1), b8_2, b8_3;
+            // (the W_hi image is no longer LOADED: it is converted from the fp16 B fragment of each step, in registers, like the A image
+            //  -- same lane, same element order -- which takes a quarter off the B bytes a wave pulls through its CU's 64-byte/clock
+            //  vector-memory path: with position tiles that path, not the matrix pipe, was the next limit)
+            auto piece = [&](int st) { return wp[(int64_t)((VD_DBG(p) & 16) ? 0 : ((st < S) ? st : S - 1)) * wstep + w_lo]; };
+            const float w_div = p.out_scale[3];          // 1 / s of vd_pack_weights_c8 (a power of two): image = W_hi * s
+            uint4 b8_2, b8_3;
+            i32x8 B8hi;
             for (int s = 0; s < S; s += 4) {
+                const int skip_n = skip_of(s + 4);           // the NEXT group's mask: the last step's fragment prefetch reads for it
                 i32x8 a8hi[MTW];
                 int tapq[4];                 // this lane half's tap offsets of the group's four steps (for the low-part reads)
 #pragma unroll
@@ -499,13 +527,21 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                     if (u == 1) b8_3 = piece(s + 3);
                     const int sn2 = (s + u + 2 < S) ? s + u + 2 : S - 1;
                     const int tap_next2 = lds_tap[2 * sn2 + half];
+                    {
+                        int w0, w1;
+                        if (VD_DBG(p) & 0x2000) { w0 = (int)bqh[u][0].x; w1 = (int)bqh[u][0].y; }     // dbg 0x2000: no conversion of the B image
+                        else vd_c8_hi_image(bqh[u][0], w0, w1, w_div);
+                        B8hi[2 * u] = w0; B8hi[2 * u + 1] = w1;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (u < 3) {
 #pragma unroll
                         for (int i = 0; i < MTW; ++i) {
+                            if ((skip >> i) & 1) continue;
                             acc[i] = mfma16<PREC>(Ah[i], bqh[u][0], acc[i]);
                             int w0, w1;
-                            vd_c8_hi_image(Ah[i], w0, w1);
+                            if (VD_DBG(p) & 0x400) { w0 = (int)Ah[i].x; w1 = (int)Ah[i].y; }        // dbg 0x400: no conversions of the A image
+                            else vd_c8_hi_image(Ah[i], w0, w1);
                             a8hi[i][2 * u] = w0; a8hi[i][2 * u + 1] = w1;
                             __builtin_amdgcn_sched_barrier(0);
                             Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
@@ -515,43 +551,48 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                         // last step of the group.  Behind tile i's main product its four low-part slots are read; the correction products
                         // follow one (a_lo W_hi) and two (a_hi W_lo) tiles later, so that consecutive writes of one accumulator are always
                         // separated by matrix instructions on other accumulators (a dependent MFMA waits for its predecessor's passes)
-                        const i32x8 B8hi = {(int)b8_0.x, (int)b8_0.y, (int)b8_0.z, (int)b8_0.w, (int)b8_1.x, (int)b8_1.y, (int)b8_1.z, (int)b8_1.w};
                         const i32x8 B8lo = {(int)b8_2.x, (int)b8_2.y, (int)b8_2.z, (int)b8_2.w, (int)b8_3.x, (int)b8_3.y, (int)b8_3.z, (int)b8_3.w};
                         i32x8 a8lo[2];
                         auto corr_lo = [&](auto IC) __attribute__((always_inline)) {
                             constexpr int i = decltype(IC)::v;
+                            if (VD_DBG(p) & 0x800) return;          // dbg 0x800: no correction products
                             acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8lo[i & 1], B8hi, acc[i], 0, 0, 0, VD_C8_SA_LO, 0, sb_hi);
                         };
                         auto corr_hi = [&](auto IC) __attribute__((always_inline)) {
                             constexpr int i = decltype(IC)::v;
+                            if (VD_DBG(p) & 0x800) return;
                             acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8hi[i], B8lo, acc[i], 0, 0, 0, VD_C8_SA_HI, 0, sb_lo);
                         };
                         vd_static_for<MTW>([&](auto IC) __attribute__((always_inline)) {
                             constexpr int i = decltype(IC)::v;
-                            acc[i] = mfma16<PREC>(Ah[i], bqh[3][0], acc[i]);
-                            int w0, w1;
-                            vd_c8_hi_image(Ah[i], w0, w1);
-                            a8hi[i][6] = w0; a8hi[i][7] = w1;
+                            if (!((skip >> i) & 1)) {
+                                acc[i] = mfma16<PREC>(Ah[i], bqh[3][0], acc[i]);
+                                int w0, w1;
+                                if (VD_DBG(p) & 0x400) { w0 = (int)Ah[i].x; w1 = (int)Ah[i].y; }
+                                else vd_c8_hi_image(Ah[i], w0, w1);
+                                a8hi[i][6] = w0; a8hi[i][7] = w1;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const uint2 lo = *reinterpret_cast<const uint2*>(smem + plane_bytes + a_off[i] + tapq[q]);
-                                a8lo[i & 1][2 * q] = (int)lo.x; a8lo[i & 1][2 * q + 1] = (int)lo.y;
+                                for (int q = 0; q < 4; ++q) {
+                                    if (VD_DBG(p) & 0x1000) { a8lo[i & 1][2 * q] = w0; a8lo[i & 1][2 * q + 1] = w1; continue; }   // dbg 0x1000: no low-part reads
+                                    const uint2 lo = *reinterpret_cast<const uint2*>(smem + plane_bytes + a_off[i] + tapq[q]);
+                                    a8lo[i & 1][2 * q] = (int)lo.x; a8lo[i & 1][2 * q + 1] = (int)lo.y;
+                                }
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
+                            if (!((skip_n >> i) & 1)) Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
                             __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (i >= 1) corr_lo(VdIC<i - 1>{});
-                            if constexpr (i >= 2) corr_hi(VdIC<i - 2>{});
+                            if constexpr (i >= 1) { if (!((skip >> (i - 1)) & 1)) corr_lo(VdIC<i - 1>{}); }
+                            if constexpr (i >= 2) { if (!((skip >> (i - 2)) & 1)) corr_hi(VdIC<i - 2>{}); }
                             __builtin_amdgcn_sched_barrier(0);
                         });
-                        corr_lo(VdIC<MTW - 1>{});
-                        corr_hi(VdIC<MTW - 2>{});
-                        corr_hi(VdIC<MTW - 1>{});
+                        if (!((skip >> (MTW - 1)) & 1)) corr_lo(VdIC<MTW - 1>{});
+                        if (!((skip >> (MTW - 2)) & 1)) corr_hi(VdIC<MTW - 2>{});
+                        if (!((skip >> (MTW - 1)) & 1)) corr_hi(VdIC<MTW - 1>{});
                         __builtin_amdgcn_sched_barrier(0);
-                        b8_0 = piece(s + 4); b8_1 = piece(s + 5);          // the next group's W_hi image
                     }
                     tap_next = tap_next2;
                 }
+                skip = skip_n;
             }
         } else if constexpr (SEQ) {
             // hi+lo formats, one plane resident: the fragment a tile's MFMAs have just consumed is refilled at once with the
@@ -680,6 +721,31 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
       }
         finish();
         continue;
+    }
+
+    if constexpr (C8) {
+        if (p.epi == VD_EPI_POS_FEAT) {
+            // position tiles: the wave's four accumulator tiles are the four positions of ONE pool window, rows 2 e and 2 e + 1 (two
+            // registers of one lane) a frame pair of one clip: the 2 x 2 x 2 pool is a max over 8 registers, no lane traffic
+            float* dstf = reinterpret_cast<float*>(p.dst);
+            const int n = wn * 32 + (lane & 31);
+            const bool n_ok = n < p.n_out;
+            const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                float m = fmaxf(acc[0][k], acc[0][k + 1]);
+#pragma unroll
+                for (int i = 1; i < MTW; ++i) m = fmaxf(m, fmaxf(acc[i][k], acc[i][k + 1]));
+                m += bias;
+                if (p.relu) m = fmaxf(m, 0.f);
+                const int row = (k & 3) + 8 * (k >> 2) + 4 * half;
+                const int o = lds_otab[row >> 1];
+                const int64_t idx = out_base + o + (int64_t)n * p.n_stride;
+                if (o >= 0 && n_ok && idx < out_total) dstf[idx] = m;
+            }
+            finish();
+            continue;
+        }
     }
 
     // pooled epilogues: registers 8*qh .. 8*qh+7 of this lane are one 2x2x2 row group.
@@ -1937,7 +2003,8 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     const int groups = (p.nclips + p.ncl - 1) / p.ncl;
     const int64_t total = (int64_t)groups * p.nbox;
     if (total <= 0) return 0;
-    size_t lds = (size_t)((X3 && !SQ) ? 2 : 1) * p.lds_plane_bytes + (size_t)(2 * p.S + (p.MW * MTW + BAL) * 4) * sizeof(int) + 16;
+    size_t lds = (size_t)((X3 && !SQ) ? 2 : 1) * p.lds_plane_bytes +
+                 (size_t)(2 * p.S + (p.MW * MTW + BAL) * 4 + (PREC == VD_PREC_F16C8 ? p.S / 4 : 0)) * sizeof(int) + 16;
     if (lds > 160 * 1024) return -3;
     if ((p.dbg & 0x100) && lds < 100 * 1024) lds = 100 * 1024;   // diagnostic (tools/stamps.py --alone): one workgroup per CU
     auto kern = conv_mfma_kernel<PREC, MTW, SO, NTW, BAL, SQ>;
@@ -1956,7 +2023,8 @@ static int launch(const VdConvParams& p, hipStream_t st) {
     if (occ < 1) occ = 1;
     // a few workgroup "generations" keep the tail short while still amortising the dispatch
     const int64_t slots = (int64_t)ncu * occ;
-    int per = (p.persist > 0 && MTW * NTW <= 4) ? (int)((total + slots * p.persist - 1) / (slots * p.persist)) : 1;
+    const int gens = p.persist & 0xFFFF;          // (the bits above are options of single programs)
+    int per = (gens > 0 && MTW * NTW <= 4) ? (int)((total + slots * gens - 1) / (slots * gens)) : 1;
     if (per < 1) per = 1;
     const int64_t grid = (total + per - 1) / per;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * ncols * p.MW), lds, st, p, per, (int)total);
@@ -1980,9 +2048,12 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     if (p.MTW * ntw < 8 && (p.gather_stride >> 6) > (int64_t)wgw * (p.MTW * ntw <= 4 ? 14 : 17)) return -2;   // patch larger than the DMA register budget
     if (p.clip_index != nullptr && (p.ncl != 1 || p.CC != 1 || p.MTW * ntw > 4)) return -2;
     if (p.prec == VD_PREC_F16C8) {      // fp16 + fp8 corrections: the last level's forward only (see include/vd_hip.h)
-        if (ntw != 1 || p.MTW != 4 || p.S % 4 != 0 || p.epi != VD_EPI_POOL_FEAT || p.out_scale == nullptr || p.select || p.atomic ||
-            p.src_split_cc > 0 || p.w_box_stride != 0 || p.emit_lo != 0)
+        if (ntw != 1 || p.MTW != 4 || p.S % 4 != 0 || (p.epi != VD_EPI_POOL_FEAT && p.epi != VD_EPI_POS_FEAT) || p.out_scale == nullptr ||
+            p.select || p.atomic || p.src_split_cc > 0 || p.emit_lo != 0)
             return -2;
+        // (position-tile programs: one box type and one packed B operand set per pool window, pool_t = 2, one wave row, no arg-max)
+        if (p.epi == VD_EPI_POS_FEAT && (p.MW != 1 || p.NT != 4 || p.pool_t != 2 || p.argmax != nullptr || p.w_box_stride <= 0)) return -2;
+        if (p.epi != VD_EPI_POS_FEAT && p.w_box_stride != 0) return -2;
         return launch<VD_PREC_F16C8, 4>(p, st);
     }
     if (p.emit_lo != 0) {   // low plane of a single-pass program's pooled outputs: staged channels-last epilogue only, and the staging tile

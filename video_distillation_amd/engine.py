@@ -113,7 +113,8 @@ class _DevPlan:
         ``scales`` (>= 6 floats of device scratch) receives the two E8M0 codes ``run(..., out_scale=scales)`` hands to the kernel."""
         assert w.dtype == torch.float32 and w.is_contiguous() and self.wpk.shape[0] == 2
         pl = self.plan
-        hip.check(hip.lib().vd_pack_weights_c8(hip.ptr(w), ctypes.c_int64(w.numel()), hip.ptr(self.widx), pl.CC, pl.S, pl.NT,
+        sets = self.n_w // (pl.CC * pl.S * pl.NT * 512)       # (position-tile programs: one operand set per box, chunk-major inside)
+        hip.check(hip.lib().vd_pack_weights_c8(hip.ptr(w), ctypes.c_int64(w.numel()), hip.ptr(self.widx), sets * pl.CC, pl.S, pl.NT,
                                                hip.ptr(self.wpk[0]), hip.ptr(self.wpk[1]), hip.ptr(scales), hip.stream_ptr(w.device)),
                   "vd_pack_weights_c8")
 
@@ -309,10 +310,22 @@ class EmbedEngine:
             self.last_c8 = (last_hilo == "c8")
             if self.last_c8 and not (prec == "f16" and pl2.NTW == 1 and pl2.MTW == 4 and pl2.S % 4 == 0):
                 raise ValueError("last_hilo='c8' needs the f16 format and the one-clip 4 x 1-tile last-level program (geometry %s)" % (geo,))
+            if self.last_c8:
+                # POSITION TILES (plan.plan_forward_pos): rows = (clip, frame) pairs of one output position, so that the taps outside
+                # the input grid -- half of them at 7 x 7 -- are skipped per tile; VD_C8_POS=0 keeps the row-major program
+                d2 = self.dims[2]
+                pl2 = P.with_skip_table(dataclasses.replace(pl2, types=[dataclasses.replace(t) for t in pl2.types]))
+                if os.environ.get("VD_C8_POS", "1") == "1":
+                    try:
+                        pl2 = P.plan_forward_pos("fwd2_pos", d2[0], d2[1], d2[2], d2[3], d2[4], d2[11])
+                    except (ValueError, AssertionError):
+                        pass
             self.fwd2x = _DevPlan(dataclasses.replace(pl2, name="fwd2_c8" if self.last_c8 else "fwd2_hilo"), self.device,
                                   hip.PREC["f16c8"] if self.last_c8 else hip.PREC[prec + "x3"])
             if self.last_c8:
                 self.c8_scales = torch.zeros(8, dtype=torch.float32, device=self.device)
+                if pl2.epi == P.EPI_POS_FEAT and os.environ.get("VD_C8_BOXMAJOR", "0") == "1":
+                    self.fwd2x.params.persist |= 0x80000       # window-major box order (VdConvParams.persist bit 19)
         # operand precision of the input-gradient passes (default: same as the forward)
         self.prec_bwd = hip.PREC[prec_bwd] if prec_bwd else self.prec
         self.planes_bwd = 2 if hip.is_x3(self.prec_bwd) else 1
