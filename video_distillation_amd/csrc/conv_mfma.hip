@@ -60,15 +60,14 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 #define VD_C8_ALO_SHIFT 9
 #define VD_C8_SA_LO (127 - VD_C8_ALO_SHIFT)
 #define VD_C8_SA_HI (127 + 2)
-__device__ __forceinline__ void vd_c8_hi_image(const uint4& a, int& w0, int& w1, const float div = 4.0f) {      // 8 f16 -> 8 e4m3 bytes of a / div
-    // (four conversions, nothing else: the PRODUCER of the plane clamps its outputs to 1792 -- emit_lo = 2 -- so a / 4 stays inside
-    //  e4m3's finite range; the instruction returns NaN beyond 464)
-    i16x2 r0 = {0, 0}, r1 = {0, 0};
-    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, __builtin_bit_cast(f16x2, a.x), div, false);
-    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, __builtin_bit_cast(f16x2, a.y), div, true);
-    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, __builtin_bit_cast(f16x2, a.z), div, false);
-    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, __builtin_bit_cast(f16x2, a.w), div, true);
-    w0 = __builtin_bit_cast(int, r0); w1 = __builtin_bit_cast(int, r1);
+__device__ __forceinline__ uint32_t vd_c8_hi_byte(uint16_t h16) {      // e4m3 byte of (fp16 value) / 4
+    // (the PRODUCER of the plane clamps its outputs to 1792 -- emit_lo = 2 -- so a / 4 stays inside e4m3's finite range; the
+    //  instruction returns NaN beyond 464)
+    const _Float16 h = __builtin_bit_cast(_Float16, h16);
+    const f16x2 hh = {h, h};
+    i16x2 r = {0, 0};
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, hh, 4.0f, false);
+    return (uint32_t)__builtin_bit_cast(int, r) & 0xffu;
 }
 __device__ __forceinline__ uint32_t vd_c8_lo_byte(float v) {            // e4m3 byte of (v - rn16(v)) * 2^9, clamped to the finite range
     float r = (v - (float)(_Float16)v) * (float)(1 << VD_C8_ALO_SHIFT);
@@ -481,118 +480,200 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 }
             }
         } else if constexpr (C8) {
-            // fp16 main product every K step; the two correction products once per FOUR steps on the fp8 instruction (K = 64 = 4 steps x
-            // 2 taps x 8 channels).  Element j = 8 q + e of a lane's 32-byte fp8 fragment is (step 4 g + q, this lane's tap half,
-            // channel e) in BOTH operands (vd_pack_weights_c8 packs B in that order; the instruction pairs element j of the A lane
-            // (row, half) with element j of the B lane (column, half): tools/micro/mfma_f8_probe.hip).  The low parts come from plane 1
-            // of the patch (8 bytes per slot), the fp8 image of the high fragment is converted from the registers the fp16 MFMA has
-            // just consumed -- no second LDS read for it.
+            // fp16 main product every K step; the two correction products once per FOUR steps (a GROUP) on the fp8 instruction (K = 64 =
+            // 4 steps x 2 taps x 8 channels).  Element j = 8 q + e of a lane's 32-byte fp8 fragment is (step 4 g + q, this lane's tap
+            // half, channel e) in BOTH operands (vd_pack_weights_c8 packs B in that order; the instruction pairs element j of the A lane
+            // (row, half) with element j of the B lane (column, half): tools/micro/mfma_f8_probe.hip).  Plane 1 of the patch holds, per
+            // 16-byte slot, the 8 low parts (x 2^9) AND the 8-byte fp8 image of the high parts (a / 4), both written by the producing
+            // program (emit_lo = 2): one ds_read_b128 per step of the group fetches both, and the loop converts nothing.
+            //
             // TILE SKIP MASKS (position-tile programs, plan_forward_pos): bit i of a group's word = M tile i of this wave takes no part
-            // in the group's four K steps -- none of its rows has those taps inside the input grid -- so its fragment reads, its
-            // conversions and its matrix instructions are skipped (wave-uniform scalar branches).  Zero for every other program.
+            // in the group's four K steps -- none of its rows has those taps inside the input grid.  The planner orders a window's
+            // tiles so that the masks it emits are 0 (all four tiles), 0b1100 (tiles 0, 1), 0b1010 (tiles 0, 2), 0b1110 (tile 0)
+            // wherever the geometry allows (7 x 7: always); each has its own compile-time body, any other mask runs a generic one.
+            // In the sparse bodies the A registers of the idle tiles hold the fragments of LATER steps of the busy ones, so that a
+            // step never waits for the LDS read the previous step issued (one or two MFMAs do not cover that latency).
             const int* sc8 = reinterpret_cast<const int*>(p.out_scale);
             const int sb_hi = sc8[0], sb_lo = sc8[1];
             auto skip_of = [&](int st) { return __builtin_amdgcn_readfirstlane(lds_skip[((st < S) ? st : S - 4) >> 2]); };
+            const int* tapv = lds_tap + half;                   // this lane half's tap offsets: tapv[2 * step]
+            auto taps_of = [&](int st, int* t4) {                // the four tap offsets of the group that starts at step st (clamped)
+                const int sc = (st < S) ? st : S - 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t4[q] = tapv[2 * (sc + q)];
+            };
+            auto rdA = [&](int i, int tap) { return *reinterpret_cast<const uint4*>(smem + a_off[i] + tap); };
+            const uint4* wq = wp;                               // B operands of the current group's first step
+            auto piece = [&](int st) { return wq[(int64_t)st * wstep + w_lo]; };      // (reads up to 6 steps past the chunk: the buffer carries slack)
             int skip = skip_of(0);
-            int tap_next = lds_tap[2 * ((1 < S) ? 1 : 0) + half];
+            int tq[4];
+            taps_of(0, tq);
             uint4 Ah[MTW];
-            {
-                const int tap0 = lds_tap[half];
 #pragma unroll
-                for (int i = 0; i < MTW; ++i) {
-                    Ah[i] = make_uint4(0, 0, 0, 0);
-                    if (!((skip >> i) & 1)) Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap0);
-                }
+            for (int i = 0; i < MTW; ++i) {
+                Ah[i] = make_uint4(0, 0, 0, 0);
+                if (!((skip >> i) & 1)) Ah[i] = rdA(i, tq[0]);
             }
-            // the four 16-byte pieces of a group's fp8 B fragments (plane 1 of the packed weights, stored at the group's four steps):
-            // pieces 0, 1 (W_hi image) are loaded at the END of the previous group, pieces 2, 3 (W_lo image) at steps 0 and 1 of the
-            // group itself -- four registers-quads in all, every load two or more K steps ahead of the correction products that use it
-            // (the W_hi image is no longer LOADED: it is converted from the fp16 B fragment of each step, in registers, like the A image
-            //  -- same lane, same element order -- which takes a quarter off the B bytes a wave pulls through its CU's 64-byte/clock
-            //  vector-memory path: with position tiles that path, not the matrix pipe, was the next limit)
-            auto piece = [&](int st) { return wp[(int64_t)((VD_DBG(p) & 16) ? 0 : ((st < S) ? st : S - 1)) * wstep + w_lo]; };
-            const float w_div = p.out_scale[3];          // 1 / s of vd_pack_weights_c8 (a power of two): image = W_hi * s
-            uint4 b8_2, b8_3;
-            i32x8 B8hi;
-            for (int s = 0; s < S; s += 4) {
-                const int skip_n = skip_of(s + 4);           // the NEXT group's mask: the last step's fragment prefetch reads for it
-                i32x8 a8hi[MTW];
-                int tapq[4];                 // this lane half's tap offsets of the group's four steps (for the low-part reads)
+            uint4 b8_0 = piece(0), b8_1 = piece(1), b8_2, b8_3;
+            i32x8 a8lo[2], a8hi[2];
+            auto corr_lo = [&](auto IC, auto RC, const i32x8& B8hi) __attribute__((always_inline)) {
+                constexpr int i = decltype(IC)::v, r = decltype(RC)::v;
+                if (VD_DBG(p) & 0x800) return;          // dbg 0x800: no correction products
+                acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8lo[r], B8hi, acc[i], 0, 0, 0, VD_C8_SA_LO, 0, sb_hi);
+            };
+            auto corr_hi = [&](auto IC, auto RC, const i32x8& B8lo) __attribute__((always_inline)) {
+                constexpr int i = decltype(IC)::v, r = decltype(RC)::v;
+                if (VD_DBG(p) & 0x800) return;
+                acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8hi[r], B8lo, acc[i], 0, 0, 0, VD_C8_SA_HI, 0, sb_lo);
+            };
+            // plane 1 of tile i at the group's four taps -> ring entries rl (low parts) and rh (fp8 image of the high parts)
+            auto rd_planes = [&](auto IC, auto RL, auto RH) __attribute__((always_inline)) {
+                constexpr int i = decltype(IC)::v, rl = decltype(RL)::v, rh = decltype(RH)::v;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) tapq[u] = lds_tap[2 * (s + u) + half];
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 x = *reinterpret_cast<const uint4*>(smem + plane_bytes + a_off[i] + tq[q]);
+                    a8lo[rl][2 * q] = (int)x.x; a8lo[rl][2 * q + 1] = (int)x.y;
+                    a8hi[rh][2 * q] = (int)x.z; a8hi[rh][2 * q + 1] = (int)x.w;
+                }
+            };
+            // one group = four K steps.  MK >= 0: compile-time mask; MK < 0: the run-time mask `skip`.
+            auto group = [&](auto MC, const int skip_n, const int tqn0) __attribute__((always_inline)) {
+                constexpr int MK = decltype(MC)::v;
+                constexpr bool P4 = (MK == 0), P2A = (MK == 0xC), P2B = (MK == 0xA), P1 = (MK == 0xE);
+                // ---- steps 0 .. 2 (and the main products of step 3) ----
+                if constexpr (P1) {
+                    // tile 0 only: its fragments of steps 1, 2, 3 go to the idle tiles' registers at once
+                    Ah[1] = rdA(0, tq[1]); Ah[2] = rdA(0, tq[2]); Ah[3] = rdA(0, tq[3]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
-                    if (u == 0) b8_2 = piece(s + 2);
-                    if (u == 1) b8_3 = piece(s + 3);
-                    const int sn2 = (s + u + 2 < S) ? s + u + 2 : S - 1;
-                    const int tap_next2 = lds_tap[2 * sn2 + half];
-                    {
-                        int w0, w1;
-                        if (VD_DBG(p) & 0x2000) { w0 = (int)bqh[u][0].x; w1 = (int)bqh[u][0].y; }     // dbg 0x2000: no conversion of the B image
-                        else vd_c8_hi_image(bqh[u][0], w0, w1, w_div);
-                        B8hi[2 * u] = w0; B8hi[2 * u + 1] = w1;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (u < 3) {
-#pragma unroll
-                        for (int i = 0; i < MTW; ++i) {
-                            if ((skip >> i) & 1) continue;
-                            acc[i] = mfma16<PREC>(Ah[i], bqh[u][0], acc[i]);
-                            int w0, w1;
-                            if (VD_DBG(p) & 0x400) { w0 = (int)Ah[i].x; w1 = (int)Ah[i].y; }        // dbg 0x400: no conversions of the A image
-                            else vd_c8_hi_image(Ah[i], w0, w1);
-                            a8hi[i][2 * u] = w0; a8hi[i][2 * u + 1] = w1;
-                            __builtin_amdgcn_sched_barrier(0);
-                            Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    } else {
-                        // last step of the group.  Behind tile i's main product its four low-part slots are read; the correction products
-                        // follow one (a_lo W_hi) and two (a_hi W_lo) tiles later, so that consecutive writes of one accumulator are always
-                        // separated by matrix instructions on other accumulators (a dependent MFMA waits for its predecessor's passes)
-                        const i32x8 B8lo = {(int)b8_2.x, (int)b8_2.y, (int)b8_2.z, (int)b8_2.w, (int)b8_3.x, (int)b8_3.y, (int)b8_3.z, (int)b8_3.w};
-                        i32x8 a8lo[2];
-                        auto corr_lo = [&](auto IC) __attribute__((always_inline)) {
-                            constexpr int i = decltype(IC)::v;
-                            if (VD_DBG(p) & 0x800) return;          // dbg 0x800: no correction products
-                            acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8lo[i & 1], B8hi, acc[i], 0, 0, 0, VD_C8_SA_LO, 0, sb_hi);
-                        };
-                        auto corr_hi = [&](auto IC) __attribute__((always_inline)) {
-                            constexpr int i = decltype(IC)::v;
-                            if (VD_DBG(p) & 0x800) return;
-                            acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8hi[i], B8lo, acc[i], 0, 0, 0, VD_C8_SA_HI, 0, sb_lo);
-                        };
-                        vd_static_for<MTW>([&](auto IC) __attribute__((always_inline)) {
-                            constexpr int i = decltype(IC)::v;
-                            if (!((skip >> i) & 1)) {
-                                acc[i] = mfma16<PREC>(Ah[i], bqh[3][0], acc[i]);
-                                int w0, w1;
-                                if (VD_DBG(p) & 0x400) { w0 = (int)Ah[i].x; w1 = (int)Ah[i].y; }
-                                else vd_c8_hi_image(Ah[i], w0, w1);
-                                a8hi[i][6] = w0; a8hi[i][7] = w1;
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    if (VD_DBG(p) & 0x1000) { a8lo[i & 1][2 * q] = w0; a8lo[i & 1][2 * q + 1] = w1; continue; }   // dbg 0x1000: no low-part reads
-                                    const uint2 lo = *reinterpret_cast<const uint2*>(smem + plane_bytes + a_off[i] + tapq[q]);
-                                    a8lo[i & 1][2 * q] = (int)lo.x; a8lo[i & 1][2 * q + 1] = (int)lo.y;
-                                }
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (!((skip_n >> i) & 1)) Ah[i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tap_next);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (i >= 1) { if (!((skip >> (i - 1)) & 1)) corr_lo(VdIC<i - 1>{}); }
-                            if constexpr (i >= 2) { if (!((skip >> (i - 2)) & 1)) corr_hi(VdIC<i - 2>{}); }
-                            __builtin_amdgcn_sched_barrier(0);
-                        });
-                        if (!((skip >> (MTW - 1)) & 1)) corr_lo(VdIC<MTW - 1>{});
-                        if (!((skip >> (MTW - 2)) & 1)) corr_hi(VdIC<MTW - 2>{});
-                        if (!((skip >> (MTW - 1)) & 1)) corr_hi(VdIC<MTW - 1>{});
+                    for (int u = 0; u < 4; ++u) {
+                        bqh[(u + DB) % (DB + 1)][0] = wq[(int64_t)(u + DB) * wstep];
+                        if (u == 0) b8_2 = piece(2);
+                        if (u == 1) b8_3 = piece(3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[0] = mfma16<PREC>(Ah[u], bqh[u][0], acc[0]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    tap_next = tap_next2;
+                } else if constexpr (P2A || P2B) {
+                    // two tiles (0 and T1): the idle pair of registers is the second fragment set, reads run two steps ahead
+                    constexpr int T1 = P2A ? 1 : 2, J0 = P2A ? 2 : 1, J1 = 3;
+                    Ah[J0] = rdA(0, tq[1]); Ah[J1] = rdA(T1, tq[1]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        bqh[(u + DB) % (DB + 1)][0] = wq[(int64_t)(u + DB) * wstep];
+                        if (u == 0) b8_2 = piece(2);
+                        if (u == 1) b8_3 = piece(3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int ra = (u & 1) ? J0 : 0, rb = (u & 1) ? J1 : T1;
+                        acc[0] = mfma16<PREC>(Ah[ra], bqh[u][0], acc[0]);
+                        if (u < 2) Ah[ra] = rdA(0, tq[u + 2]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[T1] = mfma16<PREC>(Ah[rb], bqh[u][0], acc[T1]);
+                        if (u < 2) Ah[rb] = rdA(T1, tq[u + 2]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        bqh[(u + DB) % (DB + 1)][0] = wq[(int64_t)(u + DB) * wstep];
+                        if (u == 0) b8_2 = piece(2);
+                        if (u == 1) b8_3 = piece(3);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < MTW; ++i) {
+                            if (P4 || !((skip >> i) & 1)) {
+                                acc[i] = mfma16<PREC>(Ah[i], bqh[u][0], acc[i]);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (u < 3) Ah[i] = rdA(i, tq[u + 1]);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
                 }
+                // ---- corrections of the group + the next group's first fragments ----
+                const i32x8 B8hi = {(int)b8_0.x, (int)b8_0.y, (int)b8_0.z, (int)b8_0.w, (int)b8_1.x, (int)b8_1.y, (int)b8_1.z, (int)b8_1.w};
+                const i32x8 B8lo = {(int)b8_2.x, (int)b8_2.y, (int)b8_2.z, (int)b8_2.w, (int)b8_3.x, (int)b8_3.y, (int)b8_3.z, (int)b8_3.w};
+                auto prefetch_next = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i)
+                        if (!((skip_n >> i) & 1)) Ah[i] = rdA(i, tqn0);
+                };
+                if constexpr (P4) {
+                    // main products done; a tile's plane-1 slots are read one tile ahead of its first correction, the two corrections of an
+                    // accumulator are a tile apart, so that consecutive writes of one accumulator are separated by other matrix instructions
+                    rd_planes(VdIC<0>{}, VdIC<0>{}, VdIC<0>{});
+                    rd_planes(VdIC<1>{}, VdIC<1>{}, VdIC<1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    corr_lo(VdIC<0>{}, VdIC<0>{}, B8hi);
+                    prefetch_next();
+                    __builtin_amdgcn_sched_barrier(0);
+                    corr_lo(VdIC<1>{}, VdIC<1>{}, B8hi);
+                    corr_hi(VdIC<0>{}, VdIC<0>{}, B8lo);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd_planes(VdIC<2>{}, VdIC<0>{}, VdIC<0>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    corr_hi(VdIC<1>{}, VdIC<1>{}, B8lo);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd_planes(VdIC<3>{}, VdIC<1>{}, VdIC<1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    corr_lo(VdIC<2>{}, VdIC<0>{}, B8hi);
+                    corr_lo(VdIC<3>{}, VdIC<1>{}, B8hi);
+                    corr_hi(VdIC<2>{}, VdIC<0>{}, B8lo);
+                    corr_hi(VdIC<3>{}, VdIC<1>{}, B8lo);
+                } else if constexpr (P2A || P2B) {
+                    constexpr int T1 = P2A ? 1 : 2;
+                    rd_planes(VdIC<0>{}, VdIC<0>{}, VdIC<0>{});
+                    rd_planes(VdIC<T1>{}, VdIC<1>{}, VdIC<1>{});
+                    prefetch_next();
+                    __builtin_amdgcn_sched_barrier(0);
+                    corr_lo(VdIC<0>{}, VdIC<0>{}, B8hi);
+                    corr_lo(VdIC<T1>{}, VdIC<1>{}, B8hi);
+                    corr_hi(VdIC<0>{}, VdIC<0>{}, B8lo);
+                    corr_hi(VdIC<T1>{}, VdIC<1>{}, B8lo);
+                } else if constexpr (P1) {
+                    rd_planes(VdIC<0>{}, VdIC<0>{}, VdIC<0>{});
+                    prefetch_next();
+                    __builtin_amdgcn_sched_barrier(0);
+                    corr_lo(VdIC<0>{}, VdIC<0>{}, B8hi);
+                    corr_hi(VdIC<0>{}, VdIC<0>{}, B8lo);
+                } else {
+                    vd_static_for<MTW>([&](auto IC) __attribute__((always_inline)) {
+                        constexpr int i = decltype(IC)::v;
+                        if (!((skip >> i) & 1)) {
+                            rd_planes(IC, VdIC<i & 1>{}, VdIC<i & 1>{});
+                            corr_lo(IC, VdIC<i & 1>{}, B8hi);
+                            corr_hi(IC, VdIC<i & 1>{}, B8lo);
+                        }
+                    });
+                    prefetch_next();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // groups of one mask are consecutive (the planner sorts them): one loop per specialised body
+            int s = 0;
+            auto run = [&](auto MC) __attribute__((always_inline)) {
+                constexpr int MK = decltype(MC)::v;
+                const int skip_n = skip_of(s + 4);           // the NEXT group's mask and first tap: this group's last step prefetches for it
+                const int tqn0 = tapv[2 * ((s + 4 < S) ? s + 4 : S - 4)];
+                if (MK >= 0 || skip != 0xF) group(MC, skip_n, tqn0);
+                else {                                      // nothing to do in this group (padding of a window with fewer groups): keep the rings going
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bqh[(u + DB) % (DB + 1)][0] = wq[(int64_t)(u + DB) * wstep];
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i)
+                        if (!((skip_n >> i) & 1)) Ah[i] = rdA(i, tqn0);
+                }
+                b8_0 = piece(4); b8_1 = piece(5);            // the next group's W_hi image
+                wq += (int64_t)4 * wstep;
                 skip = skip_n;
+                s += 4;
+                taps_of(s, tq);
+            };
+            while (s < S) {
+                while (s < S && skip == 0) run(VdIC<0>{});
+                while (s < S && skip == 0xA) run(VdIC<0xA>{});
+                while (s < S && skip == 0xC) run(VdIC<0xC>{});
+                while (s < S && skip == 0xE) run(VdIC<0xE>{});
+                if (s < S && skip != 0 && skip != 0xA && skip != 0xC && skip != 0xE) run(VdIC<-1>{});
             }
         } else if constexpr (SEQ) {
             // hi+lo formats, one plane resident: the fragment a tile's MFMAs have just consumed is refilled at once with the
@@ -801,16 +882,16 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 uint16_t hi, lo;
                 split16<PREC>(m0, hi, lo);
                 stg[q * NCH + n] = hi;
-                // (emit_lo = 2: plane 1 for a VD_PREC_F16C8 consumer -- per 16-byte slot the 8 low parts as e4m3 bytes, x 2^9, then 8 zero bytes)
+                // (emit_lo = 2: plane 1 for a VD_PREC_F16C8 consumer -- per 16-byte slot the 8 low parts as e4m3 bytes, x 2^9, then the e4m3 image of the 8 high parts, / 4)
                 const bool lo8 = !X3 && !EXT && p.emit_lo == 2;
                 uint8_t* stg8 = reinterpret_cast<uint8_t*>(stg);
                 const int b8 = (n >> 3) * 16 + (n & 7);
-                if (lo8) { stg8[(Q + q) * NCH * 2 + b8] = (uint8_t)vd_c8_lo_byte(m0); stg8[(Q + q) * NCH * 2 + b8 + 8] = 0; }
+                if (lo8) { stg8[(Q + q) * NCH * 2 + b8] = (uint8_t)vd_c8_lo_byte(m0); stg8[(Q + q) * NCH * 2 + b8 + 8] = (uint8_t)vd_c8_hi_byte(hi); }
                 else if (lo_out) stg[(Q + q) * NCH + n] = lo;
                 if (p.pool_t != 2) {
                     split16<PREC>(m1, hi, lo);
                     stg[(q + 1) * NCH + n] = hi;
-                    if (lo8) { stg8[(Q + q + 1) * NCH * 2 + b8] = (uint8_t)vd_c8_lo_byte(m1); stg8[(Q + q + 1) * NCH * 2 + b8 + 8] = 0; }
+                    if (lo8) { stg8[(Q + q + 1) * NCH * 2 + b8] = (uint8_t)vd_c8_lo_byte(m1); stg8[(Q + q + 1) * NCH * 2 + b8 + 8] = (uint8_t)vd_c8_hi_byte(hi); }
                     else if (lo_out) stg[(Q + q + 1) * NCH + n] = lo;
                 }
                 continue;

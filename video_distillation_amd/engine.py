@@ -38,8 +38,8 @@ class _DevPlan:
         self.gather = torch.from_numpy(gt.copy()).to(device)
         self.n_w = int(self.widx.numel())
         planes = 2 if hip.is_x3(prec) else 1
-        self.wpk = torch.empty((planes, self.n_w), dtype=torch.int16, device=device)
         self.prec = prec
+        self.wpk = self._new_wpk(planes, device)
         p = hip.VdConvParams()
         p.type_desc = self.type_desc.data_ptr(); p.tables = self.tables.data_ptr(); p.boxes = self.boxes.data_ptr()
         p.gather = self.gather.data_ptr(); p.gather_stride = int(gt.shape[1])
@@ -89,6 +89,14 @@ class _DevPlan:
         if self.breg3_ok:
             p.src_planes, p.src_rows = plan.row_source()
 
+    def _new_wpk(self, planes: int, device) -> torch.Tensor:
+        """[planes, n_w] 16-bit packed operands.  VD_PREC_F16C8 programs read their B operands through running pointers, up to six K
+        steps past a channel chunk -- i.e. past the END of the buffer for the last chunk: 32 KB of (zeroed) slack behind it."""
+        slack = 16384 if self.prec == hip.PREC["f16c8"] else 0
+        flat = torch.zeros(planes * self.n_w + slack, dtype=torch.int16, device=device) if slack else \
+            torch.empty(planes * self.n_w, dtype=torch.int16, device=device)
+        return flat[:planes * self.n_w].view(planes, self.n_w)
+
     def use_slot(self, k: int) -> None:
         """Switch to the k-th set of packed-operand buffers (``wpk`` and the dithered sets ``wpk_d``), allocated on first use.  Two
         sets let the operands of step i + 1 be packed on a side stream while the launches of step i still read theirs
@@ -97,7 +105,7 @@ class _DevPlan:
         cur = self.__dict__.get("_slot", 0)
         slots[cur] = (self.wpk, getattr(self, "wpk_d", None))
         if k not in slots:
-            slots[k] = (torch.empty_like(self.wpk), None)
+            slots[k] = (self._new_wpk(self.wpk.shape[0], self.wpk.device), None)
         self.wpk, self.wpk_d = slots[k]
         self._slot = k
 

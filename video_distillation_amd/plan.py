@@ -582,7 +582,14 @@ def plan_forward_pos(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in:
     win = []
     for a in range(Ho):
         for b in range(Wo):
-            pos = [(2 * a + (i >> 1), 2 * b + (i & 1)) for i in range(4)]
+            # tile order: 0 = the position with the most taps inside the grid in h AND w ("centre"), 1 = centre h / edge w,
+            # 2 = edge h / centre w, 3 = edge / edge -- the skip masks are then 0, 0b1100, 0b1010, 0b1110 wherever the edge
+            # position's valid taps are a subset of the centre's (7 x 7 grids: always), the patterns the kernel has bodies for
+            nh = {oh: sum(0 <= 2 * oh + kh - 3 < h_in for kh in range(KH)) for oh in (2 * a, 2 * a + 1)}
+            nw = {ow: sum(0 <= 2 * ow + kw - 3 < w_in for kw in range(KW)) for ow in (2 * b, 2 * b + 1)}
+            hc, he = sorted(nh, key=lambda o: (-nh[o], o))
+            wc, we = sorted(nw, key=lambda o: (-nw[o], o))
+            pos = [(hc, wc), (hc, we), (he, wc), (he, we)]
             ok_h = [[0 <= 2 * oh + kh - 3 < h_in for kh in range(KH)] for oh, _ in pos]
             ok_w = [[0 <= 2 * ow + kw - 3 < w_in for kw in range(KW)] for _, ow in pos]
             hs = [2 * oh + kh - 3 for i, (oh, _) in enumerate(pos) for kh in range(KH) if ok_h[i][kh]]
