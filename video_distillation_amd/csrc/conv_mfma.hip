@@ -69,6 +69,17 @@ __device__ __forceinline__ uint32_t vd_c8_hi_byte(uint16_t h16) {      // e4m3 b
     r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, hh, 4.0f, false);
     return (uint32_t)__builtin_bit_cast(int, r) & 0xffu;
 }
+__device__ __forceinline__ void vd_c8_image(const uint4& a, int& w0, int& w1, const float div) {      // 8 f16 -> 8 e4m3 bytes of a / div
+    i16x2 r0, r1;                     // (every byte is written below: no initialisation)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, __builtin_bit_cast(f16x2, a.x), div, false);
+    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, __builtin_bit_cast(f16x2, a.y), div, true);
+    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, __builtin_bit_cast(f16x2, a.z), div, false);
+    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, __builtin_bit_cast(f16x2, a.w), div, true);
+#pragma clang diagnostic pop
+    w0 = __builtin_bit_cast(int, r0); w1 = __builtin_bit_cast(int, r1);
+}
 __device__ __forceinline__ uint32_t vd_c8_lo_byte(float v) {            // e4m3 byte of (v - rn16(v)) * 2^9, clamped to the finite range
     float r = (v - (float)(_Float16)v) * (float)(1 << VD_C8_ALO_SHIFT);
     r = fminf(fmaxf(r, -448.f), 448.f);
@@ -178,7 +189,8 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
     constexpr int DB = C8 ? 3 : X3 ? (TILES <= 2 ? 5 : ((SEQ && NTW == 1) ? 3 : 2)) : VD_DB_X1;     // (C8: a ring of 4 = one correction group)   // B-fragment prefetch distance (K steps); x1: (DB+1) % (AD+1) == 0
     //   (plane-sequential: the low-plane pass has one MFMA per tile and step instead of three, so its steps are short)
     static_assert(X3 || (DB + 1) % (AD + 1) == 0, "ring sizes must divide the unroll factor");
-    constexpr int LU = (TILES <= 4) ? 14 : 17;   // DMA groups per wave (4 waves x LU x 64 slots >= the plan's patch)
+    constexpr int LU = C8 ? 6 : (TILES <= 4) ? 14 : 17;   // DMA groups per wave whose gather entries stay in registers (4 waves x LU x 64 slots >= the plan's patch;
+    //                                                       the fp8-corrected program: its position-tile patches are 23 groups, larger ones re-read the table)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -275,7 +287,11 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
     // (1) the gather entries of this wave's DMA groups: the longest dependent chain of the prologue,
     //     so they are requested first; they are the same for every channel chunk and stay in registers.
     const int32_t* gtab = p.gather + (int64_t)bi * p.gather_stride;
-    constexpr bool HOIST = (TILES < 8) && !C8;   // MTW = 8 (and the fp8-corrected program) have no registers to spare: they re-read the table per chunk
+    constexpr bool HOIST = (TILES < 8);   // MTW = 8 has no registers to spare: it re-reads the table per chunk
+#ifndef VD_C8_HOIST
+#define VD_C8_HOIST 1
+#endif
+    const bool hoist = HOIST && (!C8 || (VD_C8_HOIST && ngroups <= nwaves * LU));
     uint32_t goff[HOIST ? LU : 1];
 #pragma unroll
     for (int u = 0; u < (HOIST ? LU : 1); ++u) {
@@ -360,7 +376,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
         // (conv padding, pitch padding, clips beyond the batch) reads a 16-byte zero slot.
         // (all table entries are consumed BEFORE the first DMA is issued: with an LDS-DMA in flight
         //  hipcc waits vmcnt(0) at the next use of an ordinary load, which would serialise the DMAs)
-        if (HOIST && !(VD_DBG(p) & 4)) {
+        if (hoist && !(VD_DBG(p) & 4)) {
             int gi = wave;
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
@@ -380,7 +396,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 gi += nwaves;
             }
         }
-        if (!HOIST && !(VD_DBG(p) & 4)) {
+        if (!hoist && !(VD_DBG(p) & 4)) {
             constexpr int LB = 8;
             for (int g0 = wave; g0 < ngroups; g0 += nwaves * LB) {
                 uint32_t off[LB];
@@ -514,9 +530,20 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 Ah[i] = make_uint4(0, 0, 0, 0);
                 if (!((skip >> i) & 1)) Ah[i] = rdA(i, tq[0]);
             }
-            uint4 b8_0 = piece(0), b8_1 = piece(1), b8_2, b8_3;
+            // (the fp8 image of W_hi is not loaded: it is converted from each step's fp16 B fragment in registers -- same lane, same
+            //  element order -- which takes a quarter off the bytes a wave pulls through its CU's vector-memory path, the busiest unit
+            //  of this program: 69 % against the matrix pipes' 56 % with the image loaded)
+            const float w_div = p.out_scale[3];          // 1 / s of vd_pack_weights_c8 (a power of two): image = W_hi * s
+            uint4 b8_2, b8_3;
+            i32x8 B8hi;
+            auto img_b = [&](auto UC) __attribute__((always_inline)) {
+                constexpr int u = decltype(UC)::v;
+                int w0, w1;
+                vd_c8_image(bqh[u][0], w0, w1, w_div);
+                B8hi[2 * u] = w0; B8hi[2 * u + 1] = w1;
+            };
             i32x8 a8lo[2], a8hi[2];
-            auto corr_lo = [&](auto IC, auto RC, const i32x8& B8hi) __attribute__((always_inline)) {
+            auto corr_lo = [&](auto IC, auto RC) __attribute__((always_inline)) {
                 constexpr int i = decltype(IC)::v, r = decltype(RC)::v;
                 if (VD_DBG(p) & 0x800) return;          // dbg 0x800: no correction products
                 acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8lo[r], B8hi, acc[i], 0, 0, 0, VD_C8_SA_LO, 0, sb_hi);
@@ -549,6 +576,10 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                         bqh[(u + DB) % (DB + 1)][0] = wq[(int64_t)(u + DB) * wstep];
                         if (u == 0) b8_2 = piece(2);
                         if (u == 1) b8_3 = piece(3);
+                        if (u == 0) img_b(VdIC<0>{});
+                        if (u == 1) img_b(VdIC<1>{});
+                        if (u == 2) img_b(VdIC<2>{});
+                        if (u == 3) img_b(VdIC<3>{});
                         __builtin_amdgcn_sched_barrier(0);
                         acc[0] = mfma16<PREC>(Ah[u], bqh[u][0], acc[0]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -562,6 +593,10 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                         bqh[(u + DB) % (DB + 1)][0] = wq[(int64_t)(u + DB) * wstep];
                         if (u == 0) b8_2 = piece(2);
                         if (u == 1) b8_3 = piece(3);
+                        if (u == 0) img_b(VdIC<0>{});
+                        if (u == 1) img_b(VdIC<1>{});
+                        if (u == 2) img_b(VdIC<2>{});
+                        if (u == 3) img_b(VdIC<3>{});
                         __builtin_amdgcn_sched_barrier(0);
                         const int ra = (u & 1) ? J0 : 0, rb = (u & 1) ? J1 : T1;
                         acc[0] = mfma16<PREC>(Ah[ra], bqh[u][0], acc[0]);
@@ -577,6 +612,10 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                         bqh[(u + DB) % (DB + 1)][0] = wq[(int64_t)(u + DB) * wstep];
                         if (u == 0) b8_2 = piece(2);
                         if (u == 1) b8_3 = piece(3);
+                        if (u == 0) img_b(VdIC<0>{});
+                        if (u == 1) img_b(VdIC<1>{});
+                        if (u == 2) img_b(VdIC<2>{});
+                        if (u == 3) img_b(VdIC<3>{});
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int i = 0; i < MTW; ++i) {
@@ -590,7 +629,6 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                     }
                 }
                 // ---- corrections of the group + the next group's first fragments ----
-                const i32x8 B8hi = {(int)b8_0.x, (int)b8_0.y, (int)b8_0.z, (int)b8_0.w, (int)b8_1.x, (int)b8_1.y, (int)b8_1.z, (int)b8_1.w};
                 const i32x8 B8lo = {(int)b8_2.x, (int)b8_2.y, (int)b8_2.z, (int)b8_2.w, (int)b8_3.x, (int)b8_3.y, (int)b8_3.z, (int)b8_3.w};
                 auto prefetch_next = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -603,10 +641,10 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                     rd_planes(VdIC<0>{}, VdIC<0>{}, VdIC<0>{});
                     rd_planes(VdIC<1>{}, VdIC<1>{}, VdIC<1>{});
                     __builtin_amdgcn_sched_barrier(0);
-                    corr_lo(VdIC<0>{}, VdIC<0>{}, B8hi);
+                    corr_lo(VdIC<0>{}, VdIC<0>{});
                     prefetch_next();
                     __builtin_amdgcn_sched_barrier(0);
-                    corr_lo(VdIC<1>{}, VdIC<1>{}, B8hi);
+                    corr_lo(VdIC<1>{}, VdIC<1>{});
                     corr_hi(VdIC<0>{}, VdIC<0>{}, B8lo);
                     __builtin_amdgcn_sched_barrier(0);
                     rd_planes(VdIC<2>{}, VdIC<0>{}, VdIC<0>{});
@@ -615,8 +653,8 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                     __builtin_amdgcn_sched_barrier(0);
                     rd_planes(VdIC<3>{}, VdIC<1>{}, VdIC<1>{});
                     __builtin_amdgcn_sched_barrier(0);
-                    corr_lo(VdIC<2>{}, VdIC<0>{}, B8hi);
-                    corr_lo(VdIC<3>{}, VdIC<1>{}, B8hi);
+                    corr_lo(VdIC<2>{}, VdIC<0>{});
+                    corr_lo(VdIC<3>{}, VdIC<1>{});
                     corr_hi(VdIC<2>{}, VdIC<0>{}, B8lo);
                     corr_hi(VdIC<3>{}, VdIC<1>{}, B8lo);
                 } else if constexpr (P2A || P2B) {
@@ -625,22 +663,22 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                     rd_planes(VdIC<T1>{}, VdIC<1>{}, VdIC<1>{});
                     prefetch_next();
                     __builtin_amdgcn_sched_barrier(0);
-                    corr_lo(VdIC<0>{}, VdIC<0>{}, B8hi);
-                    corr_lo(VdIC<T1>{}, VdIC<1>{}, B8hi);
+                    corr_lo(VdIC<0>{}, VdIC<0>{});
+                    corr_lo(VdIC<T1>{}, VdIC<1>{});
                     corr_hi(VdIC<0>{}, VdIC<0>{}, B8lo);
                     corr_hi(VdIC<T1>{}, VdIC<1>{}, B8lo);
                 } else if constexpr (P1) {
                     rd_planes(VdIC<0>{}, VdIC<0>{}, VdIC<0>{});
                     prefetch_next();
                     __builtin_amdgcn_sched_barrier(0);
-                    corr_lo(VdIC<0>{}, VdIC<0>{}, B8hi);
+                    corr_lo(VdIC<0>{}, VdIC<0>{});
                     corr_hi(VdIC<0>{}, VdIC<0>{}, B8lo);
                 } else {
                     vd_static_for<MTW>([&](auto IC) __attribute__((always_inline)) {
                         constexpr int i = decltype(IC)::v;
                         if (!((skip >> i) & 1)) {
                             rd_planes(IC, VdIC<i & 1>{}, VdIC<i & 1>{});
-                            corr_lo(IC, VdIC<i & 1>{}, B8hi);
+                            corr_lo(IC, VdIC<i & 1>{});
                             corr_hi(IC, VdIC<i & 1>{}, B8lo);
                         }
                     });
@@ -662,7 +700,6 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                     for (int i = 0; i < MTW; ++i)
                         if (!((skip_n >> i) & 1)) Ah[i] = rdA(i, tqn0);
                 }
-                b8_0 = piece(4); b8_1 = piece(5);            // the next group's W_hi image
                 wq += (int64_t)4 * wstep;
                 skip = skip_n;
                 s += 4;
