@@ -167,7 +167,8 @@ class HipBackend:
         if self.eng_real is None:
             self.eng_real = engine.EmbedEngine(geo, prec=prec_real, device=device, chunk=chunk, last_hilo=(self.real_last == "x3"))
         self.eng_syn = self.eng_real if (prec_syn == prec_real and not prec_bwd) else \
-            engine.EmbedEngine(geo, prec=prec_syn, device=device, chunk=chunk, prec_bwd=prec_bwd, batch_hint=syn_batch_hint)
+            engine.EmbedEngine(geo, prec=prec_syn, device=device, chunk=chunk, prec_bwd=prec_bwd, batch_hint=syn_batch_hint,
+                               bwd0_small=os.environ.get("VD_SYN_BWD0_SMALL", "0") == "1")
         self.num_feat = geo.num_feat
         # Two HIP streams: the real-clip forward (98.5 % of the FLOPs, large launches) runs on one,
         # the synthetic-clip forward + backward + optimiser (small launches that cannot fill 256
