@@ -28,9 +28,13 @@ extern "C" {
                               (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3, 2.2x the fp16 rate): a_hi W_hi in fp16, a_lo W_hi + a_hi W_lo in
                               fp8 once per four K steps -- two MFMA-equivalents per product instead of three, the corrections
                               exact to 2^-4 of themselves (2^-16 of the product).  The real side's LAST level only (pooled
-                              features, 4 M tiles x 1 N tile per wave, K steps a multiple of 4): plane 1 of its source holds the
-                              low parts as fp8 bytes (VdConvParams.emit_lo = 2 of the producing program), plane 1 of its packed
-                              weights the fp8 fragments of vd_pack_weights_c8, out_scale points at that call's two E8M0 scales */
+                              features, 4 M tiles x 1 N tile per wave, K steps a multiple of 4): plane 1 of its source holds, per
+                              16-byte slot, the 8 low parts (x 2^9) and the fp8 image of the 8 high parts (/ 4) as e4m3 bytes
+                              (VdConvParams.emit_lo = 2 of the producing program), plane 1 of its packed weights the fp8
+                              fragments of vd_pack_weights_c8 (the W_lo image is read, the W_hi image converted in registers),
+                              out_scale points at that call's scales (two E8M0 codes, then s and 1 / s as floats).  The kernel
+                              reads its B operands through running pointers up to six K steps past a channel chunk: the packed
+                              buffer must be followed by 24 KB of readable memory.  Programs in position tiles: VD_EPI_POS_FEAT */
 
 #define VD_EPI_POOL_CL   0
 #define VD_EPI_POOL_FEAT 1
@@ -91,7 +95,9 @@ typedef struct VdConvParams {
                                      boxes over copies of dW so that same-address atomics do not serialise); 0 = one target */
     int32_t emit_lo;              /* single-pass programs with the staged POOL_CL epilogue (argmax NULL): != 0 also writes the LOW plane
                                      rn16(v - rn16(v)) of every pooled output, dst_plane_stride slots behind the high one -- the next level
-                                     can then run in the hi+lo format of the same 16-bit type (real side: level 2 in f16x3) */
+                                     can then run in the hi+lo format of the same 16-bit type (real side: level 2 in f16x3); 2 = write plane 1
+                                     for a VD_PREC_F16C8 consumer instead: per slot 8 e4m3 bytes of the low parts (x 2^9) and 8 of the high
+                                     parts (/ 4), outputs clamped to +-1792 so that the image stays finite */
     int32_t src_planes, src_rows; /* first-level programs over pixel rows (vd_pix2rows): planes (frames x 3) and rows per plane of a clip; the
                                      kernel that builds its patch from aligned loads (vd_conv0_breg, persist bit 17) derives row addresses
                                      and the zero fill from them instead of a gather table; 0 elsewhere */
