@@ -626,7 +626,9 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
                  world, args.classes // world, args.classes % world, world, (args.classes % world) * 8)) if trainer.__dict__.get("shard") == "hybrid" else
             "class-sharded x%d (owner-computes, no gradient exchange%s)" % (world, "; 1.3 KB all-reduce of the hallucinator gradient" if s2d else ""),
             {"real_clips": args.prec_real, "real_clips_last_level": backend.real_last, "syn_clips_fwd": args.prec_syn, "input_gradient": args.prec_bwd, "accumulate": "f32",
-             "real_weight_dither_groups": backend._dither, "syn_value_pass": None if backend._dither else backend.weight_format})
+             "real_weight_dither_groups": backend._dither, "syn_value_pass": None if backend._dither else backend.weight_format,
+             "real_clips_last_level_program": (None if backend.eng_real.fwd2x is None else
+                                               "position tiles" if backend.eng_real.fwd2x.plan.epi == 3 else "row-major")})
         out["config"]["pool_per_class"] = args.pool_per_class
         out["config"]["pool_kind"] = args.pool_kind
         out["config"]["real_pool"] = ("resident in HBM: fp32 clips + the same clips converted once to the first layer's 16-bit pixel "
