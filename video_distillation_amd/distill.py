@@ -27,7 +27,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -180,6 +180,9 @@ class HipBackend:
             self.s_real = torch.cuda.Stream(device=self.device, priority=pr)
             self.s_syn = torch.cuda.Stream(device=self.device, priority=ps)
         self._ev_real = None
+        self.s_prep = None                 # preparation stream (prepare_real_weights), created on first use
+        self._real_done: Dict[int, "torch.cuda.Event"] = {}      # per buffer set: behind the launches that last read it
+        self._prep_slot: Optional[int] = None
         # Mixed mode (single-pass real side + hi/lo synthetic side of the same 16-bit format).  The real side
         # multiplies by rn16(W): a SYSTEMATIC perturbation of mean f_real (~2e-4 |f|, it does not average out over
         # the 64 clips of a batch) that the exact-weight synthetic side does not share, so it lands undiminished in
@@ -238,9 +241,8 @@ class HipBackend:
         the real-clip stream waits for an event that has long fired.  Called with the real-clip stream current."""
         if not self.two_streams or os.environ.get("VD_PREP_STREAM", "1") != "1":
             return self.set_real_weights(weights, per_class)
-        if getattr(self, "s_prep", None) is None:
+        if self.s_prep is None:
             self.s_prep = torch.cuda.Stream(device=self.device, priority=-1)
-            self._real_done = {}
         k = step % 2
         cur = torch.cuda.current_stream(self.device)                   # = the real-clip stream
         self.s_prep.wait_stream(torch.cuda.default_stream(self.device))          # the freshly drawn fp32 weights
@@ -258,7 +260,7 @@ class HipBackend:
 
     def real_launches_done(self) -> None:
         """Record (on the current = real-clip stream) that the launches reading the current buffer set have been issued."""
-        if getattr(self, "s_prep", None) is not None and getattr(self, "_prep_slot", None) is not None:
+        if self.s_prep is not None and self._prep_slot is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self._real_done[self._prep_slot] = ev
@@ -800,7 +802,7 @@ class S2DTrainer:
             defer = overlap and self.defer_backward      # (as DMTrainer.defer_backward: the previous step's backward behind THIS step's first level)
             ev_l0 = None
             with on_real():
-                be.set_real_weights(weights, self.batch_real)
+                be.prepare_real_weights(weights, self.batch_real, self.steps_done)      # (operand packing on the preparation stream)
                 if defer:
                     ev_l0 = torch.cuda.Event()
                     be.eng_real.after_first_level = lambda: ev_l0.record(be.s_real)
@@ -809,6 +811,7 @@ class S2DTrainer:
                 finally:
                     if defer:
                         be.eng_real.after_first_level = None
+                be.real_launches_done()
         elif hasattr(be, "set_real_weights"):
             defer = False
             be.set_weights(weights, self.batch_real)

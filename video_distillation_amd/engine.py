@@ -40,6 +40,9 @@ class _DevPlan:
         planes = 2 if hip.is_x3(prec) else 1
         self.prec = prec
         self.wpk = self._new_wpk(planes, device)
+        self.wpk_d: Optional[torch.Tensor] = None          # dithered operand sets (pack_dither)
+        self._slots: Dict[int, tuple] = {}                 # buffer sets of use_slot()
+        self._slot = 0
         p = hip.VdConvParams()
         p.type_desc = self.type_desc.data_ptr(); p.tables = self.tables.data_ptr(); p.boxes = self.boxes.data_ptr()
         p.gather = self.gather.data_ptr(); p.gather_stride = int(gt.shape[1])
@@ -101,12 +104,10 @@ class _DevPlan:
         """Switch to the k-th set of packed-operand buffers (``wpk`` and the dithered sets ``wpk_d``), allocated on first use.  Two
         sets let the operands of step i + 1 be packed on a side stream while the launches of step i still read theirs
         (EmbedEngine.set_weights(slot=), distill.DMTrainer)."""
-        slots = self.__dict__.setdefault("_slots", {0: (self.wpk, getattr(self, "wpk_d", None))})
-        cur = self.__dict__.get("_slot", 0)
-        slots[cur] = (self.wpk, getattr(self, "wpk_d", None))
-        if k not in slots:
-            slots[k] = (self._new_wpk(self.wpk.shape[0], self.wpk.device), None)
-        self.wpk, self.wpk_d = slots[k]
+        self._slots[self._slot] = (self.wpk, self.wpk_d)
+        if k not in self._slots:
+            self._slots[k] = (self._new_wpk(self.wpk.shape[0], self.wpk.device), None)
+        self.wpk, self.wpk_d = self._slots[k]
         self._slot = k
 
     def pack(self, w: torch.Tensor) -> None:
@@ -129,7 +130,7 @@ class _DevPlan:
     def pack_dither(self, w: torch.Tensor, groups: int) -> None:
         """``groups`` dithered single-pass operand sets (vd_pack_weights_dither); ``run(..., group=g)`` multiplies by set g."""
         assert w.dtype == torch.float32 and w.is_contiguous() and self.wpk.shape[0] == 1
-        if getattr(self, "wpk_d", None) is None or self.wpk_d.shape[0] != groups:
+        if self.wpk_d is None or self.wpk_d.shape[0] != groups:
             self.wpk_d = torch.empty((groups, self.n_w), dtype=torch.int16, device=w.device)
         hip.check(hip.lib().vd_pack_weights_dither(hip.ptr(w), hip.ptr(self.widx), ctypes.c_int64(self.n_w), int(groups),
                                                    hip.ptr(self.wpk_d), self.prec, hip.stream_ptr(w.device)), "vd_pack_weights_dither")
@@ -294,6 +295,7 @@ class EmbedEngine:
         self.fwd = [_DevPlan(pl, self.device, self.prec) for pl in net["fwd"]]
         self.fwd2x = None
         self.last_c8 = False
+        self._c8_scale_slots: Dict[int, torch.Tensor] = {}    # set_weights(slot=): the fp8-corrected program's scale table per buffer set
         if last_hilo:
             if hip.is_x3(self.prec):
                 raise ValueError("last_hilo is an option of the single-pass formats (%s already carries hi+lo planes)" % prec)
@@ -368,8 +370,9 @@ class EmbedEngine:
             for dp in self.fwd + ([self.fwd2x] if self.fwd2x is not None else []):
                 dp.use_slot(slot)
             if self.last_c8:
-                sc = self.__dict__.setdefault("_c8_scale_slots", {})
-                self.c8_scales = sc.setdefault(slot, torch.zeros(8, dtype=torch.float32, device=self.device))
+                if slot not in self._c8_scale_slots:
+                    self._c8_scale_slots[slot] = torch.zeros(8, dtype=torch.float32, device=self.device)
+                self.c8_scales = self._c8_scale_slots[slot]
         for li in range(3):
             if li == 2 and self.fwd2x is not None:      # the last level multiplies by the exact hi+lo weights: nothing to dither
                 if self.last_c8:
