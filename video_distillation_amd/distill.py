@@ -233,13 +233,17 @@ class HipBackend:
         self._dither = engine.dither_groups(int(per_class), self.prec_real) if (self.dither_enabled and self.eng_syn is not self.eng_real) else 0
         self.eng_real.set_weights(weights, dither=self._dither, slot=slot)
 
-    def prepare_real_weights(self, weights, per_class: int, step: int) -> None:
+    def prepare_real_weights(self, weights, per_class: int, step: int, nclips: Optional[int] = None) -> None:
         """``set_real_weights`` on a PREPARATION stream, into the buffer set ``step % 2``: the operand packing of a step (0.2 - 0.3 ms
         of small launches: fp16 fragments, eight dithered sets for two levels, the fp8 fragments and their scale) used to sit on
         the real-clip stream between the last level of step i and the first level of step i + 1; with two buffer sets it runs
         under step i's launches -- it waits only for the launches of step i - 1, the previous readers of its buffers -- and
         the real-clip stream waits for an event that has long fired.  Called with the real-clip stream current."""
-        if not self.two_streams or os.environ.get("VD_PREP_STREAM", "1") != "1":
+        # (only where the real side is long: with the 400 clips per rank of an 8-rank job the step is 5 ms and issue-bound -- there the
+        #  extra stream's events cost up to 0.5 ms of it, `profiles/r04_rank_proxy_knobs.txt` -- so ``nclips`` below 1600 packs in line)
+        if not self.two_streams or os.environ.get("VD_PREP_STREAM", "1") != "1" or \
+                (nclips is not None and nclips < int(os.environ.get("VD_PREP_MIN_CLIPS", "1600"))):
+            self._prep_slot = None
             return self.set_real_weights(weights, per_class)
         if self.s_prep is None:
             self.s_prep = torch.cuda.Stream(device=self.device, priority=-1)
@@ -567,7 +571,7 @@ class DMTrainer:
             ev_l0 = None
             with on_real():
                 if hasattr(be, "prepare_real_weights"):
-                    be.prepare_real_weights(weights, self._per_class(), self.steps_done)
+                    be.prepare_real_weights(weights, self._per_class(), self.steps_done, nclips=int(idx.size))
                 else:
                     be.set_real_weights(weights, self._per_class())
                 if defer:       # an event behind the first level's launch of THIS step's real side (see ``_flush_backward``)
@@ -802,7 +806,7 @@ class S2DTrainer:
             defer = overlap and self.defer_backward      # (as DMTrainer.defer_backward: the previous step's backward behind THIS step's first level)
             ev_l0 = None
             with on_real():
-                be.prepare_real_weights(weights, self.batch_real, self.steps_done)      # (operand packing on the preparation stream)
+                be.prepare_real_weights(weights, self.batch_real, self.steps_done, nclips=int(idx.size))      # (operand packing on the preparation stream)
                 if defer:
                     ev_l0 = torch.cuda.Event()
                     be.eng_real.after_first_level = lambda: ev_l0.record(be.s_real)
