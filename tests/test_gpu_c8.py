@@ -74,6 +74,47 @@ def test_fp8_corrected_last_level_keeps_the_hi_lo_accuracy(geom, n):
     assert d88 < 2e-6
 
 
+def test_position_tiles_at_the_benchmark_launch_shape():
+    """BASELINE config 2's launch: 3200 clips 112x112x16 in ONE launch per level (3200 workgroups of the position-tile program, all
+    four windows' operand sets, the XCD-contiguous box order), plus a ragged count (3203: the last group holds 3 of 4 clips).
+    Size-independent properties: every clip's features equal the row-major program's to fp32 summation order, equal the same
+    clip's features in a 16-clip launch bitwise, and the hi+lo level's to the fp8 corrections' 1e-5."""
+    from video_distillation_amd import engine, plan
+    geo = plan.NetGeometry(16, 112, 112)
+    n = 3203
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = torch.randn(8, 16, 3, 112, 112, generator=g, device="cuda")
+    x = base.repeat(401, 1, 1, 1, 1)[:n].contiguous()
+    x += 0.25 * torch.randn(n, 1, 3, 1, 1, generator=g, device="cuda")            # every clip differs (a per-clip colour offset)
+    w = [p.cuda() for p in R.init_params(99, 3, 5)[:6]]
+    e8 = engine.EmbedEngine(geo, prec="f16", chunk=4096, last_hilo="c8"); e8.set_weights(w)
+    assert e8.fwd2x.plan.epi == plan.EPI_POS_FEAT and e8.fwd2x.plan.ncl == 4
+    f8 = e8.forward(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(f8).all()
+    pick = torch.tensor([0, 1, 2, 3, 1597, 1598, 1599, 1600, 3196, 3197, 3198, 3199, 3200, 3201, 3202, 777], device="cuda")
+    assert torch.equal(e8.forward(x[pick].contiguous()), f8[pick])               # a clip's features do not depend on its launch
+    old = os.environ.get("VD_C8_POS")
+    os.environ["VD_C8_POS"] = "0"
+    try:
+        e8r = engine.EmbedEngine(geo, prec="f16", chunk=4096, last_hilo="c8"); e8r.set_weights(w)
+    finally:
+        if old is None:
+            del os.environ["VD_C8_POS"]
+        else:
+            os.environ["VD_C8_POS"] = old
+    f8r = e8r.forward(x)
+    d = ((f8 - f8r).double().norm(dim=1) / f8r.double().norm(dim=1))
+    print("3203 clips: position tiles vs row-major, per clip: median %.2e max %.2e" % (float(d.median()), float(d.max())))
+    assert float(d.max()) < 3e-6
+    del e8r, f8r
+    e3 = engine.EmbedEngine(geo, prec="f16", chunk=4096, last_hilo=True); e3.set_weights(w)
+    f3 = e3.forward(x[pick].contiguous())
+    d3 = max(_rel(f8[pick][i], f3[i]) for i in range(len(pick)))
+    print("the picked clips vs the hi+lo level: %.2e" % d3)
+    assert d3 < 4e-5
+
+
 def test_fp8_corrected_level_survives_large_and_tiny_weights():
     """The weight fragments are scaled by a power of two taken from max|W| (vd_pack_weights_c8), so the mode does not depend
     on PyTorch's default initialisation: weights 64x larger / smaller give the same relative accuracy; activations beyond
