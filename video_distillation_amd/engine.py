@@ -318,18 +318,24 @@ class EmbedEngine:
             # on the block-scaled fp8 matrix instruction once per four K steps (two MFMA-equivalents per product instead of three);
             # level 1 then emits fp8 low parts (emit_lo = 2) instead of the fp16 low plane.  Needs the one-clip 4 x 1-tile program.
             self.last_c8 = (last_hilo == "c8")
-            if self.last_c8 and not (prec == "f16" and pl2.NTW == 1 and pl2.MTW == 4 and pl2.S % 4 == 0):
-                raise ValueError("last_hilo='c8' needs the f16 format and the one-clip 4 x 1-tile last-level program (geometry %s)" % (geo,))
             if self.last_c8:
                 # POSITION TILES (plan.plan_forward_pos): rows = (clip, frame) pairs of one output position, so that the taps outside
-                # the input grid -- half of them at 7 x 7 -- are skipped per tile; VD_C8_POS=0 keeps the row-major program
+                # the input grid -- half of them at 7 x 7, two thirds at 4 x 4 -- are skipped per tile; VD_C8_POS=0 keeps the
+                # row-major program, which needs the one-clip 4 x 1-tile decomposition (not every geometry has it)
                 d2 = self.dims[2]
-                pl2 = P.with_skip_table(dataclasses.replace(pl2, types=[dataclasses.replace(t) for t in pl2.types]))
-                if os.environ.get("VD_C8_POS", "1") == "1":
+                pos = None
+                if prec == "f16" and os.environ.get("VD_C8_POS", "1") == "1":
                     try:
-                        pl2 = P.plan_forward_pos("fwd2_pos", d2[0], d2[1], d2[2], d2[3], d2[4], d2[11])
+                        pos = P.plan_forward_pos("fwd2_pos", d2[0], d2[1], d2[2], d2[3], d2[4], d2[11])
                     except (ValueError, AssertionError):
-                        pass
+                        pos = None
+                if pos is not None:
+                    pl2 = pos
+                elif prec == "f16" and pl2.NTW == 1 and pl2.MTW == 4 and pl2.S % 4 == 0:
+                    pl2 = P.with_skip_table(dataclasses.replace(pl2, types=[dataclasses.replace(t) for t in pl2.types]))
+                else:
+                    raise ValueError("last_hilo='c8' needs the f16 format and either position tiles (frames dividing 32) or the one-clip "
+                                     "4 x 1-tile last-level program (geometry %s)" % (geo,))
             self.fwd2x = _DevPlan(dataclasses.replace(pl2, name="fwd2_c8" if self.last_c8 else "fwd2_hilo"), self.device,
                                   hip.PREC["f16c8"] if self.last_c8 else hip.PREC[prec + "x3"])
             if self.last_c8:
