@@ -59,7 +59,7 @@ def test_dm_distillation_then_evaluation_matches_the_oracle_loop():
     for it in range(steps):
         loss_hip.append(float(tr_hip.step(it)))
         loss_cpu.append(float(tr_cpu.step(it)))
-    assert be_hip.inner._dither == 8 and be_hip.inner.real_last == "x3"
+    assert be_hip.inner._dither == 8 and be_hip.inner.real_last in ("x3", "c8")      # (c8: hi+lo pairs with the corrections on the fp8 instruction)
     lerr = max(abs(a / b - 1) for a, b in zip(loss_hip, loss_cpu))
     syn_hip, syn_cpu = tr_hip.image_syn.cpu(), tr_cpu.image_syn
     moved = float((syn_cpu - syn0).norm() / syn0.norm())
