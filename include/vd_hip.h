@@ -129,6 +129,16 @@ int vd_conv0_persistent(const VdConvParams* params, void* stream);
  * precisions) through the planner's gather table.  n = number of packed elements. */
 int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, void* out_hi, void* out_lo,
                     int prec, void* stream);
+
+/* Several vd_pack_weights calls as ONE launch (a training / trajectory-matching step packs the same weights for a dozen tile
+   programs, each a 5 - 10 us launch): segment k is what vd_pack_weights(seg[k].w, seg[k].widx, seg[k].n, seg[k].out_hi, seg[k].out_lo,
+   seg[k].prec) would do; bitwise the same outputs.  nseg <= VD_PACK_MAX. */
+#define VD_PACK_MAX 24
+typedef struct {
+    const float* w; const int32_t* widx; int64_t n; void* out_hi; void* out_lo; int32_t prec; int32_t first_block;
+} VdPackSeg;
+typedef struct { int32_t nseg; int32_t reserved; VdPackSeg seg[VD_PACK_MAX]; } VdPackBatch;
+int vd_pack_weights_multi(const VdPackBatch* batch, void* stream);
 /* Operand planes of a VD_PREC_F16C8 program: out_hi = the fp16 fragments (as vd_pack_weights with VD_PREC_F16), out_c8 = the
  * same number of bytes holding, per four K steps, the fp8 (e4m3) fragments of W_hi x s and (W - W_hi) x s x 2^11 in the order the
  * kernel consumes them; s = the power of two that brings max|w| into [128, 256).  widx = the program's weight gather table

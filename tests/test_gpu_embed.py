@@ -407,3 +407,35 @@ def test_window_form_of_the_dense_unpool_is_bitwise_the_slot_form():
         torch.cuda.synchronize()
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         assert int((outs[0][0] != 0).sum()) > 0
+
+
+def test_batched_operand_packing_is_bitwise_the_single_launches():
+    """``engine.batched_packs`` (vd_pack_weights_multi: the operand packing of all programs of a step in one launch per 24 segments):
+    the packed forward and input-gradient operands of an engine equal those of ``VD_PACK_BATCH=0`` (one launch per program)."""
+    import os
+    from video_distillation_amd import engine, plan
+    geo = plan.NetGeometry(8, 64, 64)
+    w = [p.cuda() for p in R.init_params(5, 3, 5)[:6]]
+
+    def packed(batch):
+        old = os.environ.get("VD_PACK_BATCH")
+        os.environ["VD_PACK_BATCH"] = batch
+        try:
+            e = engine.EmbedEngine(geo, prec="f16x3", chunk=8)
+            with engine.batched_packs():
+                e.set_weights(w)
+                e._pack_bwd()
+                for rep in range(2):             # (more than 24 queued segments: two launches at the exit)
+                    for li in range(3):
+                        for dp in e.bwd[li]:
+                            dp.pack(e._weights[2 * li])
+            torch.cuda.synchronize()
+            return [dp.wpk.clone() for dp in e.fwd + [d for layer in e.bwd for d in layer]]
+        finally:
+            if old is None:
+                del os.environ["VD_PACK_BATCH"]
+            else:
+                os.environ["VD_PACK_BATCH"] = old
+    a, b = packed("0"), packed("1")
+    assert len(a) == len(b) >= 10 and all(torch.equal(x, y) for x, y in zip(a, b))
+    assert any(int(x.abs().max()) > 0 for x in b)

@@ -66,6 +66,43 @@ extern "C" int vd_pack_weights(const float* w, const int32_t* widx, int64_t n, v
     return (int)hipGetLastError();
 }
 
+__global__ void pack_weights_multi_kernel(const VdPackBatch b) {
+    int k = 0;
+#pragma unroll 1
+    while (k + 1 < b.nseg && (int)blockIdx.x >= b.seg[k + 1].first_block) ++k;      // (block-uniform: scalar loads of the kernel arguments)
+    const VdPackSeg& sg = b.seg[k];
+    const int64_t i = (int64_t)((int)blockIdx.x - sg.first_block) * blockDim.x + threadIdx.x;
+    if (i >= sg.n) return;
+    const int32_t j = sg.widx[i];
+    const float v = (j >= 0) ? sg.w[j] : 0.f;
+    uint16_t h, l;
+    split16p(sg.prec, v, h, l);
+    reinterpret_cast<uint16_t*>(sg.out_hi)[i] = h;
+    if (sg.out_lo != nullptr) reinterpret_cast<uint16_t*>(sg.out_lo)[i] = l;
+}
+
+extern "C" int vd_pack_weights_multi(const VdPackBatch* batch, void* stream) {
+    if (batch == nullptr || batch->nseg < 0 || batch->nseg > VD_PACK_MAX) return -2;
+    VdPackBatch b = *batch;
+    const int bs = 256;
+    int64_t blocks = 0;
+    int m = 0;
+    for (int k = 0; k < batch->nseg; ++k) {
+        const VdPackSeg& sg = batch->seg[k];
+        if (sg.n <= 0) continue;
+        if (sg.w == nullptr || sg.widx == nullptr || sg.out_hi == nullptr) return -1;
+        b.seg[m] = sg;
+        b.seg[m].first_block = (int32_t)blocks;
+        blocks += (sg.n + bs - 1) / bs;
+        ++m;
+    }
+    if (m == 0) return 0;
+    if (blocks > 0x7fffffff) return -2;
+    b.nseg = m;
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)blocks), dim3(bs), 0, reinterpret_cast<hipStream_t>(stream), b);
+    return (int)hipGetLastError();
+}
+
 // DITHERED single-pass weights: the real clips of a class are dealt to `groups` (a power of two) launch groups, and group g
 // multiplies by the weights rounded DOWN or UP to the neighbouring 16-bit values such that, for every weight, the mean over
 // the groups equals the fp32 value to 1/(2 groups) ulp: with lam = (w - lo) / (hi - lo) the weight rounds up in

@@ -113,6 +113,9 @@ class _DevPlan:
     def pack(self, w: torch.Tensor) -> None:
         assert w.dtype == torch.float32 and w.is_contiguous()
         lo = self.wpk[1] if self.wpk.shape[0] == 2 else None
+        if _PACK_QUEUE is not None and self.n_w > 0:          # inside ``batched_packs()``: one launch for all of them at its exit
+            _PACK_QUEUE.append((w, self.widx, self.n_w, self.wpk[0], lo, self.prec))
+            return
         hip.check(hip.lib().vd_pack_weights(hip.ptr(w), hip.ptr(self.widx), ctypes.c_int64(self.n_w),
                                             hip.ptr(self.wpk[0]), hip.ptr(lo), self.prec, hip.stream_ptr(w.device)),
                   "vd_pack_weights")
@@ -186,6 +189,44 @@ class _DevPlan:
         if prof is not None:
             e1.record()
             prof.append((self.plan.name, self.prec, 2.0 * self.plan.meta.get("macs_per_unit", 0) * nclips, e0, e1))
+
+
+_PACK_QUEUE: Optional[list] = None
+
+
+class batched_packs:
+    """``with batched_packs():`` -- the ``_DevPlan.pack`` calls inside are collected and issued as ONE launch per 24 of them at
+    the exit (vd_pack_weights_multi): a training or trajectory-matching step packs the same few weight tensors for a dozen tile
+    programs, each a 5 - 10 us launch of its own otherwise.  Bitwise the same operands.  The packed buffers must not be read
+    before the exit; nests (the outermost exit launches).  ``VD_PACK_BATCH=0``: every pack launches by itself."""
+
+    def __enter__(self):
+        global _PACK_QUEUE
+        self.outer = _PACK_QUEUE is not None or os.environ.get("VD_PACK_BATCH", "1") != "1"
+        if not self.outer:
+            _PACK_QUEUE = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PACK_QUEUE
+        if self.outer:
+            return False
+        q, _PACK_QUEUE = _PACK_QUEUE, None
+        if exc[0] is None:
+            flush_packs(q)
+        return False
+
+
+def flush_packs(q) -> None:
+    for i in range(0, len(q), hip.VD_PACK_MAX):
+        part = q[i:i + hip.VD_PACK_MAX]
+        b = hip.VdPackBatch()
+        b.nseg = len(part)
+        for k, (w, widx, n, hi, lo, prec) in enumerate(part):
+            sg = b.seg[k]
+            sg.w, sg.widx, sg.n = w.data_ptr(), widx.data_ptr(), int(n)
+            sg.out_hi, sg.out_lo, sg.prec = hi.data_ptr(), (0 if lo is None else lo.data_ptr()), int(prec)
+        hip.check(hip.lib().vd_pack_weights_multi(ctypes.byref(b), hip.stream_ptr(part[0][0].device)), "vd_pack_weights_multi")
 
 
 def run_together(plans: Sequence["_DevPlan"], *args, **kwargs) -> None:
@@ -379,28 +420,33 @@ class EmbedEngine:
                 if slot not in self._c8_scale_slots:
                     self._c8_scale_slots[slot] = torch.zeros(8, dtype=torch.float32, device=self.device)
                 self.c8_scales = self._c8_scale_slots[slot]
-        for li in range(3):
-            if li == 2 and self.fwd2x is not None:      # the last level multiplies by the exact hi+lo weights: nothing to dither
-                if self.last_c8:
-                    self.fwd2x.pack_c8(ws[4], self.c8_scales)
-                else:
-                    self.fwd2x.pack(ws[4])
-                continue
-            self.fwd[li].pack(ws[2 * li])
-            if dither >= 2:
-                self.fwd[li].pack_dither(ws[2 * li], dither)
+        with batched_packs():
+            for li in range(3):
+                if li == 2 and self.fwd2x is not None:      # the last level multiplies by the exact hi+lo weights: nothing to dither
+                    if self.last_c8:
+                        self.fwd2x.pack_c8(ws[4], self.c8_scales)
+                    else:
+                        self.fwd2x.pack(ws[4])
+                    continue
+                self.fwd[li].pack(ws[2 * li])
+                if dither >= 2:
+                    self.fwd[li].pack_dither(ws[2 * li], dither)
         self._dither = int(dither) if dither >= 2 else 0
         self._bwd_packed = False
 
     def _pack_bwd(self) -> None:
         if not self._bwd_packed:
-            for li in range(3):
-                for dp in self.bwd[li]:
-                    dp.pack(self._weights[2 * li])
-                    if os.environ.get("VD_BWD_X2_SIM") == "w" and dp.wpk.shape[0] == 2:
-                        # measurement knob: the NUMERICS of a two-MFMA input gradient (g_hi + g_lo) x W_hi -- the low
-                        # plane of the weights dropped -- at the cost of the three-MFMA program
-                        dp.wpk[1].zero_()
+            with batched_packs():
+                for li in range(3):
+                    for dp in self.bwd[li]:
+                        dp.pack(self._weights[2 * li])
+            if os.environ.get("VD_BWD_X2_SIM") == "w":
+                # measurement knob: the NUMERICS of a two-MFMA input gradient (g_hi + g_lo) x W_hi -- the low
+                # plane of the weights dropped -- at the cost of the three-MFMA program
+                for li in range(3):
+                    for dp in self.bwd[li]:
+                        if dp.wpk.shape[0] == 2:
+                            dp.wpk[1].zero_()
             self._bwd_packed = True
 
     # ------------------------------------------------------------------------------------

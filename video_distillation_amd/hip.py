@@ -27,7 +27,7 @@ EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv_mfma_multi", "vd_conv0_per
            "vd_comm_unique_id", "vd_comm_create", "vd_comm_size", "vd_comm_version", "vd_comm_rank", "vd_comm_allreduce_f32", "vd_comm_allgather_f32",
            "vd_comm_free",
            "vd_bias_grad_pooled_scratch_floats", "vd_bias_grad_pooled_ordered", "vd_standardize_ordered", "vd_head_train_bwd_ordered",
-           "vd_set_deterministic", "vd_get_deterministic", "vd_pack_weights_c8")
+           "vd_set_deterministic", "vd_get_deterministic", "vd_pack_weights_c8", "vd_pack_weights_multi")
 
 
 class VdConvParams(ctypes.Structure):
@@ -54,6 +54,18 @@ class VdConvParams(ctypes.Structure):
 class VdMatchSeg(ctypes.Structure):
     _fields_ = [("gr", ctypes.c_void_p), ("gs", ctypes.c_void_p), ("g", ctypes.c_void_p), ("rows", ctypes.c_int64),
                 ("len", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+VD_PACK_MAX = 24
+
+
+class VdPackSeg(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("widx", ctypes.c_void_p), ("n", ctypes.c_int64), ("out_hi", ctypes.c_void_p),
+                ("out_lo", ctypes.c_void_p), ("prec", ctypes.c_int32), ("first_block", ctypes.c_int32)]
+
+
+class VdPackBatch(ctypes.Structure):
+    _fields_ = [("nseg", ctypes.c_int32), ("reserved", ctypes.c_int32), ("seg", VdPackSeg * VD_PACK_MAX)]
 
 
 class VdMatchBatch(ctypes.Structure):

@@ -22,6 +22,7 @@ import torch
 
 from . import hip
 from . import plan as P
+from . import engine
 from .engine import EmbedEngine, WgradOp, _DevPlan, run_together
 
 
@@ -209,10 +210,11 @@ class TrainEngine:
         B = int(x.shape[0])
         x = x.detach().to(torch.float32).contiguous()
         labels = labels.to(self.device, torch.int64).contiguous()
-        eng.set_weights(params[:6])
-        for li in (1, 2):
-            for dp in eng.bwd[li]:
-                dp.pack(eng._weights[2 * li])
+        with engine.batched_packs():          # (forward + input-gradient operands of the three levels: one launch)
+            eng.set_weights(params[:6])
+            for li in (1, 2):
+                for dp in eng.bwd[li]:
+                    dp.pack(eng._weights[2 * li])
         feats, nb, am = self._forward(x, params)
         hs = self.head_forward(feats, mask, params[6], params[7])
         logits = hs["logits"]
@@ -243,10 +245,11 @@ class TrainEngine:
         per = B // groups
         x = x.detach().to(torch.float32).contiguous()
         labels = labels.to(self.device, torch.int64).contiguous()
-        eng.set_weights(params[:6])
-        for li in (1, 2):
-            for dp in eng.bwd[li]:
-                dp.pack(eng._weights[2 * li])
+        with engine.batched_packs():          # (forward + input-gradient operands of the three levels: one launch)
+            eng.set_weights(params[:6])
+            for li in (1, 2):
+                for dp in eng.bwd[li]:
+                    dp.pack(eng._weights[2 * li])
         feats, nb, am = self._forward(x, params)
         hs = self.head_forward(feats, mask, params[6], params[7])
         logits = hs["logits"]
@@ -372,14 +375,15 @@ class GradMatchEngine(TrainEngine):
     # -- pieces of the adjoint sweep (shared by the fused ``vjp`` and the autograd path of ConvNet3D.forward) ----------
     def _pack_adjoint(self, W: Sequence[torch.Tensor], V: Sequence[torch.Tensor]) -> None:
         eng = self.eng
-        for li in range(3):
-            for dp in eng.bwd[li]:
-                dp.pack(W[2 * li])
-            for dp in self.bwdV[li]:
-                dp.pack(V[2 * li])
-        self.sel[0].pack(V[0])
-        for li in (1, 2):
-            self.sel[li].pack(torch.cat([V[2 * li], W[2 * li]], dim=1).contiguous())
+        with engine.batched_packs():          # (some twenty programs' operands: one or two launches)
+            for li in range(3):
+                for dp in eng.bwd[li]:
+                    dp.pack(W[2 * li])
+                for dp in self.bwdV[li]:
+                    dp.pack(V[2 * li])
+            self.sel[0].pack(V[0])
+            for li in (1, 2):
+                self.sel[li].pack(torch.cat([V[2 * li], W[2 * li]], dim=1).contiguous())
 
     def _sweep_bufs(self, nb: int):
         eng, geo = self.eng, self.geo
@@ -522,9 +526,10 @@ class GradMatchEngine(TrainEngine):
         W = [p.detach().to(self.device, torch.float32).contiguous() for p in params6]
         keep_ws, eng._ws = eng._ws, ws
         try:
-            for li in ((0, 1, 2) if need_dx else (1, 2)):
-                for dp in eng.bwd[li]:
-                    dp.pack(W[2 * li])
+            with engine.batched_packs():
+                for li in ((0, 1, 2) if need_dx else (1, 2)):
+                    for dp in eng.bwd[li]:
+                        dp.pack(W[2 * li])
             g = self._views(6) if need_params else None
             geo = self.geo
             dx = torch.empty((fs["nb"], geo.frames, geo.channel, geo.height, geo.width), dtype=torch.float32,
