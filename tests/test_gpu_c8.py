@@ -199,3 +199,43 @@ def test_deferred_backward_of_the_s2d_trainer_is_the_same_arithmetic():
     print("s2d deferred vs undeferred: losses %.1e (two undeferred runs: %.1e), dynamic memories %.1e (%.1e)" % (got_l, noise_l, got_d, noise_d))
     assert got_l <= 10 * noise_l + 1e-6 and got_d <= 10 * noise_d + 1e-7
     assert float((a[1] - dynamic.reshape(a[1].shape)).abs().max()) > 0
+
+
+@pytest.mark.parametrize("geom", [(12, 64, 64), (8, 48, 80), (16, 112, 112)])
+def test_backend_picks_a_last_level_program_for_any_geometry_and_one_clip_launches(geom):
+    """``HipBackend``'s default real side at geometries with and without position tiles (frames at the last level must divide 32:
+    12 frames -> 6 do not) and with non-square clips: whatever program it picks (position tiles, row-major fp8-corrected, three
+    MFMAs), the class term of 8 real + 1 synthetic clip matches the CPU oracle (loss 1e-3, as smoke()), and a ONE-clip launch (a
+    ragged group of 1 of 4 or 8) gives that clip's features of the 8-clip launch."""
+    from video_distillation_amd import distill, plan
+    T, H, W = geom
+    geo = plan.NetGeometry(T, H, W)
+    params = R.init_params(31)
+    g = torch.Generator().manual_seed(geom[0] * 7 + geom[1])
+    nreal = 8
+    real = torch.randn(nreal, T, 3, H, W, generator=g)
+    syn = torch.randn(1, T, 3, H, W, generator=g)
+    loss_ref, grad_ref = R.dm_loss_and_grad(params, [real], syn, ipc=1)
+    be = distill.HipBackend(geo, "cuda:0")
+    assert be.real_last in ("c8", "x3")
+    prog = be.eng_real.fwd2x.plan
+    frames_last = geo.layer_dims()[2][5]
+    assert (prog.epi == plan.EPI_POS_FEAT) == (be.real_last == "c8" and 32 % frames_last == 0)
+    weights = [p.cuda() for p in params[:6]]
+    pool = real.cuda()
+    be.set_real_weights(weights, nreal)
+    f_real = be.embed_pool(pool, torch.arange(nreal, device="cuda"), nreal)
+    f_syn, handle = be.embed_syn(syn.cuda(), weights)
+    loss_c, g_syn = be.dm_loss(f_real, f_syn, 1)
+    dx = be.embed_backward(handle, g_syn)
+    torch.cuda.synchronize()
+    rel_l = abs(float(loss_c.sum()) - float(loss_ref)) / float(loss_ref)
+    rel_g = float((dx.cpu() - grad_ref).norm() / grad_ref.norm())
+    print("%s: last level %s (%s), loss rel %.2e, gradient rel-l2 %.2e" % (
+        geom, be.real_last, "position tiles" if prog.epi == plan.EPI_POS_FEAT else "row-major", rel_l, rel_g))
+    assert rel_l < 1e-3 and rel_g < 2e-3
+    # undithered engine of the same kind: one clip alone vs the same clip inside a launch of 8
+    from video_distillation_amd import engine
+    e = engine.EmbedEngine(geo, prec="f16", chunk=64, last_hilo=("c8" if be.real_last == "c8" else True)); e.set_weights(weights)
+    f8 = e.forward(pool)
+    assert torch.equal(e.forward(pool[5:6].contiguous()), f8[5:6])
