@@ -106,6 +106,23 @@ def test_forward_layer2_in_position_tiles(net, acts, n):
     np.testing.assert_allclose(out.reshape(n, -1), want, rtol=1e-9, atol=1e-9)
 
 
+def test_forward_layer2_in_position_tiles_at_the_benchmark_geometry():
+    """The same at 112x112x16 (7 x 7 grid, 8 frames: four clips per box, masks 0 / 0b1010 / 0b1100 / 0b1110 only), 5 clips."""
+    dims = P.NetGeometry(16, 112, 112).layer_dims()[2]
+    pl = P.plan_forward_pos("fwd2_pos", dims[0], dims[1], dims[2], dims[3], dims[4], dims[11])
+    masks = {int(m) for t in pl.types for m in t.tap_off[2 * pl.S:]}
+    assert masks == {0, 0xA, 0xC, 0xE}
+    g = torch.Generator().manual_seed(6)
+    n = 5
+    w = torch.randn(128, 128, 3, 7, 7, generator=g).double() * 0.02
+    b = torch.randn(128, generator=g).double() * 0.1
+    a1 = torch.relu(torch.randn(n, dims[0], dims[2], dims[3], dims[4], generator=g).double())
+    want = F.max_pool3d(torch.relu(F.conv3d(a1, w, b, stride=(1, 2, 2), padding=(1, 3, 3))), (2, 2, 2)).reshape(n, -1).numpy()
+    out = np.zeros(n * want.shape[1])
+    E.run_plan(pl, bcthw_to_cl(a1.numpy()), w.numpy().ravel(), b.numpy(), n, out)
+    np.testing.assert_allclose(out.reshape(n, -1), want, rtol=1e-9, atol=1e-9)
+
+
 def test_position_tiles_at_the_benchmark_geometry_halve_the_matrix_work():
     dims = P.NetGeometry(16, 112, 112).layer_dims()[2]
     pl = P.plan_forward_pos("fwd2_pos", dims[0], dims[1], dims[2], dims[3], dims[4], dims[11])
