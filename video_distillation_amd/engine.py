@@ -198,7 +198,8 @@ class batched_packs:
     """``with batched_packs():`` -- the ``_DevPlan.pack`` calls inside are collected and issued as ONE launch per 24 of them at
     the exit (vd_pack_weights_multi): a training or trajectory-matching step packs the same few weight tensors for a dozen tile
     programs, each a 5 - 10 us launch of its own otherwise.  Bitwise the same operands.  The packed buffers must not be read
-    before the exit; nests (the outermost exit launches).  ``VD_PACK_BATCH=0``: every pack launches by itself."""
+    before the exit; nests (the outermost exit launches).  ``VD_PACK_BATCH=0``: every pack launches by itself.  The queue is a
+    module global: one host thread drives an engine's packing (the trainers do; the class lanes of DC are streams, not threads)."""
 
     def __enter__(self):
         global _PACK_QUEUE

@@ -568,7 +568,8 @@ def plan_forward_pos(name: str, cin: int, cout: int, t_in: int, h_in: int, w_in:
     steps with zero-weight taps).  MFMAs per product: 152 instead of 304 per channel chunk at 7 x 7.  The patch holds only the
     window's real pixels (no conv padding in h / w; one zero frame at either end), the B operands are packed once per window
     (``w_box_stride``), and the pool runs ACROSS the four accumulator tiles (and over the frame pair inside a lane)."""
-    assert cin % 8 == 0 and cout == 128 and pool_t == 2
+    if cin % 8 != 0 or cout != 128 or pool_t != 2:
+        raise ValueError("%s: position tiles are planned for 128 output channels (four N tiles = four waves) and (2,2,2) pooling" % name)
     CC, NT = cin // 8, cout // 32
     T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
     To, Ho, Wo = T // 2, OH // 2, OW // 2
