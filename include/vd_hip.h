@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 3
+#define VD_ABI_VERSION 4
 
 /* operand precision of the MFMA contraction (accumulation is always fp32) */
 #define VD_PREC_BF16   0   /* bf16 operands, one MFMA per product                       */
@@ -86,8 +86,8 @@ typedef struct VdConvParams {
     const int64_t* clip_index;    /* first-layer programs (ncl = 1): source clip of batch clip b is src + clip_index[b]*clip stride (NULL: b) */
     int32_t mt_valid;             /* NTW = 2: M tiles per box that carry rows (< MW*MTW: the last wave row skips its padding tile); 0 = all */
     int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups;
-                                     vd_conv0_breg: bit 16 selects the variant that requests the next patch before the epilogue, bit 17 the one
-                                     that builds the patch from aligned register loads */
+                                     vd_conv0_breg: bit 19 = run a frame-tile program (pair_flip != 0) with the plain K loop (one LDS read per
+                                     MFMA) instead of the frame-sharing one (A/B measurements; bitwise the same results) */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
     int32_t w_set_clips;          /* single-pass forward programs: > 0 = the B operand holds several sets, w_plane_stride elements apart; the box's
                                      first clip / w_set_clips picks the set (dithered real-side weights); 0 = one set */
@@ -99,8 +99,14 @@ typedef struct VdConvParams {
                                      for a VD_PREC_F16C8 consumer instead: per slot 8 e4m3 bytes of the low parts (x 2^9) and 8 of the high
                                      parts (/ 4), outputs clamped to +-1792 so that the image stays finite */
     int32_t src_planes, src_rows; /* first-level programs over pixel rows (vd_pix2rows): planes (frames x 3) and rows per plane of a clip; the
-                                     kernel that builds its patch from aligned loads (vd_conv0_breg, persist bit 17) derives row addresses
+                                     kernel that builds its patch from aligned loads (vd_conv0_breg) derives row addresses
                                      and the zero fill from them instead of a gather table; 0 elsewhere */
+    int32_t pair_flip;            /* pooled epilogues with pool_t = 1 (two outputs per row group, out_t_stride apart): bit q set = in the q-th
+                                     row group of every MFMA tile the SECOND output lies out_t_stride BEFORE the first one (the out table
+                                     holds the first).  0 everywhere except the first level's FRAME-TILE programs (plan.plan_forward_pix:
+                                     0b0110 -- what makes their A-fragment reads free of LDS bank conflicts); != 0 also tells vd_conv0_breg
+                                     that the four tiles of a wave row are the same positions in consecutive frames */
+    int32_t reserved0;
 } VdConvParams;
 
 int vd_abi_version(void);
@@ -116,14 +122,13 @@ int vd_conv_mfma(const VdConvParams* params, void* stream);
  * -2: the programs do not share an instantiation (the caller then launches them one by one). */
 int vd_conv_mfma_multi(const VdConvParams* const* params, int n, void* stream);
 
-/* The same tile program for the FIRST layer's forward over clips without gradient (x1 precisions,
- * one box type, NT=2 MW=2 MTW=4 S=32, pooled channels-last output, no arg-max): a persistent
- * kernel, one workgroup per CU, B fragments resident in registers, next patch DMA'd into a second
- * LDS buffer under the current box's MFMAs.  Same results as vd_conv_mfma. */
-/* First-layer forward (x1 formats, 2x2-wave layout, no arg-max) with the layer's B fragments resident in registers
- * across the workgroup's box walk; same results as vd_conv_mfma on the same program, bitwise. */
+/* First-layer forward (x1 formats, one box type, NT=2 MW=2 MTW=4 S=32, pooled channels-last output, no arg-max, pixel-row source
+ * with src_planes / src_rows set) with the layer's B fragments resident in registers across the workgroup's box walk: one
+ * eight-wave workgroup per CU whose two groups of four waves alternate between the K loop of one box and everything else of
+ * the next (row loads, kw-slot expansion, pool, output slots).  On frame-tile programs (pair_flip != 0) every A fragment is read
+ * from LDS once for all the tiles of the wave it serves (68 reads per 128 MFMAs).  Same results as vd_conv_mfma on the same
+ * program, bitwise (networks.py:799, the first nn.Conv3d + ReLU + MaxPool3d of ConvNet3D.features). */
 int vd_conv0_breg(const VdConvParams* p, void* stream);
-int vd_conv0_persistent(const VdConvParams* params, void* stream);
 
 /* fp32 weights -> MFMA-fragment-ordered 16-bit operands (hi plane, and lo plane for the x3
  * precisions) through the planner's gather table.  n = number of packed elements. */

@@ -108,7 +108,7 @@ def run_plan(plan, src, w_flat, bias, nclips, out):
                         for dt, sl in sets:
                             v = vals[sl]
                             mx, am = v.max(axis=0), v.argmax(axis=0)
-                            base = clip0 * plan.out_clip_stride + out_rel + o + dt * plan.out_t_stride
+                            base = clip0 * plan.out_clip_stride + out_rel + o + dt * (-plan.out_t_stride if (plan.pair_flip >> q) & 1 else plan.out_t_stride)
                             if plan.epi == P.EPI_POOL_FEAT:
                                 out[base + n * plan.n_stride] = mx
                                 for k in n:

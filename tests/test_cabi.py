@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(lib, name), name
     lib.vd_abi_version.restype = ctypes.c_int
-    assert lib.vd_abi_version() == 3
+    assert lib.vd_abi_version() == 4
 
 
 def test_argument_errors_are_reported_before_any_device_call():

@@ -159,41 +159,33 @@ def test_full_size_properties_chunking_gather_and_streams():
     assert la[0] > 0 and not torch.equal(sa, pool[[0, 4, 8]])                    # the step did move the pixels
 
 
-def test_experimental_persistent_first_layer_matches_generic():
-    """vd_conv0_persistent (off by default: measured slower) must stay bit-compatible
-    with the generic tile-program kernel it specialises."""
+def test_first_layer_two_tile_wave_layout_agrees_with_frame_tiles():
+    """The first level in the round-4 layout (frame-pair row groups, here with two N tiles per wave: ntw0 = 2, generic kernel)
+    against the frame-tile program of round 5: other row -> lane maps and another K order per output, the same convolution --
+    equal to fp32 summation-order rounding."""
     from video_distillation_amd import distill, engine, plan
     geo = plan.NetGeometry(16, 112, 112)
     g = torch.Generator(device="cuda").manual_seed(11)
     x = torch.randn(3, 16, 3, 112, 112, device="cuda", generator=g)
-    eng = engine.EmbedEngine(geo, prec="f16", chunk=8, ntw0=1)      # the persistent kernel is fixed to the 2x2-wave layout
+    eng = engine.EmbedEngine(geo, prec="f16", chunk=8, ntw0=1)
     eng.set_weights(distill.fresh_network_weights(2, "cuda:0"))
+    assert eng.fwd[0].plan.pair_flip == plan.FRAME_TILE_FLIP and eng.fwd[0].breg_ok
     ref = eng.forward(x)
-    eng2 = engine.EmbedEngine(geo, prec="f16", chunk=8, ntw0=2)     # default layout: 1 wave column x 4 wave rows, 2 N tiles per wave
+    eng2 = engine.EmbedEngine(geo, prec="f16", chunk=8, ntw0=2)     # 1 wave column x 4 wave rows, 2 N tiles per wave
     eng2.set_weights(distill.fresh_network_weights(2, "cuda:0"))
-    assert eng2.fwd[0].plan.NTW == 2 and torch.equal(ref, eng2.forward(x))   # same K order per output: bitwise equal
-    dp = eng.fwd[0]
-    assert not dp.persistent_ok
-    p = dp.params
-    ok = (dp.plan.epi == 0 and dp.plan.pool_t == 1 and dp.plan.CC == 1 and (dp.plan.NT, dp.plan.MW, dp.plan.MTW, dp.plan.S) == (2, 2, 4, 32)
-          and len(dp.plan.types) == 1 and 2 * p.lds_plane_bytes + 8 * dp.plan.S + 16 <= 160 * 1024)
-    assert ok, "plan no longer matches the persistent kernel's fixed geometry"
-    dp.persistent_ok = True
-    try:
-        got = eng.forward(x)
-    finally:
-        dp.persistent_ok = False
+    assert eng2.fwd[0].plan.NTW == 2 and eng2.fwd[0].plan.pair_flip == 0 and not eng2.fwd[0].breg_ok
+    got = eng2.forward(x)
     torch.cuda.synchronize()
-    assert torch.equal(ref, got)
+    assert float((got - ref).norm() / ref.norm()) < 2e-5 and not torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("geom,n", [((16, 112, 112), 5), ((8, 64, 64), 37)])
 def test_first_layer_kernel_variants_are_bitwise_equal(monkeypatch, geom, n):
-    """The three first-layer kernels of the single-pass formats -- generic tile program (VD_L0_BREG=0), register-resident B
-    (1), register-resident B with the next patch requested before the epilogue and barrier-free per-wave output staging (2),
-    the same with the patch built from aligned row loads in registers instead of LDS-DMA (3), and one eight-wave workgroup per CU
-    whose two groups alternate K loop / everything else (4, default) -- run the same tile program with the same K order per output: bitwise equal features, also through the index
-    gather and with dithered operand sets switching inside a workgroup's box walk."""
+    """The first-layer kernels of the single-pass formats -- generic tile program (VD_L0_BREG=0), register-resident B in one
+    eight-wave workgroup per CU whose two groups alternate K loop / everything else with one LDS read per MFMA (4), and the same
+    with every A fragment of the frame-tile program read once for the up to three tiles it serves (5, default) -- run the same
+    tile program with the same K order per output: bitwise equal features, also through the index gather and with dithered
+    operand sets switching inside a workgroup's box walk."""
     from video_distillation_amd import distill, engine, plan
     geo = plan.NetGeometry(*geom)
     g = torch.Generator(device="cuda").manual_seed(21)
@@ -201,17 +193,17 @@ def test_first_layer_kernel_variants_are_bitwise_equal(monkeypatch, geom, n):
     idx = torch.randperm(n + 3, generator=torch.Generator().manual_seed(3))[:n - n % 8 if n >= 8 else n].cuda()
     w = distill.fresh_network_weights(9, "cuda:0")
     outs = {}
-    for variant in ("0", "1", "2", "3", "4"):
+    for variant in ("0", "4", "5"):
         monkeypatch.setenv("VD_L0_BREG", variant)
         eng = engine.EmbedEngine(geo, prec="f16", chunk=4096, ntw0=1)
         assert eng.fwd[0].breg_ok == (variant != "0") and eng.fwd[0].breg_variant == int(variant)
-        assert eng.fwd[0].breg3_ok == (variant != "0")
+        assert eng.fwd[0].plan.pair_flip == plan.FRAME_TILE_FLIP
         G = 8 if idx.numel() % 8 == 0 and idx.numel() >= 8 else 0
         eng.set_weights(w, dither=G)
         rows = eng.pool_rows(pool)
         outs[variant] = (eng.forward(pool), eng.forward(pool, index=idx, rows=rows),
                          eng.forward_sets(pool, idx, rows=rows) if G else None)
-    for variant in ("1", "2", "3", "4"):
+    for variant in ("4", "5"):
         for a, b in zip(outs["0"], outs[variant]):
             assert (a is None and b is None) or torch.equal(a, b), variant
 

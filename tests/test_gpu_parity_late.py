@@ -19,7 +19,12 @@ window carrying a large gradient moves up to 1e-2).  (At 112x112x16 a clip has 8
 one or two such ties; the bar binds on the entries that have none -- measured 0.74e-3 -- and the median over all entries is
 recorded, not asserted: 1.1e-3 there, 0.73e-3 at 64x64x8 where 27 of 32 entries are clean.)
 
-Measured values go to gpurun_out/r04_parity.json (copied to profiles/)."""
+Round 5: the same bar on FIVE seeds per geometry and on 2 and 4 classes (``test_late_regime_seeds``): every seed draws other
+class templates, noise, networks and real batches; every clean entry of every seed must meet the bar, and the maximum over
+seeds is recorded.  ``VD_PARITY_FULL=1`` runs the full cross product with the step counts of the single-seed tests (the
+record in profiles/r05_parity.json); the default sizes keep the driver's suite short.
+
+Measured values go to gpurun_out/r05_parity.json (copied to profiles/)."""
 import json
 import os
 import time
@@ -39,7 +44,7 @@ MODES = {"shipped": dict(prec_real="f16", prec_syn="f16x3", prec_bwd=None),     
 
 def _record(key, value):
     path = os.environ.get("VD_PARITY_LOG", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                        "gpurun_out", "r04_parity.json"))
+                                                        "gpurun_out", "r05_parity.json"))
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         data = json.load(open(path)) if os.path.exists(path) else {}
@@ -216,3 +221,75 @@ def test_late_regime_shipped_mode_vs_oracle_full_size():
     _report("late regime 112x112x16", rec, modes)
     _record("late_112x112x16", rec)
     _assert_shipped(rec)
+
+
+# ---- round 5: the bar on five seeds per geometry, 2 and 4 classes -------------------------------------------------------
+FULL = os.environ.get("VD_PARITY_FULL") == "1"
+SEEDS_64 = (1201, 7, 23, 101, 4242)
+SEEDS_112 = (12, 5, 31, 77, 2026)
+_SEED_CASES = ([("64", s, C) for s in SEEDS_64 for C in (2, 4)]
+               + [("112", s, 2) for s in SEEDS_112]
+               + [("112", s, 4) for s in (SEEDS_112 if FULL else SEEDS_112[:1])])
+_seen = {}
+
+
+def _assert_seed(rec):
+    """The per-entry part of ``_assert_shipped`` (a short run may have few clean entries; the aggregate test counts them)."""
+    s = rec["shipped"]["summary"]
+    assert s["dither_groups"] == 8 and s["real_last"] in ("x3", "c8") and s["prec_bwd"] == "f16x3"
+    assert s["loss_vs_fp32_max"] < 1e-3 and s["loss_vs_fp64_max"] < 1e-3
+    per = np.asarray(rec["shipped"]["grad_vs_fp64_per_class"])
+    upper = np.asarray(rec["decisions"]["mismatch_per_class"])
+    far = np.asarray(rec["decisions"]["not_near_tie_per_class"])
+    assert int(far.sum()) == 0, "a pooling decision differs from the fp64 oracle's in a window that is no near-tie: %s" % far.tolist()
+    for it in range(per.shape[0]):
+        for c in range(per.shape[1]):
+            if upper[it, c] == 0:
+                assert per[it, c] < GRAD_BAR, (it, c, per[it, c])
+            else:
+                assert per[it, c] < 5e-2, (it, c, per[it, c], int(upper[it, c]))
+
+
+@pytest.mark.parametrize("geom,seed,C", _SEED_CASES, ids=["%s-seed%d-C%d" % c for c in _SEED_CASES])
+def test_late_regime_seeds(geom, seed, C):
+    """distill_baseline.py:344-355 in the shipped mode, another seed / class count: every clean entry within 1e-3 of the fp64
+    oracle's pixel gradient, every loss within 1e-3 of the fp32 and fp64 oracle's."""
+    if geom == "64":
+        steps = (16 if FULL else 4) if C == 2 else (8 if FULL else 2)
+        rec = late_regime_run((8, 64, 64), C=C, NP=80, B=64, steps=steps, lr=50.0, seed=seed)
+    else:
+        steps = (5 if FULL else 1) if C == 2 else (2 if FULL else 1)
+        rec = late_regime_run((16, 112, 112), C=C, NP=72, B=64, steps=steps, lr=20.0, seed=seed)
+    clean = rec["shipped"]["summary_clean"]
+    print("late regime %s seed %d C %d:" % (geom, seed, C), clean, "loss max", rec["shipped"]["summary"]["loss_vs_fp64_max"])
+    _seen[(geom, seed, C)] = {"clean": clean, "loss_vs_fp32_max": rec["shipped"]["summary"]["loss_vs_fp32_max"],
+                              "loss_vs_fp64_max": rec["shipped"]["summary"]["loss_vs_fp64_max"],
+                              "grad_vs_fp64_median_all": rec["shipped"]["summary"]["grad_vs_fp64_median"],
+                              "grad_vs_fp32_median": rec["shipped"]["summary"]["grad_vs_fp32_median"],
+                              "feature_gap_over_norm_mean": float(np.mean(rec["feature_gap_over_norm"])), "steps": steps}
+    _record("seeds_%s_seed%d_C%d" % (geom, seed, C), rec)
+    _assert_seed(rec)
+
+
+def test_late_regime_seeds_aggregate():
+    """Max over seeds of the clean-entry gradient error per geometry (the number DESIGN quotes), and that the per-entry bar
+    was not vacuous: at least five clean entries per geometry over the seeds that ran."""
+    if not _seen:
+        pytest.skip("runs after test_late_regime_seeds in the same session")
+    table = {}
+    for geom in ("64", "112"):
+        rows = {k: v for k, v in _seen.items() if k[0] == geom}
+        if not rows:
+            continue
+        mx = [v["clean"]["grad_vs_fp64_max"] for v in rows.values() if v["clean"]["grad_vs_fp64_max"] is not None]
+        med = [v["clean"]["grad_vs_fp64_median"] for v in rows.values() if v["clean"]["grad_vs_fp64_median"] is not None]
+        n_clean = sum(v["clean"]["entries"] for v in rows.values())
+        table[geom] = {"runs": len(rows), "clean_entries": n_clean, "entries": sum(v["clean"]["of"] for v in rows.values()),
+                       "clean_grad_vs_fp64_max_over_seeds": max(mx) if mx else None,
+                       "clean_grad_vs_fp64_median_of_medians": float(np.median(med)) if med else None,
+                       "loss_vs_fp64_max_over_seeds": max(v["loss_vs_fp64_max"] for v in rows.values()),
+                       "per_run": {"seed%d_C%d" % (k[1], k[2]): v for k, v in sorted(rows.items())}}
+        assert n_clean >= 5, table[geom]
+        assert max(mx) < GRAD_BAR
+    print(json.dumps({g: {k: v for k, v in t.items() if k != "per_run"} for g, t in table.items()}, indent=1))
+    _record("seeds_summary", table)

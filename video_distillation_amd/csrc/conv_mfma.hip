@@ -941,7 +941,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
                     if (st == 1 && p.pool_t == 2) continue;
-                    const int base = o + st * p.out_t_stride;
+                    const int base = o + st * (((p.pair_flip >> (half + 2 * qh)) & 1) ? -p.out_t_stride : p.out_t_stride);
                     if (base >= lim) continue;
                     const uint32_t idx = feat ? (uint32_t)base + chan : (uint32_t)base * 8u + chan;
                     const int ab = amx[idx];
@@ -979,7 +979,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 if (st == 1 && p.pool_t == 2) continue;
                 float mx = mv[st] + bias;
                 if (p.relu) mx = fmaxf(mx, 0.f);
-                const int base = o + st * p.out_t_stride;
+                const int base = o + st * (((p.pair_flip >> (half + 2 * qh)) & 1) ? -p.out_t_stride : p.out_t_stride);
                 if (base >= lim) continue;
                 const uint8_t ab = (uint8_t)(av[st] | (mx > 0.f ? 0 : 0x80));
                 if (feat) {
@@ -1008,7 +1008,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
             const int q = item >> cpq_sh, cc = item & ((1 << cpq_sh) - 1);
             const int g = q >> ns_sh, st = q & ns_sh;
             const int o = lds_otab[g];
-            const int base = o + st * p.out_t_stride;
+            const int base = o + st * (((p.pair_flip >> (g & 3)) & 1) ? -p.out_t_stride : p.out_t_stride);       // (frame-tile programs: vd_hip.h)
             if (o < 0 || base >= lim) continue;
             const uint32_t slot = (uint32_t)base + (uint32_t)cc * (uint32_t)p.out_chunk_stride;
             dslots[slot] = *reinterpret_cast<const uint4*>(stg + q * NCH + cc * 8);
@@ -1043,764 +1043,24 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_mu
     conv_mfma_body<PREC, MTW, SO, NTW, BAL>(m.p[k], 1, m.total[k], b - m.first[k], m.first[k + 1] - m.first[k]);
 }
 
-template <int PREC>
-__global__ __launch_bounds__(256, 1) void conv0_persistent_kernel(const VdConvParams p, const int boxes_per_wg) {
-    constexpr int MTW = 4, S = 32, AD = 2, LU = 12;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wm = wave >> 1;
-    const int half = lane >> 5;
-    const int32_t* a_tab = p.tables + p.boxes[0];
-    const int32_t* o_tab = p.tables + p.boxes[1];
-    const int32_t* t_tab = p.tables + p.boxes[2];
-    const int plane_bytes = p.lds_plane_bytes;
-    const int ngroups = (int)(p.gather_stride >> 6);
-    const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);
-    int* lds_tap = reinterpret_cast<int*>(smem + 2 * plane_bytes);
-    for (int k = tid; k < 2 * S; k += 256) lds_tap[k] = t_tab[k];
+#define VD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")      // (no vmcnt wait: global loads stay in flight)
 
-    int a_off[MTW], o_idx[MTW][2];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
-        o_idx[i][0] = o_tab[(wm * MTW + i) * 4 + half];
-        o_idx[i][1] = o_tab[(wm * MTW + i) * 4 + half + 2];
-    }
-    // all B fragments of this wave's 32 output channels
-    uint4 breg[S];
-    {
-        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)wn * 64 + lane;
-#pragma unroll
-        for (int s = 0; s < S; ++s) breg[s] = wp[(int64_t)s * 128];
-    }
-    const int n = wn * 32 + (lane & 31);
-    const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
-    const uint32_t chan = (uint32_t)(n >> 3) * (uint32_t)p.out_chunk_stride * 8u + (uint32_t)(n & 7);
-    const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
-
-    const int total = ((p.nclips + p.ncl - 1) / p.ncl) * p.nbox;
-    const int b_lo = blockIdx.x * boxes_per_wg;
-    const int b_hi = (b_lo + boxes_per_wg < total) ? b_lo + boxes_per_wg : total;
-
-    auto issue_dma = [&](int b, int buf) {
-        const int grp = b / p.nbox, bi = b - grp * p.nbox;
-        const int clip0 = grp * p.ncl;
-        const int32_t* gtab = p.gather + (int64_t)bi * p.gather_stride;
-        const uint32_t* csrc = src + (int64_t)clip0 * p.src_clip_stride4;
-        char* base = smem + buf * plane_bytes;
-        for (int g0 = wave * LU; g0 < ngroups; g0 += 4 * LU) {
-            uint32_t off[LU];
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                const int gi = (g0 + u < ngroups) ? g0 + u : ngroups - 1;
-                const int e = gtab[gi * 64 + lane];
-                const int ci = e >> 24;
-                const bool ok = (e >= 0) && (clip0 + ci < p.nclips);
-                off[u] = ok ? ((uint32_t)ci * (uint32_t)p.src_clip_stride4 + (uint32_t)(e & 0xFFFFFF)) : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < LU; ++u) asm volatile("" : "+v"(off[u]));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                if (g0 + u < ngroups) {
-                    const uint32_t* gp = (off[u] != 0xFFFFFFFFu) ? csrc + off[u] : zslot;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                     (__attribute__((address_space(3))) void*)(base + (g0 + u) * 1024), 16, 0, 0);
-                }
-            }
-        }
-    };
-
-    if (b_lo < b_hi) issue_dma(b_lo, 0);
-    __syncthreads();   // (drains the DMA: vmcnt(0) + barrier) also publishes lds_tap
-
-    for (int b = b_lo; b < b_hi; ++b) {
-        const int buf = (b - b_lo) & 1;
-        if (b + 1 < b_hi) issue_dma(b + 1, buf ^ 1);
-        const char* pb = smem + buf * plane_bytes;
-
-        f32x16 acc[MTW];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
-        uint4 A[AD + 1][MTW];
-#pragma unroll
-        for (int d = 0; d < AD; ++d) {
-            const int tp = lds_tap[2 * d + half];
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) A[d][i] = *reinterpret_cast<const uint4*>(pb + a_off[i] + tp);
-        }
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int sn = (s + AD < S) ? s + AD : S - 1;
-            const int tp = lds_tap[2 * sn + half];
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) A[(s + AD) % (AD + 1)][i] = *reinterpret_cast<const uint4*>(pb + a_off[i] + tp);
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) acc[i] = mfma16<PREC>(A[s % (AD + 1)][i], breg[s], acc[i]);
-        }
-
-        // epilogue: bias + ReLU + (1,2,2) max-pool, two outputs per 8-row group
-        const int grp = b / p.nbox, bi = b - grp * p.nbox;
-        const int out_rel = p.boxes[bi * 8 + 3];
-        const int64_t out_base = (int64_t)grp * p.ncl * p.out_clip_stride + out_rel;
-        const int64_t lim64 = out_total - out_base;
-        const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
-        uint16_t* dst16 = reinterpret_cast<uint16_t*>(p.dst) + out_base * 8;
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-#pragma unroll
-            for (int qh = 0; qh < 2; ++qh) {
-                const int o = o_idx[i][qh];
-                if (o < 0) continue;
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    const int b4 = 8 * qh + 4 * st;
-                    float mx = fmaxf(fmaxf(acc[i][b4], acc[i][b4 + 1]), fmaxf(acc[i][b4 + 2], acc[i][b4 + 3]));
-                    mx = fmaxf(mx + bias, 0.f);
-                    const int base = o + st * p.out_t_stride;
-                    if (base >= lim) continue;
-                    uint16_t hi, lo;
-                    split16<PREC>(mx, hi, lo);
-                    dst16[(uint32_t)base * 8u + chan] = hi;
-                }
-            }
-        }
-        __syncthreads();   // next patch landed (vmcnt(0)) and everyone is done reading this one
-    }
-}
-
-#define VD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-// First-layer kernel with register-resident weights (single-pass formats, 2 x 2 waves, 4 M tiles per wave, one
-// box type, 32 K steps): the layer's B fragments -- 64 KB in all, identical for every box -- are loaded into 128
-// VGPRs once per workgroup and reused for every box it walks.  The generic program re-fetches them per box with
-// 8 vector loads per K step and workgroup, which saturates the CU's texture-address unit (PMC: 63 % busy over the
-// whole kernel); here a box costs 14 gather loads + 14 LDS-DMAs + 2 slot stores per wave and nothing inside the K
-// loop.  Single patch buffer, two workgroups per CU; pooled outputs staged through LDS exactly like the generic
-// kernel (bitwise the same results).
-template <int PREC>
-__global__ __launch_bounds__(256, 2) void conv0_breg_kernel(const VdConvParams p, const int boxes_per_wg) {
-    constexpr int MTW = 4, S = 32, LU = 14, NCH = 64, Q = 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wm = wave >> 1;
-    const int half = lane >> 5;
-    const int32_t* a_tab = p.tables + p.tab_ofs[0];
-    const int32_t* o_tab = p.tables + p.tab_ofs[1];
-    const int32_t* t_tab = p.tables + p.tab_ofs[2];
-    const int plane_bytes = p.lds_plane_bytes;
-    const int ngroups = (int)(p.gather_stride >> 6);
-    const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);
-    int* lds_tap = reinterpret_cast<int*>(smem + plane_bytes);
-    int* lds_otab = lds_tap + 2 * S;
-    // gather entries of the NEXT box, brought in by 4-byte LDS-DMA while the current box computes (no registers held
-    // across the K loop, no global-load latency at the start of a box): [LU][64 lanes] per wave
-    int* park = reinterpret_cast<int*>(smem + plane_bytes + 512) + wave * (LU * 64);
-    for (int k = tid; k < 2 * S; k += 256) lds_tap[k] = t_tab[k];
-    for (int k = tid; k < 32; k += 256) lds_otab[k] = o_tab[k];
-    int a_off[MTW];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
-    uint4 breg[S];
-    // (w_set_clips > 0: several operand sets, w_plane_stride apart, picked by the clip number -- the dithered weights of the real
-    //  side; a workgroup's boxes are consecutive, so it reloads its fragments at most once or twice in its walk)
-    auto load_breg = [&](int set) {
-        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)set * (p.w_plane_stride >> 3) + (int64_t)wn * 64 + lane;
-#pragma unroll
-        for (int s = 0; s < S; ++s) breg[s] = wp[(int64_t)s * 128];
-    };
-    int cur_set = 0;
-    const int n = wn * 32 + (lane & 31);
-    const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
-    const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
-    const int total = p.nclips * p.nbox;            // ncl == 1
-    // XCD-contiguous ranges of boxes, as in the generic kernel
-    int wgid;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
-    const int b_lo = wgid * boxes_per_wg;
-    const int b_hi = (b_lo + boxes_per_wg < total) ? b_lo + boxes_per_wg : total;
-    uint16_t* stg = reinterpret_cast<uint16_t*>(smem);
-    auto park_next = [&](int b) {      // this wave's LU x 64 gather entries of box b -> its park region (asynchronous)
-        const int32_t* gtab = p.gather + (int64_t)(b % p.nbox) * p.gather_stride + lane;
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int gi = wave + u * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gtab + ((gi < ngroups) ? gi : ngroups - 1) * 64),
-                                             (__attribute__((address_space(3))) void*)(park + u * 64), 4, 0, 0);
-        }
-    };
-    if (b_lo < b_hi) park_next(b_lo);
-    if (p.w_set_clips > 0 && b_lo < b_hi) cur_set = (b_lo / p.nbox) / p.w_set_clips;
-    load_breg(cur_set);
-    __syncthreads();                     // tables published, first entries landed
-    asm volatile("" ::: "memory");
-    for (int b = b_lo; b < b_hi; ++b) {
-        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
-        if (p.w_set_clips > 0) {
-            const int set = clip0 / p.w_set_clips;
-            if (set != cur_set) { cur_set = set; load_breg(set); }
-        }
-        // ---- gather entries (parked in LDS during the previous box), then the patch DMA ----
-        {
-            const uint32_t* csrc = src + (p.clip_index != nullptr ? p.clip_index[clip0] : (int64_t)clip0) * p.src_clip_stride4;
-            uint32_t off[LU];
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                const int e = park[u * 64 + lane];
-                off[u] = (e >= 0) ? (uint32_t)(e & 0xFFFFFF) : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < LU; ++u) asm volatile("" : "+v"(off[u]));
-            int gi = wave;
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                asm volatile("" : "+s"(gi));
-                if (gi < ngroups && !(VD_DBG(p) & 4)) {
-                    const uint32_t* gp = (off[u] != 0xFFFFFFFFu) ? csrc + off[u] : zslot;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                     (__attribute__((address_space(3))) void*)(smem + gi * 1024), 16, 0, 0);
-                }
-                gi += 4;
-            }
-            if (b + 1 < b_hi) park_next(b + 1);      // lands under this box's K loop; waited for (vmcnt) with the patch below
-        }
-        const int out_rel = p.boxes[bi * 8 + 3];
-        __syncthreads();                 // patch landed (vmcnt(0) + barrier); also publishes the LDS tables
-        // ---- K loop: A one step ahead, B from registers ----
-        f32x16 acc[MTW];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
-        // A fragments: two register sets; the set an MFMA has just consumed is refilled at once with the fragment of TWO steps
-        // ahead (tile by tile), so a read has ~1.75 K steps (224 matrix cycles) to return instead of one (128): with the
-        // partner workgroup of the CU in its DMA / epilogue phase this wave is alone on its SIMD and nothing else hides the
-        // LDS latency (same-box A/B: 1.71 -> 1.63 ms per 512 clips)
-        uint4 A[2][MTW];
-        {
-            {
-                const int tp0 = lds_tap[half], tp1 = lds_tap[2 + half];
-#pragma unroll
-                for (int i = 0; i < MTW; ++i) A[0][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp0);
-#pragma unroll
-                for (int i = 0; i < MTW; ++i) A[1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp1);
-            }
-            int tp2 = lds_tap[4 + half];                      // tap offset of step s + 2
-            if (!(VD_DBG(p) & 2))
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int tp3 = lds_tap[2 * ((s + 3 < S) ? s + 3 : S - 1) + half];
-#pragma unroll
-                for (int i = 0; i < MTW; ++i) {
-                    acc[i] = mfma16<PREC>(A[s & 1][i], breg[s], acc[i]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (s + 2 < S) A[s & 1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                tp2 = tp3;
-            }
-        }
-        VD_LDS_BARRIER();                // every wave is done reading the patch: the staging tile aliases it
-        if (VD_DBG(p) & 1) { if (acc[0][0] == 123.456f) reinterpret_cast<float*>(p.dst)[0] = 1.f; continue; }
-        // ---- epilogue: bias + ReLU + (1,2,2) max-pool, staged through LDS, 16-byte slot stores ----
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            const int gi = wm * MTW + i;
-#pragma unroll
-            for (int qh = 0; qh < 2; ++qh) {
-                const int r0 = 8 * qh;
-                float m0 = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 2], acc[i][r0 + 3]));
-                float m1 = fmaxf(fmaxf(acc[i][r0 + 4], acc[i][r0 + 5]), fmaxf(acc[i][r0 + 6], acc[i][r0 + 7]));
-                m0 = fmaxf(m0 + bias, 0.f); m1 = fmaxf(m1 + bias, 0.f);
-                const int q = (gi * 4 + half + 2 * qh) * 2;
-                uint16_t hi, lo;
-                split16<PREC>(m0, hi, lo);
-                stg[q * NCH + n] = hi;
-                split16<PREC>(m1, hi, lo);
-                stg[(q + 1) * NCH + n] = hi;
-            }
-        }
-        VD_LDS_BARRIER();
-        {
-            const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
-            const int64_t lim64 = out_total - out_base;
-            const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
-            uint4* dslots = reinterpret_cast<uint4*>(p.dst) + out_base;
-            for (int item = tid; item < (Q << 3); item += 256) {
-                const int q = item >> 3, cc = item & 7;
-                const int o = lds_otab[q >> 1];
-                const int base = o + (q & 1) * p.out_t_stride;
-                if (o < 0 || base >= lim) continue;
-                dslots[(uint32_t)base + (uint32_t)cc * (uint32_t)p.out_chunk_stride] = *reinterpret_cast<const uint4*>(stg + q * NCH + cc * 8);
-            }
-        }
-        // the staging tile has been read: the next box's DMA may overwrite it.  LDS-only barrier: a full
-        // __syncthreads() would also wait (vmcnt) for this box's slot stores to complete
-        VD_LDS_BARRIER();
-    }
-}
-
-
-// LDS accesses of the overlapped epilogue below go through inline assembly: with an LDS-DMA in flight the compiler's wait
-// insertion puts s_waitcnt vmcnt(0) in front of every LDS access it can see (it cannot tell the staging tile from the DMA's
-// destination), which would serialise the epilogue behind the landing of the next patch.
-
-template <int OFS>
-__device__ __forceinline__ void vd_lds_write_b16(uint32_t addr, uint32_t v) {       // (constant offsets ride in the instruction:
-    asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFS) : "memory");   //  one address register for all)
-}
-template <int OFS>
-__device__ __forceinline__ uint4 vd_lds_read_b128_wait(uint32_t addr) {
-    uint4 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr), "n"(OFS) : "memory");
-    return r;
-}
-
-// conv0_breg_kernel with the phases of consecutive boxes overlapped (same tile program, same arithmetic, bitwise the same
-// results): the patch of box b+1 is requested right after the K loop of box b -- one barrier says every wave is done reading
-// the patch -- and lands while the epilogue of box b runs.  The epilogue needs no workgroup barrier any more: a wave stages
-// ITS 32 pooled positions x 32 channels in a private 2 KB tile (the 8 channels of a 16-byte output slot all belong to one wave)
-// and stores its own slots.  Per box: K loop | barrier | DMA issue, epilogue under the landing | barrier.
-template <int PREC>
-__global__ __launch_bounds__(256, 2) void conv0_breg2_kernel(const VdConvParams p, const int boxes_per_wg) {
-    constexpr int MTW = 4, S = 32, LU = 14;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wm = wave >> 1;
-    const int half = lane >> 5;
-    const int32_t* a_tab = p.tables + p.tab_ofs[0];
-    const int32_t* o_tab = p.tables + p.tab_ofs[1];
-    const int32_t* t_tab = p.tables + p.tab_ofs[2];
-    const int plane_bytes = p.lds_plane_bytes;
-    const int ngroups = (int)(p.gather_stride >> 6);
-    const uint32_t* zslot = reinterpret_cast<const uint32_t*>(p.zero_slot);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);
-    int* lds_tap = reinterpret_cast<int*>(smem + plane_bytes);
-    int* park = reinterpret_cast<int*>(smem + plane_bytes + 512) + wave * (LU * 64);
-    // byte address (LDS address space) of this wave's staging tile: [32 pooled positions][32 channels] 16-bit
-    const uint32_t stg = (uint32_t)(plane_bytes + 512 + 4 * LU * 64 * (int)sizeof(int) + wave * 2048);
-    const uint32_t stg_w = stg + (uint32_t)(half * 128 + (lane & 31) * 2);     // this lane's column in the rows it writes
-    const uint32_t stg_r = stg + (uint32_t)(lane * 16);                          // the first of the two slots it reads back
-    for (int k = tid; k < 2 * S; k += 256) lds_tap[k] = t_tab[k];
-    int a_off[MTW];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
-    // output origins of the two slots this lane stores per box (box independent: one box type)
-    int o_reg[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) o_reg[k] = o_tab[wm * 16 + (((lane + 64 * k) >> 2) >> 1)];
-    uint4 breg[S];
-    auto load_breg = [&](int set) {
-        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)set * (p.w_plane_stride >> 3) + (int64_t)wn * 64 + lane;
-#pragma unroll
-        for (int s = 0; s < S; ++s) breg[s] = wp[(int64_t)s * 128];
-    };
-    int cur_set = 0;
-    const int n = wn * 32 + (lane & 31);
-    const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
-    const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
-    const int total = p.nclips * p.nbox;            // ncl == 1
-    int wgid;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
-    const int b_lo = wgid * boxes_per_wg;
-    const int b_hi = (b_lo + boxes_per_wg < total) ? b_lo + boxes_per_wg : total;
-    if (b_lo >= b_hi) return;
-    auto park_next = [&](int b) {      // this wave's LU x 64 gather entries of box b -> its park region (asynchronous)
-        const int32_t* gtab = p.gather + (int64_t)(b % p.nbox) * p.gather_stride + lane;
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int gi = wave + u * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gtab + ((gi < ngroups) ? gi : ngroups - 1) * 64),
-                                             (__attribute__((address_space(3))) void*)(park + u * 64), 4, 0, 0);
-        }
-    };
-    auto issue_patch = [&](int b) {    // gather entries from the park (landed one barrier ago), then the patch DMA of box b
-        const int clip0 = b / p.nbox;
-        const uint32_t* csrc = src + (p.clip_index != nullptr ? p.clip_index[clip0] : (int64_t)clip0) * p.src_clip_stride4;
-        uint32_t off[LU];
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int e = park[u * 64 + lane];
-            off[u] = (e >= 0) ? (uint32_t)(e & 0xFFFFFF) : 0xFFFFFFFFu;
-        }
-#pragma unroll
-        for (int u = 0; u < LU; ++u) asm volatile("" : "+v"(off[u]));
-        int gi = wave;
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            asm volatile("" : "+s"(gi));
-            if (gi < ngroups) {
-                const uint32_t* gp = (off[u] != 0xFFFFFFFFu) ? csrc + off[u] : zslot;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                 (__attribute__((address_space(3))) void*)(smem + gi * 1024), 16, 0, 0);
-            }
-            gi += 4;
-        }
-    };
-    park_next(b_lo);
-    if (p.w_set_clips > 0) cur_set = (b_lo / p.nbox) / p.w_set_clips;
-    load_breg(cur_set);
-    __syncthreads();                     // tables published, first entries landed (vmcnt(0) + barrier)
-    issue_patch(b_lo);
-    if (b_lo + 1 < b_hi) park_next(b_lo + 1);
-    __syncthreads();                     // first patch landed
-    // dbg bit 3 (library built with -DVD_DBG_HOOKS=1, tools/stamps_breg2.py): cycles this workgroup's first wave spends in each
-    // phase, summed over its boxes -> stamps[block][0..5], boxes -> [6], whole walk -> [7]
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0, t_first = 0;
-    auto tick = [&](int k) {
-        if (VD_DBG(p) & 8) {
-            unsigned long long t;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-            if (k >= 0) ph[k] += t - t_prev; else if (t_first == 0) t_first = t;
-            t_prev = t;
-        }
-    };
-    tick(-1);
-    for (int b = b_lo; b < b_hi; ++b) {
-        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
-        if (p.w_set_clips > 0) {
-            const int set = clip0 / p.w_set_clips;
-            if (set != cur_set) { cur_set = set; load_breg(set); }
-        }
-        const int out_rel = p.boxes[bi * 8 + 3];
-        // ---- K loop: A two steps ahead (refill order of conv0_breg_kernel), B from registers ----
-        f32x16 acc[MTW];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
-        {
-            uint4 A[2][MTW];
-            const int tp0 = lds_tap[half], tp1 = lds_tap[2 + half];
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) A[0][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp0);
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) A[1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp1);
-            int tp2 = lds_tap[4 + half];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int tp3 = lds_tap[2 * ((s + 3 < S) ? s + 3 : S - 1) + half];
-#pragma unroll
-                for (int i = 0; i < MTW; ++i) {
-                    acc[i] = mfma16<PREC>(A[s & 1][i], breg[s], acc[i]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (s + 2 < S) A[s & 1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                tp2 = tp3;
-            }
-        }
-        tick(0);
-        VD_LDS_BARRIER();                // every wave is done reading the patch (and the park entries of box b+1 landed a barrier ago)
-        tick(1);
-        // ---- epilogue, first half: bias + ReLU + (1,2,2) max-pool -> this wave's private staging tile (frees the accumulators:
-        //      the DMA issue below needs their registers) ----
-        vd_static_for<MTW * 2>([&](auto ic) {
-            constexpr int i = decltype(ic)::v >> 1, qh = decltype(ic)::v & 1, r0 = 8 * qh;
-            float m0 = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 2], acc[i][r0 + 3]));
-            float m1 = fmaxf(fmaxf(acc[i][r0 + 4], acc[i][r0 + 5]), fmaxf(acc[i][r0 + 6], acc[i][r0 + 7]));
-            m0 = fmaxf(m0 + bias, 0.f); m1 = fmaxf(m1 + bias, 0.f);
-            // pooled position within this wave's 32: ql = (i * 4 + half + 2 * qh) * 2 (+ 1 for the second frame); rows of 64 bytes
-            uint16_t hi, lo;
-            split16<PREC>(m0, hi, lo);
-            vd_lds_write_b16<(i * 4 + 2 * qh) * 128>(stg_w, hi);
-            split16<PREC>(m1, hi, lo);
-            vd_lds_write_b16<(i * 4 + 2 * qh) * 128 + 64>(stg_w, hi);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        tick(2);
-        if (b + 1 < b_hi) {
-            issue_patch(b + 1);          // lands under the second half of the epilogue
-            if (b + 2 < b_hi) park_next(b + 2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        tick(3);
-        // ---- epilogue, second half: the wave's own 16-byte slots, staging tile -> HBM ----
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's staging writes (LDS operations of a wave complete in order)
-        {
-            const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
-            const int64_t lim64 = out_total - out_base;
-            const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
-            uint4* dslots = reinterpret_cast<uint4*>(p.dst) + out_base;
-            vd_static_for<2>([&](auto kc) {
-                constexpr int k = decltype(kc)::v;
-                const int item = lane + 64 * k;
-                const int ql = item >> 2, ch = item & 3;
-                const uint4 v = vd_lds_read_b128_wait<k * 1024>(stg_r);
-                const int o = o_reg[k];
-                const int base = o + (ql & 1) * p.out_t_stride;
-                if (o >= 0 && base < lim)
-                    dslots[(uint32_t)base + (uint32_t)(wn * 4 + ch) * (uint32_t)p.out_chunk_stride] = v;
-            });
-        }
-        tick(4);
-        // next patch (and the park entries of box b+2) landed: vmcnt(0) of every wave, then the barrier
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        tick(5);
-    }
-    if ((VD_DBG(p) & 8) && tid == 0 && p.stamps != nullptr) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)blockIdx.x * 8;
-        for (int k = 0; k < 6; ++k) o[k] = ph[k];
-        o[6] = (unsigned long long)(b_hi - b_lo);
-        o[7] = t_prev - t_first;
-    }
-}
-
-
-// Third form of the first-level kernel (phase stamps of conv0_breg2_kernel, tools/stamps_breg2.py: of 11.7 k cycles per box the
-// ISSUE of the patch's LDS-DMA takes 3.5 k -- the 16-byte windows of neighbouring output columns start 4 bytes apart, and the
-// texture-address unit serves such dword-aligned 16-byte lanes at ~16 bytes per clock, a quarter of its aligned rate; the
-// landing after it is short).  Here the patch is built from ALIGNED loads instead: a patch row (plane, h) needs 11 consecutive
-// dwords of one pixel row, starting at a 32-byte boundary; a lane loads two aligned 16-byte chunks of it into registers and
-// writes the four overlapping kw-slots d[j..j+3] they contain with ds_write_b128 -- every source byte is fetched once (the DMA
-// fetched it three times), no gather table, no LDS-DMA.  The loads of box b+1 are issued right after the K loop of box b and
-// return under its epilogue.  Same tile program, same K order: bitwise the results of the other two kernels.
-template <int PREC>
-__global__ __launch_bounds__(256, 2) void conv0_breg3_kernel(const VdConvParams p, const int boxes_per_wg) {
-    constexpr int MTW = 4, S = 32, NI = 3;          // NI: patch-row halves per lane (256 lanes x 3 >= 2 * pf * ph)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wm = wave >> 1;
-    const int half = lane >> 5;
-    const int32_t* a_tab = p.tables + p.tab_ofs[0];
-    const int32_t* o_tab = p.tables + p.tab_ofs[1];
-    const int32_t* t_tab = p.tables + p.tab_ofs[2];
-    const int plane_bytes = p.lds_plane_bytes;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.src);
-    int* lds_tap = reinterpret_cast<int*>(smem + plane_bytes);
-    uint16_t* stg16 = reinterpret_cast<uint16_t*>(smem + plane_bytes + 512 + wave * 2048);   // this wave's [32 positions][32 channels]
-    for (int k = tid; k < 2 * S; k += 256) lds_tap[k] = t_tab[k];
-    int a_off[MTW];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
-    int o_reg[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) o_reg[k] = o_tab[wm * 16 + (((lane + 64 * k) >> 2) >> 1)];
-    // a lane's patch-row halves (box independent): item it = tid + 256 k -> row r = it >> 1 = plane * ph + h, half hf = tid & 1.
-    // (plane, h) are recomputed where needed (r / ph by a 16-bit reciprocal, exact for r < 512: checked by the host) -- the K loop
-    // leaves no registers to keep them in
-    const int ph = p.type_desc[1], pitch_h = p.type_desc[3], pitch_f = p.type_desc[4], nitems = 2 * p.type_desc[0] * ph;
-    const int ph_magic = (65536 + ph - 1) / ph;
-    const int row4 = (int)(p.src_chunk_stride4 / ((int64_t)p.src_planes * p.src_rows));     // dwords per pixel row
-    uint4 breg[S];
-    auto load_breg = [&](int set) {
-        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)set * (p.w_plane_stride >> 3) + (int64_t)wn * 64 + lane;
-#pragma unroll
-        for (int s = 0; s < S; ++s) breg[s] = wp[(int64_t)s * 128];
-    };
-    int cur_set = 0;
-    const int n = wn * 32 + (lane & 31);
-    const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
-    const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
-    const int total = p.nclips * p.nbox;            // ncl == 1
-    int wgid;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
-    const int b_lo = wgid * boxes_per_wg;
-    const int b_hi = (b_lo + boxes_per_wg < total) ? b_lo + boxes_per_wg : total;
-    if (b_lo >= b_hi) return;
-    uint4 raw[NI][2];
-    auto load_raw = [&](int b) {       // the aligned chunks of box b's patch rows -> registers (zeros outside the clip); branch free:
-        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;      // rows outside the clip load a valid row of the box and are zeroed
-        const int32_t* box = p.boxes + bi * 8;
-        const int f0 = box[6] >> 16, h0 = (int)(int16_t)(box[6] & 0xFFFF), w0 = box[7];      // plane / row / dword of the patch origin
-        int tv = tid;
-        asm volatile("" : "+v"(tv));       // (opaque per call: otherwise the row coordinates below are hoisted out of the box loop into
-                                           //  registers the K loop does not have)
-        const char* base = reinterpret_cast<const char*>(
-            src + (p.clip_index != nullptr ? p.clip_index[clip0] : (int64_t)clip0) * p.src_clip_stride4 + ((int64_t)f0 * p.src_rows + h0) * row4 + w0);
-        const uint32_t off_valid = (uint32_t)((((f0 < 0 ? -f0 : 0) * p.src_rows + (h0 < 0 ? -h0 : 0)) * row4) * 4);   // first row of the box inside the clip
-        const uint32_t hf16 = (uint32_t)(tv & 1) * 16u;
-        const bool in_row = (w0 + 4 * (tv & 1) + 8 <= row4);                         // the second chunk stays inside the pixel row
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            const int it = tv + 256 * k, r = it >> 1;
-            const int pl = (r * ph_magic) >> 16, h = r - pl * ph;
-            const bool ok = it < nitems && (unsigned)(f0 + pl) < (unsigned)p.src_planes && (unsigned)(h0 + h) < (unsigned)p.src_rows;
-            const uint32_t o1 = (ok ? (uint32_t)((pl * p.src_rows + h) * row4 * 4) : off_valid) + hf16;
-            const uint32_t o2 = (ok && in_row) ? o1 + 16u : o1;
-            const uint4 v0 = *reinterpret_cast<const uint4*>(base + o1);
-            const uint4 v1 = *reinterpret_cast<const uint4*>(base + o2);
-            raw[k][0] = ok ? v0 : make_uint4(0, 0, 0, 0);
-            raw[k][1] = (ok && in_row) ? v1 : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto expand = [&]() {              // registers -> the four overlapping kw-slots of every loaded row half
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            const int it = tv + 256 * k, r = it >> 1;
-            if (it >= nitems) continue;
-            const int pl = (r * ph_magic) >> 16, h = r - pl * ph;
-            const uint4 a = raw[k][0], c = raw[k][1];
-            uint4* dst = reinterpret_cast<uint4*>(smem + (pl * pitch_f + h * pitch_h + 4 * (tv & 1)) * 16);
-            dst[0] = a;
-            dst[1] = make_uint4(a.y, a.z, a.w, c.x);
-            dst[2] = make_uint4(a.z, a.w, c.x, c.y);
-            dst[3] = make_uint4(a.w, c.x, c.y, c.z);
-        }
-    };
-    if (p.w_set_clips > 0) cur_set = (b_lo / p.nbox) / p.w_set_clips;
-    load_raw(b_lo);
-    load_breg(cur_set);
-    expand();
-    __syncthreads();                     // tables and the first patch published
-    // dbg bit 3 (library built with -DVD_DBG_HOOKS=1, tools/stamps_breg2.py): cycles per phase summed over the box walk
-    unsigned long long phs[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0, t_first = 0;
-    auto tick = [&](int k) {
-        if (VD_DBG(p) & 8) {
-            unsigned long long t;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-            if (k >= 0) phs[k] += t - t_prev; else if (t_first == 0) t_first = t;
-            t_prev = t;
-        }
-    };
-    tick(-1);
-    for (int b = b_lo; b < b_hi; ++b) {
-        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
-        if (p.w_set_clips > 0) {
-            const int set = clip0 / p.w_set_clips;
-            if (set != cur_set) { cur_set = set; load_breg(set); }
-        }
-        const int out_rel = p.boxes[bi * 8 + 3];
-        f32x16 acc[MTW];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
-        {
-            uint4 A[2][MTW];
-            const int tp0 = lds_tap[half], tp1 = lds_tap[2 + half];
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) A[0][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp0);
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) A[1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp1);
-            int tp2 = lds_tap[4 + half];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int tp3 = lds_tap[2 * ((s + 3 < S) ? s + 3 : S - 1) + half];
-#pragma unroll
-                for (int i = 0; i < MTW; ++i) {
-                    acc[i] = mfma16<PREC>(A[s & 1][i], breg[s], acc[i]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (s + 2 < S) A[s & 1][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                tp2 = tp3;
-            }
-        }
-        tick(0);
-        // the rows of the next box: return under the epilogue (the A registers are free now).  Unconditional -- the last box
-        // reloads itself -- so that `raw` is defined in every iteration and does not stay live across the K loop
-        load_raw(b + 1 < b_hi ? b + 1 : b);
-        __builtin_amdgcn_sched_barrier(0);
-        tick(1);
-        // ---- epilogue: bias + ReLU + (1,2,2) max-pool -> this wave's private staging tile -> its own 16-byte slots ----
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-#pragma unroll
-            for (int qh = 0; qh < 2; ++qh) {
-                const int r0 = 8 * qh;
-                float m0 = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 2], acc[i][r0 + 3]));
-                float m1 = fmaxf(fmaxf(acc[i][r0 + 4], acc[i][r0 + 5]), fmaxf(acc[i][r0 + 6], acc[i][r0 + 7]));
-                m0 = fmaxf(m0 + bias, 0.f); m1 = fmaxf(m1 + bias, 0.f);
-                const int ql = (i * 4 + half + 2 * qh) * 2;           // pooled position within this wave's 32
-                uint16_t hi, lo;
-                split16<PREC>(m0, hi, lo);
-                stg16[ql * 32 + (lane & 31)] = hi;
-                split16<PREC>(m1, hi, lo);
-                stg16[(ql + 1) * 32 + (lane & 31)] = hi;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        tick(2);
-        {
-            const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
-            const int64_t lim64 = out_total - out_base;
-            const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
-            uint4* dslots = reinterpret_cast<uint4*>(p.dst) + out_base;
-            const uint4* stg4 = reinterpret_cast<const uint4*>(stg16);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int item = lane + 64 * k;
-                const int ql = item >> 2, ch = item & 3;
-                const uint4 v = stg4[item];
-                const int o = o_reg[k];
-                const int base = o + (ql & 1) * p.out_t_stride;
-                if (o >= 0 && base < lim)
-                    dslots[(uint32_t)base + (uint32_t)(wn * 4 + ch) * (uint32_t)p.out_chunk_stride] = v;
-            }
-        }
-        tick(3);
-        VD_LDS_BARRIER();                // every wave is done reading the patch of box b ...
-        tick(4);
-        if (b + 1 < b_hi) expand();      // ... so the kw-slots of box b+1 may replace it
-        VD_LDS_BARRIER();
-        tick(5);
-    }
-    if ((VD_DBG(p) & 8) && tid == 0 && p.stamps != nullptr) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + (size_t)blockIdx.x * 8;
-        for (int k = 0; k < 6; ++k) o[k] = phs[k];
-        o[6] = (unsigned long long)(b_hi - b_lo);
-        o[7] = t_prev - t_first;
-    }
-}
-
-template <int PREC>
-static int launch_conv0_breg3(const VdConvParams& p, hipStream_t st) {
-    const int64_t total = (int64_t)p.nclips * p.nbox;
-    if (total <= 0) return 0;
-    auto kern = conv0_breg3_kernel<PREC>;
-    static VdDevCache cache;
-    int ncu = 0;
-    if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
-    size_t lds = (size_t)p.lds_plane_bytes + 512 + 4 * 2048;
-    if (lds > 80 * 1024) return -3;
-    if (p.dbg & 0x100) lds = 100 * 1024;          // diagnostic (tools/stamps_breg2.py --alone): one workgroup per CU, phases without a partner
-    const int64_t slots = (int64_t)ncu * 2;
-    const int gens = p.persist > 0 ? p.persist : 4;
-    int per = (int)((total + slots * gens - 1) / (slots * gens));
-    if (per < 1) per = 1;
-    const int64_t grid = (total + per - 1) / per;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p, per);
-    return (int)hipGetLastError();
-}
-
-
-// Fourth form: ONE workgroup of eight waves per CU, two groups of four that alternate roles box by box -- while group 0 runs
+// The first level's single-pass kernel (3 -> 64 channels, K = 512: the layer's B fragments live in 128 registers per wave for a whole
+// box walk).  ONE workgroup of eight waves per CU, two groups of four that alternate roles box by box -- while group 0 runs
 // the K loop of its box (matrix pipes), group 1 finishes its previous box and prepares its next one (pool, stage, output slots,
-// row loads, kw-slot expansion: vector memory + LDS), then they swap; one s_barrier per phase, none inside a phase.  The phases
-// of conv0_breg3_kernel measured without a partner (tools/stamps_breg2.py --alone): K loop 4.8 k cycles, everything else 4.2 k;
-// two independent workgroups per CU drift into lockstep (both in their K loops, then both out of them: 3.5 k cycles per box
-// with idle matrix pipes), which this arrangement rules out by construction.  A wave of group 0 and one of group 1 share each
-// SIMD.  Same tile program, same K order per output: bitwise the results of the other first-level kernels.
-template <int PREC>
-__global__ __launch_bounds__(512, 1) void conv0_breg4_kernel(const VdConvParams p, const int boxes_per_wg) {
+// aligned row loads, kw-slot expansion: vector memory + LDS), then they swap; one s_barrier per phase, none inside a phase.
+// (Rounds 1-3 ran two independent four-wave workgroups per CU, which drift into lockstep -- both in their K loops, then both out
+// of them: 3.5 k cycles per box with idle matrix pipes; docs/history.md.)  A wave of group 0 and one of group 1 share each SIMD.
+// Same tile program, same K order per output as the generic kernel: bitwise its results.
+//
+// FS (round 5, frame-tile programs: VdConvParams.pair_flip != 0): the four M tiles of a wave are the SAME 32 positions in four
+// consecutive frames, and K step 3 j + kt multiplies tap pair j of kernel plane kt.  The A fragment of (frame f, pair j) is then
+// the operand of tile f at kt = 0, tile f - 1 at kt = 1 and tile f - 2 at kt = 2: it is read from LDS ONCE and feeds up to three
+// MFMAs -- 60 + 8 reads per box and wave instead of 128 (with one ds_read_b128 per MFMA the LDS is exactly as busy as the
+// matrix pipes: 512 KB per box at 128 bytes per clock = the box's 4 096 matrix cycles).  Steps 30 / 31 (the three left-over taps of
+// the kt planes and the zero tap) are read per tile.
+template <int PREC, bool FS>
+__global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p, const int boxes_per_wg) {
     constexpr int MTW = 4, S = 32, NI = 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1821,9 +1081,14 @@ __global__ __launch_bounds__(512, 1) void conv0_breg4_kernel(const VdConvParams 
     int a_off[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
-    int o_reg[2];
+    int o_reg[2];          // output slot of this lane's two staged rows (item = lane + 64 k: pooled row item >> 2), -1 = none
 #pragma unroll
-    for (int k = 0; k < 2; ++k) o_reg[k] = o_tab[wm * 16 + (((lane + 64 * k) >> 2) >> 1)];
+    for (int k = 0; k < 2; ++k) {
+        const int ql = (lane + 64 * k) >> 2, g = ql >> 1;
+        const int o = o_tab[wm * 16 + g];
+        const int step = ((p.pair_flip >> (g & 3)) & 1) ? -p.out_t_stride : p.out_t_stride;
+        o_reg[k] = o < 0 ? -1 : o + (ql & 1) * step;
+    }
     const int ph = p.type_desc[1], pitch_h = p.type_desc[3], pitch_f = p.type_desc[4], nitems = 2 * p.type_desc[0] * ph;
     const int ph_magic = (65536 + ph - 1) / ph;
     const int row4 = (int)(p.src_chunk_stride4 / ((int64_t)p.src_planes * p.src_rows));
@@ -1915,6 +1180,44 @@ __global__ __launch_bounds__(512, 1) void conv0_breg4_kernel(const VdConvParams 
                 for (int i = 0; i < MTW; ++i)
 #pragma unroll
                     for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+                if constexpr (FS) {
+                    // reads in the order r = 6 j + f (pair j = 0..9, frame f = 0..5), then the 8 per-tile reads of steps 30 / 31;
+                    // a ring of D fragments is kept in flight
+                    constexpr int D = 6, NR = 68;
+                    const int fstride = 3 * pitch_f * 16;
+                    uint4 R[D];
+                    int tq[10];
+#pragma unroll
+                    for (int jj = 0; jj < 10; ++jj) tq[jj] = lds_tap[6 * jj + half];
+                    const int tl0 = lds_tap[60 + half], tl1 = lds_tap[62 + half];
+                    const char* pa = patch + a_off[0];
+                    auto rd = [&](auto rc) -> uint4 {
+                        constexpr int r = decltype(rc)::v;
+                        if constexpr (r < 60) return *reinterpret_cast<const uint4*>(pa + (r % 6) * fstride + tq[r / 6]);
+                        else return *reinterpret_cast<const uint4*>(pa + ((r - 60) & 3) * fstride + ((r - 60) >> 2 ? tl1 : tl0));
+                    };
+                    vd_static_for<D>([&](auto rc) { R[decltype(rc)::v] = rd(rc); });
+                    vd_static_for<NR>([&](auto rc) {
+                        constexpr int r = decltype(rc)::v;
+                        if constexpr (r < 60) {
+                            constexpr int jj = r / 6, f = r % 6;
+                            vd_static_for<3>([&](auto kc) {
+                                constexpr int kt = decltype(kc)::v, i = f - kt;
+                                if constexpr (i >= 0 && i < MTW) {
+                                    acc[i] = mfma16<PREC>(R[r % D], breg[3 * jj + kt], acc[i]);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            });
+                        } else {
+                            acc[(r - 60) & 3] = mfma16<PREC>(R[r % D], breg[30 + ((r - 60) >> 2)], acc[(r - 60) & 3]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if constexpr (r + D < NR) {
+                            R[r % D] = rd(VdIC<r + D>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                } else {
                 uint4 A[2][MTW];
                 const int tp0 = lds_tap[half], tp1 = lds_tap[2 + half];
 #pragma unroll
@@ -1933,6 +1236,7 @@ __global__ __launch_bounds__(512, 1) void conv0_breg4_kernel(const VdConvParams 
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     tp2 = tp3;
+                }
                 }
             }
         } else {
@@ -1976,9 +1280,8 @@ __global__ __launch_bounds__(512, 1) void conv0_breg4_kernel(const VdConvParams 
                     const int item = lane + 64 * k;
                     const int ql = item >> 2, ch = item & 3;
                     const uint4 v = stg4[item];
-                    const int o = o_reg[k];
-                    const int base = o + (ql & 1) * p.out_t_stride;
-                    if (o >= 0 && base < lim)
+                    const int base = o_reg[k];
+                    if (base >= 0 && base < lim)
                         dslots[(uint32_t)base + (uint32_t)(wn * 4 + ch) * (uint32_t)p.out_chunk_stride] = v;
                 }
             }
@@ -1988,11 +1291,11 @@ __global__ __launch_bounds__(512, 1) void conv0_breg4_kernel(const VdConvParams 
     }
 }
 
-template <int PREC>
-static int launch_conv0_breg4(const VdConvParams& p, hipStream_t st) {
+template <int PREC, bool FS>
+static int launch_conv0_breg(const VdConvParams& p, hipStream_t st) {
     const int64_t total = (int64_t)p.nclips * p.nbox;
     if (total <= 0) return 0;
-    auto kern = conv0_breg4_kernel<PREC>;
+    auto kern = conv0_breg_kernel<PREC, FS>;
     static VdDevCache cache;
     int ncu = 0;
     if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
@@ -2008,110 +1311,21 @@ static int launch_conv0_breg4(const VdConvParams& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <int PREC>
-static int launch_conv0_breg2(const VdConvParams& p, hipStream_t st) {
-    const int64_t total = (int64_t)p.nclips * p.nbox;
-    if (total <= 0) return 0;
-    auto kern = conv0_breg2_kernel<PREC>;
-    static VdDevCache cache;
-    int ncu = 0;
-    if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
-    const size_t lds = (size_t)p.lds_plane_bytes + 512 + 4 * 14 * 64 * sizeof(int) + 4 * 2048;
-    if (lds > 80 * 1024) return -3;
-    const int64_t slots = (int64_t)ncu * 2;
-    const int gens = p.persist > 0 ? p.persist : 4;
-    int per = (int)((total + slots * gens - 1) / (slots * gens));
-    if (per < 1) per = 1;
-    const int64_t grid = (total + per - 1) / per;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p, per);
-    return (int)hipGetLastError();
-}
-
-template <int PREC>
-static int launch_conv0_breg(const VdConvParams& p, hipStream_t st) {
-    const int64_t total = (int64_t)p.nclips * p.nbox;
-    if (total <= 0) return 0;
-    auto kern = conv0_breg_kernel<PREC>;
-    static VdDevCache cache;
-    int ncu = 0;
-    if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
-    const size_t lds = (size_t)p.lds_plane_bytes + 512 + 4 * 14 * 64 * sizeof(int);
-    if (lds > 80 * 1024) return -3;
-    const int64_t slots = (int64_t)ncu * 2;
-    const int gens = p.persist > 0 ? p.persist : 4;
-    int per = (int)((total + slots * gens - 1) / (slots * gens));
-    if (per < 1) per = 1;
-    const int64_t grid = (total + per - 1) / per;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p, per);
-    return (int)hipGetLastError();
-}
-
 extern "C" int vd_conv0_breg(const VdConvParams* pp, void* stream) {
     if (pp == nullptr) return -1;
     const VdConvParams& p = *pp;
     if (p.NT != 2 || p.MW != 2 || p.MTW != 4 || (p.NTW != 0 && p.NTW != 1) || p.S != 32 || p.CC != 1 || p.ncl != 1 ||
         p.ntypes != 1 || p.epi != VD_EPI_POOL_CL || p.pool_t != 1 || p.argmax != nullptr || !p.relu ||
-        (p.gather_stride >> 6) > 4 * 14 || 8 * 1024 > p.lds_plane_bytes)
+        8 * 1024 > p.lds_plane_bytes || p.src_planes <= 0 || p.src_rows <= 0 || p.type_desc == nullptr)
         return -2;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // persist bit 18: one eight-wave workgroup per CU, two groups alternating K loop / everything else (conv0_breg4_kernel); same
-    // requirements as bit 17
-    if (p.persist & 0x40000) {
-        if (p.src_planes <= 0 || p.src_rows <= 0 || p.type_desc == nullptr) return -2;
-        VdConvParams q = p;
-        q.persist = p.persist & 0xFFFF;
-        if (p.prec == VD_PREC_F16) return launch_conv0_breg4<VD_PREC_F16>(q, st);
-        if (p.prec == VD_PREC_BF16) return launch_conv0_breg4<VD_PREC_BF16>(q, st);
-        return -2;
-    }
-    // persist bit 17: the patch built from aligned register loads (conv0_breg3_kernel); needs the pixel-row geometry in src_planes /
-    // src_rows, box origins in words 6 / 7 of the box rows, 8 output columns per box starting at a multiple of 4 dwords
-    if (p.persist & 0x20000) {
-        if (p.src_planes <= 0 || p.src_rows <= 0 || p.type_desc == nullptr) return -2;
-        VdConvParams q = p;
-        q.persist = p.persist & 0xFFFF;
-        if (p.prec == VD_PREC_F16) return launch_conv0_breg3<VD_PREC_F16>(q, st);
-        if (p.prec == VD_PREC_BF16) return launch_conv0_breg3<VD_PREC_BF16>(q, st);
-        return -2;
-    }
-    // persist bit 16: the variant with the next patch requested before the epilogue (conv0_breg2_kernel)
-    if (p.persist & 0x10000) {
-        VdConvParams q = p;
-        q.persist = p.persist & 0xFFFF;
-        if (p.prec == VD_PREC_F16) return launch_conv0_breg2<VD_PREC_F16>(q, st);
-        if (p.prec == VD_PREC_BF16) return launch_conv0_breg2<VD_PREC_BF16>(q, st);
-        return -2;
-    }
-    if (p.prec == VD_PREC_F16) return launch_conv0_breg<VD_PREC_F16>(p, st);
-    if (p.prec == VD_PREC_BF16) return launch_conv0_breg<VD_PREC_BF16>(p, st);
-    return -2;
-}
-
-template <int PREC>
-static int launch_conv0_persistent(const VdConvParams& p, hipStream_t st) {
-    const int total = ((p.nclips + p.ncl - 1) / p.ncl) * p.nbox;
-    if (total <= 0) return 0;
-    auto kern = conv0_persistent_kernel<PREC>;
-    static VdDevCache cache;
-    int ncu = 0;
-    if (int rc = vd_dev_prepare(reinterpret_cast<const void*>(kern), cache, ncu)) return rc;
-    const int per = (total + ncu - 1) / ncu;
-    const int grid = (total + per - 1) / per;
-    const size_t lds = (size_t)2 * p.lds_plane_bytes + (size_t)2 * p.S * sizeof(int) + 16;
-    if (lds > 160 * 1024) return -3;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p, per);
-    return (int)hipGetLastError();
-}
-
-extern "C" int vd_conv0_persistent(const VdConvParams* pp, void* stream) {
-    if (pp == nullptr) return -1;
-    const VdConvParams& p = *pp;
-    if (p.NT != 2 || p.MW != 2 || p.MTW != 4 || p.S != 32 || p.CC != 1 || p.epi != VD_EPI_POOL_CL || p.pool_t != 1 ||
-        p.argmax != nullptr || !p.relu)
-        return -2;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (p.prec == VD_PREC_F16) return launch_conv0_persistent<VD_PREC_F16>(p, st);
-    if (p.prec == VD_PREC_BF16) return launch_conv0_persistent<VD_PREC_BF16>(p, st);
+    VdConvParams q = p;
+    q.persist = p.persist & 0xFFFF;
+    // frame-tile programs (pair_flip != 0; plan.plan_forward_pix): the K loop that reads every A fragment once for all the tiles
+    // it serves, unless persist bit 19 asks for the plain one (A/B measurements, bitwise the same results)
+    const bool fs = p.pair_flip != 0 && !(p.persist & 0x80000);
+    if (p.prec == VD_PREC_F16) return fs ? launch_conv0_breg<VD_PREC_F16, true>(q, st) : launch_conv0_breg<VD_PREC_F16, false>(q, st);
+    if (p.prec == VD_PREC_BF16) return fs ? launch_conv0_breg<VD_PREC_BF16, true>(q, st) : launch_conv0_breg<VD_PREC_BF16, false>(q, st);
     return -2;
 }
 

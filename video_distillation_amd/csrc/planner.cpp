@@ -48,6 +48,7 @@ struct Plan {
     int epi = 0, pool_t = 0, relu = 1, n_out = 0, n_stride = 0;
     int64_t out_clip_stride = 0;
     int out_chunk_stride = 0, out_t_stride = 0;
+    int pair_flip = 0;                 // plan.ConvPlan.pair_flip (frame-tile programs)
     int w_step4 = 4, row_pitch4 = 0;
     int64_t clip_stride4 = 0, chunk_stride4 = 0;
     int NTW = 1;
@@ -85,6 +86,7 @@ inline int row_of(int q, int j) { return (j & 3) + 4 * (q & 1) + 8 * (j >> 2) + 
 inline double round3(double x) { return std::nearbyint(x * 1000.0) / 1000.0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+constexpr int FRAME_TILE_FLIP = 6, FRAME_TILE_OUT_STEP = 2;      // plan.FRAME_TILE_FLIP / FRAME_TILE_OUT_STEP
 const int ORDERS[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}};
 
 std::vector<std::array<int, 4>> perms4() {
@@ -158,25 +160,37 @@ BoxType build_type_order(const int box[3], const int row_stride[3], const std::v
     struct G { int ci, a, b, c; };
     std::vector<G> groups;
     const int lim[3] = {na, nb, nc};
-    for (int ci = 0; ci < ncl; ++ci)
-        for (int x = 0; x < lim[order[0]]; x += 2)
-            for (int y = 0; y < lim[order[1]]; y += 2)
-                for (int z = 0; z < lim[order[2]]; z += 2) {
-                    int abc[3];
-                    abc[order[0]] = x; abc[order[1]] = y; abc[order[2]] = z;
-                    groups.push_back({ci, abc[0], abc[1], abc[2]});
-                }
+    const bool frame = order == nullptr;      // plan._build_type_order(order=None): FRAME TILES of the first level
+    if (frame) {
+        // a row group = the pool windows (b, c) and (b, c + 4) of one frame, c in {0, 2}; a tile = the four groups of one
+        // column class in one frame; the tiles of a wave row = consecutive frames
+        for (int ci = 0; ci < ncl; ++ci)
+            for (int c = 0; c < 4; c += 2)
+                for (int a = 0; a < na; ++a)
+                    for (int b = 0; b < nb; b += 2) groups.push_back({ci, a, b, c});
+    } else {
+        for (int ci = 0; ci < ncl; ++ci)
+            for (int x = 0; x < lim[order[0]]; x += 2)
+                for (int y = 0; y < lim[order[1]]; y += 2)
+                    for (int z = 0; z < lim[order[2]]; z += 2) {
+                        int abc[3];
+                        abc[order[0]] = x; abc[order[1]] = y; abc[order[2]] = z;
+                        groups.push_back({ci, abc[0], abc[1], abc[2]});
+                    }
+    }
     const int ngr = (int)groups.size();
     std::vector<std::array<std::array<int64_t, 4>, 8>> gcoord(ngr);
     std::vector<int64_t> gout(ngr);
     for (int gi = 0; gi < ngr; ++gi) {
         const G& g = groups[gi];
         for (int j = 0; j < 8; ++j) {
-            const int dt = (j >> 2) & 1, dh = (j >> 1) & 1, dw = j & 1;
+            int dt = (j >> 2) & 1, dh = (j >> 1) & 1, dw = j & 1;
+            if (frame) { dw += 4 * dt; dt = 0; }
             gcoord[gi][j] = {g.ci, (int64_t)row_stride[0] * (g.a + dt), (int64_t)row_stride[1] * (g.b + dh),
                              (int64_t)row_stride[2] * (g.c + dw)};
         }
-        const bool ok = g.a + 2 <= valid[0] && g.b + 2 <= valid[1] && g.c + 2 <= valid[2];
+        const bool ok = frame ? (g.a < valid[0] && g.b + 2 <= valid[1])
+                              : (g.a + 2 <= valid[0] && g.b + 2 <= valid[1] && g.c + 2 <= valid[2]);
         gout[gi] = ok ? out_fn(g.ci, g.a, g.b, g.c) : -1;
     }
     const int ntile_used = (int)cdiv(ngr, 4);
@@ -205,8 +219,11 @@ BoxType build_type_order(const int box[3], const int row_stride[3], const std::v
                     int64_t slots[32];
                     for (int q = 0; q < 4; ++q) {
                         const auto& gc = gcoord[gids[perm[q]]];
-                        for (int j = 0; j < 8; ++j)
-                            slots[row_of(q, j)] = gc[j][0] * pitch_c + gc[j][1] * pitch_f + gc[j][2] * pitch_h + gc[j][3];
+                        const int jx = (frame && ((FRAME_TILE_FLIP >> q) & 1)) ? 4 : 0;      // this group lists its second window first
+                        for (int j = 0; j < 8; ++j) {
+                            const auto& rc = gc[j ^ jx];
+                            slots[row_of(q, j)] = rc[0] * pitch_c + rc[1] * pitch_f + rc[2] * pitch_h + rc[3];
+                        }
                     }
                     const double cyc = conflict_cycles(slots);
                     if (!have_t || cyc < bt_cyc) {
@@ -219,7 +236,9 @@ BoxType build_type_order(const int box[3], const int row_stride[3], const std::v
                 for (int r = 0; r < 32; ++r) a_off[(size_t)tile * 32 + r] = bt_slots[r];
                 for (int q = 0; q < 4; ++q) {
                     const int gi = tile * 4 + bt_perm[q];
-                    out[(size_t)tile * 4 + q] = gi < ngr ? gout[gi] : -1;
+                    int64_t o = gi < ngr ? gout[gi] : -1;
+                    if (frame && ((FRAME_TILE_FLIP >> q) & 1) && o >= 0) o += FRAME_TILE_OUT_STEP;   // first window = the right-hand one
+                    out[(size_t)tile * 4 + q] = o;
                 }
             }
             const double cyc = cyc_sum / ntile_used;
@@ -244,7 +263,8 @@ BoxType build_type_order(const int box[3], const int row_stride[3], const std::v
 }
 
 BoxType build_type(const int box[3], const int row_stride[3], const std::vector<Tap>& taps, const int ext[3], int mt_pad,
-                   const OutFn& out_fn, const int valid[3], int ncl, int64_t slot_cap) {
+                   const OutFn& out_fn, const int valid[3], int ncl, int64_t slot_cap, bool frame_tiles = false) {
+    if (frame_tiles) return build_type_order(box, row_stride, taps, ext, mt_pad, out_fn, valid, ncl, slot_cap, nullptr);
     bool have = false;
     double bk = 0.0;
     int bp = 0;
@@ -276,6 +296,7 @@ struct PlanSpec {
     int lds_budget;
     int ntw;
     bool pooled = true;                // pool windows of 2x2x2 conv rows (forward) vs plain rows (input gradient)
+    bool frame_tiles = false;          // first level: row groups (1, 2, 8), tiles of one frame (plan._make_plan(frame_tiles=True))
 };
 
 // plan._make_plan (pooled programs: group = 2x2x2 conv rows per pool window; plain-row programs: group = 1)
@@ -300,7 +321,8 @@ bool make_plan(const PlanSpec& sp, Plan& pl) {
         for (int ncl : sp.ncl_options) {
             const int rows_max = (sp.MW * MTW * 32) / ncl;
             const int G = sp.pooled ? 2 : 1;
-            if (rows_max < G * G * G) continue;
+            const int GA = sp.frame_tiles ? 1 : G, GB = G, GC = sp.frame_tiles ? 8 : G;
+            if (rows_max < GA * GB * GC) continue;
             const int waves = (sp.NT / sp.ntw) * sp.MW;
             const int64_t dma_cap = (int64_t)waves * (MTW * sp.ntw <= 4 ? 14 : 17) * 64;
             const int64_t budget = std::min<int64_t>(sp.lds_budget, dma_cap - 64);
@@ -308,10 +330,10 @@ bool make_plan(const PlanSpec& sp, Plan& pl) {
             bool hb = false;
             int64_t k_nbox = 0, k_slots = 0;
             int k_narrow = 0, cb[3] = {0, 0, 0};
-            for (int na = G; na < RA + G; na += G)
-                for (int nb = G; nb < RB + G; nb += G)
-                    for (int nc = G; nc < RC + G; nc += G) {
-                        if (na > RA + G - 1 || nb > RB + G - 1 || nc > RC + G - 1) continue;
+            for (int na = GA; na < RA + GA; na += GA)
+                for (int nb = GB; nb < RB + GB; nb += GB)
+                    for (int nc = GC; nc < RC + GC; nc += GC) {
+                        if (na > RA + GA - 1 || nb > RB + GB - 1 || nc > RC + GC - 1) continue;
                         if (na * nb * nc > rows_max) continue;
                         int e[3];
                         ext(na, nb, nc, e);
@@ -334,6 +356,7 @@ bool make_plan(const PlanSpec& sp, Plan& pl) {
     if (!have) return false;
     const int MTW = best_mtw, ncl = best_ncl, na = best_box[0], nb = best_box[1], nc = best_box[2];
     const int mt_pad = sp.MW * MTW;
+    if (sp.frame_tiles && !(na == MTW && nb == 8 && nc == 8 && sp.MW == 2 && ncl == 1)) return false;
     const int64_t dma_cap_final = (int64_t)(sp.NT / sp.ntw) * sp.MW * (MTW * sp.ntw <= 4 ? 14 : 17) * 64;
     const int64_t slot_cap = std::min<int64_t>((int64_t)(sp.lds_budget * 1.12), dma_cap_final);
     int e_box[3];
@@ -349,7 +372,7 @@ bool make_plan(const PlanSpec& sp, Plan& pl) {
                     if (keys[k] == key) ty = (int)k;
                 if (ty < 0) {
                     const int valid[3] = {key[0], key[1], key[2]};
-                    pl.types.push_back(sp.pooled ? build_type(best_box, sp.row_stride, taps_p, e_box, mt_pad, sp.out_index, valid, ncl, slot_cap)
+                    pl.types.push_back(sp.pooled ? build_type(best_box, sp.row_stride, taps_p, e_box, mt_pad, sp.out_index, valid, ncl, slot_cap, sp.frame_tiles)
                                                  : build_type_rows(best_box, sp.row_stride, taps_p, e_box, mt_pad, sp.out_index, valid, ncl, slot_cap));
                     keys.push_back(key);
                     ty = (int)keys.size() - 1;
@@ -439,16 +462,12 @@ bool plan_forward_pix(int cout, int t_in, int h_in, int w_in, int lds_budget, in
     const int cin = 3;
     const int T = conv_out_dim(t_in, KT, 1, 1), OH = conv_out_dim(h_in, KH, 2, 3), OW = conv_out_dim(w_in, KW, 2, 3);
     const int Ho = OH / 2, Wo = OW / 2;
-    if (T % 2) return false;
     PlanSpec sp;
     sp.src_grid[0] = t_in * cin; sp.src_grid[1] = h_in; sp.src_grid[2] = OW;
     sp.CC = 1;
     sp.row_dims[0] = T; sp.row_dims[1] = Ho * 2; sp.row_dims[2] = Wo * 2;
     sp.row_origin[0] = -cin; sp.row_origin[1] = -3; sp.row_origin[2] = 0;
     sp.row_stride[0] = cin; sp.row_stride[1] = 2; sp.row_stride[2] = 1;
-    for (int kt = 0; kt < KT; ++kt)
-        for (int c = 0; c < cin; ++c)
-            for (int kh = 0; kh < KH; ++kh) sp.taps.push_back({kt * cin + c, kh, 0});
     sp.n_out = cout; sp.NT = cout / 32; sp.MW = std::max(1, 4 / (sp.NT / ntw));
     sp.mtw_options = {4};
     if (ntw == 2) {
@@ -460,8 +479,34 @@ bool plan_forward_pix(int cout, int t_in, int h_in, int w_in, int lds_budget, in
     const int64_t chunk_stride = (int64_t)T * Ho * Wo, clip_stride = (cout / 8) * chunk_stride;
     sp.out_index = [=](int ci, int a, int b, int c) { return ci * clip_stride + ((int64_t)a * Ho + b / 2) * Wo + c / 2; };
     sp.n_stride = 0; sp.out_clip_stride = clip_stride; sp.out_chunk_stride = (int)chunk_stride;
-    if (!make_plan(sp, pl)) return false;
-    pl.out_t_stride = Ho * Wo;
+    bool done = false;
+    const char* ft = getenv("VD_L0_FRAME_TILES");
+    if ((ft == nullptr || strcmp(ft, "1") == 0) && ntw == 1 && sp.NT == 2 && Wo % 4 == 0) {
+        // FRAME TILES (plan.plan_forward_pix): K order (tap pair j, kt) over the first 20 (c, kh) taps of a kt plane, then the
+        // three left-over taps
+        int q[21][2];
+        for (int c = 0; c < cin; ++c)
+            for (int kh = 0; kh < KH; ++kh) { q[c * KH + kh][0] = c; q[c * KH + kh][1] = kh; }
+        for (int j = 0; j < 10; ++j)
+            for (int kt = 0; kt < KT; ++kt)
+                for (int e = 0; e < 2; ++e) sp.taps.push_back({kt * cin + q[2 * j + e][0], q[2 * j + e][1], 0});
+        for (int kt = 0; kt < KT; ++kt) sp.taps.push_back({kt * cin + q[20][0], q[20][1], 0});
+        sp.frame_tiles = true;
+        if (make_plan(sp, pl)) {
+            pl.out_t_stride = FRAME_TILE_OUT_STEP; pl.pair_flip = FRAME_TILE_FLIP;
+            done = true;
+        }
+    }
+    if (!done) {
+        if (T % 2) return false;
+        sp.frame_tiles = false;
+        sp.taps.clear();
+        for (int kt = 0; kt < KT; ++kt)
+            for (int c = 0; c < cin; ++c)
+                for (int kh = 0; kh < KH; ++kh) sp.taps.push_back({kt * cin + c, kh, 0});
+        if (!make_plan(sp, pl)) return false;
+        pl.out_t_stride = Ho * Wo;
+    }
     const int rowp = pix_row_pitch(w_in);
     pl.w_step4 = 1; pl.row_pitch4 = rowp / 2;
     pl.chunk_stride4 = pl.clip_stride4 = (int64_t)t_in * cin * h_in * (rowp / 2);
@@ -824,6 +869,7 @@ std::vector<uint8_t> export_program(const Plan& pl, int persist) {
     const int64_t sizes[7] = {(int64_t)desc.size(), (int64_t)tables.size(), (int64_t)boxes.size(), (int64_t)gt.size(),
                               (int64_t)pl.widx.size(), (int64_t)pl.col_off.size(), persist};
     memcpy(&h[28], sizes, sizeof(sizes));
+    h[37] = pl.pair_flip;
     {   // words 35, 36: planes / rows per plane of the source clip when the patch can be built from aligned 16-byte row loads
         // (plan.ConvPlan.row_source: first-level programs over pixel rows, 2 x 2 waves of 4 M tiles, 8 output columns per box)
         bool ok = pl.w_step4 == 1 && pl.CC == 1 && pl.ncl == 1 && pl.NTW <= 1 && pl.types.size() == 1 && pl.NT == 2 && pl.MW == 2 &&

@@ -27,7 +27,7 @@ struct VdProgram {
 static const char VD_PROG_MAGIC[8] = {'V', 'D', 'P', 'R', 'O', 'G', '0', '1'};
 enum { H_MAGIC = 0, H_CC, H_S, H_NT, H_MW, H_MTW, H_NTW, H_EPI, H_POOL_T, H_RELU, H_N_OUT, H_N_STRIDE, H_OUT_CLIP, H_OUT_CHUNK,
        H_OUT_T, H_LDS_PLANE, H_NTYPES, H_TAB0, H_TAB1, H_TAB2, H_ATOMIC, H_W_BOX, H_NCL, H_NBOX, H_GSTRIDE, H_SRC_CLIP4,
-       H_SRC_CHUNK4, H_MT_VALID, H_N_DESC, H_N_TABLES, H_N_BOXES, H_N_GATHER, H_N_WIDX, H_N_COLOFF, H_PERSIST, H_ROW_PLANES, H_ROW_ROWS, H_WORDS = 40 };
+       H_SRC_CHUNK4, H_MT_VALID, H_N_DESC, H_N_TABLES, H_N_BOXES, H_N_GATHER, H_N_WIDX, H_N_COLOFF, H_PERSIST, H_ROW_PLANES, H_ROW_ROWS, H_PAIR_FLIP, H_WORDS = 40 };
 
 extern "C" int vd_program_load(const void* blob, int64_t nbytes, int prec, VdProgram** out) {
     if (blob == nullptr || out == nullptr || nbytes < (int64_t)(H_WORDS * sizeof(int64_t))) return -1;
@@ -77,6 +77,7 @@ extern "C" int vd_program_load(const void* blob, int64_t nbytes, int prec, VdPro
     p.src_clip_stride4 = h[H_SRC_CLIP4]; p.src_chunk_stride4 = h[H_SRC_CHUNK4];
     p.mt_valid = (int)h[H_MT_VALID]; p.persist = (int)h[H_PERSIST];
     p.src_planes = (int)h[H_ROW_PLANES]; p.src_rows = (int)h[H_ROW_ROWS];     // > 0: the patch can be built from aligned row loads
+    p.pair_flip = (int)h[H_PAIR_FLIP];                                        // != 0: frame-tile program (vd_hip.h)
     p.prec = prec;
     p.wpk = g->d_wpk; p.w_plane_stride = n_w;
     *out = g;
@@ -106,9 +107,8 @@ extern "C" int vd_program_run_scaled(VdProgram* g, const void* src, int64_t src_
     // first-layer programs in the single-pass formats and the 2 x 2-wave layout run the kernel that keeps the layer's B
     // fragments in registers across its box walk (bitwise the same results; same rule as engine._DevPlan)
     const bool breg = p.prec < 2 && p.epi == VD_EPI_POOL_CL && p.pool_t == 1 && p.CC == 1 && p.ncl == 1 && p.NTW <= 1 &&
-                      p.NT == 2 && p.MW == 2 && p.MTW == 4 && p.S == 32 && p.ntypes == 1 && (p.gather_stride >> 6) <= 56 &&
+                      p.NT == 2 && p.MW == 2 && p.MTW == 4 && p.S == 32 && p.ntypes == 1 && p.src_rows > 0 &&
                       p.relu && argmax == nullptr;
-    if (breg && p.src_rows > 0) p.persist |= 0x40000;      // the eight-wave two-role form (conv0_breg4_kernel), as engine._DevPlan picks it
     return breg ? vd_conv0_breg(&p, stream) : vd_conv_mfma(&p, stream);
 }
 

@@ -56,6 +56,7 @@ class _DevPlan:
         p.n_out, p.n_stride = plan.n_out, plan.n_stride
         p.out_clip_stride = plan.out_clip_stride
         p.out_chunk_stride, p.out_t_stride = plan.out_chunk_stride, plan.out_t_stride
+        p.pair_flip = plan.pair_flip
         p.lds_plane_bytes = int(gt.shape[1]) * 16
         p.ntypes = len(plan.types)
         p.persist = int(os.environ.get("VD_PERSIST", str(P.BOX_WALK_GENERATIONS)))
@@ -68,28 +69,17 @@ class _DevPlan:
         self.col_off = None if plan.col_off is None else torch.from_numpy(plan.col_off.copy()).to(device)
         p.col_off = 0 if self.col_off is None else self.col_off.data_ptr()
         self.params = p
-        # first-layer forward in an x1 precision with a single box type -> persistent kernel
-        # (experimental, off by default: measured slower than the generic kernel)
-        self.persistent_ok = (os.environ.get("VD_PERSISTENT_L0", "0") == "1" and not hip.is_x3(prec)
-                              and plan.epi == P.EPI_POOL_CL and plan.pool_t == 1 and plan.CC == 1
-                              and (plan.NT, plan.MW, plan.MTW, plan.S) == (2, 2, 4, 32) and len(plan.types) == 1
-                              and 2 * p.lds_plane_bytes + 8 * plan.S + 16 <= 160 * 1024)
-
-        # first layer, x1 formats, 2x2-wave layout: kernel with the layer's B fragments resident in registers
-        # VD_L0_BREG: 4 (default) = one eight-wave workgroup per CU whose two groups alternate K loop / everything else
-        # (conv0_breg4_kernel), 3 = two workgroups per CU with the patch built from aligned row loads in registers (conv0_breg3_kernel),
-        # 2 = LDS-DMA patch requested before the epilogue (conv0_breg2_kernel), 1 = the round-2 phase order, 0 = the generic
-        # tile-program kernel.  All bitwise equal (tests/test_gpu_embed.py::test_first_layer_kernel_variants_are_bitwise_equal).
-        self.breg_variant = int(os.environ.get("VD_L0_BREG", "4"))
-        self.breg_ok = (self.breg_variant in (1, 2, 3, 4) and not hip.is_x3(prec)
-                        and plan.epi == P.EPI_POOL_CL and plan.pool_t == 1 and plan.CC == 1 and plan.ncl == 1 and plan.NTW == 1
-                        and (plan.NT, plan.MW, plan.MTW, plan.S) == (2, 2, 4, 32) and len(plan.types) == 1
-                        and int(gt.shape[1]) // 64 <= 56 and plan.relu)
-
-        # the aligned-load variant: pixel-row source (w_step4 == 1), 8 output columns per box starting at a multiple of 4 dwords,
-        # every patch row's 12 dwords inside its 16-byte-aligned pixel row, three row halves per lane
-        self.breg3_ok = bool(self.breg_ok and plan.row_source()[1] > 0)
-        if self.breg3_ok:
+        # first layer, single-pass formats, 2 x 2-wave layout, pixel-row source: the kernel with the layer's B fragments resident in
+        # registers (conv0_breg_kernel: one eight-wave workgroup per CU whose two groups alternate K loop / everything else).
+        # VD_L0_BREG: 5 (default) = on frame-tile programs every A fragment is read from LDS once for the tiles it serves;
+        # 4 = the plain K loop, one read per MFMA; 0 = the generic tile-program kernel.  All bitwise equal
+        # (tests/test_gpu_embed.py::test_first_layer_kernel_variants_are_bitwise_equal).
+        self.breg_variant = int(os.environ.get("VD_L0_BREG", "5"))
+        self.breg_ok = bool(self.breg_variant in (4, 5) and not hip.is_x3(prec)
+                            and plan.epi == P.EPI_POOL_CL and plan.pool_t == 1 and plan.CC == 1 and plan.ncl == 1 and plan.NTW == 1
+                            and (plan.NT, plan.MW, plan.MTW, plan.S) == (2, 2, 4, 32) and len(plan.types) == 1
+                            and plan.relu and plan.row_source()[1] > 0)
+        if plan.row_source()[1] > 0:
             p.src_planes, p.src_rows = plan.row_source()
 
     def _new_wpk(self, planes: int, device) -> torch.Tensor:
@@ -171,19 +161,12 @@ class _DevPlan:
             e0.record()
         if self.breg_ok and argmax is None and (not p.dbg or os.environ.get("VD_BREG_DBG") == "1"):
             persist = p.persist
-            if self.breg_variant == 4 and self.breg3_ok:
-                p.persist = persist | 0x40000          # (VdConvParams.persist bit 18: eight-wave workgroup, two alternating role groups)
-            elif self.breg_variant >= 3 and self.breg3_ok:
-                p.persist = persist | 0x20000          # (bit 17: patch from aligned row loads)
-            elif self.breg_variant >= 2:
-                p.persist = persist | 0x10000          # (bit 16: LDS-DMA patch requested before the epilogue)
+            if self.breg_variant == 4:
+                p.persist = persist | 0x80000          # (VdConvParams.persist bit 19: the plain K loop on a frame-tile program)
             try:
                 hip.check(hip.lib().vd_conv0_breg(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv0_breg(%s)" % self.plan.name)
             finally:
                 p.persist = persist
-        elif self.persistent_ok and argmax is None and not p.dbg:
-            hip.check(hip.lib().vd_conv0_persistent(ctypes.byref(p), hip.stream_ptr(src.device)),
-                      "vd_conv0_persistent(%s)" % self.plan.name)
         else:
             hip.check(hip.lib().vd_conv_mfma(ctypes.byref(p), hip.stream_ptr(src.device)), "vd_conv_mfma(%s)" % self.plan.name)
         if prof is not None:
@@ -328,7 +311,7 @@ class EmbedEngine:
         self.ntw = int(os.environ.get("VD_NTW", "2"))
         if ntw0 is None:
             # (x1 formats: the register-resident-B kernel runs the 2x2-wave one-N-tile layout)
-            breg = os.environ.get("VD_L0_BREG", "4") in ("1", "2", "3", "4")
+            breg = os.environ.get("VD_L0_BREG", "5") in ("4", "5")
             ntw0 = int(os.environ.get("VD_NTW0", "1" if (hip.is_x3(self.prec) or self.ntw != 2 or breg) else "2"))
         bal = (self.ntw == 2 and not hip.is_x3(self.prec) and os.environ.get("VD_BALANCED", "1") == "1")
         self.batch_hint = batch_hint      # typical clips per launch: small batches get latency-oriented programs

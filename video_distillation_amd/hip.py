@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libvd_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("conv_mfma.hip", "aux_kernels.hip", "program.hip", "planner.cpp", "comm.cpp")]
 
 PREC = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3, "f16c8": 4}      # f16c8: fp16 + fp8 corrections (the real side's last level only)
-EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv_mfma_multi", "vd_conv0_persistent", "vd_conv0_breg", "vd_pack_weights", "vd_round_operand", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_absmax_scale", "vd_dm_loss",
+EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv_mfma_multi", "vd_conv0_breg", "vd_pack_weights", "vd_round_operand", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_absmax_scale", "vd_dm_loss",
            "vd_group_sum", "vd_sgd_momentum", "vd_hallucinator_fwd", "vd_hallucinator_bwd", "vd_match_rows_fwd", "vd_match_rows_bwd", "vd_match_rows_fwd_multi", "vd_match_rows_bwd_multi", "vd_head_fwd", "vd_clip_minor_cl", "vd_clip_minor_pix", "vd_pack_dy", "vd_bias_grad", "vd_bias_grad_pooled", "vd_standardize", "vd_head_train_fwd", "vd_ce_loss", "vd_head_train_bwd", "vd_head_second_order", "vd_resplit_slots", "vd_program_load", "vd_program_pack_weights",
            "vd_program_run", "vd_program_info", "vd_program_free",
            "vd_sgd_momentum_wd", "vd_frames_normalize", "vd_replica_sum", "vd_pack_weights_dither", "vd_unpool_relu_bwd_packed", "vd_mfma_peak", "vd_program_build", "vd_program_build_dgrad", "vd_program_build_wgrad", "vd_program_run_wgrad", "vd_train_create", "vd_train_workspace_bytes", "vd_train_step", "vd_train_free", "vd_blob_free", "vd_embed_create", "vd_embed_create_ex", "vd_embed_argmax_bytes", "vd_embed_backward_workspace_bytes",
@@ -47,7 +47,7 @@ class VdConvParams(ctypes.Structure):
         ("out_clip_stride", ctypes.c_int64),
         ("out_chunk_stride", ctypes.c_int32), ("out_t_stride", ctypes.c_int32),
         ("lds_plane_bytes", ctypes.c_int32), ("prec", ctypes.c_int32), ("dbg", ctypes.c_int32), ("ntypes", ctypes.c_int32), ("tab_ofs", ctypes.c_int32 * 3), ("atomic", ctypes.c_int32), ("select", ctypes.c_int32), ("src_split_cc", ctypes.c_int32), ("src_split_off4", ctypes.c_int64), ("NTW", ctypes.c_int32), ("clip_index", ctypes.c_void_p), ("mt_valid", ctypes.c_int32), ("persist", ctypes.c_int32), ("stamps", ctypes.c_void_p),
-        ("w_set_clips", ctypes.c_int32), ("replica_stride", ctypes.c_int32), ("emit_lo", ctypes.c_int32), ("src_planes", ctypes.c_int32), ("src_rows", ctypes.c_int32),
+        ("w_set_clips", ctypes.c_int32), ("replica_stride", ctypes.c_int32), ("emit_lo", ctypes.c_int32), ("src_planes", ctypes.c_int32), ("src_rows", ctypes.c_int32), ("pair_flip", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -128,7 +128,7 @@ def lib() -> ctypes.CDLL:
             getattr(L, name).restype = {"vd_program_info": ctypes.c_int64, "vd_program_free": None, "vd_blob_free": None, "vd_embed_free": None, "vd_train_free": None, "vd_comm_free": None, "vd_train_workspace_bytes": ctypes.c_int64, "vd_bias_grad_pooled_scratch_floats": ctypes.c_int64,
                                         "vd_embed_num_features": ctypes.c_int64, "vd_embed_workspace_bytes": ctypes.c_int64,
                                         "vd_embed_argmax_bytes": ctypes.c_int64, "vd_embed_backward_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
-        if L.vd_abi_version() != 3:
+        if L.vd_abi_version() != 4:
             raise RuntimeError("libvd_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -95,6 +95,7 @@ class ConvPlan:
     atomic: bool = False         # EPI_ROWS: accumulate with fp32 atomics (several boxes add into the same rows)
     w_box_stride: int = 0        # 16-bit elements between the packed B operands of consecutive boxes (0 = shared)
     NTW: int = 1                 # N tiles per wave: wave grid = (NT / NTW) columns x MW rows
+    pair_flip: int = 0           # pool_t == 1: bit q = the q-th row group of a tile has its second output out_t_stride BEFORE the first
     rows_total: int = 0
     rows_useful: int = 0
     meta: Dict = field(default_factory=dict)
@@ -204,6 +205,7 @@ def export_program(plan: "ConvPlan", persist: int = BOX_WALK_GENERATIONS) -> byt
                mt_max if (plan.NTW == 2 and mt_max < plan.MW * plan.MTW) else 0]
     h[28:35] = [desc.size, tables.size, boxes.size, gt.size, widx.size, col.size, persist]
     h[35:37] = plan.row_source()
+    h[37] = plan.pair_flip
     arrays = [desc.reshape(-1), tables, boxes, gt.reshape(-1), widx, col]
     return h.tobytes() + b"".join(np.ascontiguousarray(a, dtype=np.int32).tobytes() for a in arrays)
 
@@ -252,15 +254,20 @@ def _choose_box(dims, group, rows_max, slot_fn, lds_budget):
 
 
 _PERMS4 = list(itertools.permutations(range(4)))
+FRAME_TILE_FLIP = 0b0110       # frame-tile programs: row groups 1 and 2 of a tile list their second window first (VdConvParams.pair_flip)
+FRAME_TILE_OUT_STEP = 2        # ... whose two windows are this many pooled columns apart (out_t_stride)
 
 
 def _build_type(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, out_fn, valid_fn, ncl, pad_search=True,
-                slot_cap=1 << 30):
+                slot_cap=1 << 30, frame_tiles=False):
     """Pooled boxes: which four row groups (pool windows) share an MFMA tile is free -- the kernel is table-driven --
     so the enumeration order of the groups (which axis runs fastest) is searched too, next to the LDS pitches."""
     if not pooled:
         return _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, out_fn, valid_fn, ncl, pad_search,
                                  slot_cap, (0, 1, 2))
+    if frame_tiles:          # one enumeration: tile = (set of four row groups of one frame), tiles of a wave row = consecutive frames
+        return _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, out_fn, valid_fn, ncl, pad_search,
+                                 slot_cap, None)
     best = None
     for order in ((0, 1, 2), (0, 2, 1), (1, 0, 2), (2, 0, 1), (1, 2, 0), (2, 1, 0)):
         bt = _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, out_fn, valid_fn, ncl, pad_search,
@@ -285,7 +292,24 @@ def _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, 
     if pooled:
         axes = (range(0, na, ga), range(0, nb, gb), range(0, nc, gc))
         groups = []
-        for ci in range(ncl):           # `order` lists the axes from slowest to fastest
+        if order is None:
+            # FRAME TILES (first level, pool (1,2,2), boxes of 8 x 8 conv rows per frame): a row group is two pool windows of ONE
+            # frame, four conv columns apart -- (b, c) and (b, c + 4), c in {0, 2}; its second output lies out_t_stride = 2 pooled
+            # columns from the first; an MFMA tile is the four groups of one column class c in one frame, and the tiles of a
+            # wave row are the SAME four groups in consecutive frames -- so the A fragment of (frame t + kt, tap pair j) is the
+            # same registers for tile t at kt and tile t + 1 at kt - 1 (csrc/conv_mfma.hip: conv0_breg_kernel<PREC, true>).
+            # With pitch_h = 9 a window's four rows cover four consecutive LDS banks starting at 2 b + c (mod 16); a 16-lane
+            # service group of ds_read_b128 holds the FIRST windows of a tile's groups 0 and 3 and the SECOND windows of groups
+            # 1 and 2, so groups 1 and 2 list their windows right-to-left (``FRAME_TILE_FLIP``, VdConvParams.pair_flip): the
+            # group then reads banks {2 b, 2 b + 4} x 4 -- no conflicts, which no left-to-right pairing achieves within the LDS
+            # budget of the patch.
+            assert (ga, gb, gc) == (1, 2, 8) and nc == 8 and nb == 8
+            for ci in range(ncl):
+                for c in (0, 2):
+                    for a in axes[0]:
+                        groups += [(ci, a, b, c) for b in axes[1]]
+        else:
+          for ci in range(ncl):           # `order` lists the axes from slowest to fastest
             for x in axes[order[0]]:
                 for y in axes[order[1]]:
                     for z in axes[order[2]]:
@@ -298,6 +322,8 @@ def _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, 
         for gi, (ci, a, b, c) in enumerate(groups):
             for j in range(8):
                 dt, dh, dw = (j >> 2) & 1, (j >> 1) & 1, j & 1
+                if order is None:
+                    dt, dw = 0, 4 * dt + dw
                 f, h, w = row_lin(a + dt, b + dh, c + dw)
                 gcoord[gi, j] = (ci, f, h, w)
         gout = np.array([out_fn(ci, a, b, c) if valid_fn(a, b, c) else -1 for ci, a, b, c in groups], dtype=np.int64)
@@ -328,7 +354,10 @@ def _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, 
                     for perm in _PERMS4:
                         slots = np.zeros(32, dtype=np.int64)
                         for q in range(4):
-                            slots[rows_of[q]] = gslot[gids[perm[q]]]
+                            gs = gslot[gids[perm[q]]]
+                            if order is None and (FRAME_TILE_FLIP >> q) & 1:      # this group lists its second window first
+                                gs = np.concatenate([gs[4:], gs[:4]])
+                            slots[rows_of[q]] = gs
                         cyc = _conflict_cycles(slots)
                         if best_t is None or cyc < best_t[0]:
                             best_t = (cyc, perm, slots)
@@ -339,7 +368,10 @@ def _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, 
                     a_off[tile * 32:(tile + 1) * 32] = slots
                     for q in range(4):
                         gi = tile * 4 + perm[q]
-                        out[tile * 4 + q] = gout[gi] if gi < ngr else -1
+                        o = gout[gi] if gi < ngr else -1
+                        if order is None and (FRAME_TILE_FLIP >> q) & 1 and o >= 0:
+                            o += FRAME_TILE_OUT_STEP               # the first window of a flipped group is the right-hand one
+                        out[tile * 4 + q] = o
                 cyc = cyc_sum / ntile_used
             else:
                 slots = rcoord[:, 0] * pitch_c + rcoord[:, 1] * pitch_f + rcoord[:, 2] * pitch_h + rcoord[:, 3]
@@ -363,7 +395,8 @@ def _build_type_order(box, group, row_lin, tap_list, patch_ext, mt_pad, pooled, 
 
 def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps, widx_fn,
                n_out, NT, MW, mtw_options, epi, pool_t, relu, out_index, out_valid, n_stride,
-               out_clip_stride, out_chunk_stride, out_shape, lds_budget, ncl_options=(1,), force_box=None, ntw=1, step_multiple=1):
+               out_clip_stride, out_chunk_stride, out_shape, lds_budget, ncl_options=(1,), force_box=None, ntw=1, step_multiple=1,
+               frame_tiles=False):
     """Generic planner.  Row (a,b,c) has its tap-(0,0,0) origin at source slot coords
     (row_stride[0]*a+row_origin[0], ...).  ``taps`` is a list of non-negative (df,dh,dw).  ``step_multiple``: pad the K steps
     (tap pairs) to a multiple of it with zero-weight taps (VD_PREC_F16C8 programs correct four steps at a time)."""
@@ -408,6 +441,8 @@ def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps
     _, MTW, ncl, box = best
     na, nb, nc = box
     mt_pad = MW * MTW
+    if frame_tiles and not (na == MTW and (nb, nc) == (8, 8) and MW == 2 and ncl == 1):
+        raise ValueError("%s: box %s does not split into frame tiles" % (name, (box,)))
     dma_cap_final = (NT // ntw) * MW * (14 if MTW * ntw <= 4 else 17) * 64
 
     def row_lin(a, b, c):
@@ -425,6 +460,8 @@ def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps
                 f0 = sa * a0 + row_origin[0]; h0 = sb * b0 + row_origin[1]; w0 = sc * c0 + row_origin[2]
                 if key not in type_key:
                     def valid_fn(a, b, c, va=va, vb=vb, vc=vc):
+                        if frame_tiles:       # (row dims are multiples of the box in c: a group's two windows, c and c + 4, always exist)
+                            return a < va and b + 2 <= vb
                         if pooled:
                             return a + group[0] <= va and b + group[1] <= vb and c + group[2] <= vc
                         return a < va and b < vb and c < vc
@@ -433,7 +470,8 @@ def _make_plan(name, src_grid, CC, row_dims, group, row_origin, row_stride, taps
                         return out_index(ci, a, b, c)  # relative to the box's out_rel
 
                     bt = _build_type(box, group, row_lin, taps_p, ext(na, nb, nc), mt_pad, pooled,
-                                     out_fn, valid_fn, ncl, slot_cap=min(int(lds_budget * 1.12), dma_cap_final))
+                                     out_fn, valid_fn, ncl, slot_cap=min(int(lds_budget * 1.12), dma_cap_final),
+                                     frame_tiles=frame_tiles)
                     type_key[key] = len(types)
                     types.append(bt)
                 boxes.append([type_key[key], f0, h0, w0, out_index(0, a0, b0, c0) - out_index(0, 0, 0, 0), 0])
@@ -690,6 +728,9 @@ def pix_row_pitch(w: int) -> int:
     return -(-(w + 8) // 8) * 8
 
 
+L0_FRAME_TILES = os.environ.get("VD_L0_FRAME_TILES", "1") == "1"      # (0: the round-4 layout, frame-pair row groups -- A/B measurements)
+
+
 @_memo
 def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_budget: int = 3700,
                      mtw_options=(4,), ntw: int = 1) -> ConvPlan:
@@ -697,13 +738,18 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
     vd_pix2rows: [clip][t*3+c][h][W+8] with 3 zero pixels in front (and >=5 behind), so that the
     'kw-slot' of output column ow -- x[t,c,h,2*ow-3 .. 2*ow+4], the 7 kernel columns plus one
     zero-weight tap -- is the 16 bytes at dword offset ow of the row: overlapping windows are
-    read straight out of HBM/L2 by the LDS-DMA, nothing is duplicated in memory."""
+    read straight out of HBM/L2 by the LDS-DMA, nothing is duplicated in memory.
+
+    FRAME TILES (round 5; whenever the pooled width is a multiple of 4 and the box is 4 x 8 x 8 conv rows): an MFMA tile holds 32
+    conv rows of ONE frame (four row groups of two pool windows, ``_build_type_order``), the four tiles of a wave row are the same
+    positions in four consecutive frames, and the K steps are ordered (tap pair j, kt) with both taps of a pair in the same kt plane.  The A
+    fragment of (frame t + kt, pair j) then serves tile t at kt, tile t + 1 at kt - 1 and tile t + 2 at kt - 2: a kernel that
+    knows this (conv0_breg5_kernel) reads 68 fragments per box and wave from LDS instead of 128, for the same 128 MFMAs in
+    the same order per output as the generic kernel, which simply runs the steps in sequence."""
     cin = 3
     T = conv_out_dim(t_in, KT, 1, 1); OH = conv_out_dim(h_in, KH, 2, 3); OW = conv_out_dim(w_in, KW, 2, 3)
     Ho, Wo = OH // 2, OW // 2
-    assert T % 2 == 0, "first-layer planner pairs frames (pool window rows are 2x2x2 groups)"
     rows = (T, Ho * 2, Wo * 2)
-    taps = [(kt * cin + c, kh, 0) for kt in range(KT) for c in range(cin) for kh in range(KH)]
     NT = cout // 32
     MW = max(1, 4 // (NT // ntw))
     if ntw == 2:                 # one wave column of 2 N tiles, 4 wave rows of 2 M tiles: same 8-tile box
@@ -733,11 +779,37 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
 
     def out_index(ci, a, b, c):
         return ci * clip_stride + (a * Ho + b // 2) * Wo + c // 2
-    plan = _make_plan(name, (t_in * cin, h_in, OW), 1, rows, (2, 2, 2), (-cin, -3, 0), (cin, 2, 1), taps,
-                      widx_fn, cout, NT, MW, mtw_options, EPI_POOL_CL, 1, True, out_index, None, 0,
-                      clip_stride, chunk_stride, (cout // 8, T, Ho, Wo, 8), lds_budget, (1,), ntw=ntw,
-                      force_box=tuple(int(v) for v in os.environ["VD_L0_BOX"].split(",")) if os.environ.get("VD_L0_BOX") else None)
-    plan.out_t_stride = Ho * Wo
+    force_box = tuple(int(v) for v in os.environ["VD_L0_BOX"].split(",")) if os.environ.get("VD_L0_BOX") else None
+    plan = None
+    if L0_FRAME_TILES and ntw == 1 and NT == 2 and tuple(mtw_options) == (4,) and Wo % 4 == 0:
+        # K order: (tap pair j, kt) for the 10 pairs of a kt plane's first 20 (c, kh) taps, then the three left-over taps
+        q = [(c, kh) for c in range(cin) for kh in range(KH)]
+        taps = [(kt * cin + q[2 * j + e][0], q[2 * j + e][1], 0) for j in range(10) for kt in range(KT) for e in range(2)]
+        taps += [(kt * cin + q[20][0], q[20][1], 0) for kt in range(KT)]
+        try:
+            plan = _make_plan(name, (t_in * cin, h_in, OW), 1, rows, (1, 2, 8), (-cin, -3, 0), (cin, 2, 1), taps,
+                              widx_fn, cout, NT, MW, mtw_options, EPI_POOL_CL, 1, True, out_index, None, 0,
+                              clip_stride, chunk_stride, (cout // 8, T, Ho, Wo, 8), lds_budget, (1,), ntw=ntw,
+                              force_box=force_box, frame_tiles=True)
+            plan.out_t_stride, plan.pair_flip = FRAME_TILE_OUT_STEP, FRAME_TILE_FLIP
+            plan.meta["frame_tiles"] = 1
+            t0 = plan.types[0]
+            fs = cin * t0.pitch_f * SLOT_BYTES
+            for t in plan.types:          # what the frame-sharing kernel relies on
+                a = t.a_off.reshape(MW, 4, 32)
+                assert all((a[:, i] - a[:, 0] == i * cin * t.pitch_f * SLOT_BYTES).all() for i in range(4)), "frame tiles: tile i != tile 0 + i frames"
+                tp = t.tap_off.reshape(-1, 2)
+                assert all((tp[3 * j + kt] - tp[3 * j] == kt * fs).all() for j in range(10) for kt in range(KT))
+        except ValueError:
+            plan = None
+    if plan is None:
+        assert T % 2 == 0, "first-layer planner pairs frames (pool window rows are 2x2x2 groups)"
+        taps = [(kt * cin + c, kh, 0) for kt in range(KT) for c in range(cin) for kh in range(KH)]
+        plan = _make_plan(name, (t_in * cin, h_in, OW), 1, rows, (2, 2, 2), (-cin, -3, 0), (cin, 2, 1), taps,
+                          widx_fn, cout, NT, MW, mtw_options, EPI_POOL_CL, 1, True, out_index, None, 0,
+                          clip_stride, chunk_stride, (cout // 8, T, Ho, Wo, 8), lds_budget, (1,), ntw=ntw,
+                          force_box=force_box)
+        plan.out_t_stride = Ho * Wo
     plan.NTW = ntw
     rowp = pix_row_pitch(w_in)
     plan.w_step4, plan.row_pitch4 = 1, rowp // 2
