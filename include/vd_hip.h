@@ -105,7 +105,9 @@ typedef struct VdConvParams {
                                      row group of every MFMA tile the SECOND output lies out_t_stride BEFORE the first one (the out table
                                      holds the first).  0 everywhere except the first level's FRAME-TILE programs (plan.plan_forward_pix:
                                      0b0110 -- what makes their A-fragment reads free of LDS bank conflicts); != 0 also tells vd_conv0_breg
-                                     that the four tiles of a wave row are the same positions in consecutive frames */
+                                     that the four tiles of a wave row are the same positions in consecutive frames; bits 8..15 / 16..31 then
+                                     carry the LDS pitches of the patch (slots per patch row / per plane), which that kernel's K loop has
+                                     as instruction offsets */
     int32_t reserved0;
 } VdConvParams;
 

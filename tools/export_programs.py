@@ -6,7 +6,7 @@ from video_distillation_amd import plan
 
 
 def export(outdir, T, H, W, x3=False):
-    net = plan.plan_network(plan.NetGeometry(T, H, W), ntw=2, ntw0=1 if x3 else 2, balanced=not x3)
+    net = plan.plan_network(plan.NetGeometry(T, H, W), ntw=2, ntw0=1, balanced=not x3)      # (what engine.EmbedEngine plans)
     os.makedirs(outdir, exist_ok=True)
     for li, pl in enumerate(net["fwd"]):
         with open(os.path.join(outdir, "fwd%d.vdprog" % li), "wb") as f:

@@ -119,6 +119,16 @@ __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, f32x16 
     }
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma16(const uint4& a, const u32x4& b, f32x16 c) {
+    if constexpr (PREC == VD_PREC_BF16 || PREC == VD_PREC_BF16X3) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+}
+
 template <int PREC>
 __device__ __forceinline__ void split16(float v, uint16_t& hi, uint16_t& lo) {
     if constexpr (PREC == VD_PREC_BF16 || PREC == VD_PREC_BF16X3) {
@@ -1043,25 +1053,45 @@ __global__ __launch_bounds__(256, VD_OCC(PREC, MTW, NTW, BAL)) void conv_mfma_mu
     conv_mfma_body<PREC, MTW, SO, NTW, BAL>(m.p[k], 1, m.total[k], b - m.first[k], m.first[k + 1] - m.first[k]);
 }
 
+// tuning switches of the first-level kernel (A/B builds: tools/l0_variants.sh)
+#ifndef VD_L0_D
+#define VD_L0_D 6          // A fragments in flight in the frame-sharing K loop
+#endif
+#ifndef VD_L0_PRIO
+#define VD_L0_PRIO 1       // s_setprio 3 around the K loop: the partner wave on the SIMD is in its vector-ALU phase (same box: 8.53 -> 8.33 ms)
+#endif
+#ifndef VD_L0_TOUCH
+#define VD_L0_TOUCH 0      // 1: touch the next box's rows from inside the K loop (one dword per row half into a register nobody reads, so that
+                           // the next phase's row loads hit the caches).  Measured SLOWER on the same box, 8.53 vs 7.90 ms per 3200 clips
+                           // (profiles/r05_l0_variants.txt): with the box scalars prefetched and the stores moved behind the expansion the
+                           // other phase is the shorter one, and everything added to the K phase lengthens the critical one
+#endif
 #define VD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")      // (no vmcnt wait: global loads stay in flight)
 
 // The first level's single-pass kernel (3 -> 64 channels, K = 512: the layer's B fragments live in 128 registers per wave for a whole
 // box walk).  ONE workgroup of eight waves per CU, two groups of four that alternate roles box by box -- while group 0 runs
-// the K loop of its box (matrix pipes), group 1 finishes its previous box and prepares its next one (pool, stage, output slots,
-// aligned row loads, kw-slot expansion: vector memory + LDS), then they swap; one s_barrier per phase, none inside a phase.
+// the K loop of its box (matrix pipes), group 1 finishes its previous box and prepares its next one (pool, stage, kw-slot
+// expansion, output slots: vector ALU + LDS), then they swap; one s_barrier per phase, none inside a phase.
 // (Rounds 1-3 ran two independent four-wave workgroups per CU, which drift into lockstep -- both in their K loops, then both out
 // of them: 3.5 k cycles per box with idle matrix pipes; docs/history.md.)  A wave of group 0 and one of group 1 share each SIMD.
 // Same tile program, same K order per output as the generic kernel: bitwise its results.
 //
-// FS (round 5, frame-tile programs: VdConvParams.pair_flip != 0): the four M tiles of a wave are the SAME 32 positions in four
-// consecutive frames, and K step 3 j + kt multiplies tap pair j of kernel plane kt.  The A fragment of (frame f, pair j) is then
-// the operand of tile f at kt = 0, tile f - 1 at kt = 1 and tile f - 2 at kt = 2: it is read from LDS ONCE and feeds up to three
-// MFMAs -- 60 + 8 reads per box and wave instead of 128 (with one ds_read_b128 per MFMA the LDS is exactly as busy as the
-// matrix pipes: 512 KB per box at 128 bytes per clock = the box's 4 096 matrix cycles).  Steps 30 / 31 (the three left-over taps of
-// the kt planes and the zero tap) are read per tile.
+// FS (round 5, frame-tile programs: VdConvParams.pair_flip != 0, LDS pitches 9 / 189 slots -- the only ones a 4 x 8 x 8 box gets):
+//  * the four M tiles of a wave are the SAME 32 positions in four consecutive frames, and K step 3 j + kt multiplies tap pair j of
+//    kernel plane kt.  The A fragment of (frame f, pair j) is then the operand of tile f at kt = 0, tile f - 1 at kt = 1 and tile
+//    f - 2 at kt = 2: it is read from LDS ONCE and feeds up to three MFMAs -- 60 + 8 reads per box and wave instead of 128 (with
+//    one ds_read_b128 per MFMA the LDS is exactly as busy as the matrix pipes: 512 KB per box at 128 bytes per clock = the box's
+//    4 096 matrix cycles).  Steps 30 / 31 (the three left-over taps of the kt planes and the zero tap) are read per tile;
+//  * every tap offset is a compile-time constant that rides in the ds_read's offset field (two address registers per wave: the
+//    lane halves' taps are 144 bytes apart except in the pair that straddles two channels);
+//  * the rows of a group's next box are TOUCHED in front of its K loop (one dword per row half into a register nobody reads) and
+//    travel from HBM into the caches under it; the row loads of the next phase hit there -- their HBM latency (1.5 - 2.5 k cycles,
+//    tools/stamps_l0.py) used to sit inside that phase -- and the box scalars they need (table row, clip index) are s_loads of
+//    the phase before.
 template <int PREC, bool FS>
 __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p, const int boxes_per_wg) {
     constexpr int MTW = 4, S = 32, NI = 3;
+    constexpr int PH = 9, PF = 189;                       // FS: LDS pitches in slots (checked by the launcher)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1078,9 +1108,9 @@ __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p
     int* lds_tap = reinterpret_cast<int*>(smem + 2 * plane_bytes);
     uint16_t* stg16 = reinterpret_cast<uint16_t*>(smem + 2 * plane_bytes + 512 + wave * 2048);
     for (int k = tid; k < 2 * S; k += 512) lds_tap[k] = t_tab[k];
-    int a_off[MTW];
+    int a_off[FS ? 1 : MTW];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
+    for (int i = 0; i < (FS ? 1 : MTW); ++i) a_off[i] = a_tab[(wm * MTW + i) * 32 + (lane & 31)];
     int o_reg[2];          // output slot of this lane's two staged rows (item = lane + 64 k: pooled row item >> 2), -1 = none
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -1089,14 +1119,19 @@ __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p
         const int step = ((p.pair_flip >> (g & 3)) & 1) ? -p.out_t_stride : p.out_t_stride;
         o_reg[k] = o < 0 ? -1 : o + (ql & 1) * step;
     }
-    const int ph = p.type_desc[1], pitch_h = p.type_desc[3], pitch_f = p.type_desc[4], nitems = 2 * p.type_desc[0] * ph;
+    const int ph = p.type_desc[1], pitch_h = FS ? PH : p.type_desc[3], pitch_f = FS ? PF : p.type_desc[4], nitems = 2 * p.type_desc[0] * ph;
     const int ph_magic = (65536 + ph - 1) / ph;
     const int row4 = (int)(p.src_chunk_stride4 / ((int64_t)p.src_planes * p.src_rows));
-    uint4 breg[S];
+    u32x4 breg[S];
+    // (inline assembly, landed where they are issued: loads the compiler tracks get their s_waitcnt vmcnt(0) at the first use -- inside
+    //  the K loop, on every pass, although the operand set changes once in hundreds of boxes -- and there it would also wait for the
+    //  row-touch loads issued in front of the loop)
     auto load_breg = [&](int set) {
-        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (int64_t)set * (p.w_plane_stride >> 3) + (int64_t)wn * 64 + lane;
+        const char* wp = reinterpret_cast<const char*>(reinterpret_cast<const uint4*>(p.wpk) + (int64_t)set * (p.w_plane_stride >> 3) + (int64_t)wn * 64 + lane);
 #pragma unroll
-        for (int s = 0; s < S; ++s) breg[s] = wp[(int64_t)s * 128];
+        for (int s = 0; s < S; ++s) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(breg[s]) : "v"(wp + (size_t)s * 2048) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     };
     int cur_set = -1;
     const int n = wn * 32 + (lane & 31);
@@ -1114,15 +1149,35 @@ __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p
     if (b_lo >= b_hi) return;
     const int nmine = (b_hi - b_lo + 1 - grp) >> 1;      // boxes b_lo + grp, b_lo + grp + 2, ... of this group
     uint4 raw[NI][2];
-    auto load_raw = [&](int b) {       // the aligned chunks of box b's patch rows -> registers (zeros outside the clip); branch free:
-        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;      // rows outside the clip load a valid row of the box and are zeroed
-        const int32_t* box = p.boxes + bi * 8;
-        const int f0 = box[6] >> 16, h0 = (int)(int16_t)(box[6] & 0xFFFF), w0 = box[7];      // plane / row / dword of the patch origin
+    // Box scalars, prepared a phase ahead of their use (round 5): the table row of the box, its clip's entry of the index list and the
+    // output origin are loads whose latencies -- two dependent ones -- used to sit in front of the row loads of every box.
+    // Wave-uniform (SGPRs); read through the CONSTANT address space -- tables the kernel never writes: s_load, no vector-memory
+    // counter involved.
+    const char* rs_base = nullptr;      // source address of the patch origin of the box whose rows are loaded next
+    int rs_f0 = 0, rs_h0 = 0, rs_w0 = 0;
+    int64_t ep_base = 0;                // output slot origin of the box that is finished next
+    typedef const int32_t __attribute__((address_space(4))) * cint_p;
+    typedef const int64_t __attribute__((address_space(4))) * clong_p;
+    const cint_p c_boxes = (cint_p)(uintptr_t)p.boxes;
+    const clong_p c_index = (clong_p)(uintptr_t)p.clip_index;
+    auto prep_rows = [&](int b) {
+        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
+        const cint_p box = c_boxes + bi * 8;
+        const int b6 = box[6], b7 = box[7];
+        const int64_t ci = p.clip_index != nullptr ? c_index[clip0] : (int64_t)clip0;
+        rs_f0 = b6 >> 16; rs_h0 = (int)(int16_t)(b6 & 0xFFFF); rs_w0 = b7;      // plane / row / dword of the patch origin
+        rs_base = reinterpret_cast<const char*>(src + ci * p.src_clip_stride4 + ((int64_t)rs_f0 * p.src_rows + rs_h0) * row4 + rs_w0);
+    };
+    auto prep_out = [&](int b) {
+        const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
+        ep_base = (int64_t)clip0 * p.out_clip_stride + c_boxes[bi * 8 + 3];
+    };
+    auto load_raw = [&]() {            // the aligned chunks of the prepared box's patch rows -> registers (zeros outside the clip); branch free:
+        const int f0 = rs_f0, h0 = rs_h0, w0 = rs_w0;             // rows outside the clip load a valid row of the box and are zeroed
+        const char* base = rs_base;
         int tv = tg;
         asm volatile("" : "+v"(tv));       // (opaque per call: otherwise the row coordinates below are hoisted out of the box loop into
                                            //  registers the K loop does not have)
-        const char* base = reinterpret_cast<const char*>(
-            src + (p.clip_index != nullptr ? p.clip_index[clip0] : (int64_t)clip0) * p.src_clip_stride4 + ((int64_t)f0 * p.src_rows + h0) * row4 + w0);
         const uint32_t off_valid = (uint32_t)((((f0 < 0 ? -f0 : 0) * p.src_rows + (h0 < 0 ? -h0 : 0)) * row4) * 4);   // first row of the box inside the clip
         const uint32_t hf16 = (uint32_t)(tv & 1) * 16u;
         const bool in_row = (w0 + 4 * (tv & 1) + 8 <= row4);                         // the second chunk stays inside the pixel row
@@ -1133,10 +1188,35 @@ __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p
             const bool ok = it < nitems && (unsigned)(f0 + pl) < (unsigned)p.src_planes && (unsigned)(h0 + h) < (unsigned)p.src_rows;
             const uint32_t o1 = (ok ? (uint32_t)((pl * p.src_rows + h) * row4 * 4) : off_valid) + hf16;
             const uint32_t o2 = (ok && in_row) ? o1 + 16u : o1;
+            // (masked with AND, not selected: a select lets the compiler sink the load under a branch, and a load that MAY have been
+            //  issued makes every later s_waitcnt vmcnt conservative -- 0 -- which then also waits for the output stores)
             const uint4 v0 = *reinterpret_cast<const uint4*>(base + o1);
             const uint4 v1 = *reinterpret_cast<const uint4*>(base + o2);
-            raw[k][0] = ok ? v0 : make_uint4(0, 0, 0, 0);
-            raw[k][1] = (ok && in_row) ? v1 : make_uint4(0, 0, 0, 0);
+            const uint32_t m0 = ok ? 0xffffffffu : 0u, m1 = (ok && in_row) ? 0xffffffffu : 0u;
+            raw[k][0] = make_uint4(v0.x & m0, v0.y & m0, v0.z & m0, v0.w & m0);
+            raw[k][1] = make_uint4(v1.x & m1, v1.y & m1, v1.z & m1, v1.w & m1);
+        }
+    };
+    // FS: the same rows TOUCHED a phase earlier -- one dword per row half into a register nobody reads, issued in front of the group's
+    // K loop: the lines travel from HBM to the L2 / vector L1 under the K loop (1.5 - 2.5 k cycles, tools/stamps_l0.py), and the loads
+    // of the next phase find them there.  (Holding the rows themselves across the K loop takes 21 registers the loop does not have:
+    // the compiler spills B fragments into the loop.)  Inline assembly: the compiler must not wait for these loads anywhere; they are
+    // older than every load it tracks, so its own in-order s_waitcnt counts stay sufficient.
+    uint32_t sink = 0;
+    auto touch_rows = [&]() {
+        const int f0 = rs_f0, h0 = rs_h0;
+        const char* base = rs_base;
+        int tv = tg;
+        asm volatile("" : "+v"(tv));
+        const uint32_t off_valid = (uint32_t)((((f0 < 0 ? -f0 : 0) * p.src_rows + (h0 < 0 ? -h0 : 0)) * row4) * 4);
+        const uint32_t hf16 = (uint32_t)(tv & 1) * 16u;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int it = tv + 256 * k, r = it >> 1;
+            const int pl = (r * ph_magic) >> 16, h = r - pl * ph;
+            const bool ok = it < nitems && (unsigned)(f0 + pl) < (unsigned)p.src_planes && (unsigned)(h0 + h) < (unsigned)p.src_rows;
+            const uint32_t o1 = (ok ? (uint32_t)((pl * p.src_rows + h) * row4 * 4) : off_valid) + hf16;
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(sink) : "v"(o1), "s"(base) : "memory");
         }
     };
     auto expand = [&]() {
@@ -1156,19 +1236,40 @@ __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p
         }
     };
     f32x16 acc[MTW];
+    // dbg bit 3 (library built with VD_DBG_HOOKS): s_memtime sums per role phase of this wave, written by wave 0 of each group to
+    // stamps[(workgroup * 2 + group) * 8 ..]: K phase up to the K loop, K loop, barrier after it, pool + stage, expand (FS: its rows
+    // are in registers; else: row-load issue + wait + expand), slots out + scalars + barrier, boxes, whole walk (tools/stamps_l0.py;
+    // every stamp is a scalar-memory round trip of its own: a few hundred cycles)
+    unsigned long long t_sum[6] = {0, 0, 0, 0, 0, 0}, t_last = 0, t_first = 0;
+    auto tick = [&](int k) {
+        if (VD_DBG(p) & 8) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            if (k >= 0) t_sum[k] += t - t_last;
+            else if (k == -2) t_first = t;
+            t_last = t;
+        }
+    };
     // group 0 prepares its first box before the first phase; group 1 does so in phase 0, under group 0's first K loop
-    if (grp == 0) { load_raw(b_lo); expand(); }
+    const int b_first = (b_lo + grp < b_hi) ? b_lo + grp : b_hi - 1;
+    prep_rows(b_first);
+    load_raw();
+    if (grp == 0) {
+        expand();
+        if (FS) prep_rows(b_first + 2 < b_hi ? b_first + 2 : b_first);      // (its first K phase loads the rows of its second box)
+    }
     {
-        const int first = b_lo + grp;
-        const int set = (p.w_set_clips > 0 && first < b_hi) ? (first / p.nbox) / p.w_set_clips : 0;
+        const int set = (p.w_set_clips > 0) ? (b_first / p.nbox) / p.w_set_clips : 0;
         cur_set = set; load_breg(set);
     }
     __syncthreads();                     // tables published, group 0's first patch in place
+    tick(-2);
     // phases 0 .. 2 * n0: in phase q group g runs a K loop when (q + g) is even, the other half of its work when odd
     const int n0 = (b_hi - b_lo + 1) >> 1;
     for (int q = 0; q <= 2 * n0; ++q) {
         const int j = (q - grp) >> 1;                    // index into this group's boxes (K loop: box j; other phase: finish j-1... see below)
-        if (((q + grp) & 1) == 0) {
+        const bool k_phase = ((q + grp) & 1) == 0;
+        if (k_phase) {
             // ---- K loop of this group's box j ----
             if (j >= 0 && j < nmine) {
                 const int b = b_lo + grp + 2 * j;
@@ -1176,27 +1277,39 @@ __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p
                     const int set = (b / p.nbox) / p.w_set_clips;
                     if (set != cur_set) { cur_set = set; load_breg(set); }
                 }
+                prep_out(b);                             // output origin of this box, for the next phase
+                if constexpr (!FS) prep_rows(j + 1 < nmine ? b + 2 : b);
+                tick(0);
 #pragma unroll
                 for (int i = 0; i < MTW; ++i)
 #pragma unroll
                     for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
                 if constexpr (FS) {
                     // reads in the order r = 6 j + f (pair j = 0..9, frame f = 0..5), then the 8 per-tile reads of steps 30 / 31;
-                    // a ring of D fragments is kept in flight
-                    constexpr int D = 6, NR = 68;
-                    const int fstride = 3 * pitch_f * 16;
+                    // a ring of D fragments is kept in flight.  Tap t of the K order (plan.plan_forward_pix) = (kt, c, kh) with
+                    // q = 7 c + kh: pair j holds q = 2 j (lanes 0-31) and 2 j + 1 (lanes 32-63) -- 144 bytes apart (pa), except
+                    // q = 6 / 7 which straddle two channels (pb); left-over taps: q = 20 of kt = 0 / 1 (step 30), of kt = 2 and the
+                    // zero tap (step 31: the upper lanes read the lower lanes' address, their B operand is zero)
+                    constexpr int D = VD_L0_D, NR = 68;
+                    constexpr int FSTRIDE = 3 * PF * 16;
                     uint4 R[D];
-                    int tq[10];
-#pragma unroll
-                    for (int jj = 0; jj < 10; ++jj) tq[jj] = lds_tap[6 * jj + half];
-                    const int tl0 = lds_tap[60 + half], tl1 = lds_tap[62 + half];
-                    const char* pa = patch + a_off[0];
+                    const char* pa = patch + a_off[0] + half * (PH * 16);
+                    const char* pb = patch + a_off[0] + half * ((PF - 6 * PH) * 16);
+                    const char* pl0 = patch + a_off[0] + half * FSTRIDE;          // step 30: kt = 0 below, kt = 1 above
+                    const char* pl1 = patch + a_off[0];                           // step 31
+                    auto tapq = [](int qq) constexpr { return ((qq / 7) * PF + (qq % 7) * PH) * 16; };
                     auto rd = [&](auto rc) -> uint4 {
                         constexpr int r = decltype(rc)::v;
-                        if constexpr (r < 60) return *reinterpret_cast<const uint4*>(pa + (r % 6) * fstride + tq[r / 6]);
-                        else return *reinterpret_cast<const uint4*>(pa + ((r - 60) & 3) * fstride + ((r - 60) >> 2 ? tl1 : tl0));
+                        if constexpr (r < 60) {
+                            constexpr int jj = r / 6, f = r % 6;
+                            return *reinterpret_cast<const uint4*>((jj == 3 ? pb : pa) + f * FSTRIDE + tapq(2 * jj));
+                        } else {
+                            constexpr int i = (r - 60) & 3, st = (r - 60) >> 2;
+                            return *reinterpret_cast<const uint4*>((st ? pl1 : pl0) + (i + 2 * st) * FSTRIDE + tapq(20));
+                        }
                     };
                     vd_static_for<D>([&](auto rc) { R[decltype(rc)::v] = rd(rc); });
+                    if (VD_L0_PRIO) __builtin_amdgcn_s_setprio(3);      // (the partner wave on this SIMD is in its vector-ALU phase)
                     vd_static_for<NR>([&](auto rc) {
                         constexpr int r = decltype(rc)::v;
                         if constexpr (r < 60) {
@@ -1216,43 +1329,44 @@ __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p
                             R[r % D] = rd(VdIC<r + D>{});
                             __builtin_amdgcn_sched_barrier(0);
                         }
+                        // the rows of this group's NEXT box (scalars: prep_rows of the phase before) start their way into the caches; the
+                        // next phase loads them.  HERE, a few MFMAs into the loop: the compiler guards the first writes of the ring
+                        // registers with s_waitcnt vmcnt (they were targets of the last phase's loads and sources of its stores), and
+                        // those waits must not see the touch loads
+                        if constexpr (r == 5 && VD_L0_TOUCH) { touch_rows(); __builtin_amdgcn_sched_barrier(0); }
                     });
+                    if (VD_L0_PRIO) __builtin_amdgcn_s_setprio(0);
                 } else {
-                uint4 A[2][MTW];
-                const int tp0 = lds_tap[half], tp1 = lds_tap[2 + half];
+                    uint4 A[2][MTW];
+                    const int tp0 = lds_tap[half], tp1 = lds_tap[2 + half];
 #pragma unroll
-                for (int i = 0; i < MTW; ++i) A[0][i] = *reinterpret_cast<const uint4*>(patch + a_off[i] + tp0);
+                    for (int i = 0; i < MTW; ++i) A[0][i] = *reinterpret_cast<const uint4*>(patch + a_off[i] + tp0);
 #pragma unroll
-                for (int i = 0; i < MTW; ++i) A[1][i] = *reinterpret_cast<const uint4*>(patch + a_off[i] + tp1);
-                int tp2 = lds_tap[4 + half];
+                    for (int i = 0; i < MTW; ++i) A[1][i] = *reinterpret_cast<const uint4*>(patch + a_off[i] + tp1);
+                    int tp2 = lds_tap[4 + half];
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const int tp3 = lds_tap[2 * ((s + 3 < S) ? s + 3 : S - 1) + half];
+                    for (int s = 0; s < S; ++s) {
+                        const int tp3 = lds_tap[2 * ((s + 3 < S) ? s + 3 : S - 1) + half];
 #pragma unroll
-                    for (int i = 0; i < MTW; ++i) {
-                        acc[i] = mfma16<PREC>(A[s & 1][i], breg[s], acc[i]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (s + 2 < S) A[s & 1][i] = *reinterpret_cast<const uint4*>(patch + a_off[i] + tp2);
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int i = 0; i < MTW; ++i) {
+                            acc[i] = mfma16<PREC>(A[s & 1][i], breg[s], acc[i]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (s + 2 < S) A[s & 1][i] = *reinterpret_cast<const uint4*>(patch + a_off[i] + tp2);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        tp2 = tp3;
                     }
-                    tp2 = tp3;
                 }
-                }
+                tick(1);
             }
         } else {
-            // ---- the other half: request the rows of box jn = (q + 1 - grp) / 2, finish box jn - 1 (its accumulators are in this
-            //      wave's registers since the previous phase), build the kw-slots of box jn ----
+            // ---- the other half: finish box jn - 1 (its accumulators are in this wave's registers since the previous phase) and build
+            //      the kw-slots of box jn = (q + 1 - grp) / 2 ----
             const int jn = (q + 1 - grp) >> 1;
             const bool have_next = jn >= 0 && jn < nmine, have_prev = jn - 1 >= 0 && jn - 1 < nmine;
-            {
-                const int bn = b_lo + grp + 2 * (have_next ? jn : (have_prev ? jn - 1 : 0));
-                load_raw(bn < b_hi ? bn : b_hi - 1);         // (unconditional: keeps `raw` out of the K loop's live ranges)
-            }
+            load_raw();                      // (unconditional: keeps `raw` out of the K loop's live ranges; box scalars: prep_rows)
             __builtin_amdgcn_sched_barrier(0);
             if (have_prev) {
-                const int b = b_lo + grp + 2 * (jn - 1);
-                const int clip0 = b / p.nbox, bi = b - clip0 * p.nbox;
-                const int out_rel = p.boxes[bi * 8 + 3];
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) {
 #pragma unroll
@@ -1269,8 +1383,18 @@ __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p
                         stg16[(ql + 1) * 32 + (lane & 31)] = hi;
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            tick(3);
+            expand();                        // this group's patch is free: its K loop ended a phase ago.  (Unconditional -- past the group's
+                                             //  last box it rebuilds that box's patch: a row load left pending on some path would make the
+                                             //  compiler wait for vector memory in front of the K loop's first LDS reads into those registers)
+            __builtin_amdgcn_sched_barrier(0);
+            tick(4);
+            // output slots LAST: the stores are the only vector-memory operations in flight when the phase ends, and nothing waits for
+            // them (in front of the expansion they sat between the row loads and their s_waitcnt, which then waited for the stores' acks)
+            if (have_prev) {
+                const int64_t out_base = ep_base;
                 const int64_t lim64 = out_total - out_base;
                 const int lim = (int)(lim64 > 0x7fffffff ? 0x7fffffff : (lim64 < 0 ? 0 : lim64));
                 uint4* dslots = reinterpret_cast<uint4*>(p.dst) + out_base;
@@ -1278,17 +1402,29 @@ __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int item = lane + 64 * k;
-                    const int ql = item >> 2, ch = item & 3;
+                    const int ch = item & 3;
                     const uint4 v = stg4[item];
                     const int base = o_reg[k];
                     if (base >= 0 && base < lim)
                         dslots[(uint32_t)base + (uint32_t)(wn * 4 + ch) * (uint32_t)p.out_chunk_stride] = v;
                 }
             }
-            if (have_next) expand();         // this group's patch is free: its K loop ended a phase ago
+            if constexpr (FS) {              // scalars of the rows this group's next K phase loads: its box jn + 1 (past the end: jn again)
+                const int bn = b_lo + grp + 2 * (jn + 1 < nmine ? jn + 1 : (jn < nmine ? jn : (nmine > 0 ? nmine - 1 : 0)));
+                prep_rows(bn < b_hi ? bn : b_hi - 1);
+            }
         }
+        tick(k_phase ? -1 : 5);
         VD_LDS_BARRIER();                    // the one barrier of a phase (all eight waves)
+        tick(k_phase ? 2 : 5);
     }
+    if ((VD_DBG(p) & 8) && p.stamps != nullptr && (tid & 255) == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stamps) + ((size_t)wgid * 2 + grp) * 8;
+        for (int k = 0; k < 6; ++k) o[k] = t_sum[k];
+        o[6] = (unsigned long long)nmine;
+        o[7] = t_last - t_first;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(sink) : "memory");      // (the touch loads' register stays reserved until they have landed)
 }
 
 template <int PREC, bool FS>
@@ -1323,7 +1459,8 @@ extern "C" int vd_conv0_breg(const VdConvParams* pp, void* stream) {
     q.persist = p.persist & 0xFFFF;
     // frame-tile programs (pair_flip != 0; plan.plan_forward_pix): the K loop that reads every A fragment once for all the tiles
     // it serves, unless persist bit 19 asks for the plain one (A/B measurements, bitwise the same results)
-    const bool fs = p.pair_flip != 0 && !(p.persist & 0x80000);
+    // (the frame-sharing loop carries the LDS pitches of the 4 x 8 x 8 box as instruction offsets: pair_flip bits 8..15 / 16..31)
+    const bool fs = (p.pair_flip & 0xF) != 0 && (p.pair_flip >> 8) == (9 | (189 << 8)) && !(p.persist & 0x80000);
     if (p.prec == VD_PREC_F16) return fs ? launch_conv0_breg<VD_PREC_F16, true>(q, st) : launch_conv0_breg<VD_PREC_F16, false>(q, st);
     if (p.prec == VD_PREC_BF16) return fs ? launch_conv0_breg<VD_PREC_BF16, true>(q, st) : launch_conv0_breg<VD_PREC_BF16, false>(q, st);
     return -2;

@@ -493,7 +493,8 @@ bool plan_forward_pix(int cout, int t_in, int h_in, int w_in, int lds_budget, in
         for (int kt = 0; kt < KT; ++kt) sp.taps.push_back({kt * cin + q[20][0], q[20][1], 0});
         sp.frame_tiles = true;
         if (make_plan(sp, pl)) {
-            pl.out_t_stride = FRAME_TILE_OUT_STEP; pl.pair_flip = FRAME_TILE_FLIP;
+            pl.out_t_stride = FRAME_TILE_OUT_STEP;
+            pl.pair_flip = FRAME_TILE_FLIP | (pl.types[0].pitch_h << 8) | (pl.types[0].pitch_f << 16);
             done = true;
         }
     }

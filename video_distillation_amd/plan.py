@@ -791,9 +791,9 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
                               widx_fn, cout, NT, MW, mtw_options, EPI_POOL_CL, 1, True, out_index, None, 0,
                               clip_stride, chunk_stride, (cout // 8, T, Ho, Wo, 8), lds_budget, (1,), ntw=ntw,
                               force_box=force_box, frame_tiles=True)
-            plan.out_t_stride, plan.pair_flip = FRAME_TILE_OUT_STEP, FRAME_TILE_FLIP
-            plan.meta["frame_tiles"] = 1
             t0 = plan.types[0]
+            plan.out_t_stride, plan.pair_flip = FRAME_TILE_OUT_STEP, FRAME_TILE_FLIP | (t0.pitch_h << 8) | (t0.pitch_f << 16)
+            plan.meta["frame_tiles"] = 1
             fs = cin * t0.pitch_f * SLOT_BYTES
             for t in plan.types:          # what the frame-sharing kernel relies on
                 a = t.a_off.reshape(MW, 4, 32)
