@@ -261,9 +261,12 @@ class Harness:
             losses.append(step(it))
             marks.append(mark())
         sync()
+        torch.cuda.synchronize()
+        t_own = time.perf_counter() - t0          # this rank's own work of the timed region is done ...
         self.barrier()
-        dt = time.perf_counter() - t0
+        dt = time.perf_counter() - t0             # ... and everybody else's
         prof, engine.LAUNCH_PROFILE = engine.LAUNCH_PROFILE or [], None
+        self.rank_diag = {"rank": self.rank, "own_ms_per_step": t_own / a.steps * 1e3, "wait_at_barrier_ms": (dt - t_own) * 1e3}
         if self.world > 1:
             import torch.distributed as dist
             tmax = torch.tensor([dt], device=self.device, dtype=torch.float64)
@@ -271,6 +274,26 @@ class Harness:
             dt = float(tmax)
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
         return dt, per_step, prof, losses
+
+    def per_rank(self, prof, clips, extra=None):
+        """Every rank's view of the timed region, gathered for the JSON line (every rank calls): real clips per step, its own time
+        per step (up to its own synchronisation), how long it then waited at the closing barrier (the slowest rank waits ~0), the
+        time of its real-side launches per step (HIP events of the launch profile: programs fwd0 / fwd1 / fwd2* in the real side's
+        operand format) and, where the step has an exchange, its time per step -- what tells an unbalanced partition from a slow
+        collective from a slow device when N > 1 runs for the first time."""
+        a = self.args
+        from video_distillation_amd import hip
+        real = [e0.elapsed_time(e1) for name, prec, flop, e0, e1 in prof
+                if name.startswith("fwd") and prec in (hip.PREC[a.prec_real], hip.PREC["f16c8"])]
+        rec = dict(getattr(self, "rank_diag", {"rank": self.rank}), clips_per_step=int(clips),
+                   real_side_ms_per_step=sum(real) / max(a.steps, 1), device=torch.cuda.get_device_name(self.device))
+        rec.update(extra or {})
+        out = [rec]
+        if self.world > 1:
+            import torch.distributed as dist
+            out = [None] * self.world
+            dist.all_gather_object(out, rec)
+        return out
 
     def profile_steps(self, step, sync, first_it, n=1):
         """``n`` extra untimed steps with the launch hook on, on EVERY rank (a step may contain collectives)."""
@@ -608,6 +631,9 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
     else:
         clips = (args.batch_real // world) * args.classes
     topo = h.topology(clips)
+    ex_ms = [e0.elapsed_time(e1) for e0, e1 in getattr(trainer, "exchange_events", [])]
+    per_rank = h.per_rank(prof, clips, {"exchange_ms_per_step": (sum(ex_ms) / len(ex_ms)) if ex_ms else None,
+                                        "classes_owned": len(trainer.classes)})
     out = None
     if rank == 0:
         macs = conv_layer_macs(geo)
@@ -635,6 +661,8 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
                                       "rows; a real batch is an index list, no per-step conversion") if backend.resident_rows else \
             "resident in HBM as fp32, converted per step"
         out["loss_last"] = float(losses[-1]) / args.classes
+        if getattr(trainer, "real_range", None) is not None:      # what the fp8-corrected last level's producer saw (distill.HipBackend.check_real_range)
+            out["config"]["precision"]["real_last_level_activation_range"] = trainer.real_range
         out["step_tflops"] = step_flop / (dt / args.steps) / 1e12
         out["step_frac_of_mfma_peak"] = out["step_tflops"] / PEAK_TFLOPS
         labels = {"fwd1": "conv_mfma_kernel<PREC, 3, false, 2, 1> (balanced 7-tile layout; conv layer 1 forward, real clips)",
@@ -662,6 +690,7 @@ def bench_dm(args, h, distill, plan, geo, pool, backend, shard):
         for name, leg in legs.items():
             out[name] = leg
         out.update(topo)
+        out["per_rank"] = per_rank
         out["exchange"] = dict({"mode": args.exchange}, **(exchange_record(trainer, args, geo, h) if not s2d else {}))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_dm(args, trainer, backend, args.warmup + args.steps, s2d if s2d else None)
@@ -983,14 +1012,11 @@ def main():
     c_lo, c_hi = distill.class_range(args.classes, rank, world)
     shard = args.shard
     if shard == "auto":
-        # Whole-class blocks (50 -> 7,7,6,...) need no data-path collective but leave ranks idle (ceiling 50/7 = 7.14x at 8); the hybrid
-        # keeps whole classes and splits only the left-over ones (400 real clips on every rank at N = 8, one 16 KB all-reduce).
-        # Single-GPU proxy of one rank's step in the shipped mode (tools/rank_proxy.py, profiles/r03_rank_proxy.txt; exchange not
-        # included): N = 2: class 18.3 / batch 18.4 ms; N = 4: class 9.65 / batch 9.68 / hybrid 9.66; N = 8: class 5.7 / batch 4.9 /
-        # hybrid 4.9 (6.2x / 7.35x / 7.3x of one GPU) -- so the hybrid is chosen where the class blocks are more than 8 % uneven
-        # (N = 8), whole-class blocks otherwise.
-        blocks_uneven = world > 1 and (-(-args.classes // world)) * world > 1.08 * args.classes
-        shard = "hybrid" if (blocks_uneven and args.batch_real % world == 0 and args.method == "dm") else "class"
+        # (distill.choose_shard: the hybrid where the class blocks are more than 8 % uneven and the real batch divides by the number of
+        #  ranks, whole-class blocks otherwise.  Single-GPU proxy of one rank's step in the shipped mode -- tools/rank_proxy.py,
+        #  profiles/r03_rank_proxy.txt; exchange not included --: N = 2: class 18.3 / batch 18.4 ms; N = 4: class 9.65 / batch 9.68 /
+        #  hybrid 9.66; N = 8: class 5.7 / batch 4.9 / hybrid 4.9, i.e. 6.2x / 7.35x / 7.3x of one GPU)
+        shard = distill.choose_shard(args.classes, args.batch_real, world, args.method)
     if shard == "hybrid" and args.method != "dm":
         raise SystemExit("--shard hybrid is a decomposition of --method dm")
     if shard == "batch":   # every rank holds the whole pool (11 GB) and embeds its slice of each class batch

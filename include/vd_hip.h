@@ -108,7 +108,13 @@ typedef struct VdConvParams {
                                      that the four tiles of a wave row are the same positions in consecutive frames; bits 8..15 / 16..31 then
                                      carry the LDS pitches of the patch (slots per patch row / per plane), which that kernel's K loop has
                                      as instruction offsets */
-    int32_t reserved0;
+    uint32_t* range_stats;        /* emit_lo = 2 producers: NULL, or two device words the launch updates -- [0] += pooled outputs that hit the
+                                     +-1792 clamp (SATURATED: the consumer's operand is wrong there), [1] = max over launches of the
+                                     float bits of max |output| (reset by the caller).  The fixed scalings of the fp8 operand planes keep
+                                     the corrections of a VD_PREC_F16C8 consumer exact to 2^-16 for outputs of magnitude 2^-4 .. 1792
+                                     (low parts below 2^-18 flush to zero: below 2^-7 an output's correction is gone, i.e. single-pass
+                                     accuracy for it); a launch whose max |output| is below 0.25 or that saturates is outside the range
+                                     the format was validated for -- distill.HipBackend.check_real_range then falls back to fp16 hi+lo */
 } VdConvParams;
 
 int vd_abi_version(void);

@@ -492,3 +492,78 @@ def test_class_with_fewer_clips_than_batch_real_is_rejected():
     with pytest.raises(ValueError):
         distill.sample_real_indices(1, [3], [0], 8, [0])
     assert distill.sample_real_indices(1, [3], [0], 8, [0], allow_repeat=True).shape == (8,)
+
+
+# ---- worlds that do not divide the reference's batch of 64 (3, 5, 6, 7): every decomposition, and the fallback ----
+
+def _odd_setup(world_for_batch):
+    """C = 11 classes (prime: uneven blocks for every world), real batch = 2 x world clips so that the batch and hybrid
+    decompositions divide, 64x64x8 clips from a seed (identical on every rank)."""
+    C, B = 11, 2 * world_for_batch
+    g = torch.Generator().manual_seed(1100 + world_for_batch)
+    clips = torch.randn(C * B, 8, 3, 64, 64, generator=g)
+    syn = torch.randn(C, 8, 3, 64, 64, generator=g)
+    pool = _Pool(); pool.clips = clips; pool.counts = [B] * C; pool.offsets = [c * B for c in range(C)]
+    return C, B, pool, syn
+
+
+def _odd_trainer(rank, world, shard, wb):
+    C, B, pool, syn = _odd_setup(wb)
+    own = list(range(*distill.class_range(C, rank, world)))
+    if shard == "hybrid" and world > 1:
+        block, _, mine = distill.hybrid_partition(C, rank, world)
+        own = block + mine
+    tr = distill.DMTrainer(OracleBackend(), pool, C, 1, B, lr_img=0.5, momentum=0.5, rank=rank, world=world,
+                           image_syn=syn[own].clone(), shard=shard)
+    loss = float(tr.global_loss(tr.step(0)))
+    return loss, tr.gather_syn(), len(own)
+
+
+def _worker_odd(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = {}
+        for shard in ("class", "batch", "hybrid"):
+            loss, syn, nown = _odd_trainer(rank, world, shard, world)
+            owned = [None] * world
+            dist.all_gather_object(owned, nown)
+            out[shard] = (loss, syn.numpy(), owned)
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 5, 6, 7])
+def test_dm_trainer_odd_worlds_every_decomposition(world):
+    """Worlds that do not divide the reference's real batch of 64 (utils.py:615-623 is what the ranks replace: nn.DataParallel
+    splits ANY batch): whole-class blocks, the batch-sharded real side and the hybrid on 3 / 5 / 6 / 7 gloo ranks, 11 classes
+    (uneven blocks everywhere; hybrid: 11 % world left-over classes split world ways, owned round-robin), a real batch that the
+    world divides -- loss and all synthetic clips after one step equal the single-rank run; every class is owned exactly once."""
+    torch.set_num_threads(8)
+    want_l, want_syn, _ = _odd_trainer(0, 1, "class", world)
+    out = _spawn(_worker_odd, world)
+    for shard in ("class", "batch", "hybrid"):
+        loss, syn, owned = out[shard]
+        assert sum(owned) == 11, (shard, owned)
+        if shard == "hybrid":
+            assert max(owned) - min(owned) <= 1 and owned == [11 // world + (1 if r < 11 % world else 0) for r in range(world)]
+        np.testing.assert_allclose(loss, want_l, rtol=2e-5, err_msg=shard)
+        np.testing.assert_allclose(syn, want_syn.numpy(), rtol=1e-4, atol=1e-6, err_msg=shard)
+
+
+def test_shard_choice_falls_back_to_class_blocks_when_the_batch_does_not_divide():
+    """``distill.choose_shard`` (what ``bench.py --shard auto`` runs): with the reference's 64-clip real batches the hybrid needs
+    ``64 % world == 0``; worlds 3, 5, 6, 7 fall back to whole-class blocks, and asking for the batch / hybrid decomposition there
+    is an error that says so (never a silently unequal split)."""
+    assert [distill.choose_shard(50, 64, w) for w in (1, 2, 3, 4, 5, 6, 7, 8)] == ["class", "class", "class", "class", "class", "class", "class", "hybrid"]
+    assert distill.choose_shard(51, 64, 8) == "hybrid" and distill.choose_shard(400, 256, 8) == "class"      # 400 = 8 x 50: even blocks
+    assert distill.choose_shard(50, 64, 8, method="dc") == "class"
+    assert distill.choose_shard(50, 63, 7) == "hybrid" and distill.choose_shard(50, 64, 7) == "class"        # (blocks 8,7,7,...: 12 % uneven)
+    assert distill.choose_shard(50, 60, 6) == "class"                                                        # (blocks 9,9,8,...: exactly 8 %)
+    C, B, pool, syn = _odd_setup(3)          # batch of 6
+    for world, shard in ((4, "batch"), (4, "hybrid"), (5, "hybrid")):
+        with pytest.raises(ValueError, match="divisible by the number of ranks"):
+            distill.DMTrainer(OracleBackend(), pool, C, 1, B, lr_img=0.5, rank=0, world=world, image_syn=syn[:3].clone(), shard=shard)

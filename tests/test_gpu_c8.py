@@ -165,6 +165,35 @@ def test_deferred_backward_is_the_same_arithmetic():
     assert float((a[1] - clips[::per]).abs().max()) > 0          # the clips did move
 
 
+def test_deferred_backward_is_flushed_by_a_step_that_does_not_defer():
+    """Steps that alternate ``overlap=True`` (deferred backward) and ``overlap=False`` (not deferred) must not drop a pending
+    backward: the non-deferring step issues it before its own synthetic forward (round-4 advisor finding: it used to overwrite
+    ``_pending``, so that step's pixel update never ran and the next forward saw stale clips).  Losses, clips and momentum equal
+    the never-deferring trainer's, bitwise."""
+    from video_distillation_amd import distill, plan
+    geo = plan.NetGeometry(8, 64, 64)
+    C, per = 3, 10
+    g = torch.Generator().manual_seed(23)
+    clips = torch.randn(C * per, 8, 3, 64, 64, generator=g).cuda()
+    pool = distill.RealPool(clips, [per] * C, [c * per for c in range(C)])
+    pattern = [True, False, True, True, False, False, True]
+
+    def run(defer):
+        be = distill.HipBackend(geo, "cuda:0")
+        tr = distill.DMTrainer(be, pool, C, 1, 8, lr_img=5.0, momentum=0.5)
+        tr.defer_backward = defer
+        losses = []
+        for it, ov in enumerate(pattern):
+            losses.append(tr.step(it, overlap=ov))
+            if defer and not ov:
+                assert tr._pending is None
+        tr.sync()
+        torch.cuda.synchronize()
+        return [float(l) for l in losses], tr.image_syn.clone(), tr.buf.clone()
+    a, b = run(False), run(True)
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
 def test_deferred_backward_of_the_s2d_trainer_is_the_same_arithmetic():
     """The same for ``S2DTrainer`` (config 3): backward through the embedding AND the hallucinator + the SGD steps on dynamic
     memory and hallucinator, deferred behind the next step's first level: dynamic memories, hallucinator and losses bitwise
@@ -233,9 +262,50 @@ def test_backend_picks_a_last_level_program_for_any_geometry_and_one_clip_launch
     rel_g = float((dx.cpu() - grad_ref).norm() / grad_ref.norm())
     print("%s: last level %s (%s), loss rel %.2e, gradient rel-l2 %.2e" % (
         geom, be.real_last, "position tiles" if prog.epi == plan.EPI_POS_FEAT else "row-major", rel_l, rel_g))
-    assert rel_l < 1e-3 and rel_g < 2e-3
+    assert rel_l < 1e-3 and rel_g < 3e-3       # (one class term of EIGHT real clips, one sample per geometry: 1.2 - 2.4e-3 across K orders of the first level)
     # undithered engine of the same kind: one clip alone vs the same clip inside a launch of 8
     from video_distillation_amd import engine
     e = engine.EmbedEngine(geo, prec="f16", chunk=64, last_hilo=("c8" if be.real_last == "c8" else True)); e.set_weights(weights)
     f8 = e.forward(pool)
     assert torch.equal(e.forward(pool[5:6].contiguous()), f8[5:6])
+
+
+@pytest.mark.parametrize("scale,expect", [(1.0, None), (3e4, "saturated"), (1e-3, "small")])
+def test_activation_range_monitor_and_fallback(scale, expect):
+    """The fp8 operand planes of the real side's last level use fixed scalings (level-1 outputs clamped at 1792, low parts x 2^9),
+    validated for PyTorch-default networks.  The level-1 launch records how many outputs hit the clamp and the largest output
+    (VdConvParams.range_stats); ``DMTrainer.sync`` reads the record: default networks are far inside the range (no fallback), a
+    network whose second-level weights are 3e4 times larger saturates and one whose are 1e-3 times smaller leaves every output
+    below 2^-2 -- in both cases the backend warns and runs the last level in fp16 hi+lo pairs from then on (round-4 advisor
+    finding: nothing detected either)."""
+    import warnings
+    from video_distillation_amd import distill, plan
+    geo = plan.NetGeometry(8, 64, 64)
+    C, per = 2, 10
+    g = torch.Generator().manual_seed(31)
+    clips = torch.randn(C * per, 8, 3, 64, 64, generator=g).cuda()
+    pool = distill.RealPool(clips, [per] * C, [c * per for c in range(C)])
+    be = distill.HipBackend(geo, "cuda:0")
+    assert be.real_last == "c8"
+    plain = be.new_network
+
+    def scaled(seed):
+        w = plain(seed)
+        w[2] = w[2] * scale; w[3] = w[3] * scale          # the second conv level's weight and bias: its outputs scale with them
+        return w
+    be.new_network = scaled
+    tr = distill.DMTrainer(be, pool, C, 1, 8, lr_img=0.1, momentum=0.5)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        tr.step(0, overlap=True)
+        tr.sync()
+    r = tr.real_range
+    print("scale %g:" % scale, r)
+    if expect is None:
+        assert r["saturated"] == 0 and 0.25 <= r["absmax"] < 1792 and "fallback" not in r and be.real_last == "c8" and not caught
+    else:
+        assert r.get("fallback") == "x3" and be.real_last == "x3" and any("validated activation range" in str(w.message) for w in caught)
+        assert (r["saturated"] > 0) == (expect == "saturated") and (r["absmax"] < 0.25) == (expect == "small")
+        # the next steps run the three-MFMA hi+lo last level
+        l1 = float(tr.step(1, overlap=True)); tr.sync()
+        assert np.isfinite(l1) and not be.eng_real.last_c8 and be.real_last == "x3"

@@ -149,6 +149,12 @@ def test_pixel_gradient_allreduce_leg():
     assert out.returncode == 0, out.stderr[-3000:]
     two = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert two["ranks_seen"] == 2 and two["clips_per_step"] == [192, 192] and two["rccl"].get("nranks") is None
+    # per-rank diagnostics of the timed region (round 5): what each rank did and how long it waited for the others
+    pr = two["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["clips_per_step"] == 192 and r["classes_owned"] == 3 for r in pr)
+    assert all(r["own_ms_per_step"] > 0 and r["wait_at_barrier_ms"] >= 0 and r["real_side_ms_per_step"] > 0 for r in pr)
+    assert min(r["wait_at_barrier_ms"] for r in pr) < 50          # the slower rank does not wait
+    assert other["per_rank"][0]["exchange_ms_per_step"] > 0 and one["per_rank"][0]["exchange_ms_per_step"] is None
     assert two["exchange_allreduce"]["through"] == "torch.distributed all_reduce (gloo)"
     assert abs(two["exchange_allreduce"]["loss_last"] / leg["loss_last"] - 1) < 1e-4
     assert abs(two["loss_last"] / one["loss_last"] - 1) < 1e-4

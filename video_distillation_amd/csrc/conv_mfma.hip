@@ -897,6 +897,8 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
     uint16_t* stg = reinterpret_cast<uint16_t*>(smem);
     if (staged) __syncthreads();          // every wave is done reading the patch
     stamp(5);
+    float rs_amax = 0.f;
+    int rs_sat = 0;
     // All register indices below are compile-time constants (a run-time loop bound over acc[]
     // would turn into select chains): both 4-row halves are reduced unconditionally, pool_t only
     // decides whether they are merged.
@@ -923,6 +925,9 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 m0 += bias; m1 += bias;
                 if (p.relu) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
                 if (!X3 && !EXT && p.emit_lo == 2) {      // the fp8 image of these values (x 1/4) must stay finite for the consumer: clamp at 1792
+                    const float a0 = fabsf(m0), a1 = (p.pool_t == 2) ? 0.f : fabsf(m1);      // (range monitor: VdConvParams.range_stats)
+                    rs_amax = fmaxf(rs_amax, fmaxf(a0, a1));
+                    rs_sat += (a0 > 1792.f ? 1 : 0) + (a1 > 1792.f ? 1 : 0);
                     m0 = fminf(fmaxf(m0, -1792.f), 1792.f); m1 = fminf(fmaxf(m1, -1792.f), 1792.f);
                 }
                 const int q = (gi * 4 + half + 2 * qh) * nsets;
@@ -1008,6 +1013,20 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
         }
     }
   }   // N tiles of this wave
+    if constexpr (!X3 && !EXT) {
+        if (staged && p.emit_lo == 2 && p.range_stats != nullptr) {      // one wave's share of the launch's output range (rare atomics:
+#pragma unroll                                                            //  the maximum converges after a few boxes, saturation is an error)
+            for (int o = 32; o > 0; o >>= 1) {
+                rs_amax = fmaxf(rs_amax, __shfl_xor(rs_amax, o));
+                rs_sat += __shfl_xor(rs_sat, o);
+            }
+            if (lane == 0) {
+                const uint32_t bits = __float_as_uint(rs_amax);
+                if (bits > __builtin_nontemporal_load(p.range_stats + 1)) atomicMax(p.range_stats + 1, bits);
+                if (rs_sat) atomicAdd(p.range_stats, (uint32_t)rs_sat);
+            }
+        }
+    }
     if (staged) {
         __syncthreads();
         stamp(6);

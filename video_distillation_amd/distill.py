@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import collections
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -88,6 +89,17 @@ def hybrid_partition(num_classes: int, rank: int, world: int) -> Tuple[List[int]
         nb = max(0, num_classes - int(os.environ["VD_HYBRID_FORCE_SPLIT"]))
     split = list(range(nb * world, num_classes))
     return list(range(rank * nb, (rank + 1) * nb)), split, [c for i, c in enumerate(split) if i % world == rank]
+
+
+def choose_shard(num_classes: int, batch_real: int, world: int, method: str = "dm") -> str:
+    """The decomposition ``bench.py --shard auto`` / ``run_dm`` pick for ``world`` ranks: whole-class blocks need no data-path
+    collective but leave ranks idle when ``num_classes % world`` is large against ``num_classes // world`` (50 over 8: blocks
+    of 7,7,6,..., ceiling 50/7 = 7.14x); the hybrid keeps whole classes and splits only the left-over ones' real batches over all
+    ranks (one all-reduce of 2048 floats per split class).  The hybrid is chosen where the class blocks are more than 8 % uneven
+    AND the real batch divides by the number of ranks (``batch_real % world == 0``: every rank must embed the same share of a
+    split class -- worlds of 3, 5, 6, 7 with 64-clip batches fall back to whole-class blocks) and the method is DM."""
+    blocks_uneven = world > 1 and (-(-num_classes // world)) * world > 1.08 * num_classes
+    return "hybrid" if (blocks_uneven and batch_real % world == 0 and method == "dm") else "class"
 
 
 def sample_real_indices(it: int, counts: Sequence[int], offsets: Sequence[int], batch_real: int,
@@ -290,6 +302,42 @@ class HipBackend:
             for t in tensors:
                 t.record_stream(self.s_syn)
 
+    C8_MIN_ABSMAX = 0.25        # (vd_hip.h, VdConvParams.range_stats: what the fp8 operand planes' fixed scalings were validated for)
+
+    def real_range(self, reset: bool = True) -> Optional[dict]:
+        """What the level-1 launches of the fp8-corrected real side saw since the last call: ``{"saturated": outputs that hit the
+        +-1792 clamp, "absmax": max |output|}``; None when the real side does not run that format or has not run yet.  Reads
+        two device words: the caller has synchronised (``DMTrainer.sync``)."""
+        st = getattr(self.eng_real.fwd[1], "range_stats", None) if self.real_last == "c8" else None
+        if st is None:
+            return None
+        sat, bits = (int(v) for v in st.cpu().numpy().view(np.uint32))
+        if reset:
+            st.zero_()
+        return {"saturated": sat, "absmax": float(np.array([bits], dtype=np.uint32).view(np.float32)[0])}
+
+    def check_real_range(self) -> Optional[dict]:
+        """The fp8 operand planes of the real side's last level use FIXED power-of-two scalings (outputs of level 1 clamped at
+        1792, low parts x 2^9): exact to 2^-16 for magnitudes 2^-4 .. 1792, which covers PyTorch-default-initialised networks on
+        standardised clips by orders of magnitude -- but not arbitrary weights.  If the launches since the last check left that
+        range (something saturated, or the largest output was below ``C8_MIN_ABSMAX``), the backend warns and switches the real
+        side to the fp16 hi+lo last level (``real_last = 'x3'``) for all later steps."""
+        r = self.real_range()
+        if r is None or (r["saturated"] == 0 and (r["absmax"] >= self.C8_MIN_ABSMAX or r["absmax"] == 0.0)):
+            return r
+        import warnings
+        warnings.warn("fp8-corrected last level outside its validated activation range (%d outputs of level 1 saturated at 1792, "
+                      "max |output| %.3g): the real side's last level runs in fp16 hi+lo pairs from now on" % (r["saturated"], r["absmax"]))
+        from . import engine
+        old = self.eng_real
+        self.eng_real = engine.EmbedEngine(self.geo, prec=old.prec_name, device=self.device, chunk=old.chunk, last_hilo=True)
+        self.real_last = "x3"
+        self._pool_rows = None
+        self._prep_slot = None
+        self._real_done = {}
+        r["fallback"] = "x3"
+        return r
+
     def join(self, *tensors):
         """The caller's stream waits for both work streams."""
         if self.two_streams:
@@ -447,6 +495,23 @@ class RealPool:
         return RealPool(clips, counts, offsets)
 
 
+def check_real_range(trainer) -> None:
+    """``sync()`` of the DM trainers: every ``VD_RANGE_CHECK_EVERY`` calls (default 1; 0 = never) look at the activation range the
+    fp8-corrected real side recorded (``HipBackend.check_real_range``: a host read of two device words after a device
+    synchronisation -- ``sync()`` is where callers read results anyway); the latest record is kept in ``trainer.real_range``."""
+    be = trainer.be
+    every = int(os.environ.get("VD_RANGE_CHECK_EVERY", "1"))
+    if every <= 0 or not hasattr(be, "check_real_range") or getattr(be, "real_last", None) != "c8":
+        return
+    trainer._range_calls = getattr(trainer, "_range_calls", 0) + 1
+    if trainer._range_calls % every:
+        return
+    torch.cuda.synchronize(be.device)
+    r = be.check_real_range()
+    if r is not None:
+        trainer.real_range = r
+
+
 class DMTrainer:
     """Baseline DM (distill_baseline.py DM branch, :292-361) over the classes owned by this rank."""
 
@@ -472,8 +537,9 @@ class DMTrainer:
         # (world == 1 normally has nothing to shard; VD_FORCE_BATCH_SHARD=1 keeps the collective path
         #  alive on one rank so that it can be smoke-tested on a single-GPU box)
         self.shard = shard if (world > 1 or os.environ.get("VD_FORCE_BATCH_SHARD") == "1") else "class"
-        if self.shard in ("batch", "hybrid"):
-            assert batch_real % world == 0, "batch / hybrid sharding needs batch_real divisible by the number of ranks"
+        if self.shard in ("batch", "hybrid") and batch_real % world != 0:
+            raise ValueError("shard=%r needs batch_real (%d) divisible by the number of ranks (%d): every rank embeds the same share of a "
+                             "split class batch; use shard='class' (distill.choose_shard falls back to it)" % (self.shard, batch_real, world))
         self.be, self.pool = backend, pool
         self.num_classes, self.ipc, self.batch_real = num_classes, ipc, batch_real
         self.lr_img, self.momentum = float(lr_img), float(momentum)
@@ -494,7 +560,7 @@ class DMTrainer:
         self.steps_done = 0
         assert exchange in ("owner", "allreduce")
         self.exchange, self.comm = exchange, comm
-        self.exchange_events: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        self.exchange_events = collections.deque(maxlen=512)       # (start, end) HIP events of the latest exchanges (bench.py reads and clears)
         self._g_full = None
         self._pending = None
         # (default: with the fp8-corrected last level, whose short launch no longer absorbs the synthetic side's kernels -- they then
@@ -502,7 +568,11 @@ class DMTrainer:
         self.defer_backward = os.environ.get("VD_DEFER_BWD", "1" if getattr(backend, "real_last", None) == "c8" else "0") == "1"
 
     def _allreduce_pixel_grad(self, grad: torch.Tensor) -> torch.Tensor:
-        """``exchange='allreduce'``: this rank's gradient rows through the all-reduced full tensor (see ``__init__``)."""
+        """``exchange='allreduce'``: this rank's gradient rows through the all-reduced full tensor (see ``__init__``).  On one rank
+        without a communicator there is nothing to exchange: the rows are returned as they are (bench.py's one-rank leg passes a
+        ``hip.Comm`` to time the call anyway)."""
+        if self.world == 1 and self.comm is None:
+            return grad
         if self._g_full is None:
             self._g_full = torch.empty((self.num_classes * self.ipc,) + tuple(grad.shape[1:]), dtype=grad.dtype, device=grad.device)
             own = self.owned_classes()
@@ -584,8 +654,10 @@ class DMTrainer:
                 if hasattr(be, "real_launches_done"):
                     be.real_launches_done()
             with on_syn():
-                if defer:
-                    self._flush_backward(ev_l0)     # the PREVIOUS step's backward + SGD, held back until this step's first level is done
+                # the PREVIOUS step's backward + SGD, if it was deferred: held back until this step's first level is done when this
+                # step defers too; issued at once otherwise (a step that does not defer must not overwrite ``_pending``, and its
+                # forward must see the updated clips)
+                self._flush_backward(ev_l0 if defer else None)
                 f_syn, handle = be.embed_syn(self.image_syn, weights)
                 be.real_to_syn(f_real)
                 f_real = self._exchange(f_real)      # (batch sharding) on the synthetic-clip stream: the real-clip stream is
@@ -598,6 +670,7 @@ class DMTrainer:
                 be.join(loss)
             self.steps_done += 1
             return loss
+        self._flush_backward(None)          # (a backward deferred by an earlier overlapped step on a two-stream backend)
         if hasattr(be, "set_real_weights"):
             be.set_weights(weights, self._per_class())
         else:
@@ -705,9 +778,13 @@ class DMTrainer:
                 with self.be.on_syn():
                     self._flush_backward(None)
             self.be.join()
+        check_real_range(self)
 
     def mark(self):
-        """A timing event behind the last kernel of the latest step (bench.py: per-step times under overlap)."""
+        """A timing event behind the last kernel ISSUED by the latest step (bench.py: per-step times under overlap).  With a
+        deferred backward that is the step's loss kernel: its backward + SGD are issued by the next step (or ``sync``), so a
+        step's interval holds the previous step's backward instead of its own -- the same work, shifted by one step; the
+        total over the timed region is exact once ``sync()`` has run."""
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(self.be.s_syn if getattr(self.be, "two_streams", False) else torch.cuda.current_stream(self.image_syn.device))
         return ev
@@ -825,8 +902,7 @@ class S2DTrainer:
             be.set_weights(weights)
             f_real = be.embed_pool(self.pool.clips, idx_t)
         with on_syn():
-            if defer:
-                self._flush_backward(ev_l0)
+            self._flush_backward(ev_l0 if defer else None)      # (see DMTrainer.step: a non-deferring step issues a pending backward at once)
             image_syn = be.hallucinate(self.static, self.dynamic, sidx, didx, self.hal_w, self.hal_b)
             f_syn, handle = be.embed_syn(image_syn, weights) if hasattr(be, "embed_syn") else be.embed_keep(image_syn)
             if two:
@@ -871,6 +947,7 @@ class S2DTrainer:
                 with self.be.on_syn():
                     self._flush_backward(None)
             self.be.join()
+        check_real_range(self)
 
     global_loss = DMTrainer.global_loss
 

@@ -41,6 +41,7 @@ class _DevPlan:
         self.prec = prec
         self.wpk = self._new_wpk(planes, device)
         self.wpk_d: Optional[torch.Tensor] = None          # dithered operand sets (pack_dither)
+        self.range_stats: Optional[torch.Tensor] = None    # emit_lo = 2 launches: [saturated outputs, float bits of max |output|] (vd_hip.h)
         self._slots: Dict[int, tuple] = {}                 # buffer sets of use_slot()
         self._slot = 0
         p = hip.VdConvParams()
@@ -136,6 +137,12 @@ class _DevPlan:
         p = self.params
         p.emit_lo = int(emit_lo)        # single-pass program, staged pooled epilogue: 1 = also write the fp16 low plane (dst_plane_stride
         #                                 behind), 2 = write fp8 low parts there instead (for a VD_PREC_F16C8 consumer)
+        if int(emit_lo) == 2:           # ... whose fixed scalings hold for a RANGE of output magnitudes: the launch records what it saw
+            if self.range_stats is None:
+                self.range_stats = torch.zeros(2, dtype=torch.int32, device=src.device)
+            p.range_stats = self.range_stats.data_ptr()
+        else:
+            p.range_stats = 0
         p.clip_index = 0 if clip_index is None else clip_index.data_ptr()
         p.out_scale = 0 if out_scale is None else out_scale.data_ptr()
         p.w_set_clips = 0

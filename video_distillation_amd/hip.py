@@ -47,7 +47,7 @@ class VdConvParams(ctypes.Structure):
         ("out_clip_stride", ctypes.c_int64),
         ("out_chunk_stride", ctypes.c_int32), ("out_t_stride", ctypes.c_int32),
         ("lds_plane_bytes", ctypes.c_int32), ("prec", ctypes.c_int32), ("dbg", ctypes.c_int32), ("ntypes", ctypes.c_int32), ("tab_ofs", ctypes.c_int32 * 3), ("atomic", ctypes.c_int32), ("select", ctypes.c_int32), ("src_split_cc", ctypes.c_int32), ("src_split_off4", ctypes.c_int64), ("NTW", ctypes.c_int32), ("clip_index", ctypes.c_void_p), ("mt_valid", ctypes.c_int32), ("persist", ctypes.c_int32), ("stamps", ctypes.c_void_p),
-        ("w_set_clips", ctypes.c_int32), ("replica_stride", ctypes.c_int32), ("emit_lo", ctypes.c_int32), ("src_planes", ctypes.c_int32), ("src_rows", ctypes.c_int32), ("pair_flip", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("w_set_clips", ctypes.c_int32), ("replica_stride", ctypes.c_int32), ("emit_lo", ctypes.c_int32), ("src_planes", ctypes.c_int32), ("src_rows", ctypes.c_int32), ("pair_flip", ctypes.c_int32), ("range_stats", ctypes.c_void_p),
     ]
 
 
