@@ -109,23 +109,31 @@ def conv_layer_macs(geo):
 
 def pmc_traffic(name, clips_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
-    runs, corrected as MI355X_MICROARCH.md prescribes).  Round 4's passes ran over tools/run_real_side.py, i.e. over the very
-    launches of one step of THIS benchmark's default configuration (3200 clips per launch, index gather, dithered operand sets,
-    low-plane output): when the run's clips per launch equal the file's, the figure is that measurement unscaled; any other
-    launch size is rescaled and labelled so.  (Counters cannot be read from inside the timed run: rocprofv3 --pmc serialises the
-    kernels.)  -> (bytes or None, source label)."""
-    for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    runs, corrected as MI355X_MICROARCH.md prescribes) over tools/run_real_side.py, i.e. over the very launches of one step of
+    THIS benchmark's default configuration (3200 clips per launch, index gather, dithered operand sets, low-plane output).
+    Counters cannot be read from inside the timed run (rocprofv3 --pmc serialises the kernels), so the figure is carried in a
+    file -- STAMPED with the hash of the kernel sources it was measured on (``hip.sources_hash``): a file whose stamp differs
+    from this checkout's sources is refused (traffic null, the reason in ``traffic_source``), as is any other launch size.
+    tools/refresh_profiles.sh re-measures the file.  -> (bytes or None, source label)."""
+    from video_distillation_amd import hip
+    mine = hip.sources_hash()
+    for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
-        if os.path.exists(path):
-            doc = json.load(open(path))
-            rec = doc.get(name)
-            if rec:
-                src = doc.get("_source", {})
-                same = int(round(clips_per_launch)) == int(rec["clips_per_launch"])
-                label = "profiles/%s: PMC passes over %s at git %s, %d clips per launch%s" % (
-                    fn, src.get("command", "tools/run_l1.py"), src.get("git"), rec["clips_per_launch"],
-                    " = this run's launch shape (measured, unscaled)" if same else "; rescaled to %d" % int(round(clips_per_launch)))
-                return rec["hbm_bytes_per_launch"] * clips_per_launch / rec["clips_per_launch"], label
+        if not os.path.exists(path):
+            continue
+        doc = json.load(open(path))
+        rec, src = doc.get(name), doc.get("_source", {})
+        if not rec:
+            continue
+        stamp = src.get("kernel_sources_sha256_16")
+        if stamp != mine:
+            return None, "profiles/%s was measured on other kernel sources (stamp %s, this checkout %s): not quoted; re-measure with " \
+                         "tools/refresh_profiles.sh" % (fn, stamp, mine)
+        if int(round(clips_per_launch)) != int(rec["clips_per_launch"]):
+            return None, "profiles/%s holds %d clips per launch, this run launches %d: not quoted" % (
+                fn, rec["clips_per_launch"], int(round(clips_per_launch)))
+        return rec["hbm_bytes_per_launch"], "profiles/%s: PMC passes over %s, %d clips per launch = this run's launch shape, kernel sources %s " \
+            "= this checkout's (measured, unscaled)" % (fn, src.get("command", "tools/run_real_side.py"), rec["clips_per_launch"], stamp)
     return None, None
 
 

@@ -28,7 +28,11 @@ try:
     rev = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
 except OSError:
     rev = None
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from video_distillation_amd import hip
 res = {"_source": {"command": "tools/run_real_side.py (the launches of one bench.py step, config 2)", "git": rev,
+                   "kernel_sources_sha256_16": hip.sources_hash(),      # bench.py quotes the file only while this matches its own sources
                    "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB"}}
 for label, prefix in KERNELS:
     fk = [k for k in f if k.startswith(prefix)]

@@ -41,6 +41,11 @@
 #else
 #define VD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef VD_NO_SETPRIO_LOOP      // (round 5: the single-pass K loop of a channel chunk runs at priority 2 -- above a partner workgroup's patch DMA /
+#define VD_PRIO_LOOP(x) __builtin_amdgcn_s_setprio(x)      //  epilogue phases on the same SIMD: level 1 -0.8 % alone, the DM step -0.1 ms in
+#else                           //  four of four same-box pairs, profiles/r05_prioloop_ab.txt)
+#define VD_PRIO_LOOP(x)
+#endif
 #ifdef VD_SETPRIO
 #define VD_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
@@ -466,6 +471,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 for (int i = 0; i < MA; ++i) A[d][i] = *reinterpret_cast<const uint4*>(smem + a_off[i] + tp);
             }
             int tp = tap_of(AD + 1);          // tap offset of step s + 2
+            VD_PRIO_LOOP(2);                  // (A/B switch: the whole K loop of a chunk above a partner workgroup's DMA / epilogue phases)
             auto k_step = [&](const int u, const int s_abs) {
                 load_b(s_abs + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
                 const int tp_next = tap_of(s_abs + AD + 2);
@@ -505,6 +511,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                     k_step(u, s + u);
                 }
             }
+            VD_PRIO_LOOP(0);
         } else if constexpr (C8) {
             // fp16 main product every K step; the two correction products once per FOUR steps (a GROUP) on the fp8 instruction (K = 64 =
             // 4 steps x 2 taps x 8 channels).  Element j = 8 q + e of a lane's 32-byte fp8 fragment is (step 4 g + q, this lane's tap

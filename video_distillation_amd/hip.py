@@ -106,6 +106,18 @@ def build(force: bool = False, verbose: bool = False, debug_hooks: bool = False)
     return out
 
 
+def sources_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources and the ABI header: what measurement files that are carried from one
+    run to the next (profiles/rNN_pmc_traffic.json -> bench.py's ``roofline.traffic``) are stamped with, so that a figure
+    measured on other kernels is refused instead of quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(SOURCES) + [os.path.join(_HERE, "..", "include", "vd_hip.h")]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 _lib: Optional[ctypes.CDLL] = None
 
 
