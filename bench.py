@@ -506,27 +506,33 @@ def run_eval(args, trainer, pool, device, rank):
     tops, trains = [], []
     from video_distillation_amd import hip
     prev_det = hip.set_deterministic(not args.eval_atomic)     # fixed summation order: the same top-1 per seed in every run
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for sd in range(max(1, args.eval_seeds)):
-        # (NOT utils.get_network: like the reference's it reseeds torch's global generator from the wall clock on every call
-        #  -- SURVEY Q5 --, which is what made rounds 1-3's "fixed-seed" networks differ from run to run: initial weights,
-        #  dropout masks and shuffles all came from the clock.  The module is constructed directly, as get_network does inside.)
-        torch.manual_seed(1000 + sd)
-        net = networks.ConvNet3D(channel=3, num_classes=C, net_width=128, net_depth=3, net_act='relu', net_norm='none',
-                                 net_pooling='maxpooling', im_size=(args.size, args.size), frames=args.frames).to(device)
-        with contextlib.redirect_stdout(sys.stderr):        # evaluate_synset prints its own progress line, like the reference
-            _, acc_train, acc_test, _ = utils.evaluate_synset(sd, net, syn, labels, loader, eargs, mode="none")
-        tops.append(float(acc_test)); trains.append(float(acc_train))
-    torch.cuda.synchronize()
-    hip.set_deterministic(prev_det)
+    try:            # (the library's accumulation mode is process-wide: restored even if a training run raises)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for sd in range(max(1, args.eval_seeds)):
+            # (NOT utils.get_network: like the reference's it reseeds torch's global generator from the wall clock on every call
+            #  -- SURVEY Q5 --, which is what made rounds 1-3's "fixed-seed" networks differ from run to run: initial weights,
+            #  dropout masks and shuffles all came from the clock.  The module is constructed directly, as get_network does inside.)
+            torch.manual_seed(1000 + sd)
+            net = networks.ConvNet3D(channel=3, num_classes=C, net_width=128, net_depth=3, net_act='relu', net_norm='none',
+                                     net_pooling='maxpooling', im_size=(args.size, args.size), frames=args.frames).to(device)
+            with contextlib.redirect_stdout(sys.stderr):        # evaluate_synset prints its own progress line, like the reference
+                _, acc_train, acc_test, _ = utils.evaluate_synset(sd, net, syn, labels, loader, eargs, mode="none")
+            tops.append(float(acc_test)); trains.append(float(acc_train))
+        torch.cuda.synchronize()
+    finally:
+        hip.set_deterministic(prev_det)
     dt = (time.perf_counter() - t0) / len(tops)
     return {"deterministic": not args.eval_atomic, "test_split": "held out (never drawn as real or initial synthetic clips)" if held_out else
             "last 4 clips of each class (drawable as real clips)",
             "top1": sum(tops) / len(tops), "acc_train": sum(trains) / len(trains), "top1_per_seed": tops, "epochs": args.eval_epochs + 1,
             "seconds": dt, "ms_per_epoch": dt / (args.eval_epochs + 1) * 1e3, "test_clips": int(idx.numel()),
-            "note": ("class template + noise pool: chance is %.3f" % (1.0 / C)) if args.pool_kind == "templates" else
-                    ("synthetic noise pool: top-1 is chance (%.3f) by construction" % (1.0 / C))}
+            "note": (("class template + noise pool: chance is %.3f.  " % (1.0 / C)) if args.pool_kind == "templates" else
+                     ("synthetic noise pool: top-1 is chance (%.3f) by construction.  " % (1.0 / C))) +
+                    "A SMOKE of evaluate_synset on the HIP path (5 networks x %d epochs on 50 clips that are %d DM steps from a real clip), "
+                    "reproducible per command line but not a metric: two DM steps more move a seed from 0.85 to 0.3.  Accuracy parity with "
+                    "the reference is fixture G16 (tests/test_gpu_eval_parity.py: mean top-1 0.6135 vs 0.6110)" % (
+                        args.eval_epochs + 1, args.warmup + args.steps)}
 
 
 def exchange_record(trainer, args, geo, h):
@@ -957,6 +963,8 @@ def spawn_ranks(args):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = str(s.getsockname()[1])
+    from video_distillation_amd import hip
+    hip.build()          # a stale library is rebuilt ONCE, here (hipcc makes no HIP call), not by N ranks racing on the same object files
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",

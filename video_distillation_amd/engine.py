@@ -9,6 +9,7 @@ parameters that are frozen (distill_baseline.py:336-337).
 from __future__ import annotations
 
 import ctypes
+import threading
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -104,8 +105,8 @@ class _DevPlan:
     def pack(self, w: torch.Tensor) -> None:
         assert w.dtype == torch.float32 and w.is_contiguous()
         lo = self.wpk[1] if self.wpk.shape[0] == 2 else None
-        if _PACK_QUEUE is not None and self.n_w > 0:          # inside ``batched_packs()``: one launch for all of them at its exit
-            _PACK_QUEUE.append((w, self.widx, self.n_w, self.wpk[0], lo, self.prec))
+        if _PACK.queue is not None and self.n_w > 0:          # inside ``batched_packs()``: one launch for all of them at its exit
+            _PACK.queue.append((w, self.widx, self.n_w, self.wpk[0], lo, self.prec))
             return
         hip.check(hip.lib().vd_pack_weights(hip.ptr(w), hip.ptr(self.widx), ctypes.c_int64(self.n_w),
                                             hip.ptr(self.wpk[0]), hip.ptr(lo), self.prec, hip.stream_ptr(w.device)),
@@ -181,28 +182,31 @@ class _DevPlan:
             prof.append((self.plan.name, self.prec, 2.0 * self.plan.meta.get("macs_per_unit", 0) * nclips, e0, e1))
 
 
-_PACK_QUEUE: Optional[list] = None
+class _PackState(threading.local):       # per host thread: packs queued by one thread are flushed on that thread's current stream
+    queue: Optional[list] = None
+
+
+_PACK = _PackState()
 
 
 class batched_packs:
     """``with batched_packs():`` -- the ``_DevPlan.pack`` calls inside are collected and issued as ONE launch per 24 of them at
     the exit (vd_pack_weights_multi): a training or trajectory-matching step packs the same few weight tensors for a dozen tile
     programs, each a 5 - 10 us launch of its own otherwise.  Bitwise the same operands.  The packed buffers must not be read
-    before the exit; nests (the outermost exit launches).  ``VD_PACK_BATCH=0``: every pack launches by itself.  The queue is a
-    module global: one host thread drives an engine's packing (the trainers do; the class lanes of DC are streams, not threads)."""
+    before the exit; nests (the outermost exit launches).  ``VD_PACK_BATCH=0``: every pack launches by itself.  The queue is
+    per host THREAD (two threads driving two engines do not flush each other's packs); within a thread the flush goes to the
+    stream that is current at the outermost exit, which is where the packs themselves would have gone."""
 
     def __enter__(self):
-        global _PACK_QUEUE
-        self.outer = _PACK_QUEUE is not None or os.environ.get("VD_PACK_BATCH", "1") != "1"
+        self.outer = _PACK.queue is not None or os.environ.get("VD_PACK_BATCH", "1") != "1"
         if not self.outer:
-            _PACK_QUEUE = []
+            _PACK.queue = []
         return self
 
     def __exit__(self, *exc):
-        global _PACK_QUEUE
         if self.outer:
             return False
-        q, _PACK_QUEUE = _PACK_QUEUE, None
+        q, _PACK.queue = _PACK.queue, None
         if exc[0] is None:
             flush_packs(q)
         return False
@@ -434,6 +438,9 @@ class EmbedEngine:
             if os.environ.get("VD_BWD_X2_SIM") == "w":
                 # measurement knob: the NUMERICS of a two-MFMA input gradient (g_hi + g_lo) x W_hi -- the low
                 # plane of the weights dropped -- at the cost of the three-MFMA program
+                if _PACK.queue:            # (inside an outer batched_packs(): the queued packs must land before their low planes are cleared)
+                    flush_packs(_PACK.queue)
+                    del _PACK.queue[:]
                 for li in range(3):
                     for dp in self.bwd[li]:
                         if dp.wpk.shape[0] == 2:

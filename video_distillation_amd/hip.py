@@ -85,6 +85,23 @@ def build(force: bool = False, verbose: bool = False, debug_hooks: bool = False)
     # one object per source (rebuilt only when that source or the header is newer), compiled concurrently, then one link
     objdir = os.path.join(_HERE, "csrc", "build_dbg" if debug_hooks else "build")
     os.makedirs(objdir, exist_ok=True)
+    # one builder at a time (several ranks / test workers may find the library stale together): an exclusive lock on the object
+    # directory; whoever waited finds the library fresh and returns
+    import fcntl
+    lock = open(os.path.join(objdir, ".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        return _build_locked(out, objdir, hipcc, force, verbose, debug_hooks)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(out: str, objdir: str, hipcc: str, force: bool, verbose: bool, debug_hooks: bool) -> str:
+    if not force and os.path.exists(out):
+        newest = max(os.path.getmtime(s) for s in SOURCES + [os.path.join(_HERE, "..", "include", "vd_hip.h")])
+        if os.path.getmtime(out) >= newest:
+            return out
     header = os.path.join(_HERE, "..", "include", "vd_hip.h")
     flags = ["-O3", "--offload-arch=gfx950", "-fPIC"] + (["-DVD_DBG_HOOKS=1"] if debug_hooks else [])
     jobs, objs = [], []
@@ -99,10 +116,12 @@ def build(force: bool = False, verbose: bool = False, debug_hooks: bool = False)
     for cmd, pr in jobs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"]
+    tmp = out + ".tmp.%d" % os.getpid()       # (linked beside the target and renamed: a reader never maps a half-written library)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    os.replace(tmp, out)
     return out
 
 
