@@ -309,3 +309,22 @@ def test_activation_range_monitor_and_fallback(scale, expect):
         # the next steps run the three-MFMA hi+lo last level
         l1 = float(tr.step(1, overlap=True)); tr.sync()
         assert np.isfinite(l1) and not be.eng_real.last_c8 and be.real_last == "x3"
+
+
+@pytest.mark.parametrize("fused", ["2", "0"])
+def test_hallucinator_backward_forms_against_autograd(fused):
+    """vd_hallucinator_bwd (utils.py:1186-1197 backward) in both forms -- the fused kernel that reads the upstream gradient once
+    (default from 1024 tiles up; forced here) and the data + parameter kernels -- against torch autograd of the same Conv3d on the
+    GPU, with memories shared between clips and at a geometry whose tiles overhang the image: all four gradients to 5e-6."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dims in (["9", "8", "64", "64"], ["3", "5", "37", "45"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "hal_check.py")] + dims, env=dict(os.environ, VD_HAL_FUSED=fused),
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if "rel-L2" in l][0]
+        vals = [float(v) for v in re.findall(r"(?:g_dyn|g_stat|g_w|g_b) ([0-9.e+-]+)", line)]
+        print(line)
+        assert len(vals) == 4 and max(vals) < 5e-6, line

@@ -842,12 +842,269 @@ __global__ __launch_bounds__(256) void hal_bwd_param_kernel(const float* __restr
     }
 }
 
+// Backward, FUSED (round 5): the upstream gradient is read from HBM ONCE.  (The two kernels above read it three times -- the data
+// part once through the L1 with nine requests per element, the parameter part once per job group -- and ran at 1.28 / 0.89 TB/s of
+// algorithmic bytes.)  A workgroup owns a tile of 8 x 32 pixels of one clip and walks its T frames; the tile + one-pixel halo of
+// the upstream gradient (3 channels) and of the dynamic memory is staged per frame into a three-slot ring in LDS (the loads of
+// frame t + 2 are in flight while frame t is computed), and every thread reads its 3 x 3 x 3 neighbourhoods from there:
+//   * g_dyn of its pixel and frame (81 multiply-adds with scalar weights), added with an atomic (clips may share a memory);
+//   * the dynamic channel's 81 weight gradients + the bias gradient, accumulated in registers over all tiles of the workgroup;
+//   * per pixel of tile + halo the temporal SUM / FIRST / LAST of the upstream gradient; after the walk g_stat of its pixel
+//     gathers them (243 multiply-adds once per column);
+//   * the static channels' 243 weight gradients are the 27 x 9 product (stat neighbourhood) x (G_kt[co] of the centre pixel)
+//     summed over pixels -- a small GEMM with the pixel as K: each wave runs it over its 64 columns on the fp32 matrix
+//     instruction (v_mfma_f32_32x32x2f32, operands straight from the LDS tiles), accumulators kept across tiles.
+// Grid-stride over tiles (<= 512 workgroups), one closing reduction + 327 atomics per workgroup.
+#define HAL_TH 8
+#define HAL_TW 32
+#define HAL_PITCH 36
+#define HAL_HALO ((HAL_TH + 2) * (HAL_TW + 2))          // 340 pixels of tile + halo
+#define HAL_AREA ((HAL_TH + 2) * HAL_PITCH)             // 360 floats per staged channel
+typedef float hal_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 2) void hal_bwd_fused_kernel(const float* __restrict__ go, const float* __restrict__ stat,
+                                                               const float* __restrict__ dyn, const int64_t* __restrict__ sidx,
+                                                               const int64_t* __restrict__ didx, const float* __restrict__ w,
+                                                               int n, int T, int H, int W, int tiles_x, int tiles_y,
+                                                               float* __restrict__ g_dyn, float* __restrict__ g_stat,
+                                                               float* __restrict__ g_w, float* __restrict__ g_b) {
+    __shared__ float go_w[3][3][HAL_AREA];       // ring slot, channel
+    __shared__ float dy_w[3][HAL_AREA];
+    __shared__ float sfl[3][3][HAL_AREA];        // SUM / FIRST / LAST, channel
+    __shared__ float st_t[3][HAL_AREA];          // static tile
+    __shared__ float g_t[256][9];                // G_kt[co] of every centre pixel: [kt * 3 + co]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ly = tid / HAL_TW, lx = tid % HAL_TW;
+    const int ctr = (ly + 1) * HAL_PITCH + lx + 1;          // this thread's pixel inside a staged channel
+    const int64_t HW = (int64_t)H * W;
+    const int64_t ntiles = (int64_t)n * tiles_x * tiles_y;
+    // halo-inclusive pixels this thread stages / sums: p0 = tid, p1 = tid + 256 (< 340)
+    const int p0 = tid, p1 = tid + 256;
+    const bool has1 = p1 < HAL_HALO;
+    const int h0y = p0 / (HAL_TW + 2), h0x = p0 % (HAL_TW + 2);
+    const int h1y = has1 ? p1 / (HAL_TW + 2) : 0, h1x = has1 ? p1 % (HAL_TW + 2) : 0;
+    const int l0 = h0y * HAL_PITCH + h0x, l1 = h1y * HAL_PITCH + h1x;
+    float accw[81];          // d/d w[co][3][kt][kh][kw]: index co * 27 + kt * 9 + kh * 3 + kw
+#pragma unroll
+    for (int k = 0; k < 81; ++k) accw[k] = 0.f;
+    float accb[3] = {0.f, 0.f, 0.f};
+    hal_f32x16 accs;         // static channels: rows r = ci * 9 + kh * 3 + kw (27 of 32), columns kt * 3 + co (9 of 32)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) accs[k] = 0.f;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t clip = tile / (tiles_x * tiles_y);
+        const int tr = (int)(tile % (tiles_x * tiles_y));
+        const int ty0 = (tr / tiles_x) * HAL_TH, tx0 = (tr % tiles_x) * HAL_TW;
+        const int64_t si = sidx ? sidx[clip] : clip, di = didx ? didx[clip] : clip;
+        const float* gp = go + clip * (int64_t)T * 3 * HW;
+        const float* dp = dyn + di * (int64_t)T * HW;
+        const float* sp = stat + si * 3 * HW;
+        // image coordinates of the two staged pixels
+        const int y0 = ty0 - 1 + h0y, x0 = tx0 - 1 + h0x, y1 = ty0 - 1 + h1y, x1 = tx0 - 1 + h1x;
+        const bool in0 = y0 >= 0 && y0 < H && x0 >= 0 && x0 < W;
+        const bool in1 = has1 && y1 >= 0 && y1 < H && x1 >= 0 && x1 < W;
+        const int64_t o0 = in0 ? (int64_t)y0 * W + x0 : 0, o1 = in1 ? (int64_t)y1 * W + x1 : 0;
+        float r0[4], r1[4];         // staged values of one frame: go[0..2], dyn
+        auto fetch = [&](int t) {
+            const bool tv = t >= 0 && t < T;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                r0[c] = (tv && in0) ? gp[((int64_t)t * 3 + c) * HW + o0] : 0.f;
+                r1[c] = (tv && in1) ? gp[((int64_t)t * 3 + c) * HW + o1] : 0.f;
+            }
+            r0[3] = (tv && in0) ? dp[(int64_t)t * HW + o0] : 0.f;
+            r1[3] = (tv && in1) ? dp[(int64_t)t * HW + o1] : 0.f;
+        };
+        auto stage = [&](int slot) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                go_w[slot][c][l0] = r0[c];
+                if (has1) go_w[slot][c][l1] = r1[c];
+            }
+            dy_w[slot][l0] = r0[3];
+            if (has1) dy_w[slot][l1] = r1[3];
+        };
+        // static tile; ring slots: frame t lives in slot (t + 3) % 3, frame -1 is zeros
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            st_t[c][l0] = in0 ? sp[(int64_t)c * HW + o0] : 0.f;
+            if (has1) st_t[c][l1] = in1 ? sp[(int64_t)c * HW + o1] : 0.f;
+        }
+        fetch(-1); stage(2);
+        fetch(0); stage(0);
+        fetch(1); stage(1);
+        float s0[3] = {0.f, 0.f, 0.f}, s1[3] = {0.f, 0.f, 0.f}, f0[3], f1[3], e0[3], e1[3];      // SUM, FIRST, LAST of the two staged pixels
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { f0[c] = 0.f; f1[c] = 0.f; e0[c] = 0.f; e1[c] = 0.f; }
+        const int gy = ty0 + ly, gx = tx0 + lx;
+        const bool valid = gy < H && gx < W;
+        float* gd = g_dyn + di * (int64_t)T * HW + (int64_t)gy * W + gx;
+        __syncthreads();
+        // data gradient in SCATTER form: the 27 upstream values of frame tau (3 channels x 3 x 3 neighbours) are read from LDS once
+        // and added into the three outputs they meet -- out[tau + 1] through tap kt = 2, out[tau] through kt = 1, out[tau - 1]
+        // through kt = 0 -- so a step reads 27 values instead of the 81 of its three-frame window
+        float o0a = 0.f, o1a = 0.f, o2a = 0.f;             // outputs t, t + 1, t + 2 under construction
+        auto scatter = [&](int slot) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int off = ctr + (k / 3 - 1) * HAL_PITCH + (k % 3 - 1);
+                const int kh = 2 - k / 3, kw = 2 - k % 3;
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    const float v = go_w[slot][co][off];
+                    o0a += v * HAL_W(co, 3, 0, kh, kw);
+                    o1a += v * HAL_W(co, 3, 1, kh, kw);
+                    o2a += v * HAL_W(co, 3, 2, kh, kw);
+                }
+            }
+        };
+        scatter(0);                                        // frame 0 -> out[-1] (dropped), out[0], out[1]
+        o0a = o1a; o1a = o2a; o2a = 0.f;
+        for (int t = 0; t < T; ++t) {
+            fetch(t + 2);                                  // lands under this frame's arithmetic
+            const int sm1 = (t + 2) % 3, sc = t % 3, sp1 = (t + 1) % 3;      // slots of frames t - 1, t, t + 1
+            // temporal sums of the staged pixels
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float a = go_w[sc][c][l0];
+                s0[c] += a;
+                if (t == 0) f0[c] = a;
+                if (t == T - 1) e0[c] = a;
+                if (has1) {
+                    const float b = go_w[sc][c][l1];
+                    s1[c] += b;
+                    if (t == 0) f1[c] = b;
+                    if (t == T - 1) e1[c] = b;
+                }
+            }
+            scatter(sp1);                                  // frame t + 1 (zeros past the clip): completes out[t]
+            if (valid) atomicAdd(gd + (int64_t)t * HW, o0a);
+            o0a = o1a; o1a = o2a; o2a = 0.f;
+            // the dynamic channel's weight gradients: g(t) at the centre x dyn(t + kt - 1) at the neighbours
+            const float gc0 = go_w[sc][0][ctr], gc1 = go_w[sc][1][ctr], gc2 = go_w[sc][2][ctr];
+            accb[0] += gc0; accb[1] += gc1; accb[2] += gc2;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const int slot = (f == 0) ? sm1 : (f == 1) ? sc : sp1;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float d = dy_w[slot][ctr + (k / 3 - 1) * HAL_PITCH + (k % 3 - 1)];
+                    accw[0 * 27 + f * 9 + k] += gc0 * d;
+                    accw[1 * 27 + f * 9 + k] += gc1 * d;
+                    accw[2 * 27 + f * 9 + k] += gc2 * d;
+                }
+            }
+            __syncthreads();                               // everybody is done with frame t - 1's slot ...
+            stage(sm1);                                    // ... which takes frame t + 2
+            __syncthreads();
+        }
+        // SUM / FIRST / LAST tiles
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            sfl[0][c][l0] = s0[c]; sfl[1][c][l0] = f0[c]; sfl[2][c][l0] = e0[c];
+            if (has1) { sfl[0][c][l1] = s1[c]; sfl[1][c][l1] = f1[c]; sfl[2][c][l1] = e1[c]; }
+        }
+        __syncthreads();
+        {   // G_kt[co] of the centre pixel: kt = 0: frames 1..T-1; kt = 1: all; kt = 2: frames 0..T-2
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                const float sm = sfl[0][co][ctr], fi = sfl[1][co][ctr], la = sfl[2][co][ctr];
+                g_t[tid][0 * 3 + co] = sm - fi; g_t[tid][1 * 3 + co] = sm; g_t[tid][2 * 3 + co] = sm - la;
+            }
+        }
+        if (g_stat != nullptr && valid) {
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                float a = 0.f;
+#pragma unroll
+                for (int co = 0; co < 3; ++co)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const int off = ctr + (k / 3 - 1) * HAL_PITCH + (k % 3 - 1);
+                        const int kh = 2 - k / 3, kw = 2 - k % 3;
+                        const float sm = sfl[0][co][off];
+                        a += HAL_W(co, ci, 1, kh, kw) * sm + HAL_W(co, ci, 0, kh, kw) * (sm - sfl[1][co][off]) +
+                             HAL_W(co, ci, 2, kh, kw) * (sm - sfl[2][co][off]);
+                    }
+                atomicAdd(&g_stat[(si * 3 + ci) * HW + (int64_t)gy * W + gx], a);
+            }
+        }
+        __syncthreads();                                   // g_t complete
+        if (g_w != nullptr) {
+            // static channels: C[r][j] += sum over this wave's 64 columns of A[r][col] * B[col][j]; A = static value at the column's
+            // neighbour (ci, kh, kw), B = G_j of the column.  v_mfma_f32_32x32x2f32: lane l supplies A[row l % 32][k = l / 32] and
+            // B[k = l / 32][column l % 32]
+            const int r = lane & 31, kk = lane >> 5;
+            const int ci = r / 9, kh = (r % 9) / 3, kw = r % 3;
+#pragma unroll 4
+            for (int stp = 0; stp < 32; ++stp) {
+                const int col = wv * 64 + stp * 2 + kk;            // a thread index = a tile pixel
+                const int cy = col / HAL_TW, cx = col % HAL_TW;
+                const float a = (r < 27) ? st_t[ci][(cy + kh) * HAL_PITCH + cx + kw] : 0.f;
+                const float b = (r < 9) ? g_t[col][r] : 0.f;
+                accs = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accs, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // tiles free for the next walk
+    }
+    if (g_w == nullptr || g_b == nullptr) return;
+    // closing reduction: 81 + 3 per-thread sums and the 27 x 9 matrix of every wave -> atomics
+    float* red = &go_w[0][0][0];                           // [4 waves][84 + 243] floats (the ring is free now)
+#pragma unroll
+    for (int k = 0; k < 81; ++k) {
+        const float tot = wave_sum(accw[k]);
+        if (lane == 0) red[wv * 327 + k] = tot;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float tot = wave_sum(accb[c]);
+        if (lane == 0) red[wv * 327 + 81 + c] = tot;
+    }
+    {   // 32 x 32 accumulator layout: lane l holds column l % 32, rows 8 * (v / 4) + 4 * (l / 32) + v % 4 for v = 0..15
+        const int j = lane & 31;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = 8 * (v / 4) + 4 * (lane >> 5) + (v % 4);
+            if (j < 9 && r < 27) red[wv * 327 + 84 + r * 9 + j] = accs[v];
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < 327; k += 256) {
+        const float tot = red[k] + red[327 + k] + red[2 * 327 + k] + red[3 * 327 + k];
+        if (k < 81) {
+            const int co = k / 27;
+            atomicAdd(&g_w[(co * 4 + 3) * 27 + (k % 27)], tot);              // [co][ci = 3][kt][kh][kw]
+        } else if (k < 84) {
+            atomicAdd(&g_b[k - 81], tot);
+        } else {
+            const int r = (k - 84) / 9, j = (k - 84) % 9;                    // r = ci * 9 + kh * 3 + kw, j = kt * 3 + co
+            const int ci = r / 9, co = j % 3, kt = j / 3;
+            atomicAdd(&g_w[((co * 4 + ci) * 3 + kt) * 9 + (r % 9)], tot);
+        }
+    }
+}
+
 extern "C" int vd_hallucinator_bwd(const float* g_out, const float* stat, const float* dyn, const int64_t* sidx,
                                    const int64_t* didx, const float* w, int n, int T, int H, int W, float* g_dyn,
                                    float* g_stat, float* g_w, float* g_b, void* stream) {
     const int64_t total = (int64_t)n * H * W;
     if (total <= 0 || T <= 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // 1 (default): the fused kernel where the launch has >= 1024 tiles (50 clips 112 x 112: 2800; measured 0.301 vs 0.330 ms, the
+    // upstream gradient read once instead of three times) -- below that its <= 512 persistent workgroups do not fill the chip and the
+    // two-kernel form is the faster one (7 clips 64 x 64 x 8: 0.056 vs 0.046 ms); 2: always fused; 0: never (tools/hal_check.py).
+    // Both forms are bound by vector-ALU and LDS issue (162 multiply-adds and ~110 LDS reads per pixel and frame), not by HBM:
+    // 203 MB of algorithmic traffic in 0.3 ms
+    static const int fused = getenv("VD_HAL_FUSED") ? atoi(getenv("VD_HAL_FUSED")) : 1;
+    const int tiles_x = (W + HAL_TW - 1) / HAL_TW, tiles_y = (H + HAL_TH - 1) / HAL_TH;
+    if (fused && (g_w != nullptr) == (g_b != nullptr) && (fused >= 2 || (int64_t)n * tiles_x * tiles_y >= 1024)) {
+        int64_t grid = (int64_t)n * tiles_x * tiles_y;
+        static const int cap = getenv("VD_HAL_GRID") ? atoi(getenv("VD_HAL_GRID")) : 512;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL(hal_bwd_fused_kernel, dim3((unsigned)grid), dim3(256), 0, st, g_out, stat, dyn, sidx, didx, w, n, T, H, W,
+                           tiles_x, tiles_y, g_dyn, g_stat, g_w, g_b);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(hal_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g_out, sidx, didx,
                        w, n, T, H, W, g_dyn, g_stat);
     int e = (int)hipGetLastError();
