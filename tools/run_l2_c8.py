@@ -1,5 +1,5 @@
 """The real side's last level alone (VD_PREC_F16C8 program of EmbedEngine(last_hilo='c8'), 3200 clips per launch), N launches on random
-operands -- for kernel traces and PMC passes of that program by itself (tools/pmc_c8.sh)."""
+operands -- for kernel traces and PMC passes of that program by itself (tools/archive_r04/pmc_c8.sh)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -8,7 +8,7 @@ nclips = 512
 li = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 alone = "--alone" in sys.argv        # one workgroup per CU: a workgroup's phases without a partner on its SIMDs
 if li == 0:
-    os.environ["VD_L0_BREG"] = "0"   # (the generic tile-program kernel carries these stamps; the breg kernels: tools/stamps_breg2.py)
+    os.environ["VD_L0_BREG"] = "0"   # (the generic tile-program kernel carries these stamps; the first-level kernel: tools/stamps_l0.py)
 geo = plan.NetGeometry(16, 112, 112)
 x = torch.randn(nclips, 16, 3, 112, 112, device="cuda")
 params = [torch.randn(s, device="cuda") * 0.02 for s in [(64,3,3,7,7),(64,),(128,64,3,7,7),(128,),(128,128,3,7,7),(128,)]]

@@ -1,4 +1,4 @@
-"""Per-stream timeline of one steady-state step out of a rocprofv3 --kernel-trace csv (tools/ab_prep_trace.sh):
+"""Per-stream timeline of one steady-state step out of a rocprofv3 --kernel-trace csv (tools/trace_step.sh):
    python tools/trace_timeline.py <kernel_trace.csv> [step_from_end]"""
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
