@@ -810,7 +810,7 @@ bool plan_wgrad(int cin, int cout, int t_in, int h_in, int w_in, int nclips, int
 
 // plan.export_program: 40 int64 header words + int32 arrays type_desc | tables | boxes | gather | widx | col_off
 // (box walks of the first-level kernels: the grid is this many generations of resident workgroups -- see plan.export_program)
-#define VD_BOX_WALK_GENERATIONS 8
+#define VD_BOX_WALK_GENERATIONS 16      // plan.BOX_WALK_GENERATIONS
 std::vector<uint8_t> export_program(const Plan& pl, int persist) {
     std::vector<int32_t> desc, tables;
     int64_t pos = 0;

@@ -181,10 +181,11 @@ PROGRAM_MAGIC = b"VDPROG01"
 PROGRAM_HEADER_WORDS = 40
 
 
-BOX_WALK_GENERATIONS = 8     # first-level kernels walk boxes: grid = this many generations of resident workgroups.  4 -> 8 in round 3:
-#                              same stand-alone time (1.47 / 1.46 ms per 512 clips), but a workgroup of the eight-wave first-level
-#                              kernel holds its CU's LDS for half as long, so the synthetic-clip stream's kernels find CUs during
-#                              the first level instead of piling onto level 1 (step 35.66 / 35.63 ms, level-1 launch 21.6 -> 20.8 ms)
+BOX_WALK_GENERATIONS = 16    # first-level kernels walk boxes: grid = this many generations of resident workgroups.  4 -> 8 in round 3 (a
+#                              workgroup of the eight-wave first-level kernel holds its CU's LDS for half as long, so the synthetic-clip
+#                              stream's kernels find CUs during the first level instead of piling onto level 1), 8 -> 16 in round 5 with
+#                              the faster kernel: stand-alone 7.95 / 7.87 / 7.91 / 8.01 ms at 8 / 4 / 16 / 32 (noise), DM step 31.78 -> 31.67 ms
+#                              (4: 31.95), two same-box pairs each
 
 
 def export_program(plan: "ConvPlan", persist: int = BOX_WALK_GENERATIONS) -> bytes:
