@@ -9,6 +9,9 @@ n, T, H, W = 50, 16, 112, 112                      # config 3's hallucinator bat
 nel = 64 * 3 * 147 + 64 + 128 * 64 * 147 + 128 + 128 * 128 * 147 + 128 + 50 * 128 + 50          # one ConvNet3D gradient list
 SPEC = {
     "hal_fwd_kernel": ("vd_hallucinator_fwd", n * (3 * H * W + T * H * W + 3 * T * H * W) * 4),
+    "hal_bwd_fused_kernel": ("vd_hallucinator_bwd (round 5, one kernel: upstream gradient, dynamic and static read once; g_dyn + g_stat written; "
+                             "bound by vector-ALU / LDS issue -- 162 multiply-adds per pixel and frame --, not by HBM)",
+                             n * (3 * T * H * W + 2 * T * H * W + 2 * 3 * H * W) * 4),
     "hal_bwd_data_kernel": ("vd_hallucinator_bwd (data half: upstream gradient read once, g_dyn + g_stat written)", n * (3 * T * H * W + T * H * W + 3 * H * W) * 4),
     "hal_bwd_param_kernel": ("vd_hallucinator_bwd (parameter half: upstream gradient + dynamic + static read)", n * (3 * T * H * W + T * H * W + 3 * H * W) * 4),
     "match_rows_fwd_multi_kernel": ("vd_match_rows_fwd_multi (match_loss forward, one gradient list pair)", 2 * nel * 4),

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerate the evidence under profiles/ on a GPU box (run from the repo root through gpurun);
-# results land in gpurun_out/prof/ and are copied to profiles/r04_* afterwards (tools/copy_profiles.sh).
+# results land in gpurun_out/prof/ and are copied to profiles/r05_* afterwards (tools/copy_profiles.sh).
 # Every rocprofv3 run is bounded by `timeout` and writes csv (the rocpd default has hung a box for its whole limit).
 # PMC passes run alone (--kernel-trace only next to --pmc), one counter group per run.
 set -u
@@ -16,6 +16,11 @@ python3 bench.py --method dc --classes 51 --ipc 5 --steps 3 --warmup 1 2>/dev/nu
 python3 bench.py --method mtt --classes 400 --frames 8 --size 64 --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_mtt.json
 VD_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 8 --steps 3 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --eval-epochs 1 --eval-seeds 1 --exchange-leg --no-extra-legs 2>/dev/null | tail -1 > $OUT/bench_8ranks_one_device.json
 python3 tools/mfma_peak.py > $OUT/mfma_peak.txt 2>/dev/null
+python3 tools/l0_ab.py 3200 8 > $OUT/l0_kernel_ab.txt 2>/dev/null
+python3 tools/stamps_l0.py 3200 5 2>/dev/null | tail -10 > $OUT/l0_phase_stamps.txt
+python3 tools/hal_check.py 50 16 112 112 2>/dev/null | tail -2 > $OUT/hal_bwd.txt
+VD_HAL_FUSED=0 python3 tools/hal_check.py 50 16 112 112 2>/dev/null | tail -2 >> $OUT/hal_bwd.txt
+python3 tools/rank_proxy.py 1 2 4 8 > $OUT/rank_proxy.txt 2>/dev/null
 python3 tools/bench_train.py 50 > $OUT/train_step.txt 2>/dev/null
 VD_DETERMINISTIC=1 python3 tools/bench_train.py 50 > $OUT/train_step_deterministic.txt 2>/dev/null
 cd /tmp
@@ -39,6 +44,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp $(ls $OUT/pmc_$c/*/*counter_collection.csv | head -1) $OUT/pmc_${c}_counter_collection.csv
 done
 cd $ROOT
+tools/trace_step.sh prof_step > /dev/null 2>&1; cp gpurun_out/prof_step_timeline.txt $OUT/step_timeline.txt 2>/dev/null
 python3 tools/pmc_real_side.py $OUT/pmc_FETCH_SIZE_counter_collection.csv $OUT/pmc_WRITE_SIZE_counter_collection.csv 3200 $OUT/pmc_traffic.json > /dev/null
 python3 tools/aux_kernel_gbps.py $OUT/aux_kernel_stats.csv $OUT/aux_kernels.json > /dev/null
 rm -rf $OUT/bench $OUT/s2d $OUT/dc $OUT/mtt $OUT/aux $OUT/syn_side $OUT/train_atomic $OUT/train_deterministic $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
