@@ -20,7 +20,7 @@ python3 tools/l0_ab.py 3200 8 > $OUT/l0_kernel_ab.txt 2>/dev/null
 python3 tools/stamps_l0.py 3200 5 2>/dev/null | tail -10 > $OUT/l0_phase_stamps.txt
 python3 tools/hal_check.py 50 16 112 112 2>/dev/null | tail -2 > $OUT/hal_bwd.txt
 VD_HAL_FUSED=0 python3 tools/hal_check.py 50 16 112 112 2>/dev/null | tail -2 >> $OUT/hal_bwd.txt
-python3 tools/rank_proxy.py 1 2 4 8 > $OUT/rank_proxy.txt 2>/dev/null
+for n in 1 2 4 8; do python3 tools/rank_proxy.py $n 2>/dev/null; done > $OUT/rank_proxy.txt       # (one process per N: x of N=1 from the first line)
 python3 tools/bench_train.py 50 > $OUT/train_step.txt 2>/dev/null
 VD_DETERMINISTIC=1 python3 tools/bench_train.py 50 > $OUT/train_step_deterministic.txt 2>/dev/null
 cd /tmp
