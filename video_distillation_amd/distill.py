@@ -508,8 +508,8 @@ def check_real_range(trainer) -> None:
         return
     torch.cuda.synchronize(be.device)
     r = be.check_real_range()
-    if r is not None:
-        trainer.real_range = r
+    if r is not None and (r["absmax"] > 0.0 or r["saturated"] > 0 or getattr(trainer, "real_range", None) is None):
+        trainer.real_range = r          # (a check with no launch since the previous one keeps the previous record)
 
 
 class DMTrainer:
