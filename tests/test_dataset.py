@@ -36,6 +36,7 @@ def _check_item(g, tag, k, x, y):
     ("ucf_train", lambda: D.UCF101(UCF, "train"), 2),
     ("ucf_test", lambda: D.UCF101(UCF, "test"), 2),
     ("hmdb_train", lambda: D.HMDB51(UCF, "train"), 1),
+    ("minihmdb_train", lambda: D.miniHMDB51(UCF, "train"), 1),
     ("mini_train", lambda: D.miniUCF101(UCF, "train"), 1),
     ("mini_seg", lambda: D.miniUCF101(UCF, "train", sample="split-random"), 1),
 ])

@@ -626,7 +626,7 @@ def _write_frame_tree(root):
         os.makedirs(d, exist_ok=True)
         for t in range(1, n + 1):
             frame(vi, t, 112).save(os.path.join(d, "frame%06d.jpg" % t), quality=60)
-    for csv_name in ("ucf101_splits1.csv", "ucf50_splits1.csv", "hmdb51_splits.csv"):
+    for csv_name in ("ucf101_splits1.csv", "ucf50_splits1.csv", "hmdb51_splits.csv", "hmdb25_splits.csv"):
         with open(os.path.join(ucf, csv_name), "w") as fp:
             fp.write("folder_name,label,split\n")
             for name, label, split, _ in vids:
@@ -679,6 +679,7 @@ def g15():
     record("ucf_train", RD.UCF101(ucf, "train", tf), 2)          # second pass: kept start frames, fresh flips
     record("ucf_test", RD.UCF101(ucf, "test", tf), 2)            # test items redraw the start every visit
     record("hmdb_train", RD.HMDB51(ucf, "train", tf), 1)
+    record("minihmdb_train", RD.miniHMDB51(ucf, "train", tf), 1)
     record("mini_train", RD.miniUCF101(ucf, "train", tf), 1)
     record("mini_seg", RD.miniUCF101(ucf, "train", tf, sample="split-random"), 1)
     kin = os.path.join(root, "kinetics_64x64x8")

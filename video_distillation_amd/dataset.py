@@ -1,11 +1,11 @@
 """Frame-folder video datasets and their HBM-resident preload.
 
-The reference reads its real clips from folders of JPEG frames through five near-identical ``Dataset`` classes
-(distill_utils/dataset.py: ``UCF101`` :146-249, ``HMDB51`` :251-351, ``miniUCF101`` :353-467, ``Kinetics400`` :79-144,
-``SSv2`` :841-895) and, under ``--preload``, stacks every item into one host tensor that ``get_images`` then slices and
+The reference reads its real clips from folders of JPEG frames through six near-identical ``Dataset`` classes
+(distill_utils/dataset.py: ``UCF101`` :146-249, ``HMDB51`` :251-351, ``miniUCF101`` :353-467, ``miniHMDB51`` :469-568,
+``Kinetics400`` :79-144, ``SSv2`` :841-895) and, under ``--preload``, stacks every item into one host tensor that ``get_images`` then slices and
 copies to the GPU per class and step (distill_baseline.py:36-45, 84-90; 7.7 GB of PCIe traffic per step at config 2).
 
-Here one class, ``FrameFolderVideos``, covers the five (a ``spec`` says where the index file is and how frames are
+Here one class, ``FrameFolderVideos``, covers the six (a ``spec`` says where the index file is and how frames are
 picked), with the reference's item semantics — including the ORDER in which the global ``numpy.random`` / ``random`` /
 ``torch`` generators are consumed, so a seeded run picks the same frames, flips and crops — and ``preload`` puts the
 whole split into HBM once: JPEG decode on host threads (PIL releases the GIL), uint8 frames through pinned staging,
@@ -50,6 +50,7 @@ SPECS = {
     'UCF101': FolderSpec('csv-splits', 'ucf101_splits1.csv', 'jpegs_112', 'window'),
     'HMDB51': FolderSpec('csv-splits', 'hmdb51_splits.csv', 'jpegs_112', 'window'),
     'miniUCF101': FolderSpec('csv-splits', 'ucf50_splits1.csv', 'jpegs_112', 'window'),
+    'miniHMDB51': FolderSpec('csv-splits', 'hmdb25_splits.csv', 'jpegs_112', 'window'),          # distill_utils/dataset.py:469-568
     'Kinetics400': FolderSpec('csv-kinetics', '{split}.csv', '{split}', 'all'),
     'SSv2': FolderSpec('json-ssv2', 'annot_{split}.json', 'frame', 'all'),
 }
@@ -234,6 +235,10 @@ def HMDB51(path, split, transform=None):
 
 def miniUCF101(path, split, transform=None, sample='random'):
     return FrameFolderVideos('miniUCF101', path, split, transform, sample)
+
+
+def miniHMDB51(path, split, transform=None):
+    return FrameFolderVideos('miniHMDB51', path, split, transform)
 
 
 def Kinetics400(path, split, transform=None):
