@@ -125,6 +125,30 @@ def test_g4_hallucinator_module(golden_dir):
     np.testing.assert_allclose(hal.encoder.bias.grad.cpu().numpy(), z["g_bias"], rtol=1e-4, atol=2e-2)
 
 
+def test_hallucinator_add_mode_on_the_fused_kernel():
+    """``Conv3DNet(mode='add')`` (utils.py:1179-1197: x = static + dynamic, Conv3d(3 -> 3)) on the fused hallucinator kernels through
+    a derived 4-channel weight, against the reference's own expression evaluated with torch ops in fp64 on the CPU (a checker):
+    output and all four gradients."""
+    from video_distillation_amd import utils
+    torch.manual_seed(41)
+    hal = utils.Conv3DNet(mode='add').cuda()
+    assert tuple(hal.encoder.weight.shape) == (3, 3, 3, 3, 3)
+    static, dynamic, up = randn(43, (4, 3, 40, 48), (4, 6, 1, 40, 48), (4, 6, 3, 40, 48))
+    s1, d1 = static.cuda().requires_grad_(True), dynamic.cuda().requires_grad_(True)
+    out = hal(s1, d1)
+    (out * up.cuda()).sum().backward()
+    w64, b64 = hal.encoder.weight.detach().double().cpu().requires_grad_(True), hal.encoder.bias.detach().double().cpu().requires_grad_(True)
+    s2, d2 = static.double().requires_grad_(True), dynamic.double().requires_grad_(True)
+    x = s2.repeat(6, 1, 1, 1, 1).permute(1, 2, 0, 3, 4) + d2.permute(0, 2, 1, 3, 4)
+    ref = torch.nn.functional.conv3d(x, w64, b64, padding=1).permute(0, 2, 1, 3, 4)
+    (ref * up.double()).sum().backward()
+    rel = lambda a, r: float((a.double().cpu() - r).norm() / r.norm())
+    errs = [rel(out.detach(), ref.detach()), rel(d1.grad, d2.grad), rel(s1.grad, s2.grad), rel(hal.encoder.weight.grad, w64.grad),
+            rel(hal.encoder.bias.grad, b64.grad)]
+    print("add-mode hallucinator vs fp64: out %.1e, g_dyn %.1e, g_stat %.1e, g_w %.1e, g_b %.1e" % tuple(errs))
+    assert max(errs) < 5e-6
+
+
 def test_g5_s2d_step_trainer(golden_dir):
     from video_distillation_amd import distill, plan
     z = np.load(os.path.join(golden_dir, "g5_s2d_step.npz"))

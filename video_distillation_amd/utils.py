@@ -6,8 +6,8 @@ docstring, so that its driver scripts can ``from video_distillation_amd.utils im
 unchanged.  ``args`` is the reference's duck-typed namespace (``device``, ``dis_metric``,
 ``lr_net``, ``epoch_eval_train``, ``batch_train``, ``model``, ``eval_mode``).
 
-Everything here runs on the HIP kernels, with one stated exception: ``Conv3DNet(mode='add')`` -- a constructor option no
-script of the reference selects (utils.py:1179 default 'concat') -- composes torch ops.
+Everything here runs on the HIP kernels -- since round 5 also ``Conv3DNet(mode='add')``, a constructor option no script of
+the reference selects (utils.py:1179, default 'concat'): the same fused kernel with a derived 4-channel weight.
 """
 from __future__ import annotations
 
@@ -181,17 +181,22 @@ class Conv3DNet(nn.Module):
         self.encoder = nn.Conv3d(in_channel, mid_channel, kernel_size, padding=1)
 
     def forward(self, static, dynamic):
-        if self.mode != 'concat':
-            if self.mode == 'add':   # unused by every shipped script; kept on torch ops
-                f = dynamic.shape[1]
-                x = static.repeat(f, 1, 1, 1, 1).permute(1, 2, 0, 3, 4) + dynamic.permute(0, 2, 1, 3, 4)
-                return self.encoder(x).permute(0, 2, 1, 3, 4)
+        if self.mode not in ('concat', 'add'):
             raise NotImplementedError
         if not dynamic.is_cuda:
             raise RuntimeError("Conv3DNet has no CPU path: move the memories to a HIP device")
-        if tuple(self.encoder.weight.shape) != (3, 4, 3, 3, 3):
+        weight = self.encoder.weight
+        if self.mode == 'add':
+            # utils.py:1193: x = static + dynamic (the one dynamic channel broadcast over the three static ones), then Conv3d(3 -> 3).
+            # The convolution is linear: conv(static + dyn, W) = conv(cat(static, dyn), W') with W'[:, :3] = W and W'[:, 3] =
+            # sum_ci W[:, ci] -- the SAME fused kernel with a derived 4-channel weight (a 108-float tensor op; autograd carries
+            # d/dW' back: dW[:, ci] = dW'[:, ci] + dW'[:, 3])
+            if tuple(weight.shape) != (3, 3, 3, 3, 3):
+                raise NotImplementedError("HIP hallucinator (mode='add') is built for Conv3d(3->3, k=3)")
+            weight = torch.cat([weight, weight.sum(1, keepdim=True)], 1)
+        elif tuple(weight.shape) != (3, 4, 3, 3, 3):
             raise NotImplementedError("HIP hallucinator is built for Conv3d(4->3, k=3)")
-        return _HallucinatorFunction.apply(static, dynamic, self.encoder.weight, self.encoder.bias)
+        return _HallucinatorFunction.apply(static, dynamic, weight, self.encoder.bias)
 
 
 # ------------------------------------------------------------------------------------------
