@@ -138,7 +138,7 @@ class _DevPlan:
         p = self.params
         p.emit_lo = int(emit_lo)        # single-pass program, staged pooled epilogue: 1 = also write the fp16 low plane (dst_plane_stride
         #                                 behind), 2 = write fp8 low parts there instead (for a VD_PREC_F16C8 consumer)
-        if int(emit_lo) == 2:           # ... whose fixed scalings hold for a RANGE of output magnitudes: the launch records what it saw
+        if int(emit_lo) == 2 and _RANGE_MONITOR:      # ... whose fixed scalings hold for a RANGE of output magnitudes: the launch records what it saw
             if self.range_stats is None:
                 self.range_stats = torch.zeros(2, dtype=torch.int32, device=src.device)
             p.range_stats = self.range_stats.data_ptr()
@@ -180,6 +180,9 @@ class _DevPlan:
         if prof is not None:
             e1.record()
             prof.append((self.plan.name, self.prec, 2.0 * self.plan.meta.get("macs_per_unit", 0) * nclips, e0, e1))
+
+
+_RANGE_MONITOR = os.environ.get("VD_RANGE_MONITOR", "1") == "1"      # (0: A/B of the monitor's cost in the level-1 epilogue)
 
 
 class _PackState(threading.local):       # per host thread: packs queued by one thread are flushed on that thread's current stream
