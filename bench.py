@@ -75,6 +75,12 @@ def parse():
                          "C*ipc-clip gradient tensor, 120 MB at config 2, summed over the ranks through vd_comm_allreduce_f32 = RCCL).  "
                          "With more than one rank the mode that is NOT timed runs as a short extra leg (exchange_allreduce / exchange_owner)")
     ap.add_argument("--exchange-leg", action="store_true", help="dm: run the other exchange mode's short leg even with --no-extra-legs")
+    ap.add_argument("--vd-comm", choices=["auto", "on", "off"], default="auto",
+                    help="the library's own RCCL communicator (hip.Comm -> vd_comm_*) for the pixel-gradient all-reduce and the `rccl` "
+                         "block of the line.  auto: on one rank (where it has been exercised on every GPU test run), OFF on more than "
+                         "one -- a SECOND communicator beside torch's, created and used for the first time on N devices, is not "
+                         "something a scaling run should depend on: the all-reduce then goes through torch.distributed's group (the "
+                         "same RCCL), and `rccl` reports that group.  on: use it at any world size")
     ap.add_argument("--syn-steps", type=int, default=10, help="--method mtt: unrolled student steps (sh/s2d/s2d_MTT_ms_K400.sh)")
     ap.add_argument("--batch-syn", type=int, default=256, help="--method mtt: composed clips per student step")
     ap.add_argument("--mtt-raw", action="store_true", help="--method mtt: raw synthetic clips (distill_baseline.py MTT) instead of "
@@ -212,7 +218,8 @@ class Harness:
         """An RCCL communicator over the ranks behind the C ABI (hip.Comm -> vd_comm_*), when the process group runs on RCCL
         (backend nccl: one device per rank); None otherwise (one process without a group, or the one-device gloo logic mode)."""
         import torch.distributed as dist
-        if self.comm is None and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        want = self.args.vd_comm == "on" or (self.args.vd_comm == "auto" and self.world == 1)
+        if self.comm is None and want and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
             from video_distillation_amd import hip
             self.comm = hip.Comm(self.rank, self.world)
         return self.comm
@@ -240,6 +247,10 @@ class Harness:
                 v = hip.Comm.version()
                 rec["rccl"] = {"version_code": v, "version": None if v is None else "%d.%d.%d" % (v // 10000, v // 100 % 100, v % 100),
                                "nranks": comm.size(), "torch_nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version())}
+            elif dist.get_backend() == "nccl":
+                rec["rccl"] = {"through": "torch.distributed process group (backend nccl = RCCL); the library's own communicator is off "
+                                          "at world > 1 unless --vd-comm on", "nranks": dist.get_world_size(),
+                               "torch_nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version())}
             else:
                 rec["rccl"] = {"note": "process group on gloo (all ranks share device 0: RCCL refuses two ranks on one device)"}
         return rec
