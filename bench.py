@@ -19,10 +19,14 @@ between HIP events recorded behind each step's last kernel.  Extra objects:
   roofline      -- the conv tile program with the largest share of the timed region's GPU time: algorithmic FLOP per launch
                    / mean launch time (HIP events on the launch stream, inside the timed region) against the 2.5 PFLOP/s
                    dense 16-bit MFMA peak; `peak_measured` = this box's MFMA-saturating microbenchmark (vd_mfma_peak);
-                   `traffic` = HBM bytes per launch from the committed PMC passes (static, see traffic_source);
+                   `traffic` = HBM bytes per launch from the committed PMC passes, quoted only while the file's stamp equals the
+                   hash of this checkout's kernel sources (else null; see traffic_source);
+  per_rank      -- every rank's real clips, own ms per step, wait at the closing barrier, real-side ms, exchange ms (N > 1:
+                   what tells an unbalanced partition from a slow collective from a slow device);
   cpu_baseline  -- the CPU oracle (torch fp32 ops == what the reference runs on a CPU) timed on this host's cores on a
                    bounded sample of the same workload, extrapolated to steps/s; rank 0, N=1 only;
-  eval          -- evaluate_synset on the synthetic clips (HIP train step + HIP inference): top-1 beside the metric;
+  eval          -- evaluate_synset on the synthetic clips (HIP train step + HIP inference): a reproducible SMOKE of that path, not
+                   an accuracy metric (accuracy parity: fixture G16, tests/test_gpu_eval_parity.py);
   sustained     -- the same step loop run for --sustain-seconds: steps/s once clocks have settled.
 """
 import argparse
