@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p
             // ---- the other half: finish box jn - 1 (its accumulators are in this wave's registers since the previous phase) and build
             //      the kw-slots of box jn = (q + 1 - grp) / 2 ----
             const int jn = (q + 1 - grp) >> 1;
-            const bool have_next = jn >= 0 && jn < nmine, have_prev = jn - 1 >= 0 && jn - 1 < nmine;
+            const bool have_prev = jn - 1 >= 0 && jn - 1 < nmine;
             load_raw();                      // (unconditional: keeps `raw` out of the K loop's live ranges; box scalars: prep_rows)
             __builtin_amdgcn_sched_barrier(0);
             if (have_prev) {
