@@ -1,0 +1,31 @@
+"""Host logic of bench.py that needs no GPU: the stamped PMC traffic figure."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pmc_traffic_is_quoted_only_for_the_stamped_kernel_sources(monkeypatch):
+    """``roofline.traffic`` travels in a file (counters cannot be read inside the timed run); the file carries the sha256 of the
+    kernel sources + ABI header it was measured on, and bench.py quotes it only while that equals the checkout's own hash and
+    the launch shape is the file's -- otherwise null with the reason (round 4 quoted a file five commits old)."""
+    import bench
+    from video_distillation_amd import hip
+    doc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
+    stamp = doc["_source"]["kernel_sources_sha256_16"]
+    rec = doc["conv1_fwd_f16"]
+    assert len(stamp) == 16 and rec["clips_per_launch"] == 3200
+    if stamp == hip.sources_hash():          # the committed file belongs to the committed sources: quoted
+        val, src = bench.pmc_traffic("conv1_fwd_f16", 3200)
+        assert val == rec["hbm_bytes_per_launch"] and "measured, unscaled" in src and stamp in src
+    else:                                    # a kernel was touched since: refused until tools/final_pmc.sh has re-measured it on a GPU box
+        val, src = bench.pmc_traffic("conv1_fwd_f16", 3200)
+        assert val is None and "other kernel sources" in src
+    monkeypatch.setattr(hip, "sources_hash", lambda: stamp)            # (from here on: as if the file were current)
+    val, src = bench.pmc_traffic("conv1_fwd_f16", 400)                 # another launch shape (an 8-rank job): not rescaled, refused
+    assert val is None and "not quoted" in src
+    monkeypatch.setattr(hip, "sources_hash", lambda: "0" * 16)         # any other kernel sources
+    val, src = bench.pmc_traffic("conv1_fwd_f16", 3200)
+    assert val is None and "other kernel sources" in src and "re-measure" in src
