@@ -247,3 +247,46 @@ def test_exported_program_blob_layout():
         np.testing.assert_array_equal(ints[o:o + int(h[31])], pl.gather_table().reshape(-1))
         np.testing.assert_array_equal(ints[o + int(h[31]):o + int(h[31]) + int(h[32])], pl.widx.reshape(-1))
         assert h[22] == pl.ncl and h[23] == pl.nbox and h[24] == pl.gather_table().shape[1]
+
+
+@pytest.mark.parametrize("geom", [(16, 112, 112), (8, 64, 64), (12, 96, 80), (6, 48, 64), (10, 40, 48)])
+def test_first_level_frame_tiles_have_the_structure_the_sharing_kernel_relies_on(geom):
+    """plan_forward_pix (round 5): wherever the pooled width is a multiple of 4 the first level is planned in FRAME TILES -- the four
+    M tiles of a wave row are the same 32 positions in consecutive frames, K step 3 j + kt holds tap pair j of kernel plane kt with
+    both taps in that plane, the A-fragment reads are free of LDS bank conflicts at pitches 9 / 189, and ``pair_flip`` carries the
+    flip mask + the pitches -- which is what lets conv0_breg_kernel<PREC, true> read one fragment for up to three MFMAs with
+    instruction-offset taps.  Geometries that do not split that way fall back to frame-pair row groups."""
+    t_in, h, w = geom
+    pl = P.plan_forward_pix("fwd0", 64, t_in, h, w)
+    OW = P.conv_out_dim(w, P.KW, 2, 3)
+    if (OW // 2) % 4 != 0 or pl.meta["box"] != (4, 8, 8):        # (e.g. 6 frames: the box chooser takes all six, 6 x 4 x 8)
+        assert pl.pair_flip == 0 and pl.out_t_stride == (P.conv_out_dim(h, P.KH, 2, 3) // 2) * (OW // 2) and "frame_tiles" not in pl.meta
+        assert geom in ((6, 48, 64), (10, 40, 48))
+        return
+    assert pl.meta.get("frame_tiles") == 1 and (pl.NT, pl.MW, pl.MTW, pl.S) == (2, 2, 4, 32)
+    assert pl.pair_flip == P.FRAME_TILE_FLIP | (9 << 8) | (189 << 16) and pl.out_t_stride == P.FRAME_TILE_OUT_STEP
+    for t in pl.types:
+        assert (t.pitch_h, t.pitch_f) == (9, 189) and t.conflict_cycles == 4.0
+        a = t.a_off.reshape(2, 4, 32)
+        for i in range(4):                                       # tile i = tile 0 one frame (three planes) further
+            assert (a[:, i] - a[:, 0] == i * 3 * 189 * 16).all()
+        tp = t.tap_off.reshape(32, 2)
+        for j in range(10):
+            q0, q1 = 2 * j, 2 * j + 1                            # (c, kh) = divmod(q, 7): both taps of a pair in one kernel plane
+            want = [((q // 7) * 189 + (q % 7) * 9) * 16 for q in (q0, q1)]
+            for kt in range(3):
+                assert tp[3 * j + kt].tolist() == [v + kt * 3 * 189 * 16 for v in want]
+        last = (2 * 189 + 6 * 9) * 16                            # q = 20: (c, kh) = (2, 6)
+        assert tp[30].tolist() == [last, last + 3 * 189 * 16] and tp[31].tolist() == [last + 2 * 3 * 189 * 16, 0]
+    # every output position appears exactly once over the out tables of a clip (both windows of every row group)
+    T = P.conv_out_dim(t_in, P.KT, 1, 1); Ho = P.conv_out_dim(h, P.KH, 2, 3) // 2; Wo = OW // 2
+    seen = np.zeros(T * Ho * Wo, dtype=np.int64)
+    for box in pl.boxes:
+        t = pl.types[int(box[0])]
+        for k, o in enumerate(t.out):
+            if o < 0:
+                continue
+            step = -pl.out_t_stride if (pl.pair_flip >> (k & 3)) & 1 else pl.out_t_stride
+            for st in range(2):
+                seen[int(box[4]) + int(o) + st * step] += 1
+    assert (seen == 1).all()
