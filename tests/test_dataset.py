@@ -148,3 +148,128 @@ def test_device_batches_follow_the_dataloader_shuffle(own_generator):
         assert got == want and len(mine) == 3
         assert torch.equal(torch.rand(1), after_ref)                      # the global generator advanced identically
         assert all(torch.equal(b[0].view(-1), b[1].float()) for b in mine)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# still-frame families (fixture G17, tools/gen_golden.py::g17)
+# ---------------------------------------------------------------------------------------------------------------------
+SSV2 = os.path.join(GOLD, "frames", "SSv2_64x8")
+
+
+@pytest.fixture(scope="module")
+def g17():
+    return np.load(os.path.join(GOLD, "g17_still_datasets.npz"))
+
+
+@pytest.mark.parametrize("tag,make,shape", [
+    ("shmdb_train", lambda: D.staticHMDB51(UCF, "train"), (16, 3, 112, 112)),
+    ("shmdb_test_image", lambda: D.staticHMDB51(UCF, "test", frames=1), (3, 112, 112)),
+    ("sucf_train", lambda: D.staticUCF101(UCF, "train"), (16, 3, 112, 112)),
+    ("sucf_part1of3", lambda: D.staticUCF101(UCF, "train", frames=4, split_num=3, split_id=1), (4, 3, 112, 112)),
+    ("sucf_part_wraps", lambda: D.staticUCF101(UCF, "test", frames=1, split_num=2, split_id=2), (3, 112, 112)),
+    ("s50_mean", lambda: D.staticUCF50(UCF, "train", frames=2, split_num=4, split_id=3, split_mode='mean'), (2, 3, 112, 112)),
+] + [("s50_feature%d" % k, (lambda k=k: D.staticUCF50(UCF, "train", frames=1, split_num=4, split_id=k, split_mode='feature')), (3, 112, 112))
+     for k in range(4)])
+def test_static_datasets_match_reference_items(g17, tag, make, shape):
+    ds = make()
+    np.testing.assert_array_equal(g17["%s_labels" % tag], np.array(ds.labels))
+    _seed()
+    k = 0
+    for _ in range(2):
+        for i in range(len(ds)):
+            x, y = ds[i]
+            assert x.shape == shape and x.dtype == torch.float32
+            assert ds.start[i] == int(g17["%s_%d_frame" % (tag, k)])
+            assert int(g17["%s_%d_label" % (tag, k)]) == y
+            np.testing.assert_array_equal(g17["%s_%d_probe" % (tag, k)], x[..., ::16, ::16].numpy())
+            sums = g17["%s_%d_sums" % (tag, k)]
+            assert float(x.double().sum()) == pytest.approx(sums[0], rel=1e-12, abs=1e-9)
+            assert float((x.double() ** 2).sum()) == pytest.approx(sums[1], rel=1e-12)
+            if x.dim() == 4:
+                assert all(torch.equal(x[0], x[t]) for t in range(1, x.shape[0]))       # one frame, repeated
+            k += 1
+    assert k == int(g17["%s_count" % tag])
+
+
+def test_static_part_ranges_and_bad_mode():
+    ds = D.staticUCF50(UCF, "train", frames=1, split_num=4, split_id=2, split_mode='feature')
+    assert ds.split_lists[0] == [12, 25, 40]                             # the index file lists them unsorted
+    assert ds._frame_range(0, 64) == (26, 41)
+    assert D.staticUCF50(UCF, "train", split_num=4, split_id=0, split_mode='feature')._frame_range(0, 64) == (1, 13)
+    assert D.staticUCF50(UCF, "train", split_num=4, split_id=3, split_mode='feature')._frame_range(0, 64) == (41, 64)
+    assert D.staticUCF101(UCF, "train", split_num=3, split_id=1)._frame_range(1, 40) == (14, 26)
+    assert D.staticHMDB51(UCF, "train")._frame_range(2, 36) == (1, 36)
+    with pytest.raises(SystemExit):
+        D.staticUCF50(UCF, "train", split_mode='other')
+    with pytest.raises(ValueError):
+        D.StillFrameVideos('UCF101', UCF, "train")
+
+
+@pytest.mark.parametrize("tag,make,path,frames_tag,fixture", [
+    ("skin", D.singleKinetics400, KIN, "kin", "g15"), ("sssv2", D.singleSSv2, SSV2, "ssv2", "g17")])
+def test_single_frame_sets_pick_a_listed_file(g15, g17, tag, make, path, frames_tag, fixture):
+    """One ``random.randint`` per item and nothing else; the image is the listed file at that position (directory order is
+    the box's, so pixels are looked up by file name in the per-frame records of the video-class fixtures)."""
+    frames = g15 if fixture == "g15" else g17
+    for split in ("train", "val"):
+        ds = make(path, split)
+        assert [os.path.basename(d) for d in ds.video_dirs] == g17["%s_%s_dirs" % (tag, split)].tolist()
+        np.testing.assert_array_equal(g17["%s_%s_labels" % (tag, split)], np.array(ds.labels))
+        picks = g17["%s_%s_picks" % (tag, split)].tolist()
+        random.seed(7)
+        np_state, torch_state = np.random.get_state()[1].copy(), torch.get_rng_state()
+        k = 0
+        for _ in range(3):
+            for i in range(len(ds)):
+                x, y = ds[i]
+                assert x.shape == (3, 64, 64) and y == ds.labels[i]
+                name = os.listdir(ds.video_dirs[i])[picks[k]]
+                r = frames["%s_%s_%d_names" % (frames_tag, split, i)].tolist().index(name)
+                np.testing.assert_array_equal(frames["%s_%s_%d_probe" % (frames_tag, split, i)][r], x[:, ::8, ::8].numpy())
+                assert float(x.double().sum()) == pytest.approx(float(frames["%s_%s_%d_sums" % (frames_tag, split, i)][r]), rel=1e-12, abs=1e-9)
+                k += 1
+        assert k == len(picks)
+        assert (np.random.get_state()[1] == np_state).all() and torch.equal(torch.get_rng_state(), torch_state)
+
+
+def test_ssv2_video_class_listing_and_items(g17):
+    for split in ("train", "val"):
+        ds = D.SSv2(SSV2, split)
+        assert [os.path.basename(d) for d in ds.video_dirs] == g17["ssv2_%s_dirs" % split].tolist()
+        np.testing.assert_array_equal(g17["ssv2_%s_labels" % split], np.array(ds.labels))
+        assert ds.skipped == (1 if split == "train" else 0)              # the 6-frame video is not a sample
+        for i in range(len(ds)):
+            x, _ = ds[i]
+            assert x.shape == (8, 3, 64, 64)
+            ref_names = g17["ssv2_%s_%d_names" % (split, i)].tolist()
+            for t, name in enumerate(os.listdir(ds.video_dirs[i])):
+                r = ref_names.index(name)
+                np.testing.assert_array_equal(g17["ssv2_%s_%d_probe" % (split, i)][r], x[t, :, ::8, ::8].numpy())
+
+
+def test_get_dataset_still_branches():
+    root = os.path.join(GOLD, "frames")
+    channel, im_size, num_classes, _, _, _, dst_train, dst_test, loader = D.get_dataset("staticUCF50", root, split_num=4, split_id=2)
+    assert (channel, im_size, num_classes) == (3, (112, 112), 50) and dst_train.frames == 16
+    assert (dst_train.split_num, dst_train.split_id) == (1, 0)           # static* branches do not forward the split arguments
+    assert next(iter(loader))[0].shape == (2, 16, 3, 112, 112)
+    _, _, nc, _, _, _, tr, te, loader = D.get_dataset("singleUCF50", root, split_num=4, split_id=2, split_mode='feature')
+    assert nc == 50 and (tr.frames, tr.split_num, tr.split_id, tr.split_mode) == (1, 4, 2, 'feature')
+    assert next(iter(loader))[0].shape == (2, 3, 112, 112)
+    _, _, nc, _, _, _, tr, te, _ = D.get_dataset("singleUCF101", root, split_num=2, split_id=1)
+    assert nc == 101 and tr.family == 'staticUCF101' and (tr.split_num, tr.split_id) == (2, 1)
+    _, im_size, nc, _, _, _, tr, _, _ = D.get_dataset("singleUCF101", root, img_size=(64, 64))
+    assert im_size == (64, 64) and tr.transform.resize == (100, 80) and tr[0][0].shape == (3, 64, 64)
+    for name in ("staticHMDB51", "singleHMDB51", "singleKinetics400", "singleSSv2"):
+        with pytest.raises(AssertionError):
+            D.get_dataset(name, root)                                    # directories this tree does not have
+
+
+def test_single_hmdb_resizes_only_for_64(tmp_path):
+    os.symlink(UCF, tmp_path / "HMDB51")
+    _, _, nc, _, _, _, tr, _, _ = D.get_dataset("singleHMDB51", str(tmp_path), img_size=(64, 64))
+    assert nc == 51 and tr.frames == 1 and tr.transform.resize == (100, 80) and tr[0][0].shape == (3, 64, 64)
+    _, _, _, _, _, _, tr, _, _ = D.get_dataset("singleHMDB51", str(tmp_path), img_size=(96, 96))
+    assert tr.transform.resize is None and tr[0][0].shape == (3, 112, 112)          # utils.py:345: no Resize / RandomCrop unless 64x64
+    _, _, _, _, _, _, tr, _, _ = D.get_dataset("staticHMDB51", str(tmp_path), img_size=(96, 80))
+    assert tr.transform.resize == (100, 80) and tr[0][0].shape == (16, 3, 96, 80)

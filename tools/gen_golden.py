@@ -11,6 +11,9 @@ Fixtures follow SURVEY.md section 8(c): G1 layer-wise fwd, G2 DM class term, G3 
 G4 hallucinator, G5 s2d DM step, G6 match_loss KATs, G7 evaluate_synset/epoch, G8 is G3
 re-used by the sharding tests.
 """
+import contextlib
+import io
+import json
 import os
 import random
 import sys
@@ -696,6 +699,106 @@ def g15():
     npz("g15_frame_datasets.npz", **out)
 
 
+def _write_still_extras(root):
+    """What the still-frame families need on top of G15's tree: the UCF50 index with per-video cut points, and an
+    SSv2-style frame set (2 train + 1 val videos x 8 frames 64x64, one more that is short)."""
+    from PIL import Image
+    ucf = os.path.join(root, "UCF101")
+    cuts = {"v_Archery_g01_c01": [40, 12, 25], "v_Biking_g01_c01": [9, 20, 31], "v_Archery_g02_c01": [8, 17, 27],
+            "v_Biking_g02_c01": [7, 15, 24], "v_Archery_g03_c01": [26, 6, 16]}          # unsorted on purpose: the reader sorts
+    with open(os.path.join(ucf, "ucf50_splits1.csv")) as fp, open(os.path.join(ucf, "ucf50_splits1_max.csv"), "w") as out:
+        rows = fp.read().strip().split("\n")
+        out.write(rows[0] + ",split_index\n")
+        for r in rows[1:]:
+            out.write('%s,"[%s]"\n' % (r, ", ".join(str(c) for c in cuts[r.split(",")[0]])))
+    ss = os.path.join(root, "SSv2_64x8")
+    rng = np.random.default_rng(77)
+    yy, xx = np.mgrid[0:64, 0:64].astype(np.float32)
+    items = [("101", "Pushing something", "train", 8), ("102", "Dropping something", "train", 8), ("103", "Pushing something", "train", 6),
+             ("201", "Dropping something", "val", 8)]
+    for vi, (vid, _, _, n) in enumerate(items):
+        d = os.path.join(ss, "frame", vid)
+        os.makedirs(d, exist_ok=True)
+        for t in range(n):
+            img = np.stack([(xx * (2 + vi) + 9 * t) % 256, (yy * 3 + 17 * vi) % 256, ((xx - yy) * 1.3 + 7 * t) % 256], -1)
+            img = img + rng.normal(0, 3, img.shape)
+            Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(os.path.join(d, "%04d.jpg" % (t + 1)), quality=60)
+    for split in ("train", "val"):
+        with open(os.path.join(ss, "annot_%s.json" % split), "w") as fp:
+            json.dump([{"id": vid, "class": c} for vid, c, sp, _ in items if sp == split], fp)
+
+
+def g17():
+    """Still-frame datasets (distill_utils/dataset.py staticHMDB51 / staticUCF101 / staticUCF50 / singleKinetics400 /
+    singleSSv2, and the SSv2 video class): what the reference's classes return for the committed tree under fixed seeds."""
+    root = os.path.join(OUT, "frames")
+    if not os.path.exists(os.path.join(root, "UCF101")):
+        _write_frame_tree(root)
+    if not os.path.exists(os.path.join(root, "SSv2_64x8")):
+        _write_still_extras(root)
+    tv = _install_transform_stubs()
+    sys.path.insert(0, REF)
+    from distill_utils import dataset as RD
+    tf = tv.Compose([tv.ToTensor(), tv.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])])
+    out = {}
+    ucf = os.path.join(root, "UCF101")
+
+    def record(tag, ds, passes=2):
+        np.random.seed(5); random.seed(7); torch.manual_seed(3)
+        k = 0
+        for _ in range(passes):
+            for i in range(len(ds)):
+                x, y = ds[i]
+                out["%s_%d_probe" % (tag, k)] = x[..., ::16, ::16].numpy()
+                out["%s_%d_sums" % (tag, k)] = np.array([float(x.double().sum()), float((x.double() ** 2).sum())])
+                out["%s_%d_label" % (tag, k)] = np.int64(y)
+                out["%s_%d_frame" % (tag, k)] = np.int64(ds.start)
+                k += 1
+        out["%s_count" % tag] = np.int64(k)
+        out["%s_labels" % tag] = np.array(ds.labels, dtype=np.int64)
+    with contextlib.redirect_stdout(io.StringIO()):
+        record("shmdb_train", RD.staticHMDB51(ucf, "train", tf))
+        record("shmdb_test_image", RD.staticHMDB51(ucf, "test", tf, frames=1))
+        record("sucf_train", RD.staticUCF101(ucf, "train", tf))
+        record("sucf_part1of3", RD.staticUCF101(ucf, "train", tf, frames=4, split_num=3, split_id=1))
+        record("sucf_part_wraps", RD.staticUCF101(ucf, "test", tf, frames=1, split_num=2, split_id=2))      # split_id >= split_num -> 0
+        record("s50_mean", RD.staticUCF50(ucf, "train", tf, frames=2, split_num=4, split_id=3, split_mode='mean'))
+        for sid in range(4):
+            record("s50_feature%d" % sid, RD.staticUCF50(ucf, "train", tf, frames=1, split_num=4, split_id=sid, split_mode='feature'))
+        for tag, make, path in (("skin", RD.singleKinetics400, os.path.join(root, "kinetics_64x64x8")),
+                                ("sssv2", RD.singleSSv2, os.path.join(root, "SSv2_64x8"))):
+            for split in ("train", "val"):
+                ds = make(path, split, tf)
+                out["%s_%s_labels" % (tag, split)] = np.array(ds.labels, dtype=np.int64)
+                out["%s_%s_dirs" % (tag, split)] = np.array([os.path.basename(d) for d in ds.video_dirs])
+                random.seed(7)
+                picks = []
+                for rep in range(3):
+                    for i in range(len(ds)):
+                        state = random.getstate()
+                        x, y = ds[i]
+                        after = random.getstate()
+                        random.setstate(state)
+                        idx = random.randint(0, 7)                      # the one draw an item makes
+                        assert random.getstate() == after
+                        name = os.listdir(ds.video_dirs[i])[idx]
+                        want = tf(__import__("PIL.Image").Image.open(os.path.join(ds.video_dirs[i], name)))
+                        assert torch.equal(x, want) and y == ds.labels[i]
+                        picks.append(idx)
+                out["%s_%s_picks" % (tag, split)] = np.array(picks, dtype=np.int64)
+        # every frame of the SSv2 tree by name (the single* checks look pixels up here), and the SSv2 video class
+        for split in ("train", "val"):
+            ds = RD.SSv2(os.path.join(root, "SSv2_64x8"), split, tf)
+            out["ssv2_%s_labels" % split] = np.array(ds.labels, dtype=np.int64)
+            out["ssv2_%s_dirs" % split] = np.array([os.path.basename(d) for d in ds.video_dirs])
+            for i in range(len(ds)):
+                x, y = ds[i]
+                out["ssv2_%s_%d_names" % (split, i)] = np.array(os.listdir(ds.video_dirs[i]))
+                out["ssv2_%s_%d_probe" % (split, i)] = x[:, :, ::8, ::8].numpy()
+                out["ssv2_%s_%d_sums" % (split, i)] = np.stack([x[t].double().sum().numpy() for t in range(x.shape[0])])
+    npz("g17_still_datasets.npz", **out)
+
+
 def g16(networks, utils):
     """The metric's accuracy half at the benchmark's scale: the REFERENCE's evaluate_synset (utils.py:848-886, imported) on the
     learnable 50-class problem of tests/synth_problem.py -- C=50, IPC=1, 64x64x8, epoch_eval_train=100, five fixed network
@@ -750,7 +853,7 @@ def main():
     for name, fn in (("g1", lambda: g1(networks)), ("g2", lambda: g2_g3(networks)), ("g4", lambda: g4_g5(networks, utils)),
                      ("g6", lambda: g6(networks, utils)), ("g7", lambda: g7(networks, utils)),
                      ("g9", lambda: g9(networks, utils)), ("g10", lambda: g10(networks, utils)),
-                     ("g11", lambda: g11(networks, utils)), ("g12", lambda: g12(networks)), ("g13", lambda: g13(networks, utils)), ("g14", lambda: g14(networks, utils)), ("g15", g15),
+                     ("g11", lambda: g11(networks, utils)), ("g12", lambda: g12(networks)), ("g13", lambda: g13(networks, utils)), ("g14", lambda: g14(networks, utils)), ("g15", g15), ("g17", g17),
                      ("g16", lambda: g16(networks, utils))):
         if not only or name in only:
             fn()

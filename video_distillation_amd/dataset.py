@@ -13,8 +13,10 @@ whole split into HBM once: JPEG decode on host threads (PIL releases the GIL), u
 ``ToTensor`` + ``Normalize``) on the device.  A 112x112x16 split of miniUCF101 (4662 clips) is 11.2 GB of fp32 clips:
 resident, and the per-step gather is an index_select on the device (``distill.RealPool``).
 
-The still-image ("static" / "single") dataset variants feed the reference's static-memory learning stage, which is not on
-the path; they are not offered.
+``StillFrameVideos`` covers the reference's still-image variants (``staticHMDB51`` :570-650, ``staticUCF101`` :652-736,
+``staticUCF50`` :738-839, ``singleKinetics400`` :18-77, ``singleSSv2`` :897-947): one frame of a video, repeated into a
+"boring" clip or handed out as an image.  They feed the reference's static-memory learning stage, which is off the hot
+path, so they are host-side only (no preload kernel of their own: an item is a clip or an image like any other).
 """
 from __future__ import annotations
 
@@ -225,6 +227,109 @@ class FrameFolderVideos(tdata.Dataset):
         return self.transform.normalise(torch.from_numpy(u8)), self.labels[index]
 
 
+# family -> (FolderSpec, how the one frame is chosen)
+_STILL_SPECS = {
+    'staticHMDB51': FolderSpec('csv-splits', 'hmdb51_splits.csv', 'jpegs_112', 'still'),
+    'staticUCF101': FolderSpec('csv-splits', 'ucf101_splits1.csv', 'jpegs_112', 'still-part'),
+    'staticUCF50': FolderSpec('csv-splits', 'ucf50_splits1_max.csv', 'jpegs_112', 'still-part'),
+    'singleKinetics400': FolderSpec('csv-kinetics', '{split}.csv', '{split}', 'listed'),
+    'singleSSv2': FolderSpec('json-ssv2', 'annot_{split}.json', 'frame', 'listed'),
+}
+
+
+class StillFrameVideos(FrameFolderVideos):
+    """One frame per item.  The ``static*`` families draw a frame NUMBER with ``np.random.randint`` -- anywhere in the
+    video (staticHMDB51, dataset.py:644), in the ``split_id``-th of ``split_num`` equal parts (staticUCF101 :730,
+    staticUCF50 ``split_mode='mean'`` :823), or between the per-video cut points of the index file's ``split_index``
+    column (staticUCF50 ``split_mode='feature'``, four parts, :824-830) -- then the flip, then ONE transform call, and
+    return the frame stacked ``frames`` times, or as a (3, H, W) image when ``frames == 1`` (:626-633).  The ``single*``
+    families (Kinetics400 / SSv2 frame sets) pick a listed file with ``random.randint`` and do not flip (:69-77, :938-947).
+    A ``split_id`` outside ``split_num`` reads as 0 (:660, :746); the last frame of a video is never drawn, as in the
+    reference (``randint``'s upper bound is the frame count)."""
+
+    def __init__(self, family: str, path: str, split: str, transform: Optional[FrameTransform] = None, frames: int = NUM_FRAMES,
+                 split_num: int = 1, split_id: int = 0, split_mode: str = 'mean'):
+        if family not in _STILL_SPECS:
+            raise ValueError("unknown still-frame family: %s" % family)
+        self.family, self.spec, self.split, self.sample = family, _STILL_SPECS[family], split, 'random'
+        self.transform = transform if transform is not None else FrameTransform((112, 112))
+        self.root = path
+        self.frames, self.split_num, self.split_mode = int(frames), int(split_num), split_mode
+        self.split_id = 0 if split_id >= split_num else int(split_id)
+        if family == 'staticUCF50' and split_mode not in ('mean', 'feature'):
+            raise SystemExit("split_mode error!")                       # the reference exits on the first item (:831-833)
+        self.split_lists: List[List[int]] = []
+        names, label_strs, self.skipped = self._read_index(path, split)
+        if family == 'staticUCF50':
+            with open(osp.join(path, self.spec.index_file)) as fp:
+                for row in csv.DictReader(fp):
+                    if row["split"] == split:
+                        self.split_lists.append(sorted(int(v) for v in row['split_index'].strip('][').split(', ')))
+        self.video_dirs = names
+        self.label_strs = label_strs
+        self.class_strs = sorted(set(label_strs))
+        self.class_2_idx = {s: i for i, s in enumerate(self.class_strs)}
+        self.labels = [self.class_2_idx[s] for s in label_strs]
+        self.targets = self.labels
+        self.start = [-1] * len(self.video_dirs)                        # kept for shape; a still item redraws every visit
+
+    def _expected_frames(self, path: str) -> int:
+        return 8                                                        # dataset.py:20, 899 (both frame sets are 8 long)
+
+    def _frame_range(self, index: int, length: int) -> Tuple[int, int]:
+        if self.spec.pick == 'still':
+            return 1, length
+        if self.family == 'staticUCF50' and self.split_mode == 'feature':
+            cuts = self.split_lists[index]
+            if self.split_id == 0:
+                return 1, cuts[0] + 1
+            if self.split_id == 3:
+                return cuts[2] + 1, length
+            return cuts[self.split_id - 1] + 1, cuts[self.split_id] + 1
+        part = length // self.split_num
+        return part * self.split_id + 1, part * (self.split_id + 1)
+
+    def draw(self, index: int) -> ClipDraw:
+        path = self.video_dirs[index]
+        listing = os.listdir(path)
+        if self.spec.pick == 'listed':
+            files = [osp.join(path, listing[random.randint(0, len(listing) - 1)])]
+            flip = False
+        else:
+            lo, hi = self._frame_range(index, len(listing))
+            number = int(np.random.randint(lo, hi))
+            self.start[index] = number
+            files = [osp.join(path, "frame{:06d}.jpg".format(number))]
+            flip = random.random() > 0.5
+        return ClipDraw(files, flip, [self.transform.draw(0, 0)])
+
+    def __getitem__(self, index: int):
+        image = self.transform.normalise(torch.from_numpy(self.read_u8(self.draw(index))))[0]
+        if self.spec.pick == 'listed' or self.frames == 1:
+            return image, self.labels[index]
+        return torch.stack([image] * self.frames, 0), self.labels[index]
+
+
+def staticHMDB51(path, split, transform=None, frames=NUM_FRAMES):
+    return StillFrameVideos('staticHMDB51', path, split, transform, frames)
+
+
+def staticUCF101(path, split, transform=None, frames=NUM_FRAMES, split_num=1, split_id=0):
+    return StillFrameVideos('staticUCF101', path, split, transform, frames, split_num, split_id)
+
+
+def staticUCF50(path, split, transform=None, frames=NUM_FRAMES, split_num=1, split_id=0, split_mode='mean'):
+    return StillFrameVideos('staticUCF50', path, split, transform, frames, split_num, split_id, split_mode)
+
+
+def singleKinetics400(path, split, transform=None):
+    return StillFrameVideos('singleKinetics400', path, split, transform)
+
+
+def singleSSv2(path, split, transform=None):
+    return StillFrameVideos('singleSSv2', path, split, transform)
+
+
 def UCF101(path, split, transform=None):
     return FrameFolderVideos('UCF101', path, split, transform)
 
@@ -259,10 +364,41 @@ _DATASETS = {
 }                                                   # (the reference has a video ``SSv2`` class but no get_dataset branch for it)
 
 
-def get_dataset(dataset: str, data_path: str, num_workers: int = 0, img_size=(112, 112)):
-    """The video branches of the reference's ``get_dataset`` (utils.py:21, 132-236, 507-508): same 9-tuple
+# still-image names -> (family, sub-directory, num_classes, fixed im_size or None, frames, passes the split arguments)   utils.py:237-454
+_STILL_DATASETS = {
+    'staticHMDB51': ('staticHMDB51', 'HMDB51', 51, None, NUM_FRAMES, False),
+    'staticUCF101': ('staticUCF101', 'UCF101', 101, None, NUM_FRAMES, False),
+    'staticUCF50': ('staticUCF50', 'UCF101', 50, None, NUM_FRAMES, False),
+    'singleHMDB51': ('staticHMDB51', 'HMDB51', 51, None, 1, False),
+    'singleUCF50': ('staticUCF50', 'UCF101', 50, None, 1, True),
+    'singleUCF101': ('staticUCF101', 'UCF101', 101, None, 1, True),
+    'singleKinetics400': ('singleKinetics400', 'Kinetics', 400, (64, 64), 1, False),
+    'singleSSv2': ('singleSSv2', 'SSv2', 174, (64, 64), 1, False),
+}
+
+
+def get_dataset(dataset: str, data_path: str, num_workers: int = 0, img_size=(112, 112), split_num: int = 1, split_id: int = 0,
+                split_mode: str = 'mean'):
+    """The video and still-frame branches of the reference's ``get_dataset`` (utils.py:21, 132-454, 507-508): same 9-tuple
     ``(channel, im_size, num_classes, class_names, mean, std, dst_train, dst_test, testloader)``.  Unknown names end the
-    process as the reference does (utils.py:505)."""
+    process as the reference does (utils.py:505).  The split arguments reach only ``singleUCF50`` / ``singleUCF101``
+    (utils.py:380-381, 411-412); ``singleHMDB51`` resizes + crops only for 64x64 targets (utils.py:345), the others for any
+    size that is not the stored 112x112."""
+    if dataset in _STILL_DATASETS:
+        family, sub, num_classes, fixed, frames, splits = _STILL_DATASETS[dataset]
+        im_size = tuple(fixed) if fixed is not None else tuple(img_size)
+        path = data_path + "/" + sub
+        assert os.path.exists(path), path
+        listed = _STILL_SPECS[family].pick == 'listed'
+        plain = listed or (dataset == 'singleHMDB51' and im_size != (64, 64))
+        transform = FrameTransform(im_size, stored=im_size if plain else (112, 112))
+        kw = dict(split_num=split_num, split_id=split_id) if splits else {}
+        if splits and family == 'staticUCF50':
+            kw['split_mode'] = split_mode
+        dst_train = StillFrameVideos(family, path, "train", transform, frames, **kw)
+        dst_test = StillFrameVideos(family, path, "val" if listed else "test", transform, frames, **kw)
+        testloader = tdata.DataLoader(dst_test, batch_size=64, shuffle=False, num_workers=num_workers)
+        return 3, im_size, num_classes, None, list(IMAGENET_MEAN), list(IMAGENET_STD), dst_train, dst_test, testloader
     if dataset not in _DATASETS:
         raise SystemExit('unknown dataset: %s' % dataset)
     family, sub, num_classes, fixed = _DATASETS[dataset]
