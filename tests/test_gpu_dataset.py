@@ -62,6 +62,19 @@ def test_preload_equals_stacked_items_and_feeds_the_pool():
     assert idx.tolist() == [0]
 
 
+@pytest.mark.parametrize("frames,shape", [(16, (3, 16, 3, 112, 112)), (1, (3, 3, 112, 112))])
+def test_preload_of_still_frame_items(frames, shape):
+    from video_distillation_amd import dataset as D
+    ds = D.staticUCF50(UCF, "train", frames=frames, split_num=4, split_id=1, split_mode='feature')
+    _seed()
+    want = torch.stack([ds[i][0] for i in range(len(ds))])
+    ds2 = D.staticUCF50(UCF, "train", frames=frames, split_num=4, split_id=1, split_mode='feature')
+    _seed()
+    clips, labels = D.preload(ds2, "cuda:0", workers=2, chunk=2)
+    assert clips.shape == shape and labels.tolist() == ds.labels
+    assert torch.equal(clips.cpu(), want)
+
+
 def test_dm_trainer_runs_on_a_preloaded_pool():
     """The decoded frames go through the path: one DM step on the pool built from the JPEG tree, finite and decreasing."""
     from video_distillation_amd import dataset as D, distill, plan

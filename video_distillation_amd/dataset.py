@@ -276,6 +276,11 @@ class StillFrameVideos(FrameFolderVideos):
     def _expected_frames(self, path: str) -> int:
         return 8                                                        # dataset.py:20, 899 (both frame sets are 8 long)
 
+    @property
+    def image_items(self) -> bool:
+        """Items are (3, H, W) images rather than (frames, 3, H, W) clips."""
+        return self.spec.pick == 'listed' or self.frames == 1
+
     def _frame_range(self, index: int, length: int) -> Tuple[int, int]:
         if self.spec.pick == 'still':
             return 1, length
@@ -305,7 +310,7 @@ class StillFrameVideos(FrameFolderVideos):
 
     def __getitem__(self, index: int):
         image = self.transform.normalise(torch.from_numpy(self.read_u8(self.draw(index))))[0]
-        if self.spec.pick == 'listed' or self.frames == 1:
+        if self.image_items:
             return image, self.labels[index]
         return torch.stack([image] * self.frames, 0), self.labels[index]
 
@@ -435,7 +440,8 @@ def frames_normalize(u8: torch.Tensor, out: torch.Tensor, mean: Sequence[float],
 def preload(dataset: FrameFolderVideos, device, indices: Optional[Sequence[int]] = None, workers: int = 8, chunk: int = 64):
     """Every item of ``dataset`` (or of ``indices``, in that order) decoded once and left in HBM.
 
-    -> ``(clips (N, T, 3, H, W) fp32 on ``device``, labels (N,) int64 on the host)``; the same values
+    -> ``(clips (N, T, 3, H, W) fp32 on ``device`` -- (N, 3, H, W) for the image items of ``StillFrameVideos`` --, labels
+    (N,) int64 on the host)``; the same values
     ``torch.stack([dataset[i][0] for i in indices])`` produces (the draws happen here, in index order; only the file reads
     run on the ``workers`` threads), with 1/4 of the bytes crossing PCIe and the normalisation done by the device.
     The copy of chunk k+1 overlaps the decode of chunk k+2 and the normalisation of chunk k (pinned double buffer, one
@@ -483,6 +489,8 @@ def preload(dataset: FrameFolderVideos, device, indices: Optional[Sequence[int]]
             drained[b].record(main)
             used[b] = True
     main.synchronize()
+    if isinstance(dataset, StillFrameVideos):                   # one decoded frame per item: an image, or that frame repeated on the device
+        clips = clips[:, 0] if dataset.image_items else clips.expand(-1, dataset.frames, -1, -1, -1).contiguous()
     return clips, labels
 
 
