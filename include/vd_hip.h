@@ -231,7 +231,9 @@ int vd_match_rows_bwd(const float* gr, const float* gs, int64_t rows, int len, i
  * utils.py:660-664) in ONE launch: segment i = tensor pair i viewed as [rows][len]; `reserved` != 0 marks a FLAT segment
  * (rows = element count, len = 1: only the global sums of 'mse' / 'cos' are wanted; a row view of 'ours' with len == 1 --
  * a trailing unit axis, e.g. the (K,128,1,1,1) logit weights -- is NOT flat: each element is its own cosine row);
- * the backward writes d/d gs of segment i to seg[i].g. */
+ * the backward writes d/d gs of segment i to seg[i].g.  VdMatchBatch.reserved: 0 = the forward adds all five sums; otherwise a
+ * mask (bit k = acc[k] is wanted) -- the sums leave the launch as same-address atomics, one per block and sum, and a caller of
+ * 'ours' (bit 0) or 'mse' (bit 1) needs one of the five. */
 #define VD_MATCH_MAX_SEG 16
 typedef struct VdMatchSeg {
     const float* gr;

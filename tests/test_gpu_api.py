@@ -527,3 +527,53 @@ def test_match_loss_trailing_unit_axis_rows_and_many_tensors():
             np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-3, atol=1e-5)
     per = float(utils.distance_wb(gr[0].cuda(), gs[0].cuda()))
     assert abs(per - float(R.distance_wb(gr[0], gs[0]))) < 1e-4 and per > 1.0        # some of the 12 sign pairs disagree
+
+
+def test_match_loss_short_rows_ragged_counts_and_several_rounds():
+    """The LDS-staged short-row path of vd_match_rows_* (rows of 2 .. 8 floats, 64 rows per wave round): row counts that
+    are no multiple of 64 or 256, every row length, and a tensor with more rows than one round of the forward's 96 blocks
+    covers (24 576) -- loss and gradient against the oracle's match_loss."""
+    from video_distillation_amd import utils
+    g = torch.Generator().manual_seed(78)
+    shapes = [(67, 5, 3, 7, 7), (3, 2, 2, 3, 5), (9, 4, 2, 2, 8), (130, 2), (100, 3, 1, 3, 3), (40, 30, 3, 7, 7), (7, 3, 2, 2, 6), (5, 4)]
+    gr = [torch.randn(s, generator=g) for s in shapes]
+    gs = [torch.randn(s, generator=g) for s in shapes]
+    args = types.SimpleNamespace(device="cuda", dis_metric="ours")
+    xs = [t.cuda().requires_grad_(True) for t in gs]
+    val = utils.match_loss(xs, [t.cuda() for t in gr], args)
+    val.backward()
+    ref_in = [t.double().requires_grad_(True) for t in gs]
+    want = R.match_loss(ref_in, [t.double() for t in gr], "ours")
+    want.backward()
+    assert abs(float(val) / float(want) - 1) < 2e-5, (float(val), float(want))
+    for a, b, shp in zip(xs, ref_in, shapes):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.float().numpy(), rtol=2e-3, atol=2e-6, err_msg=str(shp))
+    for k in (0, 5):         # one tensor at a time through distance_wb: the single-segment launch
+        per = float(utils.distance_wb(gr[k].cuda(), gs[k].cuda()))
+        assert abs(per / float(R.distance_wb(gr[k].double(), gs[k].double())) - 1) < 2e-5
+
+
+def test_match_rows_multi_sum_mask():
+    """VdMatchBatch.reserved: 0 = all five sums (what a C caller that never heard of the mask gets), otherwise only the marked
+    ones are added to acc."""
+    import ctypes
+    from video_distillation_amd import hip
+    g = torch.Generator().manual_seed(79)
+    r, s = torch.randn(300, 7, generator=g), torch.randn(300, 7, generator=g)
+    rc, sc = r.cuda(), s.cuda()
+    want = [float((1 - (r * s).sum(1) / (r.norm(dim=1) * s.norm(dim=1) + 1e-6)).sum()), float(((s - r) ** 2).sum()),
+            float((r * s).sum()), float((r * r).sum()), float((s * s).sum())]
+    L, st = hip.lib(), hip.stream_ptr(rc.device)
+    for mask in (0, 1, 2, 28, 5):
+        b = hip.VdMatchBatch()
+        b.nseg, b.reserved = 1, mask
+        sg = b.seg[0]
+        sg.gr, sg.gs, sg.g, sg.rows, sg.len, sg.reserved = rc.data_ptr(), sc.data_ptr(), 0, 300, 7, 0
+        acc = torch.zeros(5, device="cuda")
+        hip.check(L.vd_match_rows_fwd_multi(ctypes.byref(b), hip.ptr(acc), st), "vd_match_rows_fwd_multi")
+        got = acc.cpu().tolist()
+        for k in range(5):
+            if mask == 0 or (mask >> k) & 1:
+                assert abs(got[k] - want[k]) <= 2e-5 * abs(want[k]) + 1e-5, (mask, k, got[k], want[k])
+            else:
+                assert got[k] == 0.0, (mask, k, got[k])

@@ -1137,11 +1137,64 @@ __host__ __device__ inline int64_t vd_match_blocks(int64_t rows, int len) {
 // keep the loads in flight (grid-stride) and cut them to a few us.
 __host__ __device__ inline int64_t vd_match_blocks_fwd(int64_t rows, int len) {
     const int64_t b = vd_match_blocks(rows, len);
-    return b > 96 ? 96 : b;
+    return b > 96 ? 96 : b;          // (same-box, with one sum per block: 48 / 96 / 192 / 384 blocks -> 16.8 / 12.6 / 14.2 / 21.4 us per gradient list)
+}
+
+// Short rows (len <= 8: the 7-wide rows of the 5-D Conv3d gradients are 99.8 % of a ConvNet3D gradient list).  A thread per row
+// reading its own 28 bytes made every load instruction touch 64 x 28 B for 256 B used (1.4 TB/s for the list); here a wave takes
+// 64 consecutive rows = 64 * len consecutive floats with coalesced loads and hands every lane its row through LDS (row pitch
+// len | 1 floats: conflict-free).  All waves run the same number of rounds (block barriers inside).
+#define VD_MATCH_SHORT_PITCH 9
+#define VD_MATCH_FWD_THREADS 512          // forward blocks: the closing atomics cap their number (vd_match_blocks_fwd), not their size
+struct VdMatchStage { float r[8][64 * VD_MATCH_SHORT_PITCH]; float s[8][64 * VD_MATCH_SHORT_PITCH]; };      // up to 8 waves per block
+
+__device__ __forceinline__ int64_t match_short_rounds(int64_t rows, int64_t nblk) {
+    const int64_t per = nblk * (blockDim.x >> 6) * 64;
+    return (rows + per - 1) / per;
+}
+
+__device__ __forceinline__ int64_t match_short_row0(int64_t it, int64_t nblk) {      // first row of this wave's chunk in round ``it``
+    return ((it * nblk + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+}
+
+__device__ __forceinline__ int match_short_count(int64_t rows, int len, int64_t r0) {      // floats in the chunk
+    const int64_t left = rows - r0;
+    return (int)(left < 64 ? (left < 0 ? 0 : left) : 64) * len;
+}
+
+// the chunk's 64 * len consecutive floats of both tensors, coalesced, into registers (element j * 64 + lane in slot j)
+__device__ __forceinline__ void match_short_load(const float* __restrict__ gr, const float* __restrict__ gs, int64_t rows, int len,
+                                                 int64_t r0, float (&x)[8], float (&y)[8]) {
+    const int lane = threadIdx.x & 63, n = match_short_count(rows, len, r0);
+    const int64_t base = r0 * len;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = j * 64 + lane;
+        const bool in = j < len && idx < n;
+        x[j] = in ? gr[base + idx] : 0.f;
+        y[j] = in ? gs[base + idx] : 0.f;
+    }
+}
+
+// registers -> LDS: afterwards lane l of wave w finds row r0 + l at st.r[w][l * (len | 1) + k].  Block barriers on both sides.
+__device__ __forceinline__ void match_short_put(VdMatchStage& st, int len, int n, const float (&x)[8], const float (&y)[8]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, ls = len | 1, magic = 65536 / len + 1;
+    __syncthreads();                      // the previous round's reads are done
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = j * 64 + lane;
+        if (j < len && idx < n) {
+            const int row = (idx * magic) >> 16, k = idx - row * len;      // idx / len, exact for idx < 512, len <= 8
+            st.r[w][row * ls + k] = x[j];
+            st.s[w][row * ls + k] = y[j];
+        }
+    }
+    __syncthreads();
 }
 
 __device__ __forceinline__ void match_rows_fwd_body(const float* __restrict__ gr, const float* __restrict__ gs,
-                                                    int64_t rows, int len, float* __restrict__ acc, const int64_t nblk, const bool flat) {
+                                                    int64_t rows, int len, float* __restrict__ acc, const int64_t nblk, const bool flat,
+                                                    const int need = 31) {
     __shared__ float red[16];
     float s_cos = 0.f, s_mse = 0.f, s_dot = 0.f, s_rr = 0.f, s_ss = 0.f;
     if (flat) {
@@ -1167,15 +1220,25 @@ __device__ __forceinline__ void match_rows_fwd_body(const float* __restrict__ gr
             s_dot += x * y; s_rr += x * x; s_ss += y * y; s_mse += (y - x) * (y - x);
         }
     } else if (len <= 8) {
-        // one thread per row
-        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)nblk * blockDim.x) {
-            float d = 0.f, a = 0.f, b = 0.f, m = 0.f;
-            for (int k = 0; k < len; ++k) {
-                const float x = gr[r * len + k], y = gs[r * len + k];
-                d += x * y; a += x * x; b += y * y; m += (y - x) * (y - x);
+        // one thread per row, rows staged through LDS; the next round's loads fly under this round's sums
+        __shared__ VdMatchStage st;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, ls = len | 1;
+        const int64_t rounds = match_short_rounds(rows, nblk);
+        float x[8], y[8];
+        match_short_load(gr, gs, rows, len, match_short_row0(0, nblk), x, y);
+        for (int64_t it = 0; it < rounds; ++it) {
+            const int64_t r0 = match_short_row0(it, nblk);
+            match_short_put(st, len, match_short_count(rows, len, r0), x, y);
+            if (it + 1 < rounds) match_short_load(gr, gs, rows, len, match_short_row0(it + 1, nblk), x, y);
+            if (r0 + lane < rows) {
+                float d = 0.f, a = 0.f, b = 0.f, m = 0.f;
+                for (int k = 0; k < len; ++k) {
+                    const float u = st.r[w][lane * ls + k], v = st.s[w][lane * ls + k];
+                    d += u * v; a += u * u; b += v * v; m += (v - u) * (v - u);
+                }
+                s_cos += 1.f - d / (sqrtf(a) * sqrtf(b) + 0.000001f);
+                s_mse += m; s_dot += d; s_rr += a; s_ss += b;
             }
-            s_cos += 1.f - d / (sqrtf(a) * sqrtf(b) + 0.000001f);
-            s_mse += m; s_dot += d; s_rr += a; s_ss += b;
         }
     } else {
         // one wave per row
@@ -1198,23 +1261,26 @@ __device__ __forceinline__ void match_rows_fwd_body(const float* __restrict__ gr
     float v[5] = {s_cos, s_mse, s_dot, s_rr, s_ss};
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
+        // (same-address atomics cost ~11 ns each at the L2 and pile up at the end of the launch: 6.5 of 19 us for a ConvNet3D
+        //  gradient list with all five sums; a caller that needs one sum says so -- VdMatchBatch.reserved)
+        if (!((need >> k) & 1)) continue;
         const float tot = block_sum(v[k], red);
         if (threadIdx.x == 0) atomicAdd(&acc[k], tot);
     }
 }
 
-__global__ __launch_bounds__(256) void match_rows_fwd_kernel(const float* __restrict__ gr, const float* __restrict__ gs,
+__global__ __launch_bounds__(VD_MATCH_FWD_THREADS) void match_rows_fwd_kernel(const float* __restrict__ gr, const float* __restrict__ gs,
                                                               int64_t rows, int len, float* __restrict__ acc) {
     match_rows_fwd_body(gr, gs, rows, len, acc, gridDim.x, len == 1);
 }
 
 // all tensors of a gradient list in ONE launch: blockIdx.y = segment (a match_loss call used to be 8 launches of
 // 5-35 us each, i.e. launch-bound at 2-3 % of HBM bandwidth)
-__global__ __launch_bounds__(256) void match_rows_fwd_multi_kernel(const VdMatchBatch b, float* __restrict__ acc) {
+__global__ __launch_bounds__(VD_MATCH_FWD_THREADS) void match_rows_fwd_multi_kernel(const VdMatchBatch b, float* __restrict__ acc) {
     const VdMatchSeg& sg = b.seg[blockIdx.y];
     const int64_t nblk = vd_match_blocks_fwd(sg.rows, sg.reserved ? 1 : (sg.len == 1 ? 2 : sg.len));
     if ((int64_t)blockIdx.x >= nblk) return;
-    match_rows_fwd_body(sg.gr, sg.gs, sg.rows, sg.len, acc, nblk, sg.reserved != 0);
+    match_rows_fwd_body(sg.gr, sg.gs, sg.rows, sg.len, acc, nblk, sg.reserved != 0, (b.reserved & 31) ? (b.reserved & 31) : 31);
 }
 
 extern "C" int vd_match_rows_fwd_multi(const VdMatchBatch* b, float* acc, void* stream) {
@@ -1226,7 +1292,7 @@ extern "C" int vd_match_rows_fwd_multi(const VdMatchBatch* b, float* acc, void* 
         gx = gx > nb ? gx : nb;
     }
     if (b->nseg == 0) return 0;
-    hipLaunchKernelGGL(match_rows_fwd_multi_kernel, dim3((unsigned)gx, (unsigned)b->nseg), dim3(256), 0,
+    hipLaunchKernelGGL(match_rows_fwd_multi_kernel, dim3((unsigned)gx, (unsigned)b->nseg), dim3(VD_MATCH_FWD_THREADS), 0,
                        reinterpret_cast<hipStream_t>(stream), *b, acc);
     return (int)hipGetLastError();
 }
@@ -1234,7 +1300,7 @@ extern "C" int vd_match_rows_fwd_multi(const VdMatchBatch* b, float* acc, void* 
 extern "C" int vd_match_rows_fwd(const float* gr, const float* gs, int64_t rows, int len, float* acc, void* stream) {
     if (rows <= 0 || len <= 0) return 0;
     const int64_t blocks = vd_match_blocks(rows, len);
-    hipLaunchKernelGGL(match_rows_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(match_rows_fwd_kernel, dim3((unsigned)blocks), dim3(VD_MATCH_FWD_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
                        gr, gs, rows, len, acc);
     return (int)hipGetLastError();
 }
@@ -1262,15 +1328,42 @@ __device__ __forceinline__ void match_rows_bwd_body(const float* __restrict__ gr
         return;
     }
     if (len <= 8) {
-        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)nblk * blockDim.x) {
-            float d = 0.f, a = 0.f, b = 0.f;
-            for (int k = 0; k < len; ++k) {
-                const float x = gr[r * len + k], y = gs[r * len + k];
-                d += x * y; a += x * x; b += y * y;
+        // rows staged through LDS; the gradient rows go back the same way: coalesced stores (up to 1024 blocks: one or two rounds,
+        // nothing to prefetch)
+        __shared__ VdMatchStage st;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, ls = len | 1, magic = 65536 / len + 1;
+        const int64_t rounds = match_short_rounds(rows, nblk);
+        for (int64_t it = 0; it < rounds; ++it) {
+            const int64_t r0 = match_short_row0(it, nblk);
+            const int n = match_short_count(rows, len, r0);
+            __syncthreads();                      // the previous round's reads are done
+            for (int j = 0; j < len; ++j) {
+                const int idx = j * 64 + lane;
+                if (idx < n) {
+                    const int row = (idx * magic) >> 16, k = idx - row * len;
+                    st.r[w][row * ls + k] = gr[r0 * len + idx];
+                    st.s[w][row * ls + k] = gs[r0 * len + idx];
+                }
             }
-            const float nr = sqrtf(a), ns = sqrtf(b), den = nr * ns + 0.000001f;
-            const float c1 = -1.f / den, c2 = (ns > 0.f) ? d * nr / (ns * den * den) : 0.f;
-            for (int k = 0; k < len; ++k) g[r * len + k] = go * (c1 * gr[r * len + k] + c2 * gs[r * len + k]);
+            __syncthreads();
+            if (r0 + lane < rows) {
+                float d = 0.f, a = 0.f, b = 0.f;
+                for (int k = 0; k < len; ++k) {
+                    const float u = st.r[w][lane * ls + k], v = st.s[w][lane * ls + k];
+                    d += u * v; a += u * u; b += v * v;
+                }
+                const float nr = sqrtf(a), ns = sqrtf(b), den = nr * ns + 0.000001f;
+                const float c1 = -1.f / den, c2 = (ns > 0.f) ? d * nr / (ns * den * den) : 0.f;
+                for (int k = 0; k < len; ++k) st.r[w][lane * ls + k] = go * (c1 * st.r[w][lane * ls + k] + c2 * st.s[w][lane * ls + k]);
+            }
+            __syncthreads();
+            for (int j = 0; j < len; ++j) {
+                const int idx = j * 64 + lane;
+                if (idx < n) {
+                    const int row = (idx * magic) >> 16, k = idx - row * len;
+                    g[r0 * len + idx] = st.r[w][row * ls + k];
+                }
+            }
         }
     } else {
         const int lane = threadIdx.x & 63;

@@ -234,6 +234,7 @@ class _MatchLossFunction(torch.autograd.Function):
             if batches[-1].nseg == 16:
                 batches.append(hip.VdMatchBatch())
             b = batches[-1]
+            b.reserved = (1, 2, 28)[mode]               # the sums this metric reads: acc[0] / acc[1] / acc[2..4]
             sg = b.seg[b.nseg]
             sg.gr, sg.gs, sg.g, sg.rows, sg.len, sg.reserved = gr_c.data_ptr(), gs_c.data_ptr(), 0, rows, ln, int(mode != 0)
             b.nseg += 1
