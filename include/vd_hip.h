@@ -17,13 +17,21 @@
 extern "C" {
 #endif
 
-#define VD_ABI_VERSION 4
+#define VD_ABI_VERSION 5
 
 /* operand precision of the MFMA contraction (accumulation is always fp32) */
 #define VD_PREC_BF16   0   /* bf16 operands, one MFMA per product                       */
 #define VD_PREC_F16    1   /* fp16 operands, one MFMA per product                       */
 #define VD_PREC_BF16X3 2   /* hi/lo split bf16 operands, three MFMAs (fp32-class error) */
 #define VD_PREC_F16X3  3   /* hi/lo split fp16 operands, three MFMAs                    */
+/* fp16 pairs carry 22 bits only while the LOW part stays a normal fp16 number, i.e. for |v| >= 2^-2; below that the pair is a
+ * fixed-point number with an absolute step of 2^-25.  Conv3d weights of this network are 0.004 .. 0.05 in magnitude (PyTorch's
+ * default initialisation of networks.py:799: bound 1 / sqrt(fan_in)), where an unscaled pair is exact to 3e-6 .. 6e-7 of the weight
+ * -- no better than a bf16 pair, and the SAME error for every clip of a batch.  The weight-packing entry points therefore
+ * store W x 2^VD_F16X3_WSHIFT in VD_PREC_F16X3 operands (exact to 5e-8 of the weight, fp32's own rounding), and VD_PREC_F16X3 tile
+ * programs whose B operand is packed weights (w_box_stride == 0) multiply their accumulators by 2^-VD_F16X3_WSHIFT in the
+ * epilogue (exact).  Valid for |w| < 2^(16 - VD_F16X3_WSHIFT) = 256. */
+#define VD_F16X3_WSHIFT 8
 #define VD_PREC_F16C8  4   /* fp16 operands + the two hi/lo CORRECTION products on the block-scaled fp8 matrix instruction
                               (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3, 2.2x the fp16 rate): a_hi W_hi in fp16, a_lo W_hi + a_hi W_lo in
                               fp8 once per four K steps -- two MFMA-equivalents per product instead of three, the corrections
@@ -61,7 +69,7 @@ typedef struct VdConvParams {
     int64_t dst_plane_stride;     /* POOL_CL: slots between hi and lo planes                  */
     uint8_t* argmax;              /* pooled epilogues: arg-max byte per output, or NULL        */
     const int32_t* col_off;       /* ROWS: element offset of column n, or NULL (= n*n_stride)  */
-    const float* out_scale;       /* ROWS: device scalar the outputs are multiplied by, or NULL */
+    const float* out_scale;       /* ROWS and select epilogues: device scalar the accumulators are multiplied by, or NULL */
     const int32_t* type_desc;     /* [ntypes][16]                                             */
     const int32_t* tables;        /* a_off / out / tap tables                                 */
     const int32_t* boxes;         /* [nbox][8]: a_off / out / tap table offsets, out origin, type */
@@ -79,7 +87,9 @@ typedef struct VdConvParams {
     int32_t ntypes;               /* number of box types; 1 -> tab_ofs are used for every box     */
     int32_t tab_ofs[3];           /* a_off / out / tap table offsets of box type 0                */
     int32_t atomic;               /* ROWS epilogue: accumulate with fp32 atomics                  */
-    int32_t select;               /* pooled epilogues: argmax is an INPUT, emit the selected row (0 if ReLU-dead) */
+    int32_t select;               /* pooled epilogues: argmax is an INPUT, emit the selected row (0 if ReLU-dead): acc * out_scale[0] + bias.
+                                     2 (POOL_CL): as fp32 in the channels-last slot order ([clip][C/8][t][h][w][8] floats) instead of
+                                     16-bit pairs -- the caller measures its range (vd_absmax_scale) and splits it (vd_split_scaled) */
     int32_t src_split_cc;         /* >0: channel chunks >= this come from a second tensor ...     */
     int64_t src_split_off4;       /* ... that starts this many dwords after src (same strides)    */
     int32_t NTW;                  /* N tiles per wave (0/1: one; 2: an A fragment feeds two MFMAs; wave columns = NT / NTW) */
@@ -323,6 +333,16 @@ int vd_get_deterministic(void);
 /* Re-split 16-bit operand elements between the hi/lo formats (f16 pairs <-> bf16 pairs); lo pointers optional. */
 int vd_resplit_slots(const void* src_hi, const void* src_lo, int64_t n_elems, int src_prec, void* dst_hi, void* dst_lo,
                      int dst_prec, void* stream);
+/* fp32 -> 16-bit operand elements in the same order: dst_hi[i] (and dst_lo[i] for the hi+lo formats) = split of src[i] * scale[0]
+ * (scale: device scalar, NULL = 1).  Turns the fp32 output of a select = 2 program into the scaled source of the next level of
+ * the second-order sweep (the tangents d/dtheta of torch.autograd.grad(..., create_graph=True), distill_baseline.py:250). */
+int vd_split_scaled(const float* src, int64_t n_elems, const float* scale, void* dst_hi, void* dst_lo, int prec, void* stream);
+/* Device scalars of the power-of-two operand scales (vd_absmax_scale's out[0] / out[1] pairs): out[0] = a[0] * b[0] (mode 0) or
+ * min(a[0], b[0]) (mode 1: the common scale of two tensors that share an accumulator), out[1] = 1 / out[0]; b NULL = 1. */
+int vd_scale_combine(const float* a, const float* b, int mode, float* out, void* stream);
+/* sha256 (first 16 hex digits + NUL) of the kernel sources and this header the library was BUILT from (compiled in by
+ * video_distillation_amd/hip.py:build); the binding refuses a library whose stamp differs from its checkout's sources. */
+const char* vd_sources_hash(void);
 
 /* Second-order pass through the head for gradient matching (DC: match_loss(gw_syn, gw_real).backward() with
  * gw_syn = autograd.grad(CE(net(x)), params, create_graph=True), upstream DC loop / distill_baseline.py:250):

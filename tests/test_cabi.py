@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "vd_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|int64_t|void)\s+(vd_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t|void|char\*)\s+(vd_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(lib, name), name
     lib.vd_abi_version.restype = ctypes.c_int
-    assert lib.vd_abi_version() == 4
+    assert lib.vd_abi_version() == 5
 
 
 def test_argument_errors_are_reported_before_any_device_call():
@@ -89,3 +89,35 @@ def test_product_has_no_cpu_fallback():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_library_carries_the_hash_of_its_sources_and_a_stale_one_is_refused(tmp_path, monkeypatch):
+    """Round 6: the library is stamped with the sha256 of the kernel sources + header it was built from (csrc/stamp.cpp);
+    ``hip.build`` / ``hip.lib`` decide staleness by that stamp, not by mtimes -- a library built from touched sources is
+    rebuilt, and refused when it cannot be."""
+    import shutil
+    import subprocess
+    from video_distillation_amd import hip
+    hip.build()
+    want = hip.sources_hash()
+    assert hip.library_stamp() == want and len(want) == 16
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    lib.vd_sources_hash.restype = ctypes.c_char_p
+    assert lib.vd_sources_hash().decode() == hip.STAMP_PREFIX + want
+    # a copy of the library next to "touched" sources (one byte appended to a copy of a kernel file): the stamp no longer matches
+    stale = tmp_path / "libvd_hip.so"
+    shutil.copy(hip.LIB_PATH, stale)
+    src = tmp_path / "aux_kernels.hip"
+    shutil.copy(hip.SOURCES[1], src)
+    with open(src, "a") as f:
+        f.write("\n// touched\n")
+    monkeypatch.setattr(hip, "SOURCES", [hip.SOURCES[0], str(src)] + hip.SOURCES[2:])
+    monkeypatch.setattr(hip, "LIB_PATH", str(stale))
+    monkeypatch.setattr(hip, "_lib", None)
+    assert hip.sources_hash() != want and hip.library_stamp(str(stale)) == want
+
+    def no_compiler(*a, **k):
+        raise subprocess.CalledProcessError(127, "hipcc")
+    monkeypatch.setattr(hip, "build", no_compiler)
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        hip.lib()

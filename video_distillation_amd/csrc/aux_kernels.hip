@@ -44,13 +44,17 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
+// VD_PREC_F16X3 operands hold W x 2^VD_F16X3_WSHIFT (vd_hip.h: an unscaled fp16 pair of a weight of 0.006 is exact to 3e-6 only --
+// its low part is a subnormal; the tile programs undo the shift in their fp32 epilogues)
+__device__ __forceinline__ float pack_shift(int prec) { return prec == VD_PREC_F16X3 ? (float)(1 << VD_F16X3_WSHIFT) : 1.f; }
+
 // ------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ w, const int32_t* __restrict__ widx, int64_t n,
                                     uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int prec) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t k = widx[i];
-    const float v = (k >= 0) ? w[k] : 0.f;
+    const float v = (k >= 0) ? w[k] * pack_shift(prec) : 0.f;
     uint16_t h, l;
     split16p(prec, v, h, l);
     hi[i] = h;
@@ -74,7 +78,7 @@ __global__ void pack_weights_multi_kernel(const VdPackBatch b) {
     const int64_t i = (int64_t)((int)blockIdx.x - sg.first_block) * blockDim.x + threadIdx.x;
     if (i >= sg.n) return;
     const int32_t j = sg.widx[i];
-    const float v = (j >= 0) ? sg.w[j] : 0.f;
+    const float v = (j >= 0) ? sg.w[j] * pack_shift(sg.prec) : 0.f;
     uint16_t h, l;
     split16p(sg.prec, v, h, l);
     reinterpret_cast<uint16_t*>(sg.out_hi)[i] = h;
@@ -2056,6 +2060,47 @@ extern "C" int vd_resplit_slots(const void* src_hi, const void* src_lo, int64_t 
     hipLaunchKernelGGL(resplit_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        (const uint16_t*)src_hi, (const uint16_t*)src_lo, n_elems, src_prec, (uint16_t*)dst_hi, (uint16_t*)dst_lo,
                        dst_prec);
+    return (int)hipGetLastError();
+}
+
+// fp32 -> (scaled) 16-bit operand elements, same order: the fp32 tangents a select = 2 program wrote become the source slots
+// of the next level once their range is known (vd_absmax_scale).  16 bytes in, 8 (+ 8) bytes out per thread and round.
+__global__ void split_scaled_kernel(const float4* __restrict__ src, int64_t n4, const float* __restrict__ scale,
+                                    uint2* __restrict__ dhi, uint2* __restrict__ dlo, int prec) {
+    const float sc = (scale != nullptr) ? scale[0] : 1.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = src[i];
+        uint16_t h[4], l[4];
+        split16p(prec, v.x * sc, h[0], l[0]); split16p(prec, v.y * sc, h[1], l[1]);
+        split16p(prec, v.z * sc, h[2], l[2]); split16p(prec, v.w * sc, h[3], l[3]);
+        dhi[i] = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+        if (dlo != nullptr) dlo[i] = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+    }
+}
+
+extern "C" int vd_split_scaled(const float* src, int64_t n_elems, const float* scale, void* dst_hi, void* dst_lo, int prec, void* stream) {
+    if (n_elems <= 0) return 0;
+    if (src == nullptr || dst_hi == nullptr || (n_elems & 3) != 0 || prec < 0 || prec > 3) return -2;
+    if (((reinterpret_cast<uintptr_t>(src) & 15) | (reinterpret_cast<uintptr_t>(dst_hi) & 7) | (reinterpret_cast<uintptr_t>(dst_lo) & 7)) != 0) return -2;
+    const int64_t n4 = n_elems >> 2;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_scaled_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const float4*)src, n4, scale, (uint2*)dst_hi, (uint2*)dst_lo, prec);
+    return (int)hipGetLastError();
+}
+
+__global__ void scale_combine_kernel(const float* __restrict__ a, const float* __restrict__ b, int mode, float* __restrict__ out) {
+    const float x = a[0], y = (b != nullptr) ? b[0] : 1.f;
+    const float s = (mode == 1) ? fminf(x, y) : x * y;
+    out[0] = s;
+    out[1] = 1.f / s;
+}
+
+extern "C" int vd_scale_combine(const float* a, const float* b, int mode, float* out, void* stream) {
+    if (a == nullptr || out == nullptr || (mode != 0 && mode != 1)) return -2;
+    hipLaunchKernelGGL(scale_combine_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), a, b, mode, out);
     return (int)hipGetLastError();
 }
 

@@ -823,11 +823,13 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
     if (VD_DBG(p) & 1) { if (acc[0][0] == 123.456f) reinterpret_cast<float*>(p.dst)[0] = 1.f; continue; }
     const int64_t out_total = (int64_t)p.nclips * p.out_clip_stride;
     const int64_t out_base = (int64_t)clip0 * p.out_clip_stride + out_rel;
+    // fp16 hi+lo programs over packed WEIGHTS: vd_pack_weights* stored W x 2^VD_F16X3_WSHIFT (vd_hip.h), undone here (exact)
+    const float asc = (PREC == VD_PREC_F16X3 && p.w_box_stride == 0) ? 1.f / (float)(1 << VD_F16X3_WSHIFT) : 1.f;
 
     if (p.epi == VD_EPI_ROWS) {
         float* dst = reinterpret_cast<float*>(p.dst);
         if constexpr (EXT) { if (p.atomic) dst += (int64_t)box[5] * p.replica_stride; }   // this box's copy of the accumulation target
-        const float osc = (p.out_scale != nullptr) ? p.out_scale[0] : 1.f;
+        const float osc = ((p.out_scale != nullptr) ? p.out_scale[0] : 1.f) * asc;
 #pragma unroll
       for (int j = 0; j < NTW + BAL; ++j) {
         const bool ex = BAL && j == NTW;                     // the extra (seventh-tile) accumulator of a balanced wave
@@ -929,6 +931,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 float m0 = fmaxf(fmaxf(at[r0], at[r0 + 1]), fmaxf(at[r0 + 2], at[r0 + 3]));
                 float m1 = fmaxf(fmaxf(at[r0 + 4], at[r0 + 5]), fmaxf(at[r0 + 6], at[r0 + 7]));
                 if (p.pool_t == 2) m0 = fmaxf(m0, m1);
+                if constexpr (PREC == VD_PREC_F16X3) { m0 *= asc; m1 *= asc; }
                 m0 += bias; m1 += bias;
                 if (p.relu) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
                 if (!X3 && !EXT && p.emit_lo == 2) {      // the fp8 image of these values (x 1/4) must stay finite for the consumer: clamp at 1792
@@ -958,6 +961,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
             const int o = lds_otab[gi * 4 + half + 2 * qh];
             if (o < 0 || !n_ok) continue;
             if (SO && p.select) {
+                const float osc_sel = ((p.out_scale != nullptr) ? p.out_scale[0] : 1.f) * asc;
                 // the arg-max bytes are an INPUT: emit the accumulator row a previous forward selected
                 // (0 where that forward's ReLU was dead) -- the adjoint of vd_unpool_relu_bwd
 #pragma unroll
@@ -971,9 +975,11 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                     float v = 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v = (j == jsel) ? at[r0 + j] : v;
-                    v = (ab & 0x80) ? 0.f : v + bias;
+                    v = (ab & 0x80) ? 0.f : v * osc_sel + bias;
                     if (feat) {
                         dstf[idx] = v;
+                    } else if (p.select == 2) {      // fp32 in the slot order: the caller measures the range, then splits (vd_split_scaled)
+                        reinterpret_cast<float*>(p.dst)[out_base * 8 + idx] = v;
                     } else {
                         uint16_t hi, lo;
                         split16<PREC>(v, hi, lo);
@@ -999,7 +1005,9 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 if (st == 1 && p.pool_t == 2) continue;
-                float mx = mv[st] + bias;
+                float mx = mv[st];
+                if constexpr (PREC == VD_PREC_F16X3) mx *= asc;
+                mx += bias;
                 if (p.relu) mx = fmaxf(mx, 0.f);
                 const int base = o + st * (((p.pair_flip >> (half + 2 * qh)) & 1) ? -p.out_t_stride : p.out_t_stride);
                 if (base >= lim) continue;
@@ -1152,11 +1160,29 @@ __global__ __launch_bounds__(512, 1) void conv0_breg_kernel(const VdConvParams p
     // (inline assembly, landed where they are issued: loads the compiler tracks get their s_waitcnt vmcnt(0) at the first use -- inside
     //  the K loop, on every pass, although the operand set changes once in hundreds of boxes -- and there it would also wait for the
     //  row-touch loads issued in front of the loop)
+    // (round 6: loads AND their wait are one asm block per 16 fragments, outputs early-clobber -- a value the block defines has
+    //  landed when the block ends.  With the wait in a separate, operand-less asm the compiler was free to copy or spill a
+    //  fragment between its load and the wait, i.e. to read registers whose load was still in flight; nothing but the bitwise test
+    //  against the generic kernel stood against that.  The second block issues after the first one's wait: one more memory
+    //  latency per operand-set change, once in hundreds of boxes.)
     auto load_breg = [&](int set) {
-        const char* wp = reinterpret_cast<const char*>(reinterpret_cast<const uint4*>(p.wpk) + (int64_t)set * (p.w_plane_stride >> 3) + (int64_t)wn * 64 + lane);
+        const char* wbase = reinterpret_cast<const char*>(reinterpret_cast<const uint4*>(p.wpk) + (int64_t)set * (p.w_plane_stride >> 3) + (int64_t)wn * 64);
+        uint32_t voff = (uint32_t)lane * 16u;
+#define VD_L0_LD(k) "global_load_dwordx4 %" #k ", %16, %17\n\tv_add_u32 %16, 0x800, %16\n\t"
+#define VD_L0_LD16 VD_L0_LD(0) VD_L0_LD(1) VD_L0_LD(2) VD_L0_LD(3) VD_L0_LD(4) VD_L0_LD(5) VD_L0_LD(6) VD_L0_LD(7) \
+                   VD_L0_LD(8) VD_L0_LD(9) VD_L0_LD(10) VD_L0_LD(11) VD_L0_LD(12) VD_L0_LD(13) VD_L0_LD(14) VD_L0_LD(15)
 #pragma unroll
-        for (int s = 0; s < S; ++s) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(breg[s]) : "v"(wp + (size_t)s * 2048) : "memory");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int h = 0; h < 2; ++h) {
+            u32x4* b = breg + 16 * h;
+            asm volatile(VD_L0_LD16 "s_waitcnt vmcnt(0)"
+                         : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7]),
+                           "=&v"(b[8]), "=&v"(b[9]), "=&v"(b[10]), "=&v"(b[11]), "=&v"(b[12]), "=&v"(b[13]), "=&v"(b[14]), "=&v"(b[15]),
+                           "+v"(voff)
+                         : "s"(wbase)
+                         : "memory");
+        }
+#undef VD_L0_LD16
+#undef VD_L0_LD
         __builtin_amdgcn_sched_barrier(0);
     };
     int cur_set = -1;
@@ -1577,7 +1603,16 @@ extern "C" int vd_conv_mfma(const VdConvParams* pp, void* stream) {
     }
     if (ntw != 1) return -2;
     if (p.MTW != 5 && (p.atomic || p.w_box_stride != 0 || p.select || p.src_split_cc > 0)) {
-        // second-order programs (and accumulating dgrad launches): bf16 pairs only (train.GradMatchEngine)
+        // second-order programs (and accumulating dgrad launches): hi+lo pairs (train.GradMatchEngine; fp16 pairs with the
+        // power-of-two scales of its sweeps, bf16 pairs unscaled)
+        if (p.select == 2 && (p.epi != VD_EPI_POOL_CL || p.argmax == nullptr)) return -2;
+        if (p.prec == VD_PREC_F16X3) {
+            if (p.MTW == 2) return launch<VD_PREC_F16X3, 2, true>(p, st);
+            if (p.MTW == 4) return launch<VD_PREC_F16X3, 4, true>(p, st);
+            if (p.MTW == 7) return launch<VD_PREC_F16X3, 7, true>(p, st);
+            if (p.MTW == 8) return launch<VD_PREC_F16X3, 8, true>(p, st);
+            return -2;
+        }
         if (p.prec != VD_PREC_BF16X3) return -2;
         if (p.MTW == 2) return launch<VD_PREC_BF16X3, 2, true>(p, st);
         if (p.MTW == 4) return launch<VD_PREC_BF16X3, 4, true>(p, st);
@@ -1668,7 +1703,14 @@ extern "C" int vd_conv_mfma_multi(const VdConvParams* const* pp, int n, void* st
         if (p.clip_index != nullptr || p.emit_lo != 0 || p.w_box_stride != 0 || p.MTW == 5) return -2;
         so = so || p.atomic || p.select || p.src_split_cc > 0;
     }
-    if (so) {       // accumulating / second-order programs: bf16 pairs only, as in vd_conv_mfma
+    if (so) {       // accumulating / second-order programs: hi+lo pairs, as in vd_conv_mfma
+        if (a.prec == VD_PREC_F16X3) {
+            if (a.MTW == 2) return launch_multi<VD_PREC_F16X3, 2, true>(pp, n, st);
+            if (a.MTW == 4) return launch_multi<VD_PREC_F16X3, 4, true>(pp, n, st);
+            if (a.MTW == 7) return launch_multi<VD_PREC_F16X3, 7, true>(pp, n, st);
+            if (a.MTW == 8) return launch_multi<VD_PREC_F16X3, 8, true>(pp, n, st);
+            return -2;
+        }
         if (a.prec != VD_PREC_BF16X3) return -2;
         if (a.MTW == 2) return launch_multi<VD_PREC_BF16X3, 2, true>(pp, n, st);
         if (a.MTW == 4) return launch_multi<VD_PREC_BF16X3, 4, true>(pp, n, st);

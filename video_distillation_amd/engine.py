@@ -241,7 +241,7 @@ def run_together(plans: Sequence["_DevPlan"], *args, **kwargs) -> None:
     for dp in plans:
         pl, p = dp.plan, dp.params
         so = bool(p.atomic or p.select or p.src_split_cc > 0)
-        plain = pl.NTW in (0, 1) and pl.MTW in (2, 4, 7, 8) and not p.w_box_stride and not p.dbg and (not so or dp.prec == hip.PREC["bf16x3"])
+        plain = pl.NTW in (0, 1) and pl.MTW in (2, 4, 7, 8) and not p.w_box_stride and not p.dbg and (not so or hip.is_x3(dp.prec))
         key = (dp.prec, pl.MTW, pl.NT, pl.MW, so) if plain else ("single", id(dp))
         groups.setdefault(key, []).append(dp)
     for key, grp in groups.items():

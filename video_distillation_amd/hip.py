@@ -16,6 +16,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvd_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("conv_mfma.hip", "aux_kernels.hip", "program.hip", "planner.cpp", "comm.cpp")]
+STAMP_SOURCE = os.path.join(_HERE, "csrc", "stamp.cpp")      # vd_sources_hash(): compiled on every link with the hash of SOURCES + header
+HEADER = os.path.join(_HERE, "..", "include", "vd_hip.h")
 
 PREC = {"bf16": 0, "f16": 1, "bf16x3": 2, "f16x3": 3, "f16c8": 4}      # f16c8: fp16 + fp8 corrections (the real side's last level only)
 EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv_mfma_multi", "vd_conv0_breg", "vd_pack_weights", "vd_round_operand", "vd_pix2rows", "vd_unpool_relu_bwd", "vd_absmax_scale", "vd_dm_loss",
@@ -27,7 +29,9 @@ EXPORTS = ("vd_abi_version", "vd_conv_mfma", "vd_conv_mfma_multi", "vd_conv0_bre
            "vd_comm_unique_id", "vd_comm_create", "vd_comm_size", "vd_comm_version", "vd_comm_rank", "vd_comm_allreduce_f32", "vd_comm_allgather_f32",
            "vd_comm_free",
            "vd_bias_grad_pooled_scratch_floats", "vd_bias_grad_pooled_ordered", "vd_standardize_ordered", "vd_head_train_bwd_ordered",
-           "vd_set_deterministic", "vd_get_deterministic", "vd_pack_weights_c8", "vd_pack_weights_multi")
+           "vd_set_deterministic", "vd_get_deterministic", "vd_pack_weights_c8", "vd_pack_weights_multi",
+           "vd_split_scaled", "vd_scale_combine", "vd_sources_hash")
+F16X3_WSHIFT = 8          # include/vd_hip.h VD_F16X3_WSHIFT: packed fp16 hi+lo weights are W x 2^8, undone in the programs' epilogues
 
 
 class VdConvParams(ctypes.Structure):
@@ -75,14 +79,16 @@ class VdMatchBatch(ctypes.Structure):
 def build(force: bool = False, verbose: bool = False, debug_hooks: bool = False) -> str:
     """Compile the HIP sources for gfx950 into libvd_hip.so (in-tree).  ``debug_hooks`` builds the
     variant libvd_hip_dbg.so with the ablation / timing hooks of VdConvParams.dbg compiled in
-    (-DVD_DBG_HOOKS=1; used by tools/ablate.py and tools/stamps.py via VD_LIB_VARIANT=dbg)."""
+    (-DVD_DBG_HOOKS=1; used by tools/ablate.py and tools/stamps.py via VD_LIB_VARIANT=dbg).
+
+    Staleness is decided by CONTENT, not by mtime (round 6): the library carries the sha256 of the sources it was built from
+    (csrc/stamp.cpp, ``vd_sources_hash``) and is rebuilt when that differs from ``sources_hash()`` of this checkout; every
+    object file has a side file with the hash of its source + the header."""
     out = LIB_PATH.replace(".so", "_dbg.so") if debug_hooks else LIB_PATH
-    if not force and os.path.exists(out):
-        newest = max(os.path.getmtime(s) for s in SOURCES + [os.path.join(_HERE, "..", "include", "vd_hip.h")])
-        if os.path.getmtime(out) >= newest:
-            return out
+    if not force and library_stamp(out) == sources_hash():
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # one object per source (rebuilt only when that source or the header is newer), compiled concurrently, then one link
+    # one object per source (rebuilt only when that source or the header changed), compiled concurrently, then one link
     objdir = os.path.join(_HERE, "csrc", "build_dbg" if debug_hooks else "build")
     os.makedirs(objdir, exist_ok=True)
     # one builder at a time (several ranks / test workers may find the library stale together): an exclusive lock on the object
@@ -97,32 +103,67 @@ def build(force: bool = False, verbose: bool = False, debug_hooks: bool = False)
         lock.close()
 
 
+def _file_hash(*paths: str) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for path in paths:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _build_locked(out: str, objdir: str, hipcc: str, force: bool, verbose: bool, debug_hooks: bool) -> str:
-    if not force and os.path.exists(out):
-        newest = max(os.path.getmtime(s) for s in SOURCES + [os.path.join(_HERE, "..", "include", "vd_hip.h")])
-        if os.path.getmtime(out) >= newest:
-            return out
-    header = os.path.join(_HERE, "..", "include", "vd_hip.h")
+    want = sources_hash()
+    if not force and library_stamp(out) == want:
+        return out
     flags = ["-O3", "--offload-arch=gfx950", "-fPIC"] + (["-DVD_DBG_HOOKS=1"] if debug_hooks else [])
     jobs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        side = obj + ".srchash"
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), os.path.getmtime(header)):
+        key = _file_hash(src, HEADER)
+        have = open(side).read().strip() if os.path.exists(side) and os.path.exists(obj) else None
+        if force or have != key:
+            if os.path.exists(side):
+                os.remove(side)
             cmd = [hipcc] + flags + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            jobs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, pr in jobs:
+            jobs.append((cmd, subprocess.Popen(cmd), side, key))
+    for cmd, pr, side, key in jobs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
+        with open(side, "w") as f:
+            f.write(key)
+    stamp_obj = os.path.join(objdir, "stamp.cpp.o")
+    cmd = [hipcc, "-O2", "-fPIC", "-DVD_SOURCES_HASH=\"%s%s\"" % (STAMP_PREFIX, want), "-c", STAMP_SOURCE, "-o", stamp_obj]
+    subprocess.run(cmd, check=True)
     tmp = out + ".tmp.%d" % os.getpid()       # (linked beside the target and renamed: a reader never maps a half-written library)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-ldl"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + [stamp_obj, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
     os.replace(tmp, out)
     return out
+
+
+STAMP_PREFIX = "VD_SOURCES_HASH="
+
+
+def library_stamp(path: str = None) -> Optional[str]:
+    """The sources hash a built library carries (read from the file's bytes, no dlopen: a stale library must not be mapped into
+    the process that is about to rebuild it), or None if the file is missing or unstamped."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return None
+    import mmap
+    with open(path, "rb") as f:
+        with mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as m:
+            i = m.find(STAMP_PREFIX.encode())
+            if i < 0:
+                return None
+            return m[i + len(STAMP_PREFIX):i + len(STAMP_PREFIX) + 16].decode("ascii", "replace")
 
 
 def sources_hash() -> str:
@@ -131,7 +172,7 @@ def sources_hash() -> str:
     measured on other kernels is refused instead of quoted."""
     import hashlib
     h = hashlib.sha256()
-    for path in sorted(SOURCES) + [os.path.join(_HERE, "..", "include", "vd_hip.h")]:
+    for path in sorted(SOURCES) + [HEADER]:
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -150,6 +191,19 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError(
                 "libvd_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU or eager fallback for the HIP path)" % path)
+        if "VD_LIB_PATH" not in os.environ and os.environ.get("VD_LIB_VARIANT") != "dbg":
+            # the numbers of a run come from THIS file: it must be the build of this checkout's kernel sources (the stamp
+            # compiled into it, not its mtime, says so).  A stale library is rebuilt when a compiler is there, refused otherwise.
+            want = sources_hash()
+            if library_stamp(path) != want:
+                try:
+                    build()
+                except (OSError, subprocess.CalledProcessError) as e:
+                    raise RuntimeError("libvd_hip.so at %s was built from other sources (stamp %s, checkout %s) and could not be "
+                                       "rebuilt: %s" % (path, library_stamp(path), want, e))
+                if library_stamp(path) != want:
+                    raise RuntimeError("libvd_hip.so at %s carries stamp %s, the checkout's kernel sources hash to %s"
+                                       % (path, library_stamp(path), want))
         L = ctypes.CDLL(path)
         for name in EXPORTS:
             if not hasattr(L, name):
@@ -159,10 +213,19 @@ def lib() -> ctypes.CDLL:
             getattr(L, name).restype = {"vd_program_info": ctypes.c_int64, "vd_program_free": None, "vd_blob_free": None, "vd_embed_free": None, "vd_train_free": None, "vd_comm_free": None, "vd_train_workspace_bytes": ctypes.c_int64, "vd_bias_grad_pooled_scratch_floats": ctypes.c_int64,
                                         "vd_embed_num_features": ctypes.c_int64, "vd_embed_workspace_bytes": ctypes.c_int64,
                                         "vd_embed_argmax_bytes": ctypes.c_int64, "vd_embed_backward_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
-        if L.vd_abi_version() != 4:
+        if L.vd_abi_version() != 5:
             raise RuntimeError("libvd_hip.so ABI version mismatch")
+        if hasattr(L, "vd_sources_hash"):
+            L.vd_sources_hash.restype = ctypes.c_char_p
         _lib = L
     return _lib
+
+
+def loaded_stamp() -> str:
+    """Sources hash compiled into the library this process runs on (bench.py and smoke() print it)."""
+    v = lib().vd_sources_hash()
+    v = v.decode() if isinstance(v, bytes) else str(v)
+    return v[len(STAMP_PREFIX):] if v.startswith(STAMP_PREFIX) else v
 
 
 def deterministic() -> bool:

@@ -34,7 +34,7 @@ from . import plan as P
 _PRECISION = {"real": os.environ.get("VD_PREC_REAL", "f16"), "syn": os.environ.get("VD_PREC_SYN", "f16x3"),
               "bwd": os.environ.get("VD_PREC_BWD", "f16x3"), "real_last": {"c8": "x3"}.get(os.environ.get("VD_REAL_LAST", "x3"), os.environ.get("VD_REAL_LAST", "x3")),     # (module path: c8 -> x3)
               "train": os.environ.get("VD_PREC_TRAIN", "f16x3"), "train_bwd": os.environ.get("VD_PREC_TRAIN_BWD", "f16x3"),
-              "match": os.environ.get("VD_PREC_MATCH", "bf16x3"), "match_real_bwd": os.environ.get("VD_PREC_MATCH_REAL_BWD", "f16")}
+              "match": os.environ.get("VD_PREC_MATCH", "f16x3"), "match_real_bwd": os.environ.get("VD_PREC_MATCH_REAL_BWD", "f16")}
 _ENGINES: Dict[Tuple, object] = {}
 
 

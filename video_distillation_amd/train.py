@@ -308,13 +308,26 @@ class GradMatchEngine(TrainEngine):
     Every conv is a tile program of the MFMA kernel: the two convs of the upward sweep are one
     program with K-concatenated operands ([a_l | gbar_l] x [V_l | W_l], ``src_split_cc``) and the
     ``select`` epilogue; the second convT of the downward sweep accumulates with fp32 atomics.
-    Operands are bf16 hi+lo pairs (bf16x3): adjoints span many orders of magnitude."""
 
-    def __init__(self, geo: P.NetGeometry, num_classes: int, pool_kernel, device, prec: str = "bf16x3",
+    Operand formats.  ``f16x3`` (round 6, the default): fp16 hi+lo pairs, 22 bits, with every gradient-like operand brought into
+    fp16's range by an exact power-of-two scale that the fp32 epilogue of the consuming program undoes -- the first-order
+    gradients at the conv outputs (per level, TrainEngine.feat_backward), the adjoints V_l of the weights, the incoming adjoint
+    of every level of the downward sweep, and the tangents gbar_l of the upward sweep, which a program writes as fp32
+    (``select = 2``) so that their range can be MEASURED before the split (vd_absmax_scale + vd_split_scaled); V_l and gbar_l
+    share an accumulator (K-concatenated operands) and therefore a scale, the smaller of the two.  Weights are packed
+    x 2^8 (hip.F16X3_WSHIFT).  The forward of this engine is then its own fp16 hi+lo forward: activations are shared, nothing is
+    re-split.  ``bf16x3`` (rounds 1 - 5): bf16 hi+lo pairs, 16 bits, unscaled, on top of an f16x3 forward for the pooling
+    decisions -- 3 - 11x further from the exact gradient than fp32 arithmetic over the ten unrolled steps of configuration 5
+    (profiles/r05_parity_mtt_unroll.json); kept as the A/B reference (``VD_PREC_MATCH=bf16x3``)."""
+
+    V_TARGET = 128.0          # max |V_l| * scale in [64, 128): x 2^8 in the packed operand stays below fp16's 65504
+
+    def __init__(self, geo: P.NetGeometry, num_classes: int, pool_kernel, device, prec: str = "f16x3",
                  batch_hint: Optional[int] = None):
-        if prec != "bf16x3":
-            raise ValueError("GradMatchEngine: bf16x3 operands only (adjoints span fp32's exponent range and are not scaled)")
+        if prec not in ("bf16x3", "f16x3"):
+            raise ValueError("GradMatchEngine: hi+lo operand pairs only (f16x3 with power-of-two scales, or bf16x3), not %r" % (prec,))
         super().__init__(geo, num_classes, pool_kernel, device, prec=prec, prec_bwd=prec, batch_hint=batch_hint)
+        self.scaled = (prec == "f16x3")
         eng = self.eng
         self.sel = [_DevPlan(eng.fwd[0].plan, self.device, eng.prec)]
         for li in (1, 2):
@@ -328,15 +341,22 @@ class GradMatchEngine(TrainEngine):
             self.sel.append(dp)
         for dp in self.sel:
             dp.params.select = 1
-        # the pooling decisions come from an f16x3 forward (operand error ~4e-7, like fp32's own rounding;
-        # bf16 pairs are exact to ~1e-5 only and flip near-tied windows far more often than the reference)
-        self.eng_fwd = EmbedEngine(geo, prec="f16x3", device=device, chunk=1 << 30, batch_hint=batch_hint)
+        if self.scaled:
+            for dp in self.sel[:2]:
+                dp.params.select = 2          # fp32 tangents in slot order: measured, then split at their own scale
+            self.eng_fwd = None
+        else:
+            # the pooling decisions come from an f16x3 forward (operand error ~4e-7, like fp32's own rounding;
+            # bf16 pairs are exact to ~1e-5 only and flip near-tied windows far more often than the reference)
+            self.eng_fwd = EmbedEngine(geo, prec="f16x3", device=device, chunk=1 << 30, batch_hint=batch_hint)
         self.bwdV = [[_DevPlan(dp.plan, self.device, eng.prec_bwd) for dp in layer] for layer in eng.bwd]
         for layer in self.bwdV:
             for dp in layer:
                 dp.params.atomic = 1
 
     def _forward(self, x, params):
+        if self.scaled:      # the engine's own fp16 hi+lo forward: its kept activations and pixel rows ARE the sweeps' operands
+            return TrainEngine._forward(self, x, params)
         eng, ef, L, st = self.eng, self.eng_fwd, hip.lib(), hip.stream_ptr(self.device)
         ef.set_weights(params[:6])
         keep_ws, ef._ws = ef._ws, {}
@@ -373,8 +393,38 @@ class GradMatchEngine(TrainEngine):
         return loss, logits, g, state
 
     # -- pieces of the adjoint sweep (shared by the fused ``vjp`` and the autograd path of ConvNet3D.forward) ----------
+    def _scale_buf(self, name: str) -> torch.Tensor:
+        return self.eng._buf(name, (4,), torch.float32)
+
+    def _absmax_scale(self, t: torch.Tensor, name: str, target: float) -> torch.Tensor:
+        """[2^k, 2^-k, scratch, -] on the device with max|t| * 2^k in [target / 2, target) (vd_absmax_scale)."""
+        scb = self._scale_buf(name)
+        hip.check(hip.lib().vd_absmax_scale(hip.ptr(t), ctypes.c_int64(t.numel()), ctypes.c_float(target), hip.ptr(scb),
+                                            hip.stream_ptr(self.device)), "vd_absmax_scale")
+        return scb
+
+    def _combine(self, a: torch.Tensor, b: Optional[torch.Tensor], mode: int, name: str) -> torch.Tensor:
+        """mode 0: [a0 * b0, 1 / (a0 * b0)]; mode 1: [min(a0, b0), 1 / min] (device scalars, vd_scale_combine)."""
+        out = self._scale_buf(name)
+        hip.check(hip.lib().vd_scale_combine(hip.ptr(a), hip.ptr(b), mode, hip.ptr(out), hip.stream_ptr(self.device)), "vd_scale_combine")
+        return out
+
     def _pack_adjoint(self, W: Sequence[torch.Tensor], V: Sequence[torch.Tensor]) -> None:
         eng = self.eng
+        if self.scaled:
+            # every V_l at its own power-of-two scale (the accumulating input-gradient programs and the first level's select
+            # program); the K-concatenated operands [V_l | W_l] of levels 1 / 2 are packed in the upward sweep, once the range of
+            # gbar_l -- which must share V_l's scale -- is known
+            self._sv = [self._absmax_scale(V[2 * li], "vscale%d" % li, self.V_TARGET) for li in range(3)]
+            self._Vs = [V[2 * li] * self._sv[li][0] for li in range(3)]
+            with engine.batched_packs():
+                for li in range(3):
+                    for dp in eng.bwd[li]:
+                        dp.pack(W[2 * li])
+                    for dp in self.bwdV[li]:
+                        dp.pack(self._Vs[li])
+                self.sel[0].pack(self._Vs[0])
+            return
         with engine.batched_packs():          # (some twenty programs' operands: one or two launches)
             for li in range(3):
                 for dp in eng.bwd[li]:
@@ -399,17 +449,34 @@ class GradMatchEngine(TrainEngine):
         gbar2 = eng._buf("gbar2", (eng.planes, n2, 8), torch.int16)
         return n_slots0, n1, n2, slots0, act1, act2, gbar1, gbar2
 
-    def _up_sweep(self, nb: int, am, V: Sequence[torch.Tensor]) -> torch.Tensor:
+    def _up_sweep(self, nb: int, am, V: Sequence[torch.Tensor], W: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
         """gbar_{l+1} = P_l (conv(a_l, V_l) + vb_l + conv(gbar_l, W_l)), gbar_0 = 0  ->  gbar_3 (nb, num_feat): the tangent
         of the features in the parameter direction V, equally the adjoint of the feature gradient."""
         eng = self.eng
         n_slots0, n1, n2, slots0, act1, act2, gbar1, gbar2 = self._sweep_bufs(nb)
         gbar3 = torch.empty((nb, eng.num_feat), dtype=torch.float32, device=self.device)
-        self.sel[0].run(slots0, n_slots0, V[1], gbar1.data_ptr(), n1, am[0], nb)
         for dp, a, gb in ((self.sel[1], act1, gbar1), (self.sel[2], act2, gbar2)):
             off = gb.data_ptr() - a.data_ptr()
             assert off % 4 == 0
             dp.params.src_split_off4 = off // 4
+        if self.scaled:
+            L, st = hip.lib(), hip.stream_ptr(self.device)
+            g32 = [eng._buf("gbar32_1", (n1 * 8,), torch.float32), eng._buf("gbar32_2", (n2 * 8,), torch.float32)]
+            self.sel[0].run(slots0, n_slots0, V[1], g32[0].data_ptr(), 0, am[0], nb, out_scale=self._sv[0][1:])
+            self._sg = [None, None, None]
+            for li, a, n_a, gb, n_out in ((1, act1, n1, gbar1, n2), (2, act2, n2, gbar2, 0)):
+                # the tangent the level below wrote as fp32: its range, the common scale with V_l (the smaller of the two:
+                # both stay below fp16's maximum), the split, and only then [V_l * s | W_l] for this level's program
+                sg = self._absmax_scale(g32[li - 1], "gscale_up%d" % li, self.V_TARGET)
+                s_l = self._combine(sg, self._sv[li], 1, "sscale%d" % li)
+                self._sg[li] = s_l
+                hip.check(L.vd_split_scaled(hip.ptr(g32[li - 1]), ctypes.c_int64(g32[li - 1].numel()), hip.ptr(s_l), hip.ptr(gb[0]),
+                                            hip.ptr(gb[1]), eng.prec, st), "vd_split_scaled")
+                self.sel[li].pack(torch.cat([V[2 * li] * s_l[0], W[2 * li]], dim=1).contiguous())
+                dst = g32[1].data_ptr() if li == 1 else gbar3.data_ptr()
+                self.sel[li].run(a, n_a, V[2 * li + 1], dst, 0, am[li], nb, out_scale=s_l[1:])
+            return gbar3
+        self.sel[0].run(slots0, n_slots0, V[1], gbar1.data_ptr(), n1, am[0], nb)
         self.sel[1].run(act1, n1, V[3], gbar2.data_ptr(), n2, am[1], nb)
         self.sel[2].run(act2, n2, V[5], gbar3.data_ptr(), 0, am[2], nb)
         return gbar3
@@ -427,12 +494,22 @@ class GradMatchEngine(TrainEngine):
             dy = eng._buf("dy%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)       # dz_l of the first-order pass
             zb = eng._buf("zb%d" % li, (eng.planes_bwd, nslots, 8), torch.int16)
             lo = zb[1] if eng.planes_bwd == 2 else None
+            sz = inv_z = inv_dv = inv_gd = None
+            if self.scaled:
+                # zb_l = P_l^T abar_{l+1} at its own scale; dy_l carries the first-order pass's scale of this level (gscale%d of
+                # TrainEngine.feat_backward, kept in the step's workspace), V_l and gbar_l the scales of the upward sweep
+                sz = self._absmax_scale(grad, "zscale%d" % li, 1024.0)
+                inv_z = sz[1:]
+                gs = self._scale_buf("gscale%d" % li)
+                inv_dv = self._combine(gs, self._sv[li], 0, "dvscale%d" % li)[1:]
+                if hv and li > 0:
+                    inv_gd = self._combine(gs, self._sg[li], 0, "gdscale%d" % li)[1:]
             hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am[li]), ctypes.c_int64(nb), cout, To, Ho, Wo, pt, T, OH,
-                                           OW, layout, hip.ptr(zb[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(None), st),
+                                           OW, layout, hip.ptr(zb[0]), hip.ptr(lo), eng.prec_bwd, hip.ptr(sz), st),
                       "vd_unpool_relu_bwd")
             out = dx if li == 0 else eng._buf("ax%d" % li, (nb, t, h, w, cin), torch.float32)
-            run_together(eng.bwd[li], zb, nslots, None, out.data_ptr(), 0, None, nb)
-            run_together(self.bwdV[li], dy, nslots, None, out.data_ptr(), 0, None, nb)       # (accumulates on top of the stores above)
+            run_together(eng.bwd[li], zb, nslots, None, out.data_ptr(), 0, None, nb, out_scale=inv_z)
+            run_together(self.bwdV[li], dy, nslots, None, out.data_ptr(), 0, None, nb, out_scale=inv_dv)   # (accumulates on top of the stores above)
             if hv:
                 # parameter side: z_l = conv(a_l, W_l) + b_l carries zbar_l, and g_{a_l} = convT(dz_l, W_l) carries gbar_l
                 op = self._wgrad(li, nb)
@@ -440,11 +517,11 @@ class GradMatchEngine(TrainEngine):
                                                 ctypes.c_int64(To * Ho * Wo), layout, hip.ptr(hv[2 * li + 1]), st),
                           "vd_bias_grad_pooled")
                 if li == 0:
-                    op.run(x, True, 0, zb, nslots, hv[0])
+                    op.run(x, True, 0, zb, nslots, hv[0], out_scale=inv_z)
                 else:
                     a_l, g_l, n_l = (act1, gbar1, n1) if li == 1 else (act2, gbar2, n2)
-                    op.run(a_l, False, n_l, zb, nslots, hv[2 * li])
-                    op.run(g_l, False, n_l, dy, nslots, hv[2 * li])
+                    op.run(a_l, False, n_l, zb, nslots, hv[2 * li], out_scale=inv_z)
+                    op.run(g_l, False, n_l, dy, nslots, hv[2 * li], out_scale=inv_gd)
             grad, layout = out, 1
         return dx
 
@@ -489,7 +566,7 @@ class GradMatchEngine(TrainEngine):
         try:
             self._pack_adjoint(W, V)
             hv = self._views(8) if param_adjoint else None
-            gbar3 = self._up_sweep(nb, am, V)
+            gbar3 = self._up_sweep(nb, am, V, W)
             abar, wbar, bbar, _ = self.head_second_order(state, state["dlog"], gbar3, V[6].reshape(self.K, self.C).contiguous(),
                                                          V[7], param_adjoint, hessian=True)
             if hv:
@@ -555,7 +632,7 @@ class GradMatchEngine(TrainEngine):
         try:
             self._pack_adjoint(W, V)
             hv = self._views(6) if need_params else None
-            gbar3 = self._up_sweep(nb, am, V)
+            gbar3 = self._up_sweep(nb, am, V, W)
             abar = torch.zeros((nb, eng.num_feat), dtype=torch.float32, device=self.device)
             xbar = self._down_sweep(nb, am, abar, fs["x"], hv)
         finally:
