@@ -403,9 +403,13 @@ def quiet_stdout():
 def finish(h, out, extra_rank0=None):
     import torch.distributed as dist
     from video_distillation_amd import distill
+    refused = None
     if out is not None:     # data-path collectives this rank's trainers issued over the whole run (warm-up, timed, sustained, eval)
         out["collectives"] = dict(distill.COLLECTIVE_CALLS, backend=(dist.get_backend() if dist.is_initialized() else None),
                                   forced_on_one_rank=(h.world == 1 and distill.collectives_on(1)))
+        from video_distillation_amd import hip
+        out["library"] = {"sources_hash": hip.loaded_stamp(), "checkout_sources_hash": hip.sources_hash(), "abi": int(hip.lib().vd_abi_version())}
+        refused = refuse_unproven(out, h.world)
     if h.comm is not None:
         h.comm.free()
         h.comm = None
@@ -419,6 +423,35 @@ def finish(h, out, extra_rank0=None):
             os.write(_REAL_STDOUT, line)
         else:
             sys.stdout.write(line.decode())
+    if refused:
+        print("bench.py: value withheld -- " + refused, file=sys.stderr)
+        sys.exit(4)
+
+
+def refuse_unproven(out, world):
+    """An N-rank line must PROVE its N ranks: ``ranks_seen`` (an all-reduce of ones over the process group) and, where RCCL
+    itself reported a rank count (``rccl.nranks`` = ncclCommCount, or the process group's size), both must equal ``n_gpus``.
+    Otherwise ``value`` is withheld (null, the reason in ``refused``) and the run exits non-zero: a throughput of N GPUs that
+    fewer ranks produced must never be printed.  Returns the reason or None."""
+    why = []
+    if out.get("n_gpus") != world:
+        why.append("n_gpus %r but world size %d" % (out.get("n_gpus"), world))
+    if out.get("ranks_seen") != world:
+        why.append("ranks_seen %r != %d" % (out.get("ranks_seen"), world))
+    rccl = out.get("rccl")
+    if isinstance(rccl, dict) and "nranks" in rccl and rccl["nranks"] != world:
+        why.append("rccl.nranks %r != %d" % (rccl["nranks"], world))
+    cps = out.get("clips_per_step")
+    if isinstance(cps, list) and len(cps) != world:
+        why.append("clips_per_step lists %d ranks, not %d" % (len(cps), world))
+    if not why:
+        return None
+    reason = "; ".join(why)
+    for key in ("value", "value_median"):
+        if key in out:
+            out[key] = None
+    out["refused"] = reason
+    return reason
 
 
 def base_record(args, h, metric, dt, per_step, dtype, workload, parallelism, precision):

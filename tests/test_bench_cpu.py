@@ -29,3 +29,21 @@ def test_pmc_traffic_is_quoted_only_for_the_stamped_kernel_sources(monkeypatch):
     monkeypatch.setattr(hip, "sources_hash", lambda: "0" * 16)         # any other kernel sources
     val, src = bench.pmc_traffic("conv1_fwd_f16", 3200)
     assert val is None and "other kernel sources" in src and "re-measure" in src
+
+
+def test_an_n_rank_line_without_proof_of_its_ranks_has_no_value():
+    """``bench.py --gpus N`` withholds ``value`` unless the line proves N ranks: ranks_seen (all-reduce of ones), rccl.nranks
+    (ncclCommCount / the process group's size) and the per-rank lists must all say N (reference mechanism replaced:
+    nn.DataParallel, utils.py:615-623 -- there a missing device shows up as an exception, here it must not show up as a number)."""
+    import bench
+    good = {"n_gpus": 8, "value": 230.0, "value_median": 231.0, "ranks_seen": 8, "clips_per_step": [400] * 8,
+            "rccl": {"version": "2.26.6", "nranks": 8}}
+    assert bench.refuse_unproven(dict(good), 8) is None
+    assert bench.refuse_unproven({"n_gpus": 1, "value": 31.0, "ranks_seen": 1, "clips_per_step": [3200], "rccl": None}, 1) is None
+    for broken, word in (({"ranks_seen": 7}, "ranks_seen"), ({"rccl": {"nranks": 1}}, "rccl.nranks"),
+                         ({"clips_per_step": [400] * 7}, "clips_per_step"), ({"n_gpus": 4}, "n_gpus")):
+        line = dict(good, **broken)
+        why = bench.refuse_unproven(line, 8)
+        assert why and word in why and line["value"] is None and line["value_median"] is None and line["refused"] == why
+    # a gloo group on one device reports no RCCL rank count: the all-reduce of ones is the proof
+    assert bench.refuse_unproven(dict(good, rccl={"note": "process group on gloo"}), 8) is None

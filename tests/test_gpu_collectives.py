@@ -28,6 +28,16 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
+def _together(*jobs):
+    """Run the child benchmarks of one test CONCURRENTLY (round 6: these are logic runs of 2 - 3 tiny steps whose time is process
+    start-up -- import, planning, engine construction -- and the children share the one GPU without touching each other's
+    results; serially the file took 195 s of the driver's suite).  -> the jobs' results, in order."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        futs = [ex.submit(j) for j in jobs]
+        return [f.result() for f in futs]
+
+
 def _bench(extra, env=None):
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     e.update(env or {})
@@ -41,11 +51,12 @@ def _bench(extra, env=None):
 
 def test_dm_decompositions_issue_their_collectives_and_keep_the_loss():
     small = ["--classes", "6", "--pool-per-class", "70", "--eval-epochs", "1"]
-    plain = _bench(small + ["--shard", "class"])
+    shards = (("class", 1), ("batch", 2), ("hybrid", 2))
+    # (hybrid on one rank has no class left over; VD_HYBRID_FORCE_SPLIT makes the last two classes split ones)
+    plain, *runs = _together(lambda: _bench(small + ["--shard", "class"]),
+                             *[lambda sh=sh: _bench(small + ["--shard", sh], dict(FORCE, VD_HYBRID_FORCE_SPLIT="2")) for sh, _ in shards])
     assert plain["collectives"]["all_reduce"] == 0 and plain["collectives"]["backend"] is None
-    for shard, per_step in (("class", 1), ("batch", 2), ("hybrid", 2)):
-        # (hybrid on one rank has no class left over; VD_HYBRID_FORCE_SPLIT makes the last two classes split ones)
-        got = _bench(small + ["--shard", shard], dict(FORCE, VD_HYBRID_FORCE_SPLIT="2"))
+    for (shard, per_step), got in zip(shards, runs):
         c = got["collectives"]
         assert c["backend"] == "nccl" and c["forced_on_one_rank"]
         # 3 steps: the loss all-reduce each, + the feature-sum all-reduce of the batch / hybrid split; one all-gather of the
@@ -56,18 +67,20 @@ def test_dm_decompositions_issue_their_collectives_and_keep_the_loss():
 
 def test_s2d_dc_mtt_issue_their_collectives_and_keep_the_loss():
     s2d = ["--method", "s2d", "--classes", "4", "--pool-per-class", "70", "--eval-epochs", "0"]
-    a, b = _bench(s2d), _bench(s2d, FORCE)
-    assert b["collectives"]["all_reduce"] == 3 * 2 and abs(b["loss_last"] / a["loss_last"] - 1) < 1e-5
     dc = ["--method", "dc", "--classes", "3", "--ipc", "1", "--frames", "8", "--size", "64", "--batch-real", "8", "--pool-per-class", "12"]
     # (bench.py seeds torch's generators, so both runs draw the same dropout masks; the ORDER of the fp32 atomics is left, and the
     #  matching loss amplifies it when a near-tie of a pooling window goes the other way: 1e-7 in most runs, 1.1e-4 seen once --
     #  so both legs run in the ordered mode, where the training step's sums have a fixed order)
     det = {"VD_DETERMINISTIC": "1"}
-    a, b = _bench(dc, det), _bench(dc, dict(FORCE, **det))
+    mtt = ["--method", "mtt", "--classes", "8", "--frames", "8", "--size", "64", "--syn-steps", "2", "--batch-syn", "8"]
+    sa, sb, da, db, ma, mb = _together(lambda: _bench(s2d), lambda: _bench(s2d, FORCE), lambda: _bench(dc, det),
+                                       lambda: _bench(dc, dict(FORCE, **det)), lambda: _bench(mtt, det), lambda: _bench(mtt, dict(FORCE, **det)))
+    a, b = sa, sb
+    assert b["collectives"]["all_reduce"] == 3 * 2 and abs(b["loss_last"] / a["loss_last"] - 1) < 1e-5
+    a, b = da, db
     assert b["collectives"]["all_reduce"] == 3 + 1            # every step's loss, incl. the extra profiling step of bench_dc
     assert abs(b["loss_last"] / a["loss_last"] - 1) < 1e-4 and b["roofline"]["launches"] > 0
-    mtt = ["--method", "mtt", "--classes", "8", "--frames", "8", "--size", "64", "--syn-steps", "2", "--batch-syn", "8"]
-    a, b = _bench(mtt, det), _bench(mtt, dict(FORCE, **det))
+    a, b = ma, mb
     # per iteration: flat gradient + Hessian-vector product per student step (2 x 2), hallucinator + dynamic-memory gradients (2);
     # 3 timed / warm-up iterations + 1 profiling iteration
     assert b["collectives"]["all_reduce"] == 4 * (2 * 2 + 2), b["collectives"]
@@ -88,28 +101,31 @@ def test_two_ranks_share_the_gpu_over_gloo_and_match_one_rank():
         assert out.returncode == 0, out.stderr[-3000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     small = ["--classes", "7", "--pool-per-class", "70", "--eval-epochs", "1"]
-    one = _bench(small + ["--shard", "class"])
-    for k, (shard, per_step) in enumerate((("class", 1), ("batch", 2), ("hybrid", 2))):
-        if shard == "hybrid" and os.environ.get("VD_TEST_ALL_SHARDS") != "1":
-            continue                      # (the eight-rank test below runs the hybrid decomposition)
-        got = two(small + ["--shard", shard], 29551 + k)
+    s2d = ["--method", "s2d", "--classes", "4", "--pool-per-class", "70", "--eval-epochs", "0"]
+    dc = ["--method", "dc", "--classes", "3", "--ipc", "1", "--frames", "8", "--size", "64", "--batch-real", "8", "--pool-per-class", "12"]
+    mtt = ["--method", "mtt", "--classes", "8", "--frames", "8", "--size", "64", "--syn-steps", "2", "--batch-syn", "8"]
+    shards = [(k, sh, per) for k, (sh, per) in enumerate((("class", 1), ("batch", 2), ("hybrid", 2)))
+              if sh != "hybrid" or os.environ.get("VD_TEST_ALL_SHARDS") == "1"]      # (the eight-rank test below runs the hybrid decomposition)
+    # every child of this test at once: four one-rank references and the two-rank runs (a fixed rendezvous port each)
+    one, s2d_a, dc_a, mtt_a, s2d_b, dc_b, mtt_b, *two_runs = _together(
+        lambda: _bench(small + ["--shard", "class"]), lambda: _bench(s2d), lambda: _bench(dc), lambda: _bench(mtt),
+        lambda: two(s2d, 29555), lambda: two(dc, 29556), lambda: two(mtt, 29557),
+        *[lambda k=k, sh=sh: two(small + ["--shard", sh], 29551 + k) for k, sh, _ in shards])
+    for (k, shard, per_step), got in zip(shards, two_runs):
         c = got["collectives"]
         assert got["n_gpus"] == 2 and c["backend"] == "gloo" and not c["forced_on_one_rank"]
         assert c["all_reduce"] == 3 * per_step and c["all_gather"] == 1, (shard, c)
         assert abs(got["loss_last"] / one["loss_last"] - 1) < 1e-4, (shard, got["loss_last"], one["loss_last"])
         assert "top1" in got["eval"]                                          # rank 0 trained a net on the GATHERED synthetic clips
-    s2d = ["--method", "s2d", "--classes", "4", "--pool-per-class", "70", "--eval-epochs", "0"]
-    a, b = _bench(s2d), two(s2d, 29555)
+    a, b = s2d_a, s2d_b
     assert b["collectives"]["all_reduce"] == 3 * 2 and abs(b["loss_last"] / a["loss_last"] - 1) < 1e-4
     # gradient matching: classes 2 + 1, every rank's loss all-reduced per step; trajectory matching: the student batch of 8 split
     # 4 + 4, flat gradient and Hessian-vector product all-reduced per student step (tolerances: see the one-rank test above)
-    dc = ["--method", "dc", "--classes", "3", "--ipc", "1", "--frames", "8", "--size", "64", "--batch-real", "8", "--pool-per-class", "12"]
-    a, b = _bench(dc), two(dc, 29556)
+    a, b = dc_a, dc_b
     # (each rank draws its classes' dropout masks from the same seeded generator, i.e. other masks than the one-rank run's:
     #  the losses agree to the dropout noise of this tiny configuration, +-2.5 %)
     assert b["n_gpus"] == 2 and b["collectives"]["all_reduce"] == 3 + 1 and abs(b["loss_last"] / a["loss_last"] - 1) < 8e-2
-    mtt = ["--method", "mtt", "--classes", "8", "--frames", "8", "--size", "64", "--syn-steps", "2", "--batch-syn", "8"]
-    a, b = _bench(mtt), two(mtt, 29557)
+    a, b = mtt_a, mtt_b
     assert b["n_gpus"] == 2 and b["collectives"]["all_reduce"] == 4 * (2 * 2 + 2), b["collectives"]
     assert abs(b["grand_loss_last"] / a["grand_loss_last"] - 1) < 8e-2
 
@@ -131,23 +147,32 @@ def test_pixel_gradient_allreduce_leg():
     identity, so the leg's loss is the owner-computes loss); (ii) two self-spawned ranks on device 0 over gloo: the reduced
     tensor's rows give the same update as owner-computes.  The JSON line carries bytes and ms of the exchange."""
     small = ["--classes", "6", "--pool-per-class", "70", "--eval-epochs", "0", "--exchange-leg"]
-    one = _bench(small, dict(FORCE, VD_BENCH_EXCHANGE_LEG="1", MASTER_PORT="29543"))
+    long = ["--steps", "50", "--warmup", "2"]       # (round 6) the two communicators interleaved for 52 + 5 steps, not 3 + 5: torch's process
+    #                                                  group (loss all-reduce, barriers) and hip.Comm (the 120 MB-shaped gradient
+    #                                                  tensor on the synthetic-clip stream) -- the order `--exchange allreduce` issues them in
+
+    def spawned_two():
+        e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VD_BENCH_ONE_DEVICE="1")
+        e.pop("WORLD_SIZE", None); e.pop("RANK", None)
+        out = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + COMMON + small, cwd=ROOT, env=e, capture_output=True, text=True,
+                             timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    one, one_long, other, two = _together(
+        lambda: _bench(small, dict(FORCE, VD_BENCH_EXCHANGE_LEG="1", MASTER_PORT="29543")),
+        lambda: _bench(small + long, dict(FORCE, VD_BENCH_EXCHANGE_LEG="1", MASTER_PORT="29545")),
+        lambda: _bench(small + long + ["--exchange", "allreduce"], dict(FORCE, VD_BENCH_EXCHANGE_LEG="1", MASTER_PORT="29544")),
+        spawned_two)
     leg = one["exchange_allreduce"]
     assert leg["through"].startswith("vd_comm_allreduce_f32") and leg["allreduce_calls"] == 5
     assert leg["pixel_gradient_bytes_per_step"] == 6 * 16 * 3 * 112 * 112 * 4 and leg["allreduce_ms_mean"] > 0
     assert one["rccl"]["nranks"] == 1 and one["rccl"]["version_code"] > 20000 and one["exchange"]["mode"] == "owner"
     # the leg's trainer starts from the same initial clips and runs iterations 0..6; the main run's loss_last is iteration 2:
     # compare the two modes at equal iterations instead -- a main run timed in allreduce mode whose leg is owner-computes
-    other = _bench(small + ["--exchange", "allreduce"], dict(FORCE, VD_BENCH_EXCHANGE_LEG="1", MASTER_PORT="29544"))
-    assert other["exchange"]["mode"] == "allreduce" and other["exchange"]["allreduce_calls"] >= 2
-    assert abs(other["loss_last"] / one["loss_last"] - 1) < 1e-5
+    assert other["exchange"]["mode"] == "allreduce" and other["exchange"]["allreduce_calls"] >= 50 and other["steps"] == 50
+    assert other["rccl"]["nranks"] == 1 and other["ranks_seen"] == 1 and other["value"] is not None and "refused" not in other
+    assert abs(other["loss_last"] / one_long["loss_last"] - 1) < 1e-5          # 52 iterations in either mode: the same clips
     assert abs(other["exchange_owner"]["loss_last"] / leg["loss_last"] - 1) < 1e-5
-    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VD_BENCH_ONE_DEVICE="1")
-    e.pop("WORLD_SIZE", None); e.pop("RANK", None)
-    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + COMMON + small, cwd=ROOT, env=e, capture_output=True, text=True,
-                         timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
-    two = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert two["ranks_seen"] == 2 and two["clips_per_step"] == [192, 192] and two["rccl"].get("nranks") is None
     # per-rank diagnostics of the timed region (round 5): what each rank did and how long it waited for the others
     pr = two["per_rank"]

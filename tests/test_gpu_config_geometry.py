@@ -5,9 +5,10 @@ paths at 64x64x8 with at most 8 clips):
     a 51-way head, the 'ours' metric and eight class lanes, against the reference-shaped double backward on the oracle --
     dCE/dparams on the real batch (detached), on the synthetic clips with ``create_graph=True``, ``match_loss``, backward to
     the pixels (utils.py:634-687; the calls of distill_baseline.py:243-262);
-  * config 5 (Kinetics-400 "MTT+Ours"): one iteration of ``distill.S2DMTTTrainer`` with 400 classes, 256-clip
-    hallucinator-composed student batches of 64x64x8 clips, two unrolled student steps, against ``oracle.ref_cpu.mtt_step``
-    chained through the oracle's hallucinator (distill_s2d_ms.py:236-300).
+  * config 5 (Kinetics-400 "MTT+Ours"): one iteration of ``distill.S2DMTTTrainer`` with hallucinator-composed student batches of
+    64x64x8 clips and TEN unrolled student steps (the script's own syn_steps) against ``oracle.ref_cpu.mtt_step`` chained through
+    the oracle's hallucinator (distill_s2d_ms.py:236-300), routed by the HIP forwards' pooling decisions;
+  * config 3 (miniUCF101 "DM+Ours"): one ``distill.S2DTrainer`` step at 112x112x16 with four classes against the fp64 oracle.
 
 The CPU side of each test takes 10 - 30 s on the GPU box's host."""
 import numpy as np
@@ -68,48 +69,145 @@ def test_gradient_matching_class_terms_at_config4_geometry(monkeypatch):
     assert sorted(per_clip)[len(per_clip) // 2] < 3e-3 and max(per_clip) < 5e-2
 
 
-def test_mtt_ours_iteration_at_config5_geometry():
+def test_mtt_ours_ten_unrolled_steps_at_config5_geometry():
+    """Configuration 5 at ITS unroll length (sh/s2d/s2d_MTT_ms_K400.sh: syn_steps 10; rounds 4 - 5 pinned 2): one
+    ``distill.S2DMTTTrainer`` iteration -- hallucinator-composed student batches 64x64x8, ten unrolled steps, gradients of the
+    dynamic memories, the hallucinator and syn_lr (distill_s2d_ms.py:236-300) -- at 100 classes / 64-clip batches (the oracle legs
+    take 25 s; tools/parity_mtt10.py is the same comparison at 400 / 256: profiles/r06_parity_mtt10.json).
+
+    Over ten steps a FREE comparison is decided by pooling near-ties: one window routed the other way in an early step moves the
+    median memory row by percents, and whether the HIP path, fp32 arithmetic or neither has one depends on the seed (over seeds the
+    HIP path is 50x closer to fp64 than the fp32 oracle, equal to it, or 8x further: profiles/r06_parity_mtt10_seeds.txt).  So:
+    (1) ARITHMETIC on the same piecewise-linear function -- the oracle routed by the decisions the HIP forwards recorded
+    (tests/argmax_tools.py), in fp64 and in fp32: the HIP gradients must be as close to fp64 as fp32 arithmetic is, within the
+    stated factor; (2) DECISIONS -- every window the fp64 values would have routed otherwise must be a near-tie of those values."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import argmax_tools as A
     from video_distillation_amd import distill, plan
-    C, vpc, spc, dpc, T, S, batch, steps, syn_lr = 400, 1, 2, 2, 8, 64, 256, 2, 0.01
+    C, vpc, spc, dpc, T, S, batch, steps, syn_lr = 100, 1, 2, 2, 8, 64, 64, 10, 0.01
     geo = plan.NetGeometry(T, S, S)
-    g = torch.Generator().manual_seed(505)
-    start = R.init_params(5050, 3, C)
+    g = torch.Generator().manual_seed(2)
+    start = R.init_params(20, 3, C)
     target = [q + 0.02 * q.abs().mean() * torch.randn(q.shape, generator=g) for q in start]
     static = torch.randn(C * spc, 3, S, S, generator=g)
     dynamic = torch.randn(C, dpc, T, 1, S, S, generator=g)
     hal_w = torch.empty(3, 4, 3, 3, 3).uniform_(-0.096, 0.096, generator=g)
     hal_b = torch.empty(3).uniform_(-0.096, 0.096, generator=g)
     ops = distill.HipMTTOps(geo, C, "cuda:0", dropout_p=0.0, batch_hint=batch)
+    assert ops.te.scaled and ops.te.eng.prec_name == "f16x3", "the shipped format of the twice-differentiable passes: scaled fp16 hi+lo pairs"
     tr = distill.S2DMTTTrainer(ops, C, vpc, spc, dpc, static.cuda(), dynamic.cuda(), hal_w.cuda(), hal_b.cuda(), syn_lr=syn_lr,
                                lr_dynamic=0.01, lr_hal=0.01, lr_lr=1e-5, syn_steps=steps, batch_syn=batch, expert_epochs=1,
                                max_start_epoch=1)
-    rng = np.random.default_rng(55)
+    rng = np.random.default_rng(3)
     chunks = [torch.as_tensor(rng.permutation(C)[:batch]) for _ in range(steps)]
     tr.draws = [(rng.integers(0, 2, batch), rng.integers(0, 2, batch)) for _ in range(steps)]
+    tr.keep_tape = True
     grand_hip = float(tr.step(0, [start, target], start_epoch=0, index_chunks=chunks, update=False))
-    g_dyn, g_w, g_b, _, g_lr = tr.last_grads
-    # ---- the oracle: compose every step's batch with the oracle hallucinator, unroll, back-propagate the grand loss ----
-    dyn = dynamic.reshape(C * dpc, T, 1, S, S).clone().requires_grad_(True)
-    w, b = hal_w.clone().requires_grad_(True), hal_b.clone().requires_grad_(True)
-    xs, labels = [], []
-    for s, these in enumerate(chunks):
-        label, sidx, didx = tr.indices(these, s, 0)
-        xs.append(R.hallucinator(static[sidx], dyn[didx], w, b))
-        labels.append(label)
-    x_all = torch.cat(xs)
-    grand_ref, gx, glr_ref = R.mtt_step(start, target, x_all.detach(), torch.cat(labels), syn_lr,
-                                        [torch.arange(s * batch, (s + 1) * batch) for s in range(steps)])
-    gd_ref, gw_ref, gb_ref = torch.autograd.grad(x_all, [dyn, w, b], grad_outputs=gx)
-    rows = [i for i in range(C * dpc) if float(gd_ref[i].abs().sum()) > 0]
-    per_row = sorted(_rel(g_dyn[i], gd_ref[i]) for i in rows)
-    print("config-5 geometry: grand loss HIP %.6f oracle %.6f (rel %.1e); d/d syn_lr rel %.1e; dynamic-memory gradient rel-L2 all %.2e "
-          "(per touched row: median %.1e, max %.1e, %d rows); hallucinator weight / bias %.1e / %.1e" % (
-              grand_hip, float(grand_ref), abs(grand_hip / float(grand_ref) - 1), abs(float(g_lr) / float(glr_ref) - 1), _rel(g_dyn, gd_ref),
-              per_row[len(per_row) // 2], per_row[-1], len(rows), _rel(g_w.reshape(-1), gw_ref.reshape(-1)), _rel(g_b, gb_ref)))
-    assert abs(grand_hip / float(grand_ref) - 1) < 1e-4
-    assert abs(float(g_lr) / float(glr_ref) - 1) < 5e-3
-    # rows of the dynamic memory no student batch drew: exactly zero on both sides
+    g_dyn, g_w, g_b, _, g_lr = (t.detach().cpu() for t in tr.last_grads)
+    routes = [A.routes_from_argmax([a.cpu() for a in handle[0]["am"]], (batch, T, 3, S, S), start) for _, _, handle, _ in tr.last_tape]
+    tr.last_tape = None
+
+    def oracle(dt, stats=None):
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        dyn = dynamic.reshape(C * dpc, T, 1, S, S).to(dt).clone().requires_grad_(True)
+        w, b = hal_w.to(dt).clone().requires_grad_(True), hal_b.to(dt).clone().requires_grad_(True)
+        xs, labels = [], []
+        for s, these in enumerate(chunks):
+            label, sidx, didx = tr.indices(these, s, 0)
+            xs.append(R.hallucinator(static.to(dt)[sidx], dyn[didx], w, b))
+            labels.append(label)
+        x_all = torch.cat(xs)
+        grand, gx, glr = A.mtt_step_routed([q.to(dt) for q in start], [q.to(dt) for q in target], x_all.detach(), torch.cat(labels), syn_lr,
+                                           [torch.arange(s * batch, (s + 1) * batch) for s in range(steps)], routes, dt, stats)
+        gd, gw, gb = torch.autograd.grad(x_all, [dyn, w, b], grad_outputs=gx)
+        return {"grand": float(grand), "g_dyn": gd, "g_w": gw, "g_b": gb, "g_lr": float(glr)}
+    stats = []
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        f64, f32 = ex.submit(oracle, torch.float64, stats), ex.submit(oracle, torch.float32)
+        o64, o32 = f64.result(), f32.result()
+    rows = [i for i in range(C * dpc) if float(o64["g_dyn"][i].abs().sum()) > 0]
+
+    def against(r):
+        per_row = sorted(_rel(r["g_dyn"][i], o64["g_dyn"][i]) for i in rows)
+        return {"grand": abs(r["grand"] / o64["grand"] - 1), "syn_lr": abs(r["g_lr"] / o64["g_lr"] - 1), "dyn_all": _rel(r["g_dyn"], o64["g_dyn"]),
+                "dyn_row_median": per_row[len(per_row) // 2], "dyn_row_max": per_row[-1],
+                "hal_w": _rel(r["g_w"].reshape(-1), o64["g_w"].reshape(-1)), "hal_b": _rel(r["g_b"], o64["g_b"])}
+    hip = against({"grand": grand_hip, "g_dyn": g_dyn, "g_w": g_w, "g_b": g_b, "g_lr": float(g_lr)})
+    ref = against(o32)
+    mism = [[d["mismatch"] for d in st] for st in stats]
+    far = sum(d["not_near_tie"] for st in stats for d in st)
+    print("config 5, ten unrolled steps, routed by the HIP forwards' decisions: HIP vs fp64 %s | fp32 arithmetic vs fp64 %s | windows the "
+          "fp64 values would route otherwise, per step and level: %s (no near-tie: %d)" % (
+              {k: "%.1e" % v for k, v in hip.items()}, {k: "%.1e" % v for k, v in ref.items()}, mism, far))
+    # (2) decisions: near-ties only
+    assert far == 0, mism
+    # (1) arithmetic: absolute bars (the grand loss is north_star's quantity) ...
+    assert hip["grand"] < 1e-5 and hip["syn_lr"] < 1e-3 and hip["dyn_all"] < 1e-2 and hip["dyn_row_median"] < 3e-3
+    assert hip["hal_w"] < 3e-3 and hip["hal_b"] < 3e-3
+    # ... and relative to what fp32 arithmetic itself leaves on the same function: within FACTOR of it on every quantity (the
+    # small floors: where fp32 arithmetic happens to sit at 1e-7, a ratio is noise)
+    FACTOR = 3.0
+    floors = {"grand": 2e-7, "syn_lr": 2e-5, "dyn_all": 1e-4, "dyn_row_median": 2e-5, "dyn_row_max": 2e-3, "hal_w": 5e-5, "hal_b": 5e-5}
+    for k in floors:
+        assert hip[k] <= FACTOR * ref[k] + floors[k], (k, hip[k], ref[k])
+    # rows of the dynamic memory no student batch drew: exactly zero
     untouched = [i for i in range(C * dpc) if i not in set(rows)]
     assert all(float(g_dyn[i].abs().sum()) == 0.0 for i in untouched[:50])
-    assert per_row[len(per_row) // 2] < 3e-3 and per_row[-1] < 8e-2 and _rel(g_dyn, gd_ref) < 1e-2
-    assert _rel(g_w.reshape(-1), gw_ref.reshape(-1)) < 5e-3 and _rel(g_b, gb_ref) < 5e-3
+
+
+def test_s2d_step_at_config3_geometry():
+    """Configuration 3 at the benchmark's clip size (round 5 ran it once by hand at 50 classes, tools/parity_s2d50.py; the suite had
+    it at 64x64x8 only): one ``distill.S2DTrainer`` step -- 4 classes x (64 real + 1 hallucinator-composed) clips 112x112x16, shipped
+    precision mode, random memories and hallucinator -- against the same step on the oracle in fp64 (distill_s2d_ms.py:402-438):
+    loss, gradient of the selected dynamic memories, hallucinator weight / bias gradients, unselected memories exactly zero."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from video_distillation_amd import distill, plan
+    C, T, S, B, NP, vpc, spc, dpc = 4, 16, 112, 64, 66, 1, 2, 2
+    dev = torch.device("cuda:0")
+    geo = plan.NetGeometry(T, S, S)
+    g = torch.Generator(device=dev).manual_seed(33)
+    base = torch.randn(C, 1, T, 3, S, S, device=dev, generator=g)
+    clips = (base + 0.1 * torch.randn(C, NP, T, 3, S, S, device=dev, generator=g)).reshape(C * NP, T, 3, S, S)
+    pool = distill.RealPool(clips, [NP] * C, [c * NP for c in range(C)])
+    static = torch.randn(C * spc, 3, S, S, device=dev, generator=g)
+    dynamic = torch.randn(C, dpc, T, 1, S, S, device=dev, generator=g)
+    hal_w = (torch.rand(3, 4, 3, 3, 3, device=dev, generator=g) * 2 - 1) * 0.096
+    hal_b = (torch.rand(3, device=dev, generator=g) * 2 - 1) * 0.096
+    be = distill.HipBackend(geo, dev)
+    assert be.weight_format == "f16" and be.real_last in ("c8", "x3")          # the shipped mode (bench.py's defaults)
+    tr = distill.S2DTrainer(be, pool, C, vpc, spc, dpc, B, static.clone(), dynamic.clone(), hal_w.clone(), hal_b.clone(), lr_dynamic=0.01, lr_hal=1e-6)
+    sidx, didx = tr.indices(0)
+    idx = distill.sample_real_indices(0, pool.counts, pool.offsets, B, list(range(C)))
+    loss_hip = float(tr.step(0))
+    tr.sync()
+    g_dyn, g_w, g_b = (t.detach().cpu() for t in tr.last_grads)
+    # ---- the oracle, fp64: the real side's class means on host threads (no gradient), the composed clips with autograd ----
+    params = [w.cpu().double() for w in be.new_network(seed=0)]
+
+    def real_mean(c):
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        real = clips[torch.as_tensor(idx[c * B:(c + 1) * B], device=dev)].cpu().double()
+        with torch.no_grad():
+            return R.convnet3d_embed(real, params)
+    with ThreadPoolExecutor(max_workers=max(1, min(4, (os.cpu_count() or 1) // 32))) as ex:
+        f_real = list(ex.map(real_mean, range(C)))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    dy = dynamic.reshape(C * dpc, T, 1, S, S).cpu().double().requires_grad_(True)
+    w, b = hal_w.cpu().double().requires_grad_(True), hal_b.cpu().double().requires_grad_(True)
+    img = R.hallucinator(static.cpu().double()[torch.as_tensor(sidx)], dy[torch.as_tensor(didx)], w, b)
+    loss = sum(R.dm_class_term(f_real[c], R.convnet3d_embed(img[c * vpc:(c + 1) * vpc], params)) for c in range(C))
+    gd, gw, gb = torch.autograd.grad(loss, [dy, w, b])
+    g_dyn = g_dyn.reshape(gd.shape)
+    sel = sorted(set(int(v) for v in didx))
+    rows = sorted(_rel(g_dyn[r], gd[r]) for r in sel)
+    print("config-3 geometry: loss HIP %.6f oracle (fp64) %.6f (rel %.1e); dynamic-memory gradient per selected memory %s, all %.2e; hallucinator "
+          "weight / bias gradient %.1e / %.1e" % (loss_hip, float(loss), abs(loss_hip / float(loss) - 1), ["%.1e" % v for v in rows],
+                                                  _rel(g_dyn, gd), _rel(g_w, gw), _rel(g_b, gb)))
+    assert abs(loss_hip / float(loss) - 1) < 1e-4                                   # (measured 2e-6 at 50 classes; north_star's bar: 1e-3)
+    # early regime (random memories: the feature gap is of the features' own size): a memory without a differing pooling decision
+    # agrees to ~1e-4, one near-tie routed the other way moves a memory's gradient by up to a few 1e-2 (DESIGN section 2)
+    assert rows[len(rows) // 2] < 1e-3 and rows[-1] < 5e-2
+    assert _rel(g_w, gw) < 2e-3 and _rel(g_b, gb) < 2e-3
+    assert all(float(g_dyn[r].abs().sum()) == 0.0 for r in range(C * dpc) if r not in set(sel))

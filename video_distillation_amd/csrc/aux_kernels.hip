@@ -29,6 +29,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // block-wide sum; result valid in thread 0.  blockDim.x <= 1024, multiple of 64.
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
@@ -1921,11 +1927,16 @@ __global__ __launch_bounds__(64) void ce_loss_kernel(const float* __restrict__ l
     for (int k = lane; k < K; k += 64) m = fmaxf(m, z[k]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    float sum = 0.f;
-    for (int k = lane; k < K; k += 64) sum += __expf(z[k] - m);
-    sum = wave_sum(sum);
+    // The softmax in fp64, rounded once (round 6).  The fast intrinsics this kernel used (__expf / __logf: hardware exp2 / log2 with an
+    // fp32 argument scaling) leave ~4e-7 on log-sum-exp -- one common relative factor on all K probabilities of a clip, so they no
+    // longer sum to one -- where torch's fp32 log_softmax (what F.cross_entropy of distill_baseline.py:249 runs) is exact to 6e-8;
+    // over the ten unrolled student steps of MTT that was the 3 - 14x by which the HIP gradients stood further from the exact
+    // ones than fp32 arithmetic (tools/mtt_dissect.py).  K <= a few hundred values per clip: the cost is nothing.
+    double sum = 0.0;
+    for (int k = lane; k < K; k += 64) sum += exp((double)z[k] - (double)m);
+    sum = wave_sum_d(sum);
     const int64_t yl = labels[clip];
-    const float lse = m + __logf(sum);
+    const double lse = (double)m + log(sum);
     if (yl < 0 || yl >= K) {
         // a label outside [0, K): torch raises; without a host sync the loud failure is a NaN loss and gradient
         const float nan = __uint_as_float(0x7fc00000u);
@@ -1934,9 +1945,10 @@ __global__ __launch_bounds__(64) void ce_loss_kernel(const float* __restrict__ l
         return;
     }
     const int y = (int)yl;
-    if (lane == 0) loss_per_clip[clip] = lse - z[y];
-    const float invB = 1.f / (float)B;
-    for (int k = lane; k < K; k += 64) dlogits[(int64_t)clip * K + k] = (__expf(z[k] - lse) - (k == y ? 1.f : 0.f)) * invB;
+    if (lane == 0) loss_per_clip[clip] = (float)(lse - (double)z[y]);
+    const double invB = 1.0 / (double)B;
+    for (int k = lane; k < K; k += 64)
+        dlogits[(int64_t)clip * K + k] = (float)((exp((double)z[k] - lse) - (k == y ? 1.0 : 0.0)) * invB);
 }
 
 extern "C" int vd_ce_loss(const float* logits, const int64_t* labels, int B, int K, float* loss_per_clip, float* dlogits,
@@ -2141,33 +2153,42 @@ __global__ __launch_bounds__(256) void head_second_order_kernel(
     // dlogbar is handed out through dlogbar_out and logitbar = 0.
     const bool hess = (logits != nullptr);
     const float* z = hess ? logits + (int64_t)clip * K : nullptr;
-    float m = -3.402823466e38f, ssum = 1.f;
+    float m = -3.402823466e38f;
+    double ssum = 1.0;              // (softmax and the Hessian's <p, dlogbar> in fp64: see ce_loss_kernel)
     if (hess) {
         for (int k = 0; k < K; ++k) m = fmaxf(m, z[k]);
-        ssum = 0.f;
-        for (int k = 0; k < K; ++k) ssum += __expf(z[k] - m);
+        ssum = 0.0;
+        for (int k = 0; k < K; ++k) ssum += exp((double)z[k] - (double)m);
     }
     __syncthreads();
     const int32_t* am = amax_t + (int64_t)clip * K;
     const float* dl = dlogits + (int64_t)clip * K;
-    float part = 0.f;
+    double part = 0.0;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const int t = am[k];
         const float* dr = dropped + ((int64_t)clip * Tp + t) * C;
         float a = v_b[k];
         for (int c = 0; c < C; ++c) a += w[k * C + c] * u[t * C + c] + v_w[k * C + c] * dr[c];
-        const float p = hess ? __expf(z[k] - m) / ssum : 0.f;
+        const double pd = hess ? exp((double)z[k] - (double)m) / ssum : 0.0;
         dlb[k] = a;
-        pk[k] = p;
-        part += p * a;
+        pk[k] = (float)pd;
+        part += pd * (double)a;
         if (dlogbar_out != nullptr) dlogbar_out[(int64_t)clip * K + k] = a;
     }
-    __shared__ float dot_s;
-    const float dot0 = block_sum(part, red);       // valid in thread 0 only
-    if (threadIdx.x == 0) dot_s = dot0;
+    __shared__ double dot_s;
+    __shared__ double red_d[16];
+    part = wave_sum_d(part);
+    if ((threadIdx.x & 63) == 0) red_d[threadIdx.x >> 6] = part;
     __syncthreads();
-    const float dot = dot_s;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) dlb[k] = hess ? pk[k] * (dlb[k] - dot) / (float)B : 0.f;
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+        for (int i = 0; i < (int)((blockDim.x + 63) >> 6); ++i) tsum += red_d[i];
+        dot_s = tsum;
+    }
+    __syncthreads();
+    const double dot = dot_s;
+    for (int k = threadIdx.x; k < K; k += blockDim.x)
+        dlb[k] = hess ? (float)((double)pk[k] * ((double)dlb[k] - dot) / (double)B) : 0.f;
     __syncthreads();
     if (wbar != nullptr) {
         // adjoint of the logit conv's own parameters (Hessian-vector product for MTT):

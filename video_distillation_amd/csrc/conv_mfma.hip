@@ -32,7 +32,7 @@
 
 #include "../../include/vd_hip.h"
 
-// tuning switches (A/B builds via tools/ab.py; defaults are the shipped configuration)
+// tuning switches (compile-time A/B builds; defaults are the shipped configuration)
 #ifndef VD_DB_X1
 #define VD_DB_X1 3
 #endif
@@ -937,7 +937,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                 if (!X3 && !EXT && p.emit_lo == 2) {      // the fp8 image of these values (x 1/4) must stay finite for the consumer: clamp at 1792
                     const float a0 = fabsf(m0), a1 = (p.pool_t == 2) ? 0.f : fabsf(m1);      // (range monitor: VdConvParams.range_stats)
                     rs_amax = fmaxf(rs_amax, fmaxf(a0, a1));
-                    rs_sat += (a0 > 1792.f ? 1 : 0) + (a1 > 1792.f ? 1 : 0);
+                    rs_sat += (!(a0 <= 1792.f) ? 1 : 0) + (!(a1 <= 1792.f) ? 1 : 0);      // (NaN counts as saturated: fmaxf drops it from the maximum)
                     m0 = fminf(fmaxf(m0, -1792.f), 1792.f); m1 = fminf(fmaxf(m1, -1792.f), 1792.f);
                 }
                 const int q = (gi * 4 + half + 2 * qh) * nsets;

@@ -493,9 +493,26 @@ bool plan_forward_pix(int cout, int t_in, int h_in, int w_in, int lds_budget, in
         for (int kt = 0; kt < KT; ++kt) sp.taps.push_back({kt * cin + q[20][0], q[20][1], 0});
         sp.frame_tiles = true;
         if (make_plan(sp, pl)) {
-            pl.out_t_stride = FRAME_TILE_OUT_STEP;
-            pl.pair_flip = FRAME_TILE_FLIP | (pl.types[0].pitch_h << 8) | (pl.types[0].pitch_f << 16);
-            done = true;
+            // what the frame-sharing kernel relies on (plan.plan_forward_pix checks the same; a violation falls back to the frame-pair layout):
+            // tile i of a wave row = tile 0 + i frames, tap 3 j + kt = tap 3 j + kt frames
+            bool ok = true;
+            for (const BoxType& t : pl.types) {
+                const int fs = cin * t.pitch_f * SLOT_BYTES;
+                if ((int)t.a_off.size() < sp.MW * 4 * 32 || (int)t.tap_off.size() < 2 * 30) { ok = false; break; }
+                for (int w = 0; w < sp.MW && ok; ++w)
+                    for (int i = 1; i < 4 && ok; ++i)
+                        for (int r = 0; r < 32; ++r)
+                            if (t.a_off[(w * 4 + i) * 32 + r] - t.a_off[(w * 4) * 32 + r] != i * fs) { ok = false; break; }
+                for (int j = 0; j < 10 && ok; ++j)
+                    for (int kt = 1; kt < KT && ok; ++kt)
+                        for (int e = 0; e < 2; ++e)
+                            if (t.tap_off[2 * (3 * j + kt) + e] - t.tap_off[2 * (3 * j) + e] != kt * fs) { ok = false; break; }
+            }
+            if (ok) {
+                pl.out_t_stride = FRAME_TILE_OUT_STEP;
+                pl.pair_flip = FRAME_TILE_FLIP | (pl.types[0].pitch_h << 8) | (pl.types[0].pitch_f << 16);
+                done = true;
+            }
         }
     }
     if (!done) {

@@ -38,7 +38,7 @@ from . import plan as P
 PARAM_SHAPES = ((64, 3, 3, 7, 7), (64,), (128, 64, 3, 7, 7), (128,), (128, 128, 3, 7, 7), (128,))
 
 
-COLLECTIVE_CALLS = {"all_reduce": 0, "all_gather": 0, "bytes": 0}      # issued by the trainers of this process (bench.py reports them)
+COLLECTIVE_CALLS = {"all_reduce": 0, "all_gather": 0, "bytes": 0, "control_all_reduce": 0}      # issued by the trainers of this process (bench.py reports them; control: 4-byte decisions, not data)
 
 
 def _all_reduce(t: torch.Tensor) -> None:
@@ -49,6 +49,14 @@ def _all_reduce(t: torch.Tensor) -> None:
     COLLECTIVE_CALLS["all_reduce"] += 1
     COLLECTIVE_CALLS["bytes"] += t.numel() * t.element_size()
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def _all_reduce_max(t: torch.Tensor) -> None:
+    """Max-all-reduce of a small decision flag (control path: counted apart from the data-path collectives)."""
+    import torch.distributed as dist
+    COLLECTIVE_CALLS["control_all_reduce"] += 1
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
 
 
 def _all_gather(parts: List[torch.Tensor], t: torch.Tensor) -> None:
@@ -316,15 +324,23 @@ class HipBackend:
             st.zero_()
         return {"saturated": sat, "absmax": float(np.array([bits], dtype=np.uint32).view(np.float32)[0])}
 
-    def check_real_range(self) -> Optional[dict]:
+    def check_real_range(self, force_fallback: bool = False) -> Optional[dict]:
         """The fp8 operand planes of the real side's last level use FIXED power-of-two scalings (outputs of level 1 clamped at
         1792, low parts x 2^9): exact to 2^-16 for magnitudes 2^-4 .. 1792, which covers PyTorch-default-initialised networks on
         standardised clips by orders of magnitude -- but not arbitrary weights.  If the launches since the last check left that
         range (something saturated, or the largest output was below ``C8_MIN_ABSMAX``), the backend warns and switches the real
         side to the fp16 hi+lo last level (``real_last = 'x3'``) for all later steps."""
         r = self.real_range()
-        if r is None or (r["saturated"] == 0 and (r["absmax"] >= self.C8_MIN_ABSMAX or r["absmax"] == 0.0)):
+        if r is None or not (self.range_is_bad(r) or force_fallback):
             return r
+        return self.fall_back_to_hi_lo(r)
+
+    def range_is_bad(self, r: Optional[dict]) -> bool:
+        """Saturated (or non-finite: the launch counts NaN / Inf outputs as saturated) or too small for the low parts' scaling."""
+        return r is not None and (r["saturated"] > 0 or not np.isfinite(r["absmax"]) or (0.0 < r["absmax"] < self.C8_MIN_ABSMAX))
+
+    def fall_back_to_hi_lo(self, r: Optional[dict] = None) -> dict:
+        r = dict(r or {"saturated": 0, "absmax": 0.0})
         import warnings
         warnings.warn("fp8-corrected last level outside its validated activation range (%d outputs of level 1 saturated at 1792, "
                       "max |output| %.3g): the real side's last level runs in fp16 hi+lo pairs from now on" % (r["saturated"], r["absmax"]))
@@ -507,7 +523,17 @@ def check_real_range(trainer) -> None:
     if trainer._range_calls % every:
         return
     torch.cuda.synchronize(be.device)
-    r = be.check_real_range()
+    # every rank must run the SAME last-level format into the exchanged sums / gathered clips: the decision is the maximum over
+    # the ranks (a rank used to decide on its own), and the step it was taken at goes into the record
+    force = False
+    if collectives_on(getattr(trainer, "world", 1)):
+        flag = torch.tensor([1.0 if be.range_is_bad(be.real_range(reset=False)) else 0.0], device=be.device)
+        _all_reduce_max(flag)
+        force = bool(flag.item() > 0)
+    r = be.check_real_range(force_fallback=force)
+    if r is not None and r.get("fallback"):
+        r["fallback_at_sync"] = trainer._range_calls
+        r["fallback_decided_by"] = "max over ranks" if force else "this rank"
     if r is not None and (r["absmax"] > 0.0 or r["saturated"] > 0 or getattr(trainer, "real_range", None) is None):
         trainer.real_range = r          # (a check with no launch since the previous one keeps the previous record)
 
@@ -1274,6 +1300,8 @@ class MTTTrainer:
         self.rank, self.world = rank, world
         self.steps_done = 0
         self.last_grads = None
+        self.keep_tape = False      # True: ``last_tape`` keeps the unrolled steps' handles (arg-max bytes of every student forward) after step()
+        self.last_tape = None
 
     # -- what differs between raw synthetic clips and the s2d composition ---------------------------------------------
     def _num_items(self) -> int:
@@ -1359,6 +1387,7 @@ class MTTTrainer:
                 hv = torch.zeros_like(tbar)
             tbar = tbar + self._allreduce(hv)
         self.last_grads = self._finish(update) + (g_lr,)
+        self.last_tape = tape if self.keep_tape else None
         if update:
             mu = self.LR_MOMENTUM
             self.lr_buf = g_lr.clone() if self.steps_done == 0 else mu * self.lr_buf + g_lr

@@ -509,7 +509,7 @@ def _memo(fn):
     cache = {}
 
     def wrapped(*args, **kwargs):
-        key = (args, tuple(sorted(kwargs.items())), os.environ.get("VD_L0_BOX"), os.environ.get("VD_NTW2_MTW"))
+        key = (args, tuple(sorted(kwargs.items())), os.environ.get("VD_L0_BOX"), os.environ.get("VD_NTW2_MTW"), os.environ.get("VD_L0_FRAME_TILES"))
         if key not in cache:
             cache[key] = fn(*args, **kwargs)
         return cache[key]
@@ -729,7 +729,10 @@ def pix_row_pitch(w: int) -> int:
     return -(-(w + 8) // 8) * 8
 
 
-L0_FRAME_TILES = os.environ.get("VD_L0_FRAME_TILES", "1") == "1"      # (0: the round-4 layout, frame-pair row groups -- A/B measurements)
+def l0_frame_tiles() -> bool:
+    """VD_L0_FRAME_TILES (0: the round-4 layout, frame-pair row groups -- A/B measurements), read at every planning call like
+    csrc/planner.cpp does, and part of the planners' memo key: both planners always see the same value."""
+    return os.environ.get("VD_L0_FRAME_TILES", "1") == "1"
 
 
 @_memo
@@ -782,7 +785,7 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
         return ci * clip_stride + (a * Ho + b // 2) * Wo + c // 2
     force_box = tuple(int(v) for v in os.environ["VD_L0_BOX"].split(",")) if os.environ.get("VD_L0_BOX") else None
     plan = None
-    if L0_FRAME_TILES and ntw == 1 and NT == 2 and tuple(mtw_options) == (4,) and Wo % 4 == 0:
+    if l0_frame_tiles() and ntw == 1 and NT == 2 and tuple(mtw_options) == (4,) and Wo % 4 == 0:
         # K order: (tap pair j, kt) for the 10 pairs of a kt plane's first 20 (c, kh) taps, then the three left-over taps
         q = [(c, kh) for c in range(cin) for kh in range(KH)]
         taps = [(kt * cin + q[2 * j + e][0], q[2 * j + e][1], 0) for j in range(10) for kt in range(KT) for e in range(2)]
@@ -796,11 +799,13 @@ def plan_forward_pix(name: str, cout: int, t_in: int, h_in: int, w_in: int, lds_
             plan.out_t_stride, plan.pair_flip = FRAME_TILE_OUT_STEP, FRAME_TILE_FLIP | (t0.pitch_h << 8) | (t0.pitch_f << 16)
             plan.meta["frame_tiles"] = 1
             fs = cin * t0.pitch_f * SLOT_BYTES
-            for t in plan.types:          # what the frame-sharing kernel relies on
+            for t in plan.types:          # what the frame-sharing kernel relies on (a violation falls back to the frame-pair layout)
                 a = t.a_off.reshape(MW, 4, 32)
-                assert all((a[:, i] - a[:, 0] == i * cin * t.pitch_f * SLOT_BYTES).all() for i in range(4)), "frame tiles: tile i != tile 0 + i frames"
+                if not all((a[:, i] - a[:, 0] == i * cin * t.pitch_f * SLOT_BYTES).all() for i in range(4)):
+                    raise ValueError("frame tiles: tile i != tile 0 + i frames")
                 tp = t.tap_off.reshape(-1, 2)
-                assert all((tp[3 * j + kt] - tp[3 * j] == kt * fs).all() for j in range(10) for kt in range(KT))
+                if not all((tp[3 * j + kt] - tp[3 * j] == kt * fs).all() for j in range(10) for kt in range(KT)):
+                    raise ValueError("frame tiles: tap 3 j + kt != tap 3 j + kt frames")
         except ValueError:
             plan = None
     if plan is None:
@@ -1164,7 +1169,7 @@ def plan_network(geo: NetGeometry, lds_budget: int = 3700, ntw: int = 1, ntw0: i
     and of the first-layer forward programs; ``batch_hint`` = clips per launch the programs will typically see
     (small batches get latency-oriented decompositions, see ``latency_variant``)."""
     key = (geo.frames, geo.height, geo.width, geo.channel, geo.widths, geo.pools_t, lds_budget, ntw, ntw0, balanced, batch_hint, bwd0_small,
-           bwd0_block_w(geo.width))
+           bwd0_block_w(geo.width), l0_frame_tiles())
     if key in _PLAN_CACHE:
         return _PLAN_CACHE[key]
     dims = geo.layer_dims()

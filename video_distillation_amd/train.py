@@ -586,6 +586,8 @@ class GradMatchEngine(TrainEngine):
         x = x.detach().to(self.device, torch.float32).contiguous()
         keep_ws, eng._ws = eng._ws, {}
         try:
+            if self.scaled:      # (the fused entry, loss_and_grads, packs the engine's forward operands itself)
+                eng.set_weights([p.detach() for p in params6])
             feats, nb, am = self._forward(x, [p.detach() for p in params6])
             ws = eng._ws
         finally:
