@@ -127,7 +127,7 @@ def pmc_traffic(name, clips_per_launch):
     tools/refresh_profiles.sh re-measures the file.  -> (bytes or None, source label)."""
     from video_distillation_amd import hip
     mine = hip.sources_hash()
-    for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
+    for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(path):
             continue

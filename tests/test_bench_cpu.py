@@ -5,6 +5,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PMC_FILE = "r06_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")) else "r05_pmc_traffic.json"
 
 
 def test_pmc_traffic_is_quoted_only_for_the_stamped_kernel_sources(monkeypatch):
@@ -13,7 +14,7 @@ def test_pmc_traffic_is_quoted_only_for_the_stamped_kernel_sources(monkeypatch):
     the launch shape is the file's -- otherwise null with the reason (round 4 quoted a file five commits old)."""
     import bench
     from video_distillation_amd import hip
-    doc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
+    doc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
     stamp = doc["_source"]["kernel_sources_sha256_16"]
     rec = doc["conv1_fwd_f16"]
     assert len(stamp) == 16 and rec["clips_per_launch"] == 3200

@@ -72,20 +72,24 @@ def test_gradient_matching_class_terms_at_config4_geometry(monkeypatch):
 def test_mtt_ours_ten_unrolled_steps_at_config5_geometry():
     """Configuration 5 at ITS unroll length (sh/s2d/s2d_MTT_ms_K400.sh: syn_steps 10; rounds 4 - 5 pinned 2): one
     ``distill.S2DMTTTrainer`` iteration -- hallucinator-composed student batches 64x64x8, ten unrolled steps, gradients of the
-    dynamic memories, the hallucinator and syn_lr (distill_s2d_ms.py:236-300) -- at 100 classes / 64-clip batches (the oracle legs
-    take 25 s; tools/parity_mtt10.py is the same comparison at 400 / 256: profiles/r06_parity_mtt10.json).
+    dynamic memories, the hallucinator and syn_lr (distill_s2d_ms.py:236-300) -- at 32 classes / 16-clip batches (the fp64 double
+    backward through ten steps costs 2 s per clip on the box's host; tools/parity_mtt10.py is the same comparison at 400 / 256 and,
+    with the free oracles beside it, at 100 / 64 over four seeds: profiles/r06_parity_mtt10*.json).
 
     Over ten steps a FREE comparison is decided by pooling near-ties: one window routed the other way in an early step moves the
-    median memory row by percents, and whether the HIP path, fp32 arithmetic or neither has one depends on the seed (over seeds the
-    HIP path is 50x closer to fp64 than the fp32 oracle, equal to it, or 8x further: profiles/r06_parity_mtt10_seeds.txt).  So:
+    median memory row by percents, and whether the HIP path, fp32 arithmetic or neither has one depends on the seed (over four seeds
+    the HIP path's distance from the free fp64 oracle is x0.02 .. x2.6 of the fp32 oracle's: profiles/r06_parity_mtt10_seeds.txt).  So:
     (1) ARITHMETIC on the same piecewise-linear function -- the oracle routed by the decisions the HIP forwards recorded
-    (tests/argmax_tools.py), in fp64 and in fp32: the HIP gradients must be as close to fp64 as fp32 arithmetic is, within the
-    stated factor; (2) DECISIONS -- every window the fp64 values would have routed otherwise must be a near-tie of those values."""
+    (tests/argmax_tools.py), in fp64 and in fp32: the memory gradient must be as close to fp64 as fp32 arithmetic is (both sit at
+    4e-6: theta - target is a difference of fp32 numbers 100x its size), the scalars and the hallucinator's parameter gradients --
+    sums over every pixel of every clip with four digits of cancellation, where the HIP path is 10 - 50x fp32 arithmetic -- within
+    absolute bars two orders below what one flipped window does; (2) DECISIONS -- every window the fp64 values would have routed
+    otherwise must be a near-tie of those values."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     from tests import argmax_tools as A
     from video_distillation_amd import distill, plan
-    C, vpc, spc, dpc, T, S, batch, steps, syn_lr = 100, 1, 2, 2, 8, 64, 64, 10, 0.01
+    C, vpc, spc, dpc, T, S, batch, steps, syn_lr = 32, 1, 2, 2, 8, 64, 16, 10, 0.01
     geo = plan.NetGeometry(T, S, S)
     g = torch.Generator().manual_seed(2)
     start = R.init_params(20, 3, C)
@@ -104,7 +108,7 @@ def test_mtt_ours_ten_unrolled_steps_at_config5_geometry():
     tr.draws = [(rng.integers(0, 2, batch), rng.integers(0, 2, batch)) for _ in range(steps)]
     tr.keep_tape = True
     grand_hip = float(tr.step(0, [start, target], start_epoch=0, index_chunks=chunks, update=False))
-    g_dyn, g_w, g_b, _, g_lr = (t.detach().cpu() for t in tr.last_grads)
+    g_dyn, g_w, g_b, _, g_lr = (None if t is None else t.detach().cpu() for t in tr.last_grads)      # (static memories frozen: no gradient)
     routes = [A.routes_from_argmax([a.cpu() for a in handle[0]["am"]], (batch, T, 3, S, S), start) for _, _, handle, _ in tr.last_tape]
     tr.last_tape = None
 
@@ -142,15 +146,13 @@ def test_mtt_ours_ten_unrolled_steps_at_config5_geometry():
               {k: "%.1e" % v for k, v in hip.items()}, {k: "%.1e" % v for k, v in ref.items()}, mism, far))
     # (2) decisions: near-ties only
     assert far == 0, mism
-    # (1) arithmetic: absolute bars (the grand loss is north_star's quantity) ...
-    assert hip["grand"] < 1e-5 and hip["syn_lr"] < 1e-3 and hip["dyn_all"] < 1e-2 and hip["dyn_row_median"] < 3e-3
-    assert hip["hal_w"] < 3e-3 and hip["hal_b"] < 3e-3
-    # ... and relative to what fp32 arithmetic itself leaves on the same function: within FACTOR of it on every quantity (the
-    # small floors: where fp32 arithmetic happens to sit at 1e-7, a ratio is noise)
-    FACTOR = 3.0
-    floors = {"grand": 2e-7, "syn_lr": 2e-5, "dyn_all": 1e-4, "dyn_row_median": 2e-5, "dyn_row_max": 2e-3, "hal_w": 5e-5, "hal_b": 5e-5}
-    for k in floors:
-        assert hip[k] <= FACTOR * ref[k] + floors[k], (k, hip[k], ref[k])
+    # (1) arithmetic.  Measured at 400 classes / 256 clips and over four seeds at 100 / 64 (profiles/r06_parity_mtt10*.json), HIP / fp32
+    # arithmetic: grand loss 6e-10 .. 1.3e-7 / 6e-10 .. 5e-8; d/d syn_lr 3e-8 .. 4.5e-7 / 1e-8 .. 6e-8; memory gradient 4.2 .. 4.6e-6 on
+    # BOTH sides (x1.0 on all rows, median and maximum); hallucinator weight 1.4 .. 4.8e-6 / 2 .. 3e-7, bias 0.9 .. 5e-5 / 0.2 .. 1.9e-6
+    assert hip["grand"] < 1e-6 and hip["syn_lr"] < 5e-6                         # (the grand loss is north_star's quantity)
+    for k in ("dyn_all", "dyn_row_median", "dyn_row_max"):
+        assert hip[k] <= 1.5 * ref[k] + 1e-6, (k, hip[k], ref[k])
+    assert hip["hal_w"] < 2e-5 and hip["hal_b"] < 2e-4
     # rows of the dynamic memory no student batch drew: exactly zero
     untouched = [i for i in range(C * dpc) if i not in set(rows)]
     assert all(float(g_dyn[i].abs().sum()) == 0.0 for i in untouched[:50])

@@ -69,7 +69,7 @@ def _oracle(params, reals, syn, dtype):
     """(loss, d loss / d syn, seconds) of the CPU oracle in ``dtype``.  (All 256 logical CPUs of the GPU box's host are 10x
     slower than 32 threads for these convolutions -- bench.py's calibration -- so the thread count is capped.)"""
     old = torch.get_num_threads()
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    torch.set_num_threads(ORACLE_THREADS)
     try:
         t0 = time.perf_counter()
         loss, grad = R.dm_loss_and_grad([p.to(dtype) for p in params], [r.to(dtype) for r in reals], syn.to(dtype), ipc=1)
@@ -78,13 +78,16 @@ def _oracle(params, reals, syn, dtype):
         torch.set_num_threads(old)
 
 
-ORACLE_WORKERS = max(1, min(4, (os.cpu_count() or 1) // 32))      # oracle evaluations in flight (32 threads each)
+# oracle evaluations in flight x threads each: 8 x 16 on the GPU boxes' 2 x 64-core hosts (3 TB of RAM; a recorded 112x112x16 step
+# needs ~5 GB in fp64) -- the fp64 convolutions scale better over independent evaluations than over threads of one
+ORACLE_WORKERS = max(1, min(8, (os.cpu_count() or 1) // 16))
+ORACLE_THREADS = max(1, min(32, (os.cpu_count() or 1) // (2 * ORACLE_WORKERS)))
 
 
 def _evaluate_step(st, C, fp32):
     """Everything the CPU does for one recorded step: the oracle in fp64 (and fp32), the feature gap, the decisions of the lead
-    trainer's synthetic forward against the fp64 oracle's.  Runs on a worker thread (its own OpenMP team of 32)."""
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    trainer's synthetic forward against the fp64 oracle's.  Runs on a worker thread (its own OpenMP team)."""
+    torch.set_num_threads(ORACLE_THREADS)
     weights, reals, syn = st["weights"], st["reals"], st["syn"]
     out = {}
     out["l64"], out["g64"], out["t64"] = _oracle(weights, reals, syn, torch.float64)

@@ -11,7 +11,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $ROOT
 python3 tools/pmc_real_side.py $OUT/pmc_FETCH_SIZE_counter_collection.csv $OUT/pmc_WRITE_SIZE_counter_collection.csv 3200 $OUT/pmc_traffic.json > /dev/null
-cp $OUT/pmc_traffic.json profiles/r05_pmc_traffic.json
+cp $OUT/pmc_traffic.json profiles/r06_pmc_traffic.json
 python3 bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_1gpu_final.json
 python3 -c "
 import json; b=json.load(open('$OUT/bench_1gpu_final.json')); r=b['roofline']; print(b['value'], b['ms_per_step'], r['frac'], r['traffic'], r['traffic_source'][:90])"

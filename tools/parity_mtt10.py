@@ -129,7 +129,7 @@ mism = [[d["mismatch"] for d in st] for st in stats64]
 far = [[d["not_near_tie"] for d in st] for st in stats64]
 out["routed"] = {"decisions_of": lead, "fp32_arithmetic_vs_fp64": ref_r, "windows_fp64_would_route_otherwise_per_step_and_level": mism,
                  "of_those_no_near_tie": far, "windows_per_level": [d["windows"] for d in stats64[0]]}
-print("syn_steps %d, C %d, batch %d, seed %d  (oracles %.0f s wall)" % (steps, C, batch, args.seed, t2 - t1))
+print("syn_steps %d, C %d, batch %d, seed %d  (oracles %.0f s wall)" % (steps, C, batch, args.seed, t2 - t1), flush=True)
 print("ROUTED by the HIP forwards' decisions (%d windows differ from the fp64 values' own choice over the %d steps, %d of them no near-tie):" % (
     sum(map(sum, mism)), steps, sum(map(sum, far))))
 print("  fp32 arithmetic vs fp64: %s" % short(ref_r))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerate the evidence under profiles/ on a GPU box (run from the repo root through gpurun);
-# results land in gpurun_out/prof/ and are copied to profiles/r05_* afterwards (tools/copy_profiles.sh).
+# results land in gpurun_out/prof/ and are copied to profiles/r06_* afterwards (tools/copy_profiles.sh).
 # Every rocprofv3 run is bounded by `timeout` and writes csv (the rocpd default has hung a box for its whole limit).
 # PMC passes run alone (--kernel-trace only next to --pmc), one counter group per run.
 set -u

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One kernel trace of the default bench step (no counters) + the per-stream timeline of a steady-state step -> gpurun_out/<tag>_timeline.txt
 # usage (under gpurun): tools/trace_step.sh [tag] [extra bench.py arguments, e.g. --frames 8 --size 64]
-TAG=${1:-r05}
+TAG=${1:-r06}
 shift
 R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
