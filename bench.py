@@ -974,6 +974,12 @@ def bench_mtt(args, h, distill, geo):
                           networks.get_precision())
         out["grand_loss_last"] = float(losses[-1])
         out["syn_lr"] = float(tr.syn_lr)
+        out["operand_format_of_the_twice_differentiable_passes"] = {
+            "format": networks.get_precision()["match"],
+            "note": "f16x3 = fp16 hi+lo pairs, 22 bits, every gradient-like operand at a measured power-of-two scale, weights x 2^8 "
+                    "(round 6); bf16x3 = bf16 pairs, 16 bits, unscaled (rounds 1 - 5; VD_PREC_MATCH=bf16x3).  Parity at this "
+                    "configuration's own unroll length: profiles/r06_parity_mtt10*.json; same-box cost of the format: "
+                    "profiles/r06_bench_mtt.json vs profiles/r06_bench_mtt_bf16x3.json (tools/refresh_profiles.sh runs both)"}
         out["step_tflops"] = step_flop / (dt / args.steps) / 1e12
         out["step_frac_of_mfma_peak"] = out["step_tflops"] / PEAK_TFLOPS
         roof = roofline_from_profile(prof, device, {})

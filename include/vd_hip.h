@@ -337,8 +337,9 @@ int vd_resplit_slots(const void* src_hi, const void* src_lo, int64_t n_elems, in
  * (scale: device scalar, NULL = 1).  Turns the fp32 output of a select = 2 program into the scaled source of the next level of
  * the second-order sweep (the tangents d/dtheta of torch.autograd.grad(..., create_graph=True), distill_baseline.py:250). */
 int vd_split_scaled(const float* src, int64_t n_elems, const float* scale, void* dst_hi, void* dst_lo, int prec, void* stream);
-/* Device scalars of the power-of-two operand scales (vd_absmax_scale's out[0] / out[1] pairs): out[0] = a[0] * b[0] (mode 0) or
- * min(a[0], b[0]) (mode 1: the common scale of two tensors that share an accumulator), out[1] = 1 / out[0]; b NULL = 1. */
+/* Device scalars of the power-of-two operand scales (a, b, out: 4-float blocks as vd_absmax_scale writes them -- scale, 1 / scale,
+ * the float bits of max|g|): out[0] = a[0] * b[0] (mode 0) or min(a[0], b[0]) (mode 1: the common scale of two tensors that share
+ * an accumulator; a tensor whose max|g| word is 0 -- all zeros -- constrains nothing), out[1] = 1 / out[0]; b NULL = 1. */
 int vd_scale_combine(const float* a, const float* b, int mode, float* out, void* stream);
 /* sha256 (first 16 hex digits + NUL) of the kernel sources and this header the library was BUILT from (compiled in by
  * video_distillation_amd/hip.py:build); the binding refuses a library whose stamp differs from its checkout's sources. */

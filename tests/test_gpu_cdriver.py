@@ -79,29 +79,35 @@ def test_c_driver_dm_class_term_forward_backward_sgd(tmp_path):
     T, H, W, NR = 8, 64, 64, 4
     d = str(tmp_path)
     params = R.init_params(31)[:6]
-    g = torch.Generator().manual_seed(32)
-    real = torch.randn(NR, T, 3, H, W, generator=g)
-    syn = torch.randn(1, T, 3, H, W, generator=g)
     np.concatenate([p.numpy().reshape(-1) for p in params]).astype(np.float32).tofile(os.path.join(d, "weights.bin"))
-    real.numpy().astype(np.float32).tofile(os.path.join(d, "real.bin"))
-    syn.numpy().astype(np.float32).tofile(os.path.join(d, "syn.bin"))
     exe = os.path.join(d, "dm_class_term")
     libdir = os.path.dirname(hip.LIB_PATH)
     subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-o", exe, os.path.join(ROOT, "examples", "dm_class_term.cpp"),
                     "-L" + libdir, "-lvd_hip", "-Wl,-rpath," + libdir], check=True)
-    out = subprocess.run([exe, d, str(NR), str(T), str(H), str(W)], check=True, capture_output=True, text=True)
-    print(out.stdout.strip())
-    res = np.fromfile(os.path.join(d, "dm_out.bin"), dtype=np.float32)
-    n = syn.numel()
-    loss, grad, syn_after = float(res[0]), torch.from_numpy(res[1:1 + n]).view_as(syn), torch.from_numpy(res[1 + n:]).view_as(syn)
-    loss_ref, grad_ref = R.dm_loss_and_grad(params, [real], syn, ipc=1)
-    rel_l = abs(loss - float(loss_ref)) / float(loss_ref)
-    rel_g = float((grad - grad_ref).norm() / grad_ref.norm())
-    print("C DM class term vs oracle: loss rel %.2e, gradient rel-l2 %.2e" % (rel_l, rel_g))
-    assert rel_l < 1e-3 and rel_g < 3.5e-3       # (a class mean over FOUR single-pass real clips, one sample: 1.5 - 2.7e-3 across K orders of the
-    #                                               first level; the 64-clip bar is tests/test_gpu_parity_late.py's 1e-3)
-    want_after, _ = R.sgd_momentum_step(syn, grad, None, 0.5, 0.5)                  # first step: buf = g
-    np.testing.assert_allclose(syn_after.numpy(), want_after.numpy(), rtol=1e-5, atol=1e-6)
+    # a class mean over FOUR single-pass real clips, one synthetic clip: a single sample of the gradient error scatters between 1.5e-3 and
+    # 2.7e-3 with the first level's K order (the 64-clip bar is tests/test_gpu_parity_late.py's 1e-3).  Three draws of the clips: every
+    # sample within 3.5e-3, their MEAN within 2.5e-3 -- an accumulation-order change moves single samples, a regression moves the mean
+    rels = []
+    for seed in (32, 33, 34):
+        g = torch.Generator().manual_seed(seed)
+        real = torch.randn(NR, T, 3, H, W, generator=g)
+        syn = torch.randn(1, T, 3, H, W, generator=g)
+        real.numpy().astype(np.float32).tofile(os.path.join(d, "real.bin"))
+        syn.numpy().astype(np.float32).tofile(os.path.join(d, "syn.bin"))
+        out = subprocess.run([exe, d, str(NR), str(T), str(H), str(W)], check=True, capture_output=True, text=True)
+        print(out.stdout.strip())
+        res = np.fromfile(os.path.join(d, "dm_out.bin"), dtype=np.float32)
+        n = syn.numel()
+        loss, grad, syn_after = float(res[0]), torch.from_numpy(res[1:1 + n]).view_as(syn), torch.from_numpy(res[1 + n:]).view_as(syn)
+        loss_ref, grad_ref = R.dm_loss_and_grad(params, [real], syn, ipc=1)
+        rel_l = abs(loss - float(loss_ref)) / float(loss_ref)
+        rel_g = float((grad - grad_ref).norm() / grad_ref.norm())
+        print("C DM class term vs oracle (clips drawn from seed %d): loss rel %.2e, gradient rel-l2 %.2e" % (seed, rel_l, rel_g))
+        assert rel_l < 1e-3 and rel_g < 3.5e-3
+        rels.append(rel_g)
+        want_after, _ = R.sgd_momentum_step(syn, grad, None, 0.5, 0.5)                  # first step: buf = g
+        np.testing.assert_allclose(syn_after.numpy(), want_after.numpy(), rtol=1e-5, atol=1e-6)
+    assert sum(rels) / len(rels) < 2.5e-3, rels
 
 
 @pytest.mark.parametrize("geom,B,K,prec,prec_bwd", [((8, 64, 64), 6, 5, "f16x3", "f16x3"), ((8, 64, 64), 9, 4, "f16x3", "f16"),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # gpurun_out/prof/* (written by tools/refresh_profiles.sh on the GPU box) -> profiles/r06_*
 P=gpurun_out/prof
-for f in bench_1gpu.json bench_1gpu_again.json bench_1gpu_under_rocprof.json bench_s2d.json bench_config1_shape.json bench_dc.json bench_mtt.json \
+for f in bench_1gpu.json bench_1gpu_again.json bench_1gpu_under_rocprof.json bench_s2d.json bench_config1_shape.json bench_dc.json bench_mtt.json bench_mtt_bf16x3.json bench_dc_bf16x3.json mfma_rounding.txt \
          bench_8ranks_one_device.json mfma_peak.txt train_step.txt train_step_deterministic.txt aux_kernels.json \
          bench_kernel_stats.csv s2d_kernel_stats.csv dc_kernel_stats.csv mtt_kernel_stats.csv aux_kernel_stats.csv syn_side_kernel_stats.csv \
          train_atomic_kernel_stats.csv train_deterministic_kernel_stats.csv pmc_traffic.json pmc_sq_summary.json l0_kernel_ab.txt l0_phase_stamps.txt hal_bwd.txt rank_proxy.txt step_timeline.txt; do

@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import ref_cpu as R
+from tests import argmax_tools as A
 from video_distillation_amd import distill, networks, plan
 
 ap = argparse.ArgumentParser()
@@ -25,6 +26,7 @@ ap.add_argument("--classes", type=int, default=400)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--groups", default="all,w0,w1,w2,head,biases")
 ap.add_argument("--out", default=None)
+ap.add_argument("--routed", action="store_true", help="the oracles take the pooling decisions the first mode's HIP forward recorded (arithmetic only)")
 args = ap.parse_args()
 C, B, T, S, lr = args.classes, args.batch, 8, 64, 0.01
 geo = plan.NetGeometry(T, S, S)
@@ -49,23 +51,44 @@ def rel(a, b):
     return float((a - b).norm() / n) if n > 0 else float(a.norm())
 
 
+ROUTES = None
+
+
 def oracle(dt, V):
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     th = [p.to(dt).clone().requires_grad_(True) for p in theta]
     xx = x.to(dt).clone().requires_grad_(True)
-    ce = F.cross_entropy(R.convnet3d_logits(xx, th), labels)
+    ce = F.cross_entropy(R.convnet3d_logits(xx, th) if ROUTES is None else A.routed_logits(xx, th, ROUTES), labels)
     gr = torch.autograd.grad(ce, th, create_graph=True)
     s = sum((v.to(dt) * gi).sum() for v, gi in zip(V, gr))
     out = torch.autograd.grad(s, [xx] + th)
     return [gi.detach() for gi in gr], out[0], list(out[1:])
 
 
+hip = {}
+for mode in args.modes.split(","):
+    fmt_name, _, target = mode.partition("@")          # "f16x3@32768": the gradient operands' scale target (VD_GRAD_TARGET) for this leg
+    os.environ["VD_GRAD_TARGET"] = target or "1024"
+    networks.set_precision(match=fmt_name)
+    ops = distill.HipMTTOps(geo, C, "cuda:0", dropout_p=0.0, batch_hint=B)
+    gr, handle = ops.grads([p.cuda() for p in theta], x.cuda(), labels.cuda())
+    if args.routed and ROUTES is None:
+        ROUTES = A.routes_from_argmax([a.cpu() for a in handle[0]["am"]], (B, T, 3, S, S), theta)
+    gr = [t.cpu() for t in gr]
+    for name, V in directions.items():
+        dx, hv = ops.hvp(handle, [v.cuda() for v in V])
+        hip[(mode, name)] = (gr, dx.cpu(), [t.cpu() for t in hv])
+    del ops, handle
+    torch.cuda.empty_cache()
 t0 = time.time()
 jobs = [(name, dt) for name in directions for dt in (torch.float64, torch.float32)]
 with ThreadPoolExecutor(max_workers=max(1, min(4, (os.cpu_count() or 1) // 32))) as ex:
     res = list(ex.map(lambda j: oracle(j[1], directions[j[0]]), jobs))
 ref = {j: r for j, r in zip(jobs, res)}
 t_or = time.time() - t0
+
+
+out = {"classes": C, "batch": B, "oracle_seconds": t_or, "routed": bool(args.routed), "directions": {}}
 
 
 def report(gr, xbar, hv, g64, x64, h64):
@@ -75,18 +98,6 @@ def report(gr, xbar, hv, g64, x64, h64):
             "xbar_clip_max": per_clip[-1], "xbar_channel_sums": chan, "hv": [rel(a, b) for a, b in zip(hv, h64)]}
 
 
-out = {"classes": C, "batch": B, "oracle_seconds": t_or, "directions": {}}
-hip = {}
-for mode in args.modes.split(","):
-    networks.set_precision(match=mode)
-    ops = distill.HipMTTOps(geo, C, "cuda:0", dropout_p=0.0, batch_hint=B)
-    gr, handle = ops.grads([p.cuda() for p in theta], x.cuda(), labels.cuda())
-    gr = [t.cpu() for t in gr]
-    for name, V in directions.items():
-        dx, hv = ops.hvp(handle, [v.cuda() for v in V])
-        hip[(mode, name)] = (gr, dx.cpu(), [t.cpu() for t in hv])
-    del ops, handle
-    torch.cuda.empty_cache()
 fmt = lambda r: "g %s | xbar all %.1e clip med %.1e max %.1e chan-sums %s | hv %s" % (
     " ".join("%.0e" % v for v in r["g"]), r["xbar_all"], r["xbar_clip_median"], r["xbar_clip_max"],
     " ".join("%.0e" % v for v in r["xbar_channel_sums"]), " ".join("%.0e" % v for v in r["hv"]))

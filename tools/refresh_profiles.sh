@@ -14,6 +14,8 @@ python3 bench.py --method s2d --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT
 python3 bench.py --frames 8 --size 64 --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_config1_shape.json
 python3 bench.py --method dc --classes 51 --ipc 5 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_dc.json
 python3 bench.py --method mtt --classes 400 --frames 8 --size 64 --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_mtt.json
+VD_PREC_MATCH=bf16x3 python3 bench.py --method mtt --classes 400 --frames 8 --size 64 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_mtt_bf16x3.json
+VD_PREC_MATCH=bf16x3 python3 bench.py --method dc --classes 51 --ipc 5 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_dc_bf16x3.json
 VD_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 8 --steps 3 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --eval-epochs 1 --eval-seeds 1 --exchange-leg --no-extra-legs 2>/dev/null | tail -1 > $OUT/bench_8ranks_one_device.json
 python3 tools/mfma_peak.py > $OUT/mfma_peak.txt 2>/dev/null
 python3 tools/l0_ab.py 3200 8 > $OUT/l0_kernel_ab.txt 2>/dev/null
@@ -47,6 +49,7 @@ cd $ROOT
 tools/trace_step.sh prof_step > /dev/null 2>&1; cp gpurun_out/prof_step_timeline.txt $OUT/step_timeline.txt 2>/dev/null
 python3 tools/pmc_real_side.py $OUT/pmc_FETCH_SIZE_counter_collection.csv $OUT/pmc_WRITE_SIZE_counter_collection.csv 3200 $OUT/pmc_traffic.json > /dev/null
 python3 tools/aux_kernel_gbps.py $OUT/aux_kernel_stats.csv $OUT/aux_kernels.json > /dev/null
+tools/micro/mfma_round_probe > $OUT/mfma_rounding.txt 2>&1
 rm -rf $OUT/bench $OUT/s2d $OUT/dc $OUT/mtt $OUT/aux $OUT/syn_side $OUT/train_atomic $OUT/train_deterministic $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 bash tools/pmc_sq.sh > $OUT/pmc_sq.log 2>&1
 python3 tools/pmc_sq_summary.py gpurun_out/pmc_sq $OUT/pmc_sq_summary.json > /dev/null 2>&1

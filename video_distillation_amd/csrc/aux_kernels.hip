@@ -2105,7 +2105,11 @@ extern "C" int vd_split_scaled(const float* src, int64_t n_elems, const float* s
 
 __global__ void scale_combine_kernel(const float* __restrict__ a, const float* __restrict__ b, int mode, float* __restrict__ out) {
     const float x = a[0], y = (b != nullptr) ? b[0] : 1.f;
-    const float s = (mode == 1) ? fminf(x, y) : x * y;
+    float s = x * y;
+    if (mode == 1) {      // common scale of two tensors: the smaller one -- but an all-zero tensor (absmax word 0) constrains nothing
+        const bool a_empty = (a[2] == 0.f), b_empty = (b == nullptr) || (b[2] == 0.f);
+        s = a_empty ? (b_empty ? 1.f : y) : (b_empty ? x : fminf(x, y));
+    }
     out[0] = s;
     out[1] = 1.f / s;
 }

@@ -182,6 +182,12 @@ class _DevPlan:
             prof.append((self.plan.name, self.prec, 2.0 * self.plan.meta.get("macs_per_unit", 0) * nclips, e0, e1))
 
 
+def GRAD_TARGET() -> float:
+    """max |g| * scale of a gradient operand lies in [target / 2, target) (vd_absmax_scale) before its 16-bit split: fp16's largest
+    number is 65504, an fp16 PAIR carries 22 bits for elements down to 2^-2, i.e. 2^-12 of the largest at 1024 (VD_GRAD_TARGET: A/B)."""
+    return float(os.environ.get("VD_GRAD_TARGET", "1024"))
+
+
 _RANGE_MONITOR = os.environ.get("VD_RANGE_MONITOR", "1") == "1"      # (0: A/B of the monitor's cost in the level-1 epilogue)
 
 
@@ -615,7 +621,7 @@ class EmbedEngine:
                     # exponent range with an exact power-of-two scale (DM gradients shrink by orders of
                     # magnitude per layer and would otherwise fall into fp16's subnormals)
                     scb = self._buf("gscale%d" % li, (4,), torch.float32)
-                    hip.check(L.vd_absmax_scale(hip.ptr(grad), ctypes.c_int64(grad.numel()), ctypes.c_float(1024.0),
+                    hip.check(L.vd_absmax_scale(hip.ptr(grad), ctypes.c_int64(grad.numel()), ctypes.c_float(GRAD_TARGET()),
                                                 hip.ptr(scb), st), "vd_absmax_scale")
                     sc, inv = scb, scb[1:]
                 hip.check(L.vd_unpool_relu_bwd(hip.ptr(grad), hip.ptr(am), ctypes.c_int64(nb), cout, To, Ho, Wo, pt,

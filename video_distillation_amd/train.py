@@ -23,7 +23,7 @@ import torch
 from . import hip
 from . import plan as P
 from . import engine
-from .engine import EmbedEngine, WgradOp, _DevPlan, run_together
+from .engine import EmbedEngine, WgradOp, _DevPlan, run_together, GRAD_TARGET
 
 
 def standardize(x: torch.Tensor) -> torch.Tensor:
@@ -157,7 +157,7 @@ class TrainEngine:
             sc = inv = None
             if scaled:
                 scb = eng._buf("gscale%d" % li, (4,), torch.float32)
-                hip.check(L.vd_absmax_scale(hip.ptr(grad), ctypes.c_int64(grad.numel()), ctypes.c_float(1024.0),
+                hip.check(L.vd_absmax_scale(hip.ptr(grad), ctypes.c_int64(grad.numel()), ctypes.c_float(GRAD_TARGET()),
                                             hip.ptr(scb), st), "vd_absmax_scale")
                 sc, inv = scb, scb[1:]
             if dense:
@@ -498,7 +498,7 @@ class GradMatchEngine(TrainEngine):
             if self.scaled:
                 # zb_l = P_l^T abar_{l+1} at its own scale; dy_l carries the first-order pass's scale of this level (gscale%d of
                 # TrainEngine.feat_backward, kept in the step's workspace), V_l and gbar_l the scales of the upward sweep
-                sz = self._absmax_scale(grad, "zscale%d" % li, 1024.0)
+                sz = self._absmax_scale(grad, "zscale%d" % li, GRAD_TARGET())
                 inv_z = sz[1:]
                 gs = self._scale_buf("gscale%d" % li)
                 inv_dv = self._combine(gs, self._sv[li], 0, "dvscale%d" % li)[1:]
