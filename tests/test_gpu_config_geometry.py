@@ -66,7 +66,8 @@ def test_gradient_matching_class_terms_at_config4_geometry(monkeypatch):
     assert abs(loss_hip / loss_ref - 1) < 1e-3                                # north_star's bar on the matching loss
     # pixel gradient: clips without a differing pooling decision agree to ~1e-3; one arg-max near-tie resolved the other way moves
     # a clip's gradient by up to a few 1e-2 -- most clips must be tight, every clip within the flip bound
-    assert sorted(per_clip)[len(per_clip) // 2] < 3e-3 and max(per_clip) < 5e-2
+    # (round 6, scaled fp16 pairs + shifted weights: 3.1 - 3.4e-4 on eight of the ten clips, 1.6 / 1.7e-3 on two; round 5: median 1.5e-3)
+    assert sorted(per_clip)[len(per_clip) // 2] < 1e-3 and max(per_clip) < 5e-2
 
 
 def test_mtt_ours_ten_unrolled_steps_at_config5_geometry():

@@ -385,5 +385,8 @@ def test_late_regime_seeds_aggregate():
                        "per_run": {"seed%d_C%d" % (k[1], k[2]): v for k, v in sorted(rows.items())}}
         assert n_clean >= 5, table[geom]
         assert max(mx) < GRAD_BAR
+        # (round 6) with the weights of the hi+lo programs packed x 2^8 the synthetic forward's decisions equal the fp64 oracle's on every
+        # entry of the record (126 of 126; round 5: 356 of 410): at least four fifths must stay clean, or the bar above binds on too few
+        assert n_clean >= 0.8 * table[geom]["entries"], table[geom]
     print(json.dumps({g: {k: v for k, v in t.items() if k != "per_run"} for g, t in table.items()}, indent=1))
     _record("seeds_summary", table)

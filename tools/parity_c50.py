@@ -1,7 +1,7 @@
 """The late-regime parity run of tests/test_gpu_parity_late.py at the BENCHMARK's class count: C = 50 classes x (64 real + 1 syn) clips
 112x112x16, shipped mode, one step (the suite runs 2 and 4 classes: the fp64 oracle takes ~8 s per class term).  Every class is one
 (step, class) entry: clean entries must be within 1e-3 of the fp64 oracle's pixel gradient, the loss within 1e-3.
-   python tools/parity_c50.py [seed] [C] [small]     -> gpurun_out/r05_parity_c50.json + a summary on stdout
+   python tools/parity_c50.py [seed] [C] [small]     -> gpurun_out/r06_parity_c50.json + a summary on stdout
 ("small": config 1's shape, 64x64x8, with the suite's settings for it)"""
 import json
 import os
@@ -57,7 +57,7 @@ ok = (s["loss_vs_fp64_max"] < 1e-3 and s["loss_vs_fp32_max"] < 1e-3 and far == 0
 print("clean entries %d of %d: median %.3e max %.3e; all entries median %.3e; loss vs fp64 %.2e; decisions outside near-ties %d; %s (%.0f s)" % (
     clean["entries"], clean["of"], clean["grad_vs_fp64_median"] or float("nan"), clean["grad_vs_fp64_max"] or float("nan"),
     s["grad_vs_fp64_median"], s["loss_vs_fp64_max"], far, "WITHIN THE BARS" if ok else "OUT OF TOLERANCE", time.time() - t0))
-out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r05_parity_c50.json")
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r06_parity_c50.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 data = json.load(open(out)) if os.path.exists(out) else {}
 data["seed%d_C%d%s" % (seed, C, "_64x64x8" if small else "")] = rec

@@ -1,7 +1,7 @@
 """Configuration 4 at its FULL class count: one gradient-matching step of distill.GMTrainer over all 51 classes x (64 real + 5 synthetic)
 clips 112x112x16 ('ours' metric, eight class lanes, shipped precisions) against the reference-shaped double backward on the oracle,
 class by class (tests/test_gpu_config_geometry.py runs two of the 51 classes; the oracle takes a few seconds per class term).
-   python tools/parity_dc51.py [classes]      -> gpurun_out/r05_parity_dc51.json + a summary on stdout"""
+   python tools/parity_dc51.py [classes]      -> gpurun_out/r06_parity_dc51.json + a summary on stdout"""
 import json
 import os
 import sys
@@ -91,7 +91,7 @@ print("config 4, %d classes x (64 + 5) clips 112x112x16: matching loss HIP %.4f 
       "clip: median %.2e, p90 %.2e, max %.2e over %d clips; %s   (setup %.0f s, HIP step %.2f s, oracle %.0f s)" % (
           ncls, loss_hip, loss_ref, abs(loss_hip / loss_ref - 1), np.median(per), np.quantile(per, 0.9), per.max(), per.size,
           ("within the test's bars on loss (1e-3) and median (3e-3); clips above 1e-2: %d, above 5e-2: %d" % (int((per > 1e-2).sum()), int((per > 5e-2).sum()))) if ok else "OUT OF TOLERANCE", t1 - t0, t2 - t1, t3 - t2))
-out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r05_parity_dc51.json")
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r06_parity_dc51.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 json.dump({"classes": ncls, "loss_hip": loss_hip, "loss_oracle_fp32": loss_ref, "loss_rel": abs(loss_hip / loss_ref - 1),
            "grad_rel_l2_per_clip": per.tolist(), "median": float(np.median(per)), "p90": float(np.quantile(per, 0.9)), "max": float(per.max()),

@@ -1,7 +1,7 @@
 """Configuration 3 at its full size against the oracle: one distill.S2DTrainer step (static + dynamic memories through the
 hallucinator, DM loss, backward to the dynamic memories and the hallucinator) over C = 50 classes x (64 real + 1 composed) clips
 112x112x16 in the shipped precision mode, against the same step on the CPU oracle in fp64 (class by class).
-   python tools/parity_s2d50.py [classes] [seed]      -> gpurun_out/r05_parity_s2d50.json + a summary on stdout"""
+   python tools/parity_s2d50.py [classes] [seed]      -> gpurun_out/r06_parity_s2d50.json + a summary on stdout"""
 import json
 import os
 import sys
@@ -73,6 +73,6 @@ print("config 3, %d classes x (64 real + 1 composed) clips 112x112x16, shipped m
       "rel-L2 %.2e (per selected memory: median %.2e, max %.2e); hallucinator weight / bias gradient %.2e / %.2e; unselected memories exactly zero: %s   "
       "(HIP side %.0f s, oracle %.0f s)" % (C, loss_hip, float(loss), out["loss_rel"], out["g_dynamic_rel_l2"], float(np.median(rows)), max(rows),
                                             out["g_hal_w_rel_l2"], out["g_hal_b_rel_l2"], zero_ok, t1 - t0, t2 - t1))
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r05_parity_s2d50.json")
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r06_parity_s2d50.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
