@@ -262,7 +262,8 @@ def test_backend_picks_a_last_level_program_for_any_geometry_and_one_clip_launch
     rel_g = float((dx.cpu() - grad_ref).norm() / grad_ref.norm())
     print("%s: last level %s (%s), loss rel %.2e, gradient rel-l2 %.2e" % (
         geom, be.real_last, "position tiles" if prog.epi == plan.EPI_POS_FEAT else "row-major", rel_l, rel_g))
-    assert rel_l < 1e-3 and rel_g < 3e-3       # (one class term of EIGHT real clips, one sample per geometry: 1.2 - 2.4e-3 across K orders of the first level)
+    assert rel_l < 1e-3 and rel_g < 2e-3       # (one class term of EIGHT real clips, one sample per geometry; round 4's bar, which round 5 had loosened to
+    #                                               3e-3; measured in round 6: 4.9e-4 / 4.2e-4 / 6.0e-4 at the three geometries)
     # undithered engine of the same kind: one clip alone vs the same clip inside a launch of 8
     from video_distillation_amd import engine
     e = engine.EmbedEngine(geo, prec="f16", chunk=64, last_hilo=("c8" if be.real_last == "c8" else True)); e.set_weights(weights)

@@ -84,9 +84,9 @@ def test_c_driver_dm_class_term_forward_backward_sgd(tmp_path):
     libdir = os.path.dirname(hip.LIB_PATH)
     subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-o", exe, os.path.join(ROOT, "examples", "dm_class_term.cpp"),
                     "-L" + libdir, "-lvd_hip", "-Wl,-rpath," + libdir], check=True)
-    # a class mean over FOUR single-pass real clips, one synthetic clip: a single sample of the gradient error scatters between 1.5e-3 and
-    # 2.7e-3 with the first level's K order (the 64-clip bar is tests/test_gpu_parity_late.py's 1e-3).  Three draws of the clips: every
-    # sample within 3.5e-3, their MEAN within 2.5e-3 -- an accumulation-order change moves single samples, a regression moves the mean
+    # a class mean over FOUR single-pass real clips, one synthetic clip (the 64-clip bar is tests/test_gpu_parity_late.py's 1e-3).  Three
+    # draws of the clips: every sample within round 4's 2e-3 (round 5 had loosened it to 3.5e-3 for one sample), their MEAN within 1.5e-3
+    # -- an accumulation-order change moves single samples, a regression moves the mean.  Measured in round 6: 1.07 / 1.08 / 1.02e-3
     rels = []
     for seed in (32, 33, 34):
         g = torch.Generator().manual_seed(seed)
@@ -103,11 +103,11 @@ def test_c_driver_dm_class_term_forward_backward_sgd(tmp_path):
         rel_l = abs(loss - float(loss_ref)) / float(loss_ref)
         rel_g = float((grad - grad_ref).norm() / grad_ref.norm())
         print("C DM class term vs oracle (clips drawn from seed %d): loss rel %.2e, gradient rel-l2 %.2e" % (seed, rel_l, rel_g))
-        assert rel_l < 1e-3 and rel_g < 3.5e-3
+        assert rel_l < 1e-3 and rel_g < 2e-3
         rels.append(rel_g)
         want_after, _ = R.sgd_momentum_step(syn, grad, None, 0.5, 0.5)                  # first step: buf = g
         np.testing.assert_allclose(syn_after.numpy(), want_after.numpy(), rtol=1e-5, atol=1e-6)
-    assert sum(rels) / len(rels) < 2.5e-3, rels
+    assert sum(rels) / len(rels) < 1.5e-3, rels
 
 
 @pytest.mark.parametrize("geom,B,K,prec,prec_bwd", [((8, 64, 64), 6, 5, "f16x3", "f16x3"), ((8, 64, 64), 9, 4, "f16x3", "f16"),
