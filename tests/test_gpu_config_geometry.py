@@ -81,11 +81,9 @@ def test_mtt_ours_ten_unrolled_steps_at_config5_geometry():
     median memory row by percents, and whether the HIP path, fp32 arithmetic or neither has one depends on the seed (over four seeds
     the HIP path's distance from the free fp64 oracle is x0.02 .. x2.6 of the fp32 oracle's: profiles/r06_parity_mtt10_seeds.txt).  So:
     (1) ARITHMETIC on the same piecewise-linear function -- the oracle routed by the decisions the HIP forwards recorded
-    (tests/argmax_tools.py), in fp64 and in fp32: the memory gradient must be as close to fp64 as fp32 arithmetic is (both sit at
-    4e-6: theta - target is a difference of fp32 numbers 100x its size), the scalars and the hallucinator's parameter gradients --
-    sums over every pixel of every clip with four digits of cancellation, where the HIP path is 10 - 50x fp32 arithmetic -- within
-    absolute bars two orders below what one flipped window does; (2) DECISIONS -- every window the fp64 values would have routed
-    otherwise must be a near-tie of those values."""
+    (tests/argmax_tools.py), in fp64 and in fp32: EVERY quantity -- grand loss, d/d syn_lr, the memory gradient (all rows, median,
+    worst), the hallucinator's weight and bias gradients -- must be within 3x of fp32 arithmetic's own distance from fp64;
+    (2) DECISIONS -- every window the fp64 values would have routed otherwise must be a near-tie of those values."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     from tests import argmax_tools as A
@@ -147,13 +145,15 @@ def test_mtt_ours_ten_unrolled_steps_at_config5_geometry():
               {k: "%.1e" % v for k, v in hip.items()}, {k: "%.1e" % v for k, v in ref.items()}, mism, far))
     # (2) decisions: near-ties only
     assert far == 0, mism
-    # (1) arithmetic.  Measured at 400 classes / 256 clips and over four seeds at 100 / 64 (profiles/r06_parity_mtt10*.json), HIP / fp32
-    # arithmetic: grand loss 6e-10 .. 1.3e-7 / 6e-10 .. 5e-8; d/d syn_lr 3e-8 .. 4.5e-7 / 1e-8 .. 6e-8; memory gradient 4.2 .. 4.6e-6 on
-    # BOTH sides (x1.0 on all rows, median and maximum); hallucinator weight 1.4 .. 4.8e-6 / 2 .. 3e-7, bias 0.9 .. 5e-5 / 0.2 .. 1.9e-6
-    assert hip["grand"] < 1e-6 and hip["syn_lr"] < 5e-6                         # (the grand loss is north_star's quantity)
-    for k in ("dyn_all", "dyn_row_median", "dyn_row_max"):
-        assert hip[k] <= 1.5 * ref[k] + 1e-6, (k, hip[k], ref[k])
-    assert hip["hal_w"] < 2e-5 and hip["hal_b"] < 2e-4
+    # (1) arithmetic: every quantity within 3x of what fp32 arithmetic leaves on the same function (+ a floor where that is 1e-8 and a
+    # ratio is noise).  Measured here, HIP / fp32 arithmetic: grand loss 8.6e-8 / 2.5e-8, d/d syn_lr 2.3e-8 / 2.3e-8, memory gradient
+    # 3.1e-6 / 3.1e-6 (median row 3.8e-6 / 3.7e-6, worst row 4.3e-6 / 4.2e-6: both sit on the fp32 difference theta - target),
+    # hallucinator weight 1.7e-7 / 1.3e-7, bias 3.7e-7 / 4.1e-7.  (Before the accumulation's sign alternated per channel chunk --
+    # conv_mfma.hip ALT: the matrix instruction's rounding is biased toward minus infinity, coherently over all outputs -- the two
+    # hallucinator sums stood at 7.6e-7 and 3.4e-6 here, 4.8e-6 and 5.1e-5 at 400 classes / 256 clips.)
+    floors = {"grand": 2e-7, "syn_lr": 2e-7, "dyn_all": 1e-6, "dyn_row_median": 1e-6, "dyn_row_max": 1e-6, "hal_w": 5e-7, "hal_b": 2e-6}
+    for k in floors:
+        assert hip[k] <= 3.0 * ref[k] + floors[k], (k, hip[k], ref[k])
     # rows of the dynamic memory no student batch drew: exactly zero
     untouched = [i for i in range(C * dpc) if i not in set(rows)]
     assert all(float(g_dyn[i].abs().sum()) == 0.0 for i in untouched[:50])

@@ -4,10 +4,13 @@
 # Every rocprofv3 run is bounded by `timeout` and writes csv (the rocpd default has hung a box for its whole limit).
 # PMC passes run alone (--kernel-trace only next to --pmc), one counter group per run.
 set -u
+# PART=1: bench lines, same-box A/Bs, stand-alone timings; PART=2: rocprofv3 kernel stats, PMC passes, timeline (default: both).
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
-rm -rf $OUT; mkdir -p $OUT
+PART=${PART:-12}
 export TMPDIR=/tmp
+if [[ $PART == *1* ]]; then
+rm -rf $OUT; mkdir -p $OUT
 python3 bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_1gpu.json
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs --sustain-seconds 0 2>/dev/null | tail -1 > $OUT/bench_1gpu_again.json
 python3 bench.py --method s2d --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_s2d.json
@@ -25,6 +28,10 @@ VD_HAL_FUSED=0 python3 tools/hal_check.py 50 16 112 112 2>/dev/null | tail -2 >>
 for n in 1 2 4 8; do python3 tools/rank_proxy.py $n 2>/dev/null; done > $OUT/rank_proxy.txt       # (one process per N: x of N=1 from the first line)
 python3 tools/bench_train.py 50 > $OUT/train_step.txt 2>/dev/null
 VD_DETERMINISTIC=1 python3 tools/bench_train.py 50 > $OUT/train_step_deterministic.txt 2>/dev/null
+tools/micro/mfma_round_probe > $OUT/mfma_rounding.txt 2>&1
+fi
+[[ $PART == *2* ]] || { ls -la $OUT; exit 0; }
+mkdir -p $OUT
 cd /tmp
 prof() {  # name, then the program and its arguments
   local name=$1; shift
@@ -49,7 +56,6 @@ cd $ROOT
 tools/trace_step.sh prof_step > /dev/null 2>&1; cp gpurun_out/prof_step_timeline.txt $OUT/step_timeline.txt 2>/dev/null
 python3 tools/pmc_real_side.py $OUT/pmc_FETCH_SIZE_counter_collection.csv $OUT/pmc_WRITE_SIZE_counter_collection.csv 3200 $OUT/pmc_traffic.json > /dev/null
 python3 tools/aux_kernel_gbps.py $OUT/aux_kernel_stats.csv $OUT/aux_kernels.json > /dev/null
-tools/micro/mfma_round_probe > $OUT/mfma_rounding.txt 2>&1
 rm -rf $OUT/bench $OUT/s2d $OUT/dc $OUT/mtt $OUT/aux $OUT/syn_side $OUT/train_atomic $OUT/train_deterministic $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 bash tools/pmc_sq.sh > $OUT/pmc_sq.log 2>&1
 python3 tools/pmc_sq_summary.py gpurun_out/pmc_sq $OUT/pmc_sq_summary.json > /dev/null 2>&1

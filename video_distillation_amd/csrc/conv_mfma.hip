@@ -195,6 +195,14 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
     constexpr bool EXT = SO || MTW == 5;
     constexpr bool SEQ = X3 && SQ;                      // hi+lo formats: one operand plane resident at a time (see SQ above)
     constexpr int LPL = (X3 && !SEQ) ? 2 : 1;           // patch planes resident in LDS
+    // ALT (hi+lo formats, round 6): the matrix instruction rounds with a DIRECTED bias -- 600 chained v_mfma_f32_32x32x16_f16 end 1.4 ulp
+    // BELOW the exact sum whatever the sign of the products (tools/micro/mfma_round_probe, profiles/r06_mfma_rounding.txt) -- which is
+    // 1e-7 of an output and invisible per element, but coherent: sums over 1e7 - 1e8 outputs of the gradient programs (bias gradients,
+    // the hallucinator's parameter gradients) do not average it out the way a CPU's round-to-nearest does.  So the accumulation's SIGN
+    // alternates per channel chunk: at every chunk boundary the accumulators are negated (16 x TILES v_xor per wave and chunk) and the
+    // B fragments of odd chunks get their sign bits flipped as they are loaded -- the same products, accumulated into -sum in every
+    // other chunk, so that the hardware's pull toward minus infinity pulls the result up as often as down.  One chunk: nothing changes.
+    constexpr bool ALT = X3 && !C8;
     constexpr int TILES = MTW * NTW + BAL;              // accumulator tiles per wave
     constexpr int MA = MTW + BAL;                       // M tiles (A fragments per K step) a wave touches
     static_assert(BAL == 0 || (NTW == 2 && !X3 && !SO), "balanced layout: single-pass formats, two N tiles per wave");
@@ -355,6 +363,15 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
         //  second-order instantiations: two scalar registers the hot programs do not pay for)
         // (single-pass programs: w_set_clips > 0 selects one of several operand sets, w_plane_stride apart, by the box's first
         //  clip -- the dithered weights of the real side, distill.HipBackend.embed_pool)
+        if constexpr (ALT) {
+            if (ph == 0 && cc > 0) {
+#pragma unroll
+                for (int i = 0; i < TILES; ++i)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[i][k] = -acc[i][k];
+            }
+        }
+        const uint32_t bsgn = (ALT && (cc & 1)) ? 0x80008000u : 0u;        // sign bits of the two 16-bit values of a dword
         const int64_t wset = (!X3 && !EXT && p.w_set_clips > 0) ? (int64_t)(clip0 / p.w_set_clips) * w_lo : (int64_t)0;
         const uint4* wp = wbase + wset + ((EXT || C8) ? (((int64_t)bi * p.w_box_stride) >> 3) : (int64_t)0) + ((int64_t)cc * S * p.NT + wn * NTW) * 64 + lane;
         auto load_b = [&](int s, uint4* bh, uint4* bl) {
@@ -363,6 +380,10 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
             for (int j = 0; j < NTW; ++j) {
                 bh[j] = wp[(int64_t)sc * wstep + j * 64];
                 if constexpr (X3 && !C8 && (!SEQ || ph == 0)) bl[j] = wp[(int64_t)sc * wstep + j * 64 + w_lo];   // (C8: plane 1 holds fp8 pieces, loaded by the K loop itself)
+                if constexpr (ALT) {
+                    bh[j].x ^= bsgn; bh[j].y ^= bsgn; bh[j].z ^= bsgn; bh[j].w ^= bsgn;
+                    if constexpr (!SEQ || ph == 0) { bl[j].x ^= bsgn; bl[j].y ^= bsgn; bl[j].z ^= bsgn; bl[j].w ^= bsgn; }
+                }
             }
         };
         uint4 bqh[DB + 1][NTW], bql[DB + 1][NTW];
@@ -818,6 +839,14 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
       });
     }
 
+    if constexpr (ALT) {            // an even number of chunks leaves -sum in the accumulators
+        if (!(p.CC & 1)) {
+#pragma unroll
+            for (int i = 0; i < TILES; ++i)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[i][k] = -acc[i][k];
+        }
+    }
     // ---- epilogue ---------------------------------------------------------------------
     stamp(4);
     if (VD_DBG(p) & 1) { if (acc[0][0] == 123.456f) reinterpret_cast<float*>(p.dst)[0] = 1.f; continue; }
