@@ -97,7 +97,11 @@ typedef struct VdConvParams {
     int32_t mt_valid;             /* NTW = 2: M tiles per box that carry rows (< MW*MTW: the last wave row skips its padding tile); 0 = all */
     int32_t persist;              /* 0: one workgroup per box; g>0: each workgroup walks boxes so that the grid is g generations of resident workgroups;
                                      vd_conv0_breg: bit 19 = run a frame-tile program (pair_flip != 0) with the plain K loop (one LDS read per
-                                     MFMA) instead of the frame-sharing one (A/B measurements; bitwise the same results) */
+                                     MFMA) instead of the frame-sharing one (A/B measurements; bitwise the same results);
+                                     bit 20 (hi+lo formats) = do NOT alternate the accumulation's sign per channel chunk: the matrix instruction rounds
+                                     with a bias toward minus infinity (1.4 ulp per 600 v_mfma_f32_32x32x16_f16, whatever the sign), coherent over
+                                     all outputs of a launch; by default a hi+lo program negates its accumulators at every chunk boundary and flips
+                                     the sign of odd chunks' B fragments, which makes the bias zero-mean (sums over 1e8 outputs: 1e-5 -> 1e-6) */
     uint64_t* stamps;             /* dbg bit 3: [grid][8] s_memtime stamps of workgroup phases  */
     int32_t w_set_clips;          /* single-pass forward programs: > 0 = the B operand holds several sets, w_plane_stride elements apart; the box's
                                      first clip / w_set_clips picks the set (dithered real-side weights); 0 = one set */

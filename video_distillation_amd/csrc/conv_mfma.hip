@@ -363,15 +363,18 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
         //  second-order instantiations: two scalar registers the hot programs do not pay for)
         // (single-pass programs: w_set_clips > 0 selects one of several operand sets, w_plane_stride apart, by the box's first
         //  clip -- the dithered weights of the real side, distill.HipBackend.embed_pool)
+        // (the sign flip is applied where a fragment is USED, a step or two after its load was issued: flipped at the load it would have to
+        //  land at once -- the B prefetch ring would be gone, measured -7 .. -10 % on the hi+lo programs.  persist bit 20: alternation off, A/B)
+        const bool alt_on = ALT && !(p.persist & 0x100000);
         if constexpr (ALT) {
-            if (ph == 0 && cc > 0) {
+            if (alt_on && ph == 0 && cc > 0) {
 #pragma unroll
                 for (int i = 0; i < TILES; ++i)
 #pragma unroll
                     for (int k = 0; k < 16; ++k) acc[i][k] = -acc[i][k];
             }
         }
-        const uint32_t bsgn = (ALT && (cc & 1)) ? 0x80008000u : 0u;        // sign bits of the two 16-bit values of a dword
+        const uint32_t bsgn = (alt_on && (cc & 1)) ? 0x80008000u : 0u;      // sign bits of the two 16-bit values of a dword
         const int64_t wset = (!X3 && !EXT && p.w_set_clips > 0) ? (int64_t)(clip0 / p.w_set_clips) * w_lo : (int64_t)0;
         const uint4* wp = wbase + wset + ((EXT || C8) ? (((int64_t)bi * p.w_box_stride) >> 3) : (int64_t)0) + ((int64_t)cc * S * p.NT + wn * NTW) * 64 + lane;
         auto load_b = [&](int s, uint4* bh, uint4* bl) {
@@ -380,10 +383,6 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
             for (int j = 0; j < NTW; ++j) {
                 bh[j] = wp[(int64_t)sc * wstep + j * 64];
                 if constexpr (X3 && !C8 && (!SEQ || ph == 0)) bl[j] = wp[(int64_t)sc * wstep + j * 64 + w_lo];   // (C8: plane 1 holds fp8 pieces, loaded by the K loop itself)
-                if constexpr (ALT) {
-                    bh[j].x ^= bsgn; bh[j].y ^= bsgn; bh[j].z ^= bsgn; bh[j].w ^= bsgn;
-                    if constexpr (!SEQ || ph == 0) { bl[j].x ^= bsgn; bl[j].y ^= bsgn; bl[j].z ^= bsgn; bl[j].w ^= bsgn; }
-                }
             }
         };
         uint4 bqh[DB + 1][NTW], bql[DB + 1][NTW];
@@ -769,7 +768,11 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                         load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
                         uint4 bh[NTW], bl[NTW];
 #pragma unroll
-                        for (int j = 0; j < NTW; ++j) { bh[j] = bqh[u][j]; bl[j] = bql[u][j]; }
+                        for (int j = 0; j < NTW; ++j) {
+                            bh[j] = bqh[u][j]; bl[j] = bql[u][j];
+                            bh[j].x ^= bsgn; bh[j].y ^= bsgn; bh[j].z ^= bsgn; bh[j].w ^= bsgn;
+                            if constexpr (PH == 0) { bl[j].x ^= bsgn; bl[j].y ^= bsgn; bl[j].z ^= bsgn; bl[j].w ^= bsgn; }
+                        }
                         const int sn2 = (s + u + 2 < S) ? s + u + 2 : S - 1;
                         const int tap_next2 = lds_tap[2 * sn2 + half];
                         __builtin_amdgcn_sched_barrier(0);
@@ -814,7 +817,11 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
                     load_b(s + u + DB, bqh[(u + DB) % (DB + 1)], bql[(u + DB) % (DB + 1)]);
                     uint4 bh[NTW], bl[NTW];
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j) { bh[j] = bqh[u][j]; bl[j] = bql[u][j]; }
+                    for (int j = 0; j < NTW; ++j) {
+                        bh[j] = bqh[u][j]; bl[j] = bql[u][j];
+                        bh[j].x ^= bsgn; bh[j].y ^= bsgn; bh[j].z ^= bsgn; bh[j].w ^= bsgn;
+                        bl[j].x ^= bsgn; bl[j].y ^= bsgn; bl[j].z ^= bsgn; bl[j].w ^= bsgn;
+                    }
                     const int sn2 = (s + u + 2 < S) ? s + u + 2 : S - 1;
                     const int tap_next2 = lds_tap[2 * sn2 + half];
                     __builtin_amdgcn_sched_barrier(0);
@@ -840,7 +847,7 @@ __device__ __forceinline__ void conv_mfma_body(const VdConvParams& p, const int 
     }
 
     if constexpr (ALT) {            // an even number of chunks leaves -sum in the accumulators
-        if (!(p.CC & 1)) {
+        if (!(p.persist & 0x100000) && !(p.CC & 1)) {
 #pragma unroll
             for (int i = 0; i < TILES; ++i)
 #pragma unroll

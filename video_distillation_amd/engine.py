@@ -62,6 +62,8 @@ class _DevPlan:
         p.lds_plane_bytes = int(gt.shape[1]) * 16
         p.ntypes = len(plan.types)
         p.persist = int(os.environ.get("VD_PERSIST", str(P.BOX_WALK_GENERATIONS)))
+        if os.environ.get("VD_NO_ALT") == "1":       # A/B: hi+lo programs without the per-chunk sign alternation of their accumulation (conv_mfma.hip ALT)
+            p.persist |= 0x100000
         p.tab_ofs[0], p.tab_ofs[1], p.tab_ofs[2] = int(desc[0][7]), int(desc[0][8]), int(desc[0][9])
         self.zero = torch.zeros(64, dtype=torch.uint8, device=device)
         p.zero_slot = self.zero.data_ptr()
