@@ -3,7 +3,8 @@ products on the block-scaled fp8 instruction -- what the real side's LAST level 
 if the REAL batch's level-1 forward used it instead of fp16 hi+lo pairs: one class term at the configuration's geometry (64 real + 5
 synthetic clips 112x112x16, 51-way head, 'ours'), the real forward's level-1 pre-activations replaced by
 
-    exact + [ variant(a0, w1) - exact ].detach()        variant = c8 | single-pass f16
+    exact + [ variant(a0, w1) - exact ].detach()        variant = c8 | f16 (single pass) | w16 (hi+lo activations x ONE rn16 weight
+                                                         plane: two products) | a16 (ONE rn16 activation plane x hi+lo weights: two products)
 
 so that the decisions (ReLU, pooling arg-max) and values downstream are the variant's while every derivative is the exact one --
 the effect of the operand format alone.  Prints the relative change of gw_real per parameter and of the pixel gradient of
@@ -27,6 +28,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 404
 levels = sys.argv[3] if len(sys.argv) > 3 else "1"
 K, ipc, T, S = 51, 5, 16, 112
+KINDS = ("c8", "f16", "w16", "a16")
 DT = torch.float32        # base arithmetic (its own 1e-7 is common to every variant: the base is shared, only the delta differs)
 
 
@@ -45,6 +47,10 @@ def conv(a, w):
 def variant_preact(a, w, kind):
     """conv(a, w) in the operand format ``kind`` (no bias)."""
     a_hi, w_hi = rn16(a), rn16(w)
+    if kind == "w16":                      # exact activations x rn16 weights: hi+lo activation pairs against ONE weight plane (two products)
+        return conv(a, w_hi)
+    if kind == "a16":                      # rn16 activations x exact weights: ONE activation plane against hi+lo weight pairs (two products)
+        return conv(a_hi, w)
     main = conv(a_hi, w_hi)
     if kind == "f16":
         return main
@@ -84,21 +90,21 @@ lab_r, lab_s = torch.full((B,), 7), torch.full((ipc,), 7)
 
 t0 = time.time()
 gw = {}
-for kind in (None, "c8", "f16"):
+for kind in (None,) + KINDS:
     gw[kind] = [t.detach() for t in torch.autograd.grad(F.cross_entropy(logits_with(real, params, kind), lab_r), params)]
     print("real side %-5s done (%.0f s)" % (kind or "exact", time.time() - t0), flush=True)
 names = ["w0", "b0", "w1", "b1", "w2", "b2", "wh", "bh"]
-for kind in ("c8", "f16"):
+for kind in KINDS:
     print("gw_real, level(s) %s in %-3s vs exact: %s" % (levels, kind, "  ".join("%s %.1e" % (n, rel(a, b)) for n, a, b in zip(names, gw[kind], gw[None]))))
 
 xs = syn.clone().requires_grad_(True)
 gw_syn = torch.autograd.grad(F.cross_entropy(R.convnet3d_logits(xs, params), lab_s), params, create_graph=True)
 gx = {}
-for kind in (None, "c8", "f16"):
+for kind in (None,) + KINDS:
     loss = R.match_loss(gw_syn, gw[kind], "ours")
     (gx[kind],) = torch.autograd.grad(loss, xs, retain_graph=True)
     print("match_loss with gw_real %-5s: %.6f" % (kind or "exact", float(loss)), flush=True)
-for kind in ("c8", "f16"):
+for kind in KINDS:
     per = [rel(gx[kind][i], gx[None][i]) for i in range(ipc)]
     print("pixel gradient of match_loss, real level(s) %s in %-3s vs exact: per synthetic clip %s, all %.2e" % (
         levels, kind, ["%.1e" % v for v in per], rel(gx[kind], gx[None])))
